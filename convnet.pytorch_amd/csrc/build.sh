@@ -1,0 +1,24 @@
+#!/bin/bash
+# Build libconvnet_hip.so (gfx950) in-tree; with "emul" also build the TEST-ONLY CPU emulator
+# library used by the `-m "not gpu"` kernel-logic tests.
+set -e
+cd "$(dirname "$0")"
+SRCS="runtime.hip igemm.hip wgrad.hip bn.hip pool.hip loss.hip optim.hip probe.hip"
+OUT=..
+if [ "$1" != "emul-only" ]; then
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-result \
+      $SRCS -o $OUT/libconvnet_hip.so
+  echo "built $OUT/libconvnet_hip.so"
+fi
+if [ "$1" = "emul" ] || [ "$1" = "emul-only" ]; then
+  CXX=/opt/rocm/lib/llvm/bin/clang++
+  OBJS=""
+  for s in $SRCS; do
+    $CXX -x c++ -std=c++17 -O2 -fPIC -DCN_EMULATE -Wno-unused-result -Wno-shift-negative-value -c $s -o /tmp/cn_emul_${s%.hip}.o &
+  done
+  wait
+  for s in $SRCS; do OBJS="$OBJS /tmp/cn_emul_${s%.hip}.o"; done
+  $CXX -std=c++17 -O2 -fPIC -DCN_EMULATE -c cn_emul.cpp -o /tmp/cn_emul_rt.o
+  $CXX -shared -o $OUT/libconvnet_emul.so $OBJS /tmp/cn_emul_rt.o
+  echo "built $OUT/libconvnet_emul.so"
+fi

@@ -1,0 +1,266 @@
+// cn_common.h -- shared device helpers for the gfx950 (CDNA4 / MI355X) kernels.
+//
+// Everything hardware-specific that the kernels rely on is funnelled through the small set of
+// cn_* wrappers below (MFMA, LDS transpose-read, wave shuffles) so that (a) the assumed lane maps
+// are stated in exactly one place and (b) the TEST-ONLY SIMT emulator (cn_emul.h) can provide a
+// host implementation of the same contract.  The maps are pinned on hardware by cn_probe_*.
+#pragma once
+
+#ifdef CN_EMULATE
+#include "cn_emul.h"
+#else
+#include <hip/hip_runtime.h>
+#endif
+#include <stdint.h>
+#include <stddef.h>
+
+// ---------------------------------------------------------------- error codes (C ABI)
+#define CN_OK 0
+#define CN_EINVAL (-1)
+#define CN_ESHAPE (-2)
+#define CN_EHIP (-3)
+#define CN_EWORKSPACE (-4)
+
+// dtype codes of the C ABI
+#define CN_F32 0
+#define CN_BF16 1
+
+void cn_set_error(const char* fmt, ...);
+int cn_check_launch(const char* what);
+
+// ---------------------------------------------------------------- launch macro
+#ifdef CN_EMULATE
+#define CN_LAUNCH(kern, grid, block, stream, ...)                                   \
+  do {                                                                              \
+    (void)(stream);                                                                 \
+    cn_emul::launch((grid), (block), [=]() { kern(__VA_ARGS__); });                 \
+  } while (0)
+#else
+#define CN_LAUNCH(kern, grid, block, stream, ...) \
+  hipLaunchKernelGGL(kern, (grid), (block), 0, (stream), __VA_ARGS__)
+#endif
+
+// ---------------------------------------------------------------- vector types
+typedef short s16x8 __attribute__((ext_vector_type(8)));   // 8 x bf16 bit patterns (16 B)
+typedef short s16x4 __attribute__((ext_vector_type(4)));   // 4 x bf16 bit patterns (8 B)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+struct bf16_t { unsigned short v; };
+
+// ---------------------------------------------------------------- bf16 <-> f32 (RNE)
+__host__ __device__ __forceinline__ float cn_bf16_to_f32(unsigned short h) {
+  union { unsigned int u; float f; } c;
+  c.u = ((unsigned int)h) << 16;
+  return c.f;
+}
+__host__ __device__ __forceinline__ unsigned short cn_f32_to_bf16(float f) {
+  union { unsigned int u; float f; } c;
+  c.f = f;
+  unsigned int u = c.u;
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__host__ __device__ __forceinline__ unsigned int cn_pack_bf16x2(float lo, float hi) {
+  return (unsigned int)cn_f32_to_bf16(lo) | ((unsigned int)cn_f32_to_bf16(hi) << 16);
+}
+
+// element traits: T = float or bf16_t
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<float> {
+  static constexpr int kBytes = 4;
+  static constexpr int kChunk = 4;  // elements per 16-byte chunk
+  static constexpr int kCode = CN_F32;
+};
+template <> struct ElemTraits<bf16_t> {
+  static constexpr int kBytes = 2;
+  static constexpr int kChunk = 8;
+  static constexpr int kCode = CN_BF16;
+};
+
+// Unpack a 16-byte chunk into floats / pack floats into a chunk.
+template <typename T> struct Chunk;
+template <> struct Chunk<float> {
+  static constexpr int N = 4;
+  __host__ __device__ static __forceinline__ void unpack(const u32x4& c, float* f) {
+    union { unsigned int u; float f; } x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { x.u = c[i]; f[i] = x.f; }
+  }
+  __host__ __device__ static __forceinline__ u32x4 pack(const float* f) {
+    u32x4 c;
+    union { unsigned int u; float f; } x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { x.f = f[i]; c[i] = x.u; }
+    return c;
+  }
+};
+template <> struct Chunk<bf16_t> {
+  static constexpr int N = 8;
+  __host__ __device__ static __forceinline__ void unpack(const u32x4& c, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = cn_bf16_to_f32((unsigned short)(c[i] & 0xffffu));
+      f[2 * i + 1] = cn_bf16_to_f32((unsigned short)(c[i] >> 16));
+    }
+  }
+  __host__ __device__ static __forceinline__ u32x4 pack(const float* f) {
+    u32x4 c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c[i] = cn_pack_bf16x2(f[2 * i], f[2 * i + 1]);
+    return c;
+  }
+};
+
+template <typename T> __host__ __device__ __forceinline__ float cn_load_elem(const T* p);
+template <> __host__ __device__ __forceinline__ float cn_load_elem<float>(const float* p) { return *p; }
+template <> __host__ __device__ __forceinline__ float cn_load_elem<bf16_t>(const bf16_t* p) {
+  return cn_bf16_to_f32(p->v);
+}
+template <typename T> __host__ __device__ __forceinline__ void cn_store_elem(T* p, float v);
+template <> __host__ __device__ __forceinline__ void cn_store_elem<float>(float* p, float v) { *p = v; }
+template <> __host__ __device__ __forceinline__ void cn_store_elem<bf16_t>(bf16_t* p, float v) {
+  p->v = cn_f32_to_bf16(v);
+}
+
+// ---------------------------------------------------------------- fast division (host-precomputed)
+// q = n / d for 0 <= n < 2^31 using one mulhi + shift.
+struct FastDiv {
+  unsigned int mul, shr, d;
+};
+static inline FastDiv cn_make_fastdiv(unsigned int d) {
+  FastDiv f;
+  f.d = d;
+  if (d <= 1) { f.mul = 0; f.shr = 0; return f; }
+  unsigned int lg = 0;
+  while ((1ull << lg) < d) ++lg;  // ceil(log2(d))
+  unsigned int p = 31 + lg;
+  unsigned long long m = ((1ull << p) + d - 1) / d;
+  f.mul = (unsigned int)m;
+  f.shr = p - 32;
+  return f;
+}
+__host__ __device__ __forceinline__ unsigned int cn_fastdiv(unsigned int n, const FastDiv& f) {
+  if (f.d == 1) return n;
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umulhi(n, f.mul) >> f.shr;
+#else
+  return (unsigned int)(((unsigned long long)n * f.mul) >> 32) >> f.shr;
+#endif
+}
+
+// ---------------------------------------------------------------- MFMA wrappers
+// Assumed gfx950 lane maps (wave64, lane l), pinned by cn_probe_mfma():
+//   32x32x16 bf16 : A[i][k]: i = l&31, k = 8*(l>>5)+e (e=0..7);  B[k][j]: j = l&31, same k.
+//   32x32x2  f32  : A[i][k]: i = l&31, k = l>>5;                 B[k][j]: j = l&31, k = l>>5.
+//   C/D (both)    : j = l&31, i = (r&3) + 8*(r>>2) + 4*(l>>5), r = 0..15.
+#ifndef CN_EMULATE
+typedef __bf16 cn_bf16x8_native __attribute__((ext_vector_type(8)));
+typedef __bf16 cn_bf16x4_native __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x16 cn_mfma_32x32x16_bf16(s16x8 a, s16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cn_bf16x8_native, a),
+                                                 __builtin_bit_cast(cn_bf16x8_native, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 cn_mfma_32x32x2_f32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+// LDS transpose read (ds_read_b64_tr_b16).  Within each 16-lane group, lane L supplies the
+// address of 4 consecutive 16-bit elements in[L][0..3]; lane i receives
+//   out[i][j] = in[4*j + (i>>2)][i&3]      (i, L = lane & 15; j = 0..3)
+__device__ __forceinline__ s16x4 cn_lds_read_tr16_b64(const void* lds_ptr) {
+  typedef __attribute__((address_space(3))) cn_bf16x4_native* lds_p;
+  cn_bf16x4_native t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(lds_ptr));
+  return __builtin_bit_cast(s16x4, t);
+}
+__device__ __forceinline__ float cn_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
+__device__ __forceinline__ float cn_shfl_down(float v, int d) { return __shfl_down(v, d, 64); }
+__device__ __forceinline__ int cn_shfl_xor_i(int v, int mask) { return __shfl_xor(v, mask, 64); }
+#else
+static inline f32x16 cn_mfma_32x32x16_bf16(s16x8 a, s16x8 b, f32x16 c) {
+  struct P { s16x8 a, b; } mine{a, b};
+  const void* const* all = cn_emul::wave_gather(&mine);
+  int l = cn_emul::lane();
+  int j = l & 31;
+  f32x16 d = c;
+  for (int r = 0; r < 16; ++r) {
+    int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    float acc = 0.f;
+    for (int k = 0; k < 16; ++k) {
+      const P* pa = (const P*)all[i + 32 * (k >> 3)];
+      const P* pb = (const P*)all[j + 32 * (k >> 3)];
+      acc += cn_bf16_to_f32((unsigned short)pa->a[k & 7]) * cn_bf16_to_f32((unsigned short)pb->b[k & 7]);
+    }
+    d[r] += acc;
+  }
+  cn_emul::wave_release();
+  return d;
+}
+static inline f32x16 cn_mfma_32x32x2_f32(float a, float b, f32x16 c) {
+  struct P { float a, b; } mine{a, b};
+  const void* const* all = cn_emul::wave_gather(&mine);
+  int l = cn_emul::lane();
+  int j = l & 31;
+  f32x16 d = c;
+  for (int r = 0; r < 16; ++r) {
+    int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    float acc = d[r];
+    for (int k = 0; k < 2; ++k)
+      acc = fmaf(((const P*)all[i + 32 * k])->a, ((const P*)all[j + 32 * k])->b, acc);
+    d[r] = acc;
+  }
+  cn_emul::wave_release();
+  return d;
+}
+static inline s16x4 cn_lds_read_tr16_b64(const void* lds_ptr) {
+  s16x4 mine;
+  memcpy(&mine, lds_ptr, 8);
+  const void* const* all = cn_emul::wave_gather(&mine);
+  int l = cn_emul::lane();
+  int g = l & ~15, i = l & 15;
+  s16x4 out;
+  for (int j = 0; j < 4; ++j) out[j] = (*(const s16x4*)all[g + 4 * j + (i >> 2)])[i & 3];
+  cn_emul::wave_release();
+  return out;
+}
+static inline float cn_shfl_xor(float v, int mask) {
+  const void* const* all = cn_emul::wave_gather(&v);
+  float r = *(const float*)all[cn_emul::lane() ^ mask];
+  cn_emul::wave_release();
+  return r;
+}
+static inline float cn_shfl_down(float v, int d) {
+  const void* const* all = cn_emul::wave_gather(&v);
+  int src = cn_emul::lane() + d;
+  float r = src < 64 ? *(const float*)all[src] : v;
+  cn_emul::wave_release();
+  return r;
+}
+static inline int cn_shfl_xor_i(int v, int mask) {
+  const void* const* all = cn_emul::wave_gather(&v);
+  int r = *(const int*)all[cn_emul::lane() ^ mask];
+  cn_emul::wave_release();
+  return r;
+}
+#endif
+
+// 16-byte global / LDS accessors
+__host__ __device__ __forceinline__ u32x4 cn_ld16(const void* p) { return *(const u32x4*)p; }
+__host__ __device__ __forceinline__ void cn_st16(void* p, const u32x4& v) { *(u32x4*)p = v; }
+__host__ __device__ __forceinline__ u32x4 cn_zero16() {
+  u32x4 z = {0u, 0u, 0u, 0u};
+  return z;
+}
+
+// XCD-aware (8 XCDs) bijective remap of a linear workgroup id so that consecutive logical tiles
+// run on the same XCD (shared private L2).  Pure speed: any placement is still correct.
+__host__ __device__ __forceinline__ unsigned int cn_xcd_remap(unsigned int bid, unsigned int nwg) {
+  const unsigned int nx = 8;
+  if (nwg < nx * 2) return bid;
+  unsigned int xcd = bid % nx, slot = bid / nx;
+  unsigned int q = nwg / nx, r = nwg % nx;
+  unsigned int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + slot;
+}

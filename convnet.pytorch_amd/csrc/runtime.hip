@@ -1,0 +1,48 @@
+// runtime.hip -- error reporting + library identification for the C ABI (include/convnet_hip.h).
+// Every cn_* entry point returns 0 on success or a negative CN_E* code; the human-readable reason
+// is kept in a thread-local buffer that cn_last_error() returns.  Nothing here allocates device
+// memory or synchronises the device.
+#include "cn_api_internal.h"
+#include <stdarg.h>
+#include <stdio.h>
+
+static thread_local char g_err[512] = "";
+
+void cn_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int cn_check_launch(const char* what) {
+#ifdef CN_EMULATE
+  (void)what;
+  return CN_OK;
+#else
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    cn_set_error("%s: HIP launch failed: %s", what, hipGetErrorString(e));
+    return CN_EHIP;
+  }
+  return CN_OK;
+#endif
+}
+
+extern "C" const char* cn_last_error(void) { return g_err; }
+
+extern "C" int cn_is_emulator(void) {
+#ifdef CN_EMULATE
+  return 1;
+#else
+  return 0;
+#endif
+}
+
+extern "C" const char* cn_build_info(void) {
+#ifdef CN_EMULATE
+  return "convnet_hip TEST-ONLY SIMT emulator build (host C++)";
+#else
+  return "convnet_hip gfx950 (CDNA4 / MI355X) HIP build";
+#endif
+}
