@@ -1,0 +1,152 @@
+"""ctypes binding of libconvnet_hip.so (C ABI declared in include/convnet_hip.h).
+
+This is the drop-in boundary: everything above it is Python host code mirroring the reference's
+operator / trainer interface, everything below it is hand-written HIP for gfx950.  The library is
+built in-tree by ``__graft_entry__.build()`` (or ``csrc/build.sh``).
+
+There is deliberately NO fallback: if the HIP library is missing, loading raises.  The only other
+library this module can bind is the TEST-ONLY SIMT emulator build of the *same kernel sources*
+(``libconvnet_emul.so``), and only when ``CONVNET_AMD_EMULATE=1`` is set explicitly (the CPU test
+suite does that); it is refused whenever a GPU is visible.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB = os.path.join(_HERE, 'libconvnet_hip.so')
+EMUL_LIB = os.path.join(_HERE, 'libconvnet_emul.so')
+
+F32, BF16 = 0, 1
+
+c_p = ctypes.c_void_p
+c_i = ctypes.c_int
+c_f = ctypes.c_float
+c_ll = ctypes.c_longlong
+c_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/convnet_hip.h one to one
+_SIGNATURES = {
+    'cn_last_error': (ctypes.c_char_p, []),
+    'cn_build_info': (ctypes.c_char_p, []),
+    'cn_is_emulator': (c_i, []),
+    'cn_conv2d_fwd': (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 11 + [c_i, c_i, c_i, c_p]),
+    'cn_conv2d_dgrad': (c_i, [c_p, c_p, c_p] + [c_i] * 11 + [c_i, c_i, c_p]),
+    'cn_conv2d_wgrad_workspace': (c_sz, [c_i] * 12),
+    'cn_conv2d_wgrad': (c_i, [c_p, c_p, c_p, c_i] + [c_i] * 11 + [c_i, c_f, c_f, c_p, c_sz, c_p]),
+    'cn_bn_workspace': (c_sz, [c_i, c_i, c_i]),
+    'cn_bn_fwd_train': (c_i, [c_p] * 8 + [c_f, c_f, c_p, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
+    'cn_bn_fwd_infer': (c_i, [c_p] * 7 + [c_f, c_p, c_i, c_i, c_i, c_i, c_p]),
+    'cn_bn_bwd': (c_i, [c_p] * 9 + [c_f, c_f, c_p, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
+    'cn_maxpool_fwd': (c_i, [c_p, c_p, c_p] + [c_i] * 8 + [c_p]),
+    'cn_maxpool_bwd': (c_i, [c_p, c_p, c_p] + [c_i] * 8 + [c_p]),
+    'cn_avgpool_fwd': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    'cn_avgpool_bwd': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    'cn_nchw_to_nhwc': (c_i, [c_p, c_p] + [c_i] * 6 + [c_p]),
+    'cn_nhwc_to_nchw': (c_i, [c_p, c_p] + [c_i] * 6 + [c_p]),
+    'cn_eltwise': (c_i, [c_i, c_p, c_p, c_p, c_ll, c_i, c_p]),
+    'cn_softmax_ce': (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_f, c_p, c_f, c_p]),
+    'cn_sgd_momentum': (c_i, [c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_f, c_p, c_p]),
+    'cn_grad_norm_workspace': (c_sz, []),
+    'cn_grad_norm_clip': (c_i, [c_p, c_ll, c_f, c_f, c_p, c_p, c_f, c_p, c_p]),
+    'cn_weight_prep': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    'cn_colsum_workspace': (c_sz, [c_i]),
+    'cn_colsum': (c_i, [c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_p, c_p]),
+    'cn_cast_from_f32': (c_i, [c_p, c_p, c_ll, c_i, c_p]),
+    'cn_fill_f32': (c_i, [c_p, c_ll, c_f, c_p]),
+    'cn_probe_mfma_bf16': (c_i, [c_p, c_p, c_p, c_p]),
+    'cn_probe_mfma_f32': (c_i, [c_p, c_p, c_p, c_p]),
+    'cn_probe_tr16': (c_i, [c_p, c_p, c_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))
+
+_lib = None
+_emulated = False
+
+
+class ConvNetHipError(RuntimeError):
+    pass
+
+
+def _bind(path):
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError = symbol missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def emulation_requested():
+    return os.environ.get('CONVNET_AMD_EMULATE', '0') == '1'
+
+
+def load():
+    """Load (once) and return the bound library."""
+    global _lib, _emulated
+    if _lib is not None:
+        return _lib
+    if emulation_requested():
+        if torch.cuda.is_available():
+            raise ConvNetHipError('CONVNET_AMD_EMULATE=1 is refused when a GPU is visible: '
+                                  'the emulator is a CPU-only test harness, not a product path')
+        if not os.path.exists(EMUL_LIB):
+            raise ConvNetHipError('emulator library missing: run csrc/build.sh emul')
+        _lib = _bind(EMUL_LIB)
+        _emulated = True
+        return _lib
+    if not os.path.exists(HIP_LIB):
+        raise ConvNetHipError(
+            'libconvnet_hip.so not found at %s -- build it with `python -c "import __graft_entry__ as g; '
+            'g.build()"` (hipcc --offload-arch=gfx950).  There is no CPU / PyTorch fallback.' % HIP_LIB)
+    _lib = _bind(HIP_LIB)
+    _emulated = False
+    return _lib
+
+
+def is_emulated():
+    load()
+    return _emulated
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().cn_last_error()
+        raise ConvNetHipError('%s failed (rc=%d): %s' % (what, rc, msg.decode() if msg else ''))
+
+
+def dtype_code(dtype):
+    if dtype == torch.float32:
+        return F32
+    if dtype == torch.bfloat16:
+        return BF16
+    raise ConvNetHipError('unsupported compute dtype %s (float32 / bfloat16 only)' % dtype)
+
+
+def chunk_elems(dtype):
+    return 4 if dtype == torch.float32 else 8
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream_of(t):
+    """Raw hipStream_t of torch's current stream on the tensor's device (NULL for the emulator)."""
+    if t.is_cuda:
+        return torch.cuda.current_stream(t.device).cuda_stream
+    if not is_emulated():
+        raise ConvNetHipError('tensor is on %s but the HIP library needs device memory' % t.device)
+    return None
+
+
+def require_device(t, name='tensor'):
+    if not t.is_cuda and not is_emulated():
+        raise ConvNetHipError('%s must live on a HIP device (got %s)' % (name, t.device))
+    if not t.is_contiguous():
+        raise ConvNetHipError('%s must be contiguous' % name)

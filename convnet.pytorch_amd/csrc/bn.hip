@@ -1,0 +1,439 @@
+// bn.hip -- BatchNorm2d (training + inference) with fused residual-add and ReLU, NHWC, gfx950.
+//
+// Replaces nn.BatchNorm2d + nn.ReLU(inplace) + the `out += residual` of the reference blocks
+// (/root/reference models/resnet.py:98-118,141-165,128-134,162-163) and their autograd backward.
+// Semantics follow torch.nn.BatchNorm2d defaults as the reference instantiates them
+// (eps=1e-5, momentum=0.1, affine, track_running_stats): normalise with the *biased* batch
+// variance, update running_var with the *unbiased* one, num_batches_tracked += 1.
+//
+// All kernels are HBM-bound streaming kernels: channels are the fastest (NHWC) dimension, every
+// lane owns one 16-byte channel chunk and walks over pixels, so loads are fully coalesced and the
+// per-channel reductions need no cross-lane traffic until one small LDS step per workgroup.
+// Cross-workgroup reduction is two-stage (partials + finalize) => deterministic, no atomics.
+//
+//   forward (train):  bn_stats -> bn_finalize -> bn_apply        (reads y twice, writes z once)
+//   backward:         bn_bwd_reduce -> bn_bwd_finalize -> bn_bwd_apply
+#include "cn_common.h"
+#include "cn_api_internal.h"
+
+static inline int bn_next_pow2_log2(int v) {
+  int s = 0;
+  while ((1 << s) < v) ++s;
+  return s;
+}
+
+struct BnMap {
+  int tpr_log2;  // threads per row (power of two, <= 256)
+  int gy;        // column groups
+  int rpp;       // rows per pass of one workgroup
+};
+static BnMap bn_map(int cpr) {
+  BnMap m;
+  int l = bn_next_pow2_log2(cpr);
+  if (l > 8) l = 8;
+  m.tpr_log2 = l;
+  m.gy = (cpr + (1 << l) - 1) >> l;
+  m.rpp = 256 >> l;
+  return m;
+}
+static int bn_row_blocks(long long M, const BnMap& m, int target_blocks) {
+  long long passes = (M + m.rpp - 1) / m.rpp;
+  long long nb = target_blocks / m.gy;
+  if (nb < 1) nb = 1;
+  long long cap = (passes + 3) / 4;  // at least ~4 passes per workgroup
+  if (cap < 1) cap = 1;
+  if (nb > cap) nb = cap;
+  return (int)nb;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const char* y, float* partial, int M, int C,
+                                                      int tpr_log2) {
+  constexpr int CH = ElemTraits<T>::kChunk;
+  constexpr int EB = ElemTraits<T>::kBytes;
+  __shared__ float red[256 * 2 * CH];
+  const int tid = threadIdx.x;
+  const int tpr = 1 << tpr_log2, rpp = 256 >> tpr_log2;
+  const int cpr = C / CH;
+  const int tcol = tid & (tpr - 1), rsub = tid >> tpr_log2;
+  const int col = blockIdx.y * tpr + tcol;
+  float s[CH], q[CH];
+#pragma unroll
+  for (int e = 0; e < CH; ++e) { s[e] = 0.f; q[e] = 0.f; }
+  if (col < cpr) {
+    const int step = gridDim.x * rpp;
+#pragma unroll 4
+    for (int row = blockIdx.x * rpp + rsub; row < M; row += step) {
+      u32x4 v = cn_ld16(y + ((size_t)row * C + (size_t)col * CH) * EB);
+      float f[CH];
+      Chunk<T>::unpack(v, f);
+#pragma unroll
+      for (int e = 0; e < CH; ++e) { s[e] += f[e]; q[e] = fmaf(f[e], f[e], q[e]); }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < CH; ++e) { red[tid * 2 * CH + e] = s[e]; red[tid * 2 * CH + CH + e] = q[e]; }
+  __syncthreads();
+  if (rsub == 0 && col < cpr) {
+    for (int r = 1; r < rpp; ++r) {
+      const float* o = red + (r * tpr + tcol) * 2 * CH;
+#pragma unroll
+      for (int e = 0; e < CH; ++e) { s[e] += o[e]; q[e] += o[CH + e]; }
+    }
+    float* dst = partial + (size_t)blockIdx.x * 2 * C + col * CH;
+#pragma unroll
+    for (int e = 0; e < CH; ++e) { dst[e] = s[e]; dst[C + e] = q[e]; }
+  }
+}
+
+// One thread per channel: fixed-order sum of the partials, statistics, running-stat update and the
+// fused scale/shift the apply kernel consumes.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* partial, int nrb, int M, int C,
+                                                         const float* gamma, const float* beta,
+                                                         float* running_mean, float* running_var,
+                                                         long long* num_batches_tracked, float momentum,
+                                                         float eps, float* save_mean, float* save_invstd,
+                                                         float* scale, float* shift) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c == 0 && num_batches_tracked != nullptr) *num_batches_tracked += 1;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int r = 0; r < nrb; ++r) {
+    s += (double)partial[(size_t)r * 2 * C + c];
+    q += (double)partial[(size_t)r * 2 * C + C + c];
+  }
+  const double mean = s / (double)M;
+  double var = q / (double)M - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  save_mean[c] = (float)mean;
+  save_invstd[c] = invstd;
+  if (running_mean != nullptr) {
+    const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
+    running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
+    running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+  }
+  const float g = gamma != nullptr ? gamma[c] : 1.f;
+  const float b = beta != nullptr ? beta[c] : 0.f;
+  const float sc = g * invstd;
+  scale[c] = sc;
+  shift[c] = b - (float)mean * sc;
+}
+
+// Inference coefficients from the running statistics.
+__global__ __launch_bounds__(256) void bn_infer_coeffs_kernel(int C, const float* gamma, const float* beta,
+                                                             const float* running_mean,
+                                                             const float* running_var, float eps,
+                                                             float* scale, float* shift) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = 1.f / sqrtf(running_var[c] + eps);
+  const float g = gamma != nullptr ? gamma[c] : 1.f;
+  const float b = beta != nullptr ? beta[c] : 0.f;
+  scale[c] = g * invstd;
+  shift[c] = b - running_mean[c] * g * invstd;
+}
+
+// z = act(y*scale[c] + shift[c] (+ residual))
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const char* y, const char* res, char* z,
+                                                      const float* scale, const float* shift, int M, int C,
+                                                      int relu, int tpr_log2) {
+  constexpr int CH = ElemTraits<T>::kChunk;
+  constexpr int EB = ElemTraits<T>::kBytes;
+  const int tid = threadIdx.x;
+  const int tpr = 1 << tpr_log2, rpp = 256 >> tpr_log2;
+  const int cpr = C / CH;
+  const int col = blockIdx.y * tpr + (tid & (tpr - 1)), rsub = tid >> tpr_log2;
+  if (col >= cpr) return;
+  float sc[CH], sh[CH];
+#pragma unroll
+  for (int e = 0; e < CH; ++e) { sc[e] = scale[col * CH + e]; sh[e] = shift[col * CH + e]; }
+  const int step = gridDim.x * rpp;
+#pragma unroll 4
+  for (int row = blockIdx.x * rpp + rsub; row < M; row += step) {
+    const size_t off = ((size_t)row * C + (size_t)col * CH) * EB;
+    float f[CH];
+    Chunk<T>::unpack(cn_ld16(y + off), f);
+#pragma unroll
+    for (int e = 0; e < CH; ++e) f[e] = fmaf(f[e], sc[e], sh[e]);
+    if (res != nullptr) {
+      float r[CH];
+      Chunk<T>::unpack(cn_ld16(res + off), r);
+#pragma unroll
+      for (int e = 0; e < CH; ++e) f[e] += r[e];
+    }
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < CH; ++e) f[e] = f[e] > 0.f ? f[e] : 0.f;
+    }
+    cn_st16(z + off, Chunk<T>::pack(f));
+  }
+}
+
+// Per-channel sum(g) and sum(g * xhat), g = dz * relu_mask.
+//   mask source: zmask (the saved activation output, needed when a residual was added) or, when
+//   zmask == nullptr and relu != 0, recomputed from y*scale+shift > 0.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const char* dz, const char* y, const char* zmask,
+                                                           const float* mean, const float* invstd,
+                                                           const float* scale, const float* shift,
+                                                           float* partial, int M, int C, int relu,
+                                                           int tpr_log2) {
+  constexpr int CH = ElemTraits<T>::kChunk;
+  constexpr int EB = ElemTraits<T>::kBytes;
+  __shared__ float red[256 * 2 * CH];
+  const int tid = threadIdx.x;
+  const int tpr = 1 << tpr_log2, rpp = 256 >> tpr_log2;
+  const int cpr = C / CH;
+  const int tcol = tid & (tpr - 1), rsub = tid >> tpr_log2;
+  const int col = blockIdx.y * tpr + tcol;
+  float s1[CH], s2[CH];
+#pragma unroll
+  for (int e = 0; e < CH; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  if (col < cpr) {
+    float mu[CH], is[CH], sc[CH], sh[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+      mu[e] = mean[col * CH + e];
+      is[e] = invstd[col * CH + e];
+      sc[e] = scale[col * CH + e];
+      sh[e] = shift[col * CH + e];
+    }
+    const int step = gridDim.x * rpp;
+#pragma unroll 2
+    for (int row = blockIdx.x * rpp + rsub; row < M; row += step) {
+      const size_t off = ((size_t)row * C + (size_t)col * CH) * EB;
+      float g[CH], v[CH];
+      Chunk<T>::unpack(cn_ld16(dz + off), g);
+      Chunk<T>::unpack(cn_ld16(y + off), v);
+      if (relu) {
+        if (zmask != nullptr) {
+          float zz[CH];
+          Chunk<T>::unpack(cn_ld16(zmask + off), zz);
+#pragma unroll
+          for (int e = 0; e < CH; ++e) g[e] = zz[e] > 0.f ? g[e] : 0.f;
+        } else {
+#pragma unroll
+          for (int e = 0; e < CH; ++e) g[e] = fmaf(v[e], sc[e], sh[e]) > 0.f ? g[e] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < CH; ++e) {
+        s1[e] += g[e];
+        s2[e] = fmaf(g[e], (v[e] - mu[e]) * is[e], s2[e]);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < CH; ++e) { red[tid * 2 * CH + e] = s1[e]; red[tid * 2 * CH + CH + e] = s2[e]; }
+  __syncthreads();
+  if (rsub == 0 && col < cpr) {
+    for (int r = 1; r < rpp; ++r) {
+      const float* o = red + (r * tpr + tcol) * 2 * CH;
+#pragma unroll
+      for (int e = 0; e < CH; ++e) { s1[e] += o[e]; s2[e] += o[CH + e]; }
+    }
+    float* dst = partial + (size_t)blockIdx.x * 2 * C + col * CH;
+#pragma unroll
+    for (int e = 0; e < CH; ++e) { dst[e] = s1[e]; dst[C + e] = s2[e]; }
+  }
+}
+
+// dgamma/dbeta (optionally accumulated) and the three per-channel coefficients of
+//   dy = c1*g + c2*y + c3     ( = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)) )
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* partial, int nrb, int M, int C,
+                                                             const float* gamma, const float* mean,
+                                                             const float* invstd, float* dgamma,
+                                                             float* dbeta, float beta_acc, float gscale,
+                                                             float* coef) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = 0; r < nrb; ++r) {
+    s1 += (double)partial[(size_t)r * 2 * C + c];
+    s2 += (double)partial[(size_t)r * 2 * C + C + c];
+  }
+  const float g = gamma != nullptr ? gamma[c] : 1.f;
+  if (dgamma != nullptr) dgamma[c] = (beta_acc != 0.f ? beta_acc * dgamma[c] : 0.f) + (float)s2 * gscale;
+  if (dbeta != nullptr) dbeta[c] = (beta_acc != 0.f ? beta_acc * dbeta[c] : 0.f) + (float)s1 * gscale;
+  const double k = (double)g * (double)invstd[c];
+  const double a2 = k * (double)invstd[c] * s2 / (double)M;
+  coef[c] = (float)k;
+  coef[C + c] = (float)(-a2);
+  coef[2 * C + c] = (float)(a2 * (double)mean[c] - k * s1 / (double)M);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char* dz, const char* y, const char* zmask,
+                                                          const float* scale, const float* shift,
+                                                          const float* coef, char* dy, char* dres, int M,
+                                                          int C, int relu, int tpr_log2) {
+  constexpr int CH = ElemTraits<T>::kChunk;
+  constexpr int EB = ElemTraits<T>::kBytes;
+  const int tid = threadIdx.x;
+  const int tpr = 1 << tpr_log2, rpp = 256 >> tpr_log2;
+  const int cpr = C / CH;
+  const int col = blockIdx.y * tpr + (tid & (tpr - 1)), rsub = tid >> tpr_log2;
+  if (col >= cpr) return;
+  float c1[CH], c2[CH], c3[CH], sc[CH], sh[CH];
+#pragma unroll
+  for (int e = 0; e < CH; ++e) {
+    c1[e] = coef[col * CH + e];
+    c2[e] = coef[C + col * CH + e];
+    c3[e] = coef[2 * C + col * CH + e];
+    sc[e] = scale[col * CH + e];
+    sh[e] = shift[col * CH + e];
+  }
+  const int step = gridDim.x * rpp;
+#pragma unroll 2
+  for (int row = blockIdx.x * rpp + rsub; row < M; row += step) {
+    const size_t off = ((size_t)row * C + (size_t)col * CH) * EB;
+    float g[CH], v[CH];
+    Chunk<T>::unpack(cn_ld16(dz + off), g);
+    Chunk<T>::unpack(cn_ld16(y + off), v);
+    if (relu) {
+      if (zmask != nullptr) {
+        float zz[CH];
+        Chunk<T>::unpack(cn_ld16(zmask + off), zz);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) g[e] = zz[e] > 0.f ? g[e] : 0.f;
+      } else {
+#pragma unroll
+        for (int e = 0; e < CH; ++e) g[e] = fmaf(v[e], sc[e], sh[e]) > 0.f ? g[e] : 0.f;
+      }
+    }
+    if (dres != nullptr) cn_st16(dres + off, Chunk<T>::pack(g));
+    float o[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) o[e] = fmaf(c1[e], g[e], fmaf(c2[e], v[e], c3[e]));
+    cn_st16(dy + off, Chunk<T>::pack(o));
+  }
+}
+
+// Inference-mode backward is not part of the reference hot path (validate() runs under no_grad).
+
+// ------------------------------------------------------------------------------------------------
+#define BN_TARGET_BLOCKS 2048
+
+extern "C" size_t cn_bn_workspace(int M, int C, int dtype) {
+  const int CH = dtype == CN_BF16 ? 8 : 4;
+  if (C % CH != 0 || M <= 0) return 0;
+  BnMap m = bn_map(C / CH);
+  int nrb = bn_row_blocks(M, m, BN_TARGET_BLOCKS);
+  return (size_t)nrb * 2 * C * sizeof(float);
+}
+
+static int bn_check(const char* who, int M, int C, int dtype) {
+  if (dtype != CN_BF16 && dtype != CN_F32) { cn_set_error("%s: bad dtype %d", who, dtype); return CN_EINVAL; }
+  const int CH = dtype == CN_BF16 ? 8 : 4;
+  if (M <= 0 || C <= 0 || C % CH != 0) {
+    cn_set_error("%s: need M>0 and C (%d) a multiple of %d", who, C, CH);
+    return CN_ESHAPE;
+  }
+  return CN_OK;
+}
+
+// Training forward.  stats_out = [save_mean | save_invstd | scale | shift] (4*C floats).
+extern "C" int cn_bn_fwd_train(const void* y, const void* residual, void* z, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var,
+                               long long* num_batches_tracked, float momentum, float eps, float* stats_out,
+                               int M, int C, int relu, int dtype, void* workspace, size_t ws_bytes,
+                               void* stream_) {
+  int rc = bn_check("bn_fwd_train", M, C, dtype);
+  if (rc) return rc;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int CH = dtype == CN_BF16 ? 8 : 4;
+  BnMap m = bn_map(C / CH);
+  int nrb = bn_row_blocks(M, m, BN_TARGET_BLOCKS);
+  if (workspace == nullptr || ws_bytes < (size_t)nrb * 2 * C * sizeof(float)) {
+    cn_set_error("bn_fwd_train: workspace too small");
+    return CN_EWORKSPACE;
+  }
+  float* partial = (float*)workspace;
+  dim3 grid((unsigned)nrb, (unsigned)m.gy);
+  if (dtype == CN_BF16)
+    CN_LAUNCH(bn_stats_kernel<bf16_t>, grid, dim3(256), stream, (const char*)y, partial, M, C, m.tpr_log2);
+  else
+    CN_LAUNCH(bn_stats_kernel<float>, grid, dim3(256), stream, (const char*)y, partial, M, C, m.tpr_log2);
+  CN_LAUNCH(bn_finalize_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), stream, (const float*)partial, nrb,
+            M, C, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, stats_out,
+            stats_out + C, stats_out + 2 * C, stats_out + 3 * C);
+  int nab = bn_row_blocks(M, m, BN_TARGET_BLOCKS * 2);
+  dim3 agrid((unsigned)nab, (unsigned)m.gy);
+  if (dtype == CN_BF16)
+    CN_LAUNCH(bn_apply_kernel<bf16_t>, agrid, dim3(256), stream, (const char*)y, (const char*)residual,
+              (char*)z, (const float*)(stats_out + 2 * C), (const float*)(stats_out + 3 * C), M, C, relu,
+              m.tpr_log2);
+  else
+    CN_LAUNCH(bn_apply_kernel<float>, agrid, dim3(256), stream, (const char*)y, (const char*)residual, (char*)z,
+              (const float*)(stats_out + 2 * C), (const float*)(stats_out + 3 * C), M, C, relu, m.tpr_log2);
+  return cn_check_launch("bn_fwd_train");
+}
+
+// Inference forward from running statistics.  coeffs = scratch of 2*C floats.
+extern "C" int cn_bn_fwd_infer(const void* y, const void* residual, void* z, const float* gamma,
+                               const float* beta, const float* running_mean, const float* running_var,
+                               float eps, float* coeffs, int M, int C, int relu, int dtype, void* stream_) {
+  int rc = bn_check("bn_fwd_infer", M, C, dtype);
+  if (rc) return rc;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int CH = dtype == CN_BF16 ? 8 : 4;
+  BnMap m = bn_map(C / CH);
+  CN_LAUNCH(bn_infer_coeffs_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), stream, C, gamma, beta,
+            running_mean, running_var, eps, coeffs, coeffs + C);
+  int nab = bn_row_blocks(M, m, BN_TARGET_BLOCKS * 2);
+  dim3 agrid((unsigned)nab, (unsigned)m.gy);
+  if (dtype == CN_BF16)
+    CN_LAUNCH(bn_apply_kernel<bf16_t>, agrid, dim3(256), stream, (const char*)y, (const char*)residual,
+              (char*)z, (const float*)coeffs, (const float*)(coeffs + C), M, C, relu, m.tpr_log2);
+  else
+    CN_LAUNCH(bn_apply_kernel<float>, agrid, dim3(256), stream, (const char*)y, (const char*)residual, (char*)z,
+              (const float*)coeffs, (const float*)(coeffs + C), M, C, relu, m.tpr_log2);
+  return cn_check_launch("bn_fwd_infer");
+}
+
+// Training backward.  stats = the 4*C floats written by cn_bn_fwd_train; coef_scratch = 3*C floats.
+// dgamma/dbeta are written (beta_acc = 0) or accumulated (beta_acc = 1).  dres (optional) receives
+// the masked upstream gradient for the residual branch.
+extern "C" int cn_bn_bwd(const void* dz, const void* y, const void* zmask, const float* gamma,
+                         const float* stats, void* dy, void* dres, float* dgamma, float* dbeta,
+                         float beta_acc, float gscale, float* coef_scratch, int M, int C, int relu, int dtype,
+                         void* workspace, size_t ws_bytes, void* stream_) {
+  int rc = bn_check("bn_bwd", M, C, dtype);
+  if (rc) return rc;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int CH = dtype == CN_BF16 ? 8 : 4;
+  BnMap m = bn_map(C / CH);
+  int nrb = bn_row_blocks(M, m, BN_TARGET_BLOCKS);
+  if (workspace == nullptr || ws_bytes < (size_t)nrb * 2 * C * sizeof(float)) {
+    cn_set_error("bn_bwd: workspace too small");
+    return CN_EWORKSPACE;
+  }
+  float* partial = (float*)workspace;
+  const float* mean = stats;
+  const float* invstd = stats + C;
+  const float* scale = stats + 2 * C;
+  const float* shift = stats + 3 * C;
+  dim3 grid((unsigned)nrb, (unsigned)m.gy);
+  if (dtype == CN_BF16)
+    CN_LAUNCH(bn_bwd_reduce_kernel<bf16_t>, grid, dim3(256), stream, (const char*)dz, (const char*)y,
+              (const char*)zmask, mean, invstd, scale, shift, partial, M, C, relu, m.tpr_log2);
+  else
+    CN_LAUNCH(bn_bwd_reduce_kernel<float>, grid, dim3(256), stream, (const char*)dz, (const char*)y,
+              (const char*)zmask, mean, invstd, scale, shift, partial, M, C, relu, m.tpr_log2);
+  CN_LAUNCH(bn_bwd_finalize_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), stream, (const float*)partial,
+            nrb, M, C, gamma, mean, invstd, dgamma, dbeta, beta_acc, gscale, coef_scratch);
+  int nab = bn_row_blocks(M, m, BN_TARGET_BLOCKS * 2);
+  dim3 agrid((unsigned)nab, (unsigned)m.gy);
+  if (dtype == CN_BF16)
+    CN_LAUNCH(bn_bwd_apply_kernel<bf16_t>, agrid, dim3(256), stream, (const char*)dz, (const char*)y,
+              (const char*)zmask, scale, shift, (const float*)coef_scratch, (char*)dy, (char*)dres, M, C, relu,
+              m.tpr_log2);
+  else
+    CN_LAUNCH(bn_bwd_apply_kernel<float>, agrid, dim3(256), stream, (const char*)dz, (const char*)y,
+              (const char*)zmask, scale, shift, (const float*)coef_scratch, (char*)dy, (char*)dres, M, C, relu,
+              m.tpr_log2);
+  return cn_check_launch("bn_bwd");
+}

@@ -1,0 +1,304 @@
+// pool.hip -- MaxPool2d, global average pool, layout conversion and small elementwise helpers
+// (NHWC, 16-byte channel chunks per lane, gfx950).
+//
+// Replaces nn.MaxPool2d(3, 2, 1) (/root/reference models/resnet.py:230), nn.AdaptiveAvgPool2d(1)
+// (models/resnet.py:241), the `inputs.to(device, dtype)` boundary (trainer.py:116-117) and the
+// autograd fan-in add of the residual blocks (models/resnet.py:115,162).
+// Max-pool semantics follow ATen's CPU kernel the oracle runs: padding is -inf, the FIRST maximum
+// in (kh, kw) scan order wins (strict >), and backward routes the gradient to that element only.
+// The forward stores the winning tap (uint8) so backward is a gather: deterministic, no atomics.
+#include "cn_common.h"
+#include "cn_api_internal.h"
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const char* x, char* y, unsigned char* idx, int N,
+                                                         int H, int W, int C, int P, int Q, int k, int st,
+                                                         int pad) {
+  constexpr int CH = ElemTraits<T>::kChunk;
+  constexpr int EB = ElemTraits<T>::kBytes;
+  const int cpr = C / CH;
+  const long long total = (long long)N * P * Q * cpr;
+  for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
+    const int col = (int)(id % cpr);
+    long long pix = id / cpr;
+    const int q = (int)(pix % Q);
+    pix /= Q;
+    const int pp = (int)(pix % P);
+    const int n = (int)(pix / P);
+    float best[CH];
+    int bi[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+    bool first = true;
+    for (int r = 0; r < k; ++r) {
+      const int h = pp * st - pad + r;
+      if ((unsigned)h >= (unsigned)H) continue;
+      for (int s = 0; s < k; ++s) {
+        const int w = q * st - pad + s;
+        if ((unsigned)w >= (unsigned)W) continue;
+        float f[CH];
+        Chunk<T>::unpack(cn_ld16(x + (((size_t)(n * H + h) * W + w) * C + (size_t)col * CH) * EB), f);
+        const int t = r * k + s;
+#pragma unroll
+        for (int e = 0; e < CH; ++e)
+          if (first || f[e] > best[e]) { best[e] = f[e]; bi[e] = t; }
+        first = false;
+      }
+    }
+    const size_t o = ((size_t)(n * P + pp) * Q + q) * C + (size_t)col * CH;
+    cn_st16(y + o * EB, Chunk<T>::pack(best));
+#pragma unroll
+    for (int e = 0; e < CH; ++e) idx[o + e] = (unsigned char)bi[e];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const char* dy, const unsigned char* idx, char* dx,
+                                                         int N, int H, int W, int C, int P, int Q, int k,
+                                                         int st, int pad) {
+  constexpr int CH = ElemTraits<T>::kChunk;
+  constexpr int EB = ElemTraits<T>::kBytes;
+  const int cpr = C / CH;
+  const long long total = (long long)N * H * W * cpr;
+  for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
+    const int col = (int)(id % cpr);
+    long long pix = id / cpr;
+    const int w = (int)(pix % W);
+    pix /= W;
+    const int h = (int)(pix % H);
+    const int n = (int)(pix / H);
+    float acc[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) acc[e] = 0.f;
+    // windows p with p*st - pad <= h <= p*st - pad + k - 1
+    int p_lo = h + pad - k + 1;
+    p_lo = p_lo > 0 ? (p_lo + st - 1) / st : 0;
+    int p_hi = (h + pad) / st;
+    if (p_hi > P - 1) p_hi = P - 1;
+    int q_lo = w + pad - k + 1;
+    q_lo = q_lo > 0 ? (q_lo + st - 1) / st : 0;
+    int q_hi = (w + pad) / st;
+    if (q_hi > Q - 1) q_hi = Q - 1;
+    for (int pp = p_lo; pp <= p_hi; ++pp)
+      for (int q = q_lo; q <= q_hi; ++q) {
+        const int t = (h - (pp * st - pad)) * k + (w - (q * st - pad));
+        const size_t o = ((size_t)(n * P + pp) * Q + q) * C + (size_t)col * CH;
+        float g[CH];
+        Chunk<T>::unpack(cn_ld16(dy + o * EB), g);
+#pragma unroll
+        for (int e = 0; e < CH; ++e)
+          if ((int)idx[o + e] == t) acc[e] += g[e];
+      }
+    cn_st16(dx + (((size_t)(n * H + h) * W + w) * C + (size_t)col * CH) * EB, Chunk<T>::pack(acc));
+  }
+}
+
+// out[n][c] = mean over HW of x[n][hw][c]
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const char* x, char* y, int N, int HW, int C) {
+  constexpr int CH = ElemTraits<T>::kChunk;
+  constexpr int EB = ElemTraits<T>::kBytes;
+  const int cpr = C / CH;
+  const int total = N * cpr;
+  const float inv = 1.f / (float)HW;
+  for (int id = blockIdx.x * 256 + threadIdx.x; id < total; id += gridDim.x * 256) {
+    const int col = id % cpr, n = id / cpr;
+    float acc[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) acc[e] = 0.f;
+    for (int i = 0; i < HW; ++i) {
+      float f[CH];
+      Chunk<T>::unpack(cn_ld16(x + (((size_t)n * HW + i) * C + (size_t)col * CH) * EB), f);
+#pragma unroll
+      for (int e = 0; e < CH; ++e) acc[e] += f[e];
+    }
+#pragma unroll
+    for (int e = 0; e < CH; ++e) acc[e] *= inv;
+    cn_st16(y + ((size_t)n * C + (size_t)col * CH) * EB, Chunk<T>::pack(acc));
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const char* dy, char* dx, int N, int HW, int C) {
+  constexpr int CH = ElemTraits<T>::kChunk;
+  constexpr int EB = ElemTraits<T>::kBytes;
+  const int cpr = C / CH;
+  const long long total = (long long)N * HW * cpr;
+  const float inv = 1.f / (float)HW;
+  for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
+    const int col = (int)(id % cpr);
+    const long long pix = id / cpr;
+    const int n = (int)(pix / HW);
+    float g[CH];
+    Chunk<T>::unpack(cn_ld16(dy + ((size_t)n * C + (size_t)col * CH) * EB), g);
+#pragma unroll
+    for (int e = 0; e < CH; ++e) g[e] *= inv;
+    cn_st16(dx + ((size_t)pix * C + (size_t)col * CH) * EB, Chunk<T>::pack(g));
+  }
+}
+
+// NCHW fp32 (host/loader layout, reference trainer.py:116-117) -> NHWC T with zero channel padding.
+// Lanes run along pixels so each plane read is coalesced; one 16-byte store per (pixel, chunk).
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* x, char* y, int N, int C, int HW,
+                                                          int Cpad) {
+  constexpr int CH = ElemTraits<T>::kChunk;
+  constexpr int EB = ElemTraits<T>::kBytes;
+  const int cpr = Cpad / CH;
+  const long long total = (long long)N * HW * cpr;
+  for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
+    const int hw = (int)(id % HW);
+    const long long rest = id / HW;
+    const int col = (int)(rest % cpr);
+    const int n = (int)(rest / cpr);
+    float f[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+      const int c = col * CH + e;
+      f[e] = c < C ? x[((size_t)n * C + c) * HW + hw] : 0.f;
+    }
+    cn_st16(y + (((size_t)n * HW + hw) * Cpad + (size_t)col * CH) * EB, Chunk<T>::pack(f));
+  }
+}
+
+// NHWC T -> NCHW fp32 (only used to hand feature maps back in the reference layout)
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const char* x, float* y, int N, int C, int HW,
+                                                          int Cpad) {
+  const long long total = (long long)N * C * HW;
+  for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
+    const int hw = (int)(id % HW);
+    const long long rest = id / HW;
+    const int c = (int)(rest % C);
+    const int n = (int)(rest / C);
+    y[id] = cn_load_elem<T>((const T*)x + ((size_t)n * HW + hw) * Cpad + c);
+  }
+}
+
+// a += b (gradient fan-in of a residual fork), a = relu(x), da = dz * (z > 0)
+template <typename T, int OP>
+__global__ __launch_bounds__(256) void eltwise_kernel(char* a, const char* b, const char* c, long long nchunks) {
+  constexpr int CH = ElemTraits<T>::kChunk;
+  for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < nchunks; id += (long long)gridDim.x * 256) {
+    float fa[CH], fb[CH];
+    if (OP == 0) {  // a += b
+      Chunk<T>::unpack(cn_ld16(a + id * 16), fa);
+      Chunk<T>::unpack(cn_ld16(b + id * 16), fb);
+#pragma unroll
+      for (int e = 0; e < CH; ++e) fa[e] += fb[e];
+    } else if (OP == 1) {  // a = relu(b)
+      Chunk<T>::unpack(cn_ld16(b + id * 16), fb);
+#pragma unroll
+      for (int e = 0; e < CH; ++e) fa[e] = fb[e] > 0.f ? fb[e] : 0.f;
+    } else {  // a = b * (c > 0)
+      float fc[CH];
+      Chunk<T>::unpack(cn_ld16(b + id * 16), fb);
+      Chunk<T>::unpack(cn_ld16(c + id * 16), fc);
+#pragma unroll
+      for (int e = 0; e < CH; ++e) fa[e] = fc[e] > 0.f ? fb[e] : 0.f;
+    }
+    cn_st16(a + id * 16, Chunk<T>::pack(fa));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+static unsigned pool_grid(long long total) {
+  long long nb = (total + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  if (nb < 1) nb = 1;
+  return (unsigned)nb;
+}
+static int pool_check(const char* who, int C, int dtype) {
+  if (dtype != CN_BF16 && dtype != CN_F32) { cn_set_error("%s: bad dtype %d", who, dtype); return CN_EINVAL; }
+  const int CH = dtype == CN_BF16 ? 8 : 4;
+  if (C <= 0 || C % CH != 0) { cn_set_error("%s: C=%d must be a multiple of %d", who, C, CH); return CN_ESHAPE; }
+  return CN_OK;
+}
+#define POOL_DISPATCH(kern, grid, stream, ...)                                          \
+  do {                                                                                  \
+    if (dtype == CN_BF16) CN_LAUNCH(kern<bf16_t>, grid, dim3(256), stream, __VA_ARGS__); \
+    else CN_LAUNCH(kern<float>, grid, dim3(256), stream, __VA_ARGS__);                   \
+  } while (0)
+
+extern "C" int cn_maxpool_fwd(const void* x, void* y, unsigned char* idx, int N, int H, int W, int C, int k,
+                              int stride, int pad, int dtype, void* stream) {
+  int rc = pool_check("maxpool_fwd", C, dtype);
+  if (rc) return rc;
+  if (k * k > 255 || pad * 2 > k) { cn_set_error("maxpool_fwd: unsupported window"); return CN_ESHAPE; }
+  const int P = (H + 2 * pad - k) / stride + 1, Q = (W + 2 * pad - k) / stride + 1;
+  const int CH = dtype == CN_BF16 ? 8 : 4;
+  dim3 grid(pool_grid((long long)N * P * Q * (C / CH)));
+  POOL_DISPATCH(maxpool_fwd_kernel, grid, (hipStream_t)stream, (const char*)x, (char*)y, idx, N, H, W, C, P, Q, k,
+                stride, pad);
+  return cn_check_launch("maxpool_fwd");
+}
+
+extern "C" int cn_maxpool_bwd(const void* dy, const unsigned char* idx, void* dx, int N, int H, int W, int C,
+                              int k, int stride, int pad, int dtype, void* stream) {
+  int rc = pool_check("maxpool_bwd", C, dtype);
+  if (rc) return rc;
+  const int P = (H + 2 * pad - k) / stride + 1, Q = (W + 2 * pad - k) / stride + 1;
+  const int CH = dtype == CN_BF16 ? 8 : 4;
+  dim3 grid(pool_grid((long long)N * H * W * (C / CH)));
+  POOL_DISPATCH(maxpool_bwd_kernel, grid, (hipStream_t)stream, (const char*)dy, idx, (char*)dx, N, H, W, C, P, Q, k,
+                stride, pad);
+  return cn_check_launch("maxpool_bwd");
+}
+
+extern "C" int cn_avgpool_fwd(const void* x, void* y, int N, int HW, int C, int dtype, void* stream) {
+  int rc = pool_check("avgpool_fwd", C, dtype);
+  if (rc) return rc;
+  const int CH = dtype == CN_BF16 ? 8 : 4;
+  dim3 grid(pool_grid((long long)N * (C / CH)));
+  POOL_DISPATCH(avgpool_fwd_kernel, grid, (hipStream_t)stream, (const char*)x, (char*)y, N, HW, C);
+  return cn_check_launch("avgpool_fwd");
+}
+
+extern "C" int cn_avgpool_bwd(const void* dy, void* dx, int N, int HW, int C, int dtype, void* stream) {
+  int rc = pool_check("avgpool_bwd", C, dtype);
+  if (rc) return rc;
+  const int CH = dtype == CN_BF16 ? 8 : 4;
+  dim3 grid(pool_grid((long long)N * HW * (C / CH)));
+  POOL_DISPATCH(avgpool_bwd_kernel, grid, (hipStream_t)stream, (const char*)dy, (char*)dx, N, HW, C);
+  return cn_check_launch("avgpool_bwd");
+}
+
+extern "C" int cn_nchw_to_nhwc(const float* x, void* y, int N, int C, int H, int W, int Cpad, int dtype,
+                               void* stream) {
+  int rc = pool_check("nchw_to_nhwc", Cpad, dtype);
+  if (rc) return rc;
+  if (Cpad < C) { cn_set_error("nchw_to_nhwc: Cpad < C"); return CN_ESHAPE; }
+  const int CH = dtype == CN_BF16 ? 8 : 4;
+  dim3 grid(pool_grid((long long)N * H * W * (Cpad / CH)));
+  POOL_DISPATCH(nchw_to_nhwc_kernel, grid, (hipStream_t)stream, x, (char*)y, N, C, H * W, Cpad);
+  return cn_check_launch("nchw_to_nhwc");
+}
+
+extern "C" int cn_nhwc_to_nchw(const void* x, float* y, int N, int C, int H, int W, int Cpad, int dtype,
+                               void* stream) {
+  if (dtype != CN_BF16 && dtype != CN_F32) { cn_set_error("nhwc_to_nchw: bad dtype"); return CN_EINVAL; }
+  dim3 grid(pool_grid((long long)N * C * H * W));
+  POOL_DISPATCH(nhwc_to_nchw_kernel, grid, (hipStream_t)stream, (const char*)x, y, N, C, H * W, Cpad);
+  return cn_check_launch("nhwc_to_nchw");
+}
+
+// op: 0  a += b;  1  a = relu(b);  2  a = b * (c > 0).   n = element count (multiple of the chunk).
+extern "C" int cn_eltwise(int op, void* a, const void* b, const void* c, long long n, int dtype, void* stream) {
+  if (dtype != CN_BF16 && dtype != CN_F32) { cn_set_error("eltwise: bad dtype"); return CN_EINVAL; }
+  const int CH = dtype == CN_BF16 ? 8 : 4;
+  if (n % CH != 0) { cn_set_error("eltwise: n=%lld not a multiple of %d", n, CH); return CN_ESHAPE; }
+  if (n == 0) return CN_OK;
+  const long long nch = n / CH;
+  dim3 grid(pool_grid(nch));
+  hipStream_t s = (hipStream_t)stream;
+#define ELT(T, OP) CN_LAUNCH((eltwise_kernel<T, OP>), grid, dim3(256), s, (char*)a, (const char*)b, (const char*)c, nch)
+  if (dtype == CN_BF16) {
+    if (op == 0) ELT(bf16_t, 0); else if (op == 1) ELT(bf16_t, 1); else if (op == 2) ELT(bf16_t, 2);
+    else { cn_set_error("eltwise: bad op"); return CN_EINVAL; }
+  } else {
+    if (op == 0) ELT(float, 0); else if (op == 1) ELT(float, 1); else if (op == 2) ELT(float, 2);
+    else { cn_set_error("eltwise: bad op"); return CN_EINVAL; }
+  }
+#undef ELT
+  return cn_check_launch("eltwise");
+}

@@ -1,0 +1,301 @@
+// wgrad.hip -- Conv2d / Linear weight gradient on MFMA for gfx950.
+//
+// Replaces the wgrad half of nn.Conv2d / nn.Linear backward that the reference reaches through
+// loss.backward() (/root/reference trainer.py:162; layers built at models/resnet.py:75-78,126-132,
+// 178-179,226-227,242).
+//
+//   dW[co][t][ci] = sum_m dY[m][co] * X[gather(m, t)][ci],   m = (n, ho, wo),
+//   gather(m, t) = (n, ho*stride_h + dh[t], wo*stride_w + dw[t])   (zero outside the image)
+//
+// Both GEMM operands are stored with the *reduction* index (pixel m) as the slow dimension, so the
+// MFMA fragments need a transpose: bf16 uses the gfx950 LDS transpose read (ds_read_b64_tr_b16),
+// fp32 reads single dwords (32 consecutive channels per half-wave, conflict free).
+// The reduction over up to 3.2 M pixels is split across workgroups; partial tiles go to an fp32
+// workspace and a second kernel reduces them in a fixed order (deterministic, no atomics) while
+// writing the KRSC gradient (optionally accumulating, for chunked batches).
+#include "cn_common.h"
+#include "cn_api_internal.h"
+
+#define WG_MAX_TAPS 64
+
+struct WgradParams {
+  const char* x;
+  const char* dy;
+  float* part;
+  int N, Hi, Wi, Ci, Ho, Wo, Co;
+  int stride_h, stride_w;
+  int ntaps, cpt, cpt_shift, ncols;
+  int M, m_per_split, nsplit;
+  int n_itiles, n_jtiles;
+  FastDiv div_hw, div_w;
+  int tap_dhdw[WG_MAX_TAPS];
+};
+
+template <typename T, int BI, int BJ>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
+  constexpr int EB = ElemTraits<T>::kBytes;
+  constexpr int CH = ElemTraits<T>::kChunk;
+  constexpr bool kBf16 = (EB == 2);
+  constexpr int BKP = kBf16 ? 64 : 32;        // pixels per stage
+  constexpr int TI = BI / 64, TJ = BJ / 64;   // 32x32 MFMA tiles per wave (2x2 waves)
+  constexpr int PI = BI * EB + 64;            // LDS row pitches (bytes)
+  constexpr int PJ = BJ * EB + 64;
+  constexpr int CI_ = BI / CH, CJ_ = BJ / CH;  // 16-byte chunks per tile row
+  constexpr int RI = 256 / CI_, RJ = 256 / CJ_;  // rows covered per pass of the 256 threads
+  constexpr int NI = BKP / RI, NJ = BKP / RJ;    // passes
+  static_assert(NI >= 1 && NJ >= 1, "tile too wide for one pass");
+  __shared__ __attribute__((aligned(16))) char lds[BKP * (PI + PJ)];
+  char* tI = lds;
+  char* tJ = lds + BKP * PI;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wi = wave & 1, wj = wave >> 1;
+
+  unsigned int tile = cn_xcd_remap(blockIdx.x, gridDim.x);
+  const int jt = tile % p.n_jtiles;
+  tile /= p.n_jtiles;
+  const int it = tile % p.n_itiles;
+  const int split = tile / p.n_itiles;
+  const int i0 = it * BI, j0 = jt * BJ;
+  const int m_begin = split * p.m_per_split;
+  int m_end = m_begin + p.m_per_split;
+  if (m_end > p.M) m_end = p.M;
+  const int HoWo = p.Ho * p.Wo;
+
+  // fixed per-thread columns
+  const int colI = tid % CI_, rowI0 = tid / CI_;
+  const int colJ = tid % CJ_, rowJ0 = tid / CJ_;
+  const bool validI = i0 + colI * CH < p.Co;
+  const int jc = j0 / CH + colJ;  // global column chunk in [tap][ci] space
+  const bool validJ = jc < p.ntaps * p.cpt;
+  int tap = 0, cchunk = jc;
+  if (p.ntaps > 1) {
+    tap = validJ ? (jc >> p.cpt_shift) : 0;
+    cchunk = jc & (p.cpt - 1);
+  }
+  const int dhdw = p.tap_dhdw[tap];
+  const int dh = (int)(short)(dhdw & 0xffff), dw = dhdw >> 16;
+
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int a = 0; a < TI; ++a)
+#pragma unroll
+    for (int b = 0; b < TJ; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  u32x4 regI[NI], regJ[NJ];
+  auto load_stage = [&](int mb) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      int m = mb + rowI0 + i * RI;
+      bool ok = validI && m < m_end;
+      size_t off = ((size_t)m * (size_t)p.Co + (size_t)(i0 + colI * CH)) * EB;
+      regI[i] = ok ? cn_ld16(p.dy + off) : cn_zero16();
+    }
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+      int m = mb + rowJ0 + i * RJ;
+      bool ok = validJ && m < m_end;
+      int mm = ok ? m : 0;
+      int n = (int)cn_fastdiv((unsigned)mm, p.div_hw);
+      int rem = mm - n * HoWo;
+      int ho = (int)cn_fastdiv((unsigned)rem, p.div_w);
+      int wo = rem - ho * p.Wo;
+      int hi = ho * p.stride_h + dh, wq = wo * p.stride_w + dw;
+      ok = ok && (unsigned)hi < (unsigned)p.Hi && (unsigned)wq < (unsigned)p.Wi;
+      size_t off = ((size_t)((n * p.Hi + hi) * p.Wi + wq) * (size_t)p.Ci + (size_t)(cchunk * CH)) * EB;
+      regJ[i] = ok ? cn_ld16(p.x + off) : cn_zero16();
+    }
+  };
+  auto store_stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) cn_st16(tI + (rowI0 + i * RI) * PI + colI * 16, regI[i]);
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) cn_st16(tJ + (rowJ0 + i * RJ) * PJ + colJ * 16, regJ[i]);
+  };
+  auto compute = [&]() {
+    if constexpr (kBf16) {
+      const int L = lane & 15, g1 = (lane >> 4) & 1, h = lane >> 5;
+#pragma unroll
+      for (int kk = 0; kk < BKP / 16; ++kk) {
+        const int rbase = kk * 16 + h * 8 + (L >> 2);
+        const int cbase = g1 * 16 + (L & 3) * 4;
+        s16x8 af[TI], bfr[TJ];
+#pragma unroll
+        for (int a = 0; a < TI; ++a) {
+          const char* q = tI + rbase * PI + ((wi * TI + a) * 32 + cbase) * 2;
+          s16x4 lo = cn_lds_read_tr16_b64(q);
+          s16x4 hi = cn_lds_read_tr16_b64(q + 4 * PI);
+          af[a] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int b = 0; b < TJ; ++b) {
+          const char* q = tJ + rbase * PJ + ((wj * TJ + b) * 32 + cbase) * 2;
+          s16x4 lo = cn_lds_read_tr16_b64(q);
+          s16x4 hi = cn_lds_read_tr16_b64(q + 4 * PJ);
+          bfr[b] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int a = 0; a < TI; ++a)
+#pragma unroll
+          for (int b = 0; b < TJ; ++b) acc[a][b] = cn_mfma_32x32x16_bf16(af[a], bfr[b], acc[a][b]);
+      }
+    } else {
+#pragma unroll 4
+      for (int kk = 0; kk < BKP / 2; ++kk) {
+        const int row = kk * 2 + (lane >> 5);
+        float af[TI], bfr[TJ];
+#pragma unroll
+        for (int a = 0; a < TI; ++a)
+          af[a] = *(const float*)(tI + row * PI + ((wi * TI + a) * 32 + (lane & 31)) * 4);
+#pragma unroll
+        for (int b = 0; b < TJ; ++b)
+          bfr[b] = *(const float*)(tJ + row * PJ + ((wj * TJ + b) * 32 + (lane & 31)) * 4);
+#pragma unroll
+        for (int a = 0; a < TI; ++a)
+#pragma unroll
+          for (int b = 0; b < TJ; ++b) acc[a][b] = cn_mfma_32x32x2_f32(af[a], bfr[b], acc[a][b]);
+      }
+    }
+  };
+
+  if (m_begin < m_end) {
+    load_stage(m_begin);
+    for (int mb = m_begin; mb < m_end; mb += BKP) {
+      store_stage();
+      __syncthreads();
+      if (mb + BKP < m_end) load_stage(mb + BKP);
+      compute();
+      __syncthreads();
+    }
+  }
+
+  // partial tile -> workspace [split][Co][ncols]
+  float* out = p.part + (size_t)split * (size_t)p.Co * (size_t)p.ncols;
+#pragma unroll
+  for (int a = 0; a < TI; ++a)
+#pragma unroll
+    for (int b = 0; b < TJ; ++b) {
+      const int col = j0 + (wj * TJ + b) * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = i0 + (wi * TI + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (co < p.Co && col < p.ncols) out[(size_t)co * p.ncols + col] = acc[a][b][r];
+      }
+    }
+}
+
+// Fixed-order reduction of the split partials into the KRSC fp32 gradient (C_real <= Ci channels
+// kept per tap: the stem's input is channel-padded).  beta = 1 accumulates (chunked batches).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, float* dw, int nsplit, int Co,
+                                                          int ntaps, int Ci, int Creal, float beta,
+                                                          float scale) {
+  const long long total = (long long)Co * ntaps * Creal;
+  const long long stride_split = (long long)Co * ntaps * Ci;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * 256) {
+    int c = (int)(idx % Creal);
+    long long rest = idx / Creal;  // co*ntaps + t
+    const float* src = part + rest * Ci + c;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += src[(long long)k * stride_split];
+    s *= scale;
+    dw[idx] = beta != 0.f ? beta * dw[idx] + s : s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct WgradPlan {
+  int BI, BJ, BKP, n_itiles, n_jtiles, nsplit, m_per_split, ncols;
+};
+
+static WgradPlan wg_plan(int M, int Co, int ntaps, int Ci, int dtype) {
+  WgradPlan pl;
+  pl.ncols = ntaps * Ci;
+  pl.BI = Co <= 64 ? 64 : 128;
+  pl.BJ = 128;
+  pl.BKP = dtype == CN_BF16 ? 64 : 32;
+  pl.n_itiles = (Co + pl.BI - 1) / pl.BI;
+  pl.n_jtiles = (pl.ncols + pl.BJ - 1) / pl.BJ;
+  int tiles = pl.n_itiles * pl.n_jtiles;
+  int stages = (M + pl.BKP - 1) / pl.BKP;
+  int want = (1024 + tiles - 1) / tiles;          // aim for ~4 workgroups per CU
+  int max_split = (stages + 7) / 8;               // at least 8 stages per split
+  if (max_split < 1) max_split = 1;
+  int nsplit = want < max_split ? want : max_split;
+  if (nsplit < 1) nsplit = 1;
+  int sps = (stages + nsplit - 1) / nsplit;       // stages per split
+  pl.m_per_split = sps * pl.BKP;
+  pl.nsplit = (M + pl.m_per_split - 1) / pl.m_per_split;
+  return pl;
+}
+
+extern "C" size_t cn_conv2d_wgrad_workspace(int N, int H, int W, int C, int K, int R, int S, int stride_h,
+                                            int stride_w, int pad_h, int pad_w, int dtype) {
+  const int P = (H + 2 * pad_h - R) / stride_h + 1;
+  const int Q = (W + 2 * pad_w - S) / stride_w + 1;
+  if (P <= 0 || Q <= 0 || N <= 0) return 0;
+  WgradPlan pl = wg_plan(N * P * Q, K, R * S, C, dtype);
+  return (size_t)pl.nsplit * (size_t)K * (size_t)pl.ncols * sizeof(float);
+}
+
+template <typename T>
+static void wg_launch(const WgradParams& p, const WgradPlan& pl, hipStream_t stream) {
+  dim3 grid((unsigned)(pl.n_itiles * pl.n_jtiles * pl.nsplit));
+  if (pl.BI == 64) CN_LAUNCH((wgrad_kernel<T, 64, 128>), grid, dim3(256), stream, p);
+  else CN_LAUNCH((wgrad_kernel<T, 128, 128>), grid, dim3(256), stream, p);
+}
+
+extern "C" int cn_conv2d_wgrad(const void* x, const void* dy, float* dw_krsc, int C_real, int N, int H, int W,
+                               int C, int K, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w,
+                               int dtype, float beta, float scale, void* workspace, size_t ws_bytes,
+                               void* stream) {
+  const int P = (H + 2 * pad_h - R) / stride_h + 1;
+  const int Q = (W + 2 * pad_w - S) / stride_w + 1;
+  if (P <= 0 || Q <= 0 || N <= 0) { cn_set_error("conv2d_wgrad: empty output"); return CN_ESHAPE; }
+  const int CH = dtype == CN_BF16 ? 8 : 4;
+  if (dtype != CN_BF16 && dtype != CN_F32) { cn_set_error("conv2d_wgrad: bad dtype"); return CN_EINVAL; }
+  if (C % CH != 0 || K % CH != 0) {
+    cn_set_error("conv2d_wgrad: C=%d / K=%d must be multiples of the 16-byte chunk (%d)", C, K, CH);
+    return CN_ESHAPE;
+  }
+  if (R * S > WG_MAX_TAPS) { cn_set_error("conv2d_wgrad: too many taps"); return CN_ESHAPE; }
+  if (C_real <= 0 || C_real > C) { cn_set_error("conv2d_wgrad: bad C_real"); return CN_EINVAL; }
+  WgradPlan pl = wg_plan(N * P * Q, K, R * S, C, dtype);
+  size_t need = (size_t)pl.nsplit * (size_t)K * (size_t)pl.ncols * sizeof(float);
+  if (ws_bytes < need || workspace == nullptr) {
+    cn_set_error("conv2d_wgrad: workspace %zu < %zu bytes", ws_bytes, need);
+    return CN_EWORKSPACE;
+  }
+  WgradParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = (const char*)x; p.dy = (const char*)dy; p.part = (float*)workspace;
+  p.N = N; p.Hi = H; p.Wi = W; p.Ci = C; p.Ho = P; p.Wo = Q; p.Co = K;
+  p.stride_h = stride_h; p.stride_w = stride_w;
+  p.ntaps = R * S; p.cpt = C / CH; p.ncols = pl.ncols;
+  p.cpt_shift = 0;
+  while ((1 << p.cpt_shift) < p.cpt) ++p.cpt_shift;
+  if (p.ntaps > 1 && (1 << p.cpt_shift) != p.cpt) {
+    cn_set_error("conv2d_wgrad: multi-tap conv needs power-of-two C/chunk (C=%d)", C);
+    return CN_ESHAPE;
+  }
+  p.M = N * P * Q; p.m_per_split = pl.m_per_split; p.nsplit = pl.nsplit;
+  p.n_itiles = pl.n_itiles; p.n_jtiles = pl.n_jtiles;
+  p.div_hw = cn_make_fastdiv((unsigned)(P * Q));
+  p.div_w = cn_make_fastdiv((unsigned)Q);
+  for (int r = 0; r < R; ++r)
+    for (int s = 0; s < S; ++s) p.tap_dhdw[r * S + s] = ((r - pad_h) & 0xffff) | ((s - pad_w) << 16);
+  if (dtype == CN_BF16) wg_launch<bf16_t>(p, pl, (hipStream_t)stream);
+  else wg_launch<float>(p, pl, (hipStream_t)stream);
+  int rc = cn_check_launch("wgrad");
+  if (rc) return rc;
+  long long total = (long long)K * R * S * C_real;
+  unsigned nb = (unsigned)((total + 255) / 256);
+  if (nb > 4096) nb = 4096;
+  CN_LAUNCH(wgrad_reduce_kernel, dim3(nb), dim3(256), (hipStream_t)stream, (const float*)workspace, dw_krsc,
+            pl.nsplit, K, R * S, C, C_real, beta, scale);
+  return cn_check_launch("wgrad_reduce");
+}

@@ -1,0 +1,179 @@
+"""Device-resident model state: flat fp32 parameter / gradient arenas and data-parallel buckets.
+
+MI355X-first re-design of what the reference gets from ``model.to(device, dtype)`` +
+``nn.parallel.DistributedDataParallel`` (/root/reference main.py:236, trainer.py:79-82):
+
+* every parameter is a view into ONE flat fp32 arena (master weights) and its ``.grad`` a view
+  into a parallel flat gradient arena, so ``optimizer.step`` / ``zero_grad`` / grad-norm are single
+  kernels and a gradient bucket is just a contiguous slice handed to RCCL;
+* conv / linear weights keep the reference's ``[O, I, kh, kw]`` *shape* (state_dict compatible) but
+  live in KRSC memory order (channels_last strides) - the order the kernels produce and consume;
+* the arena is ordered by backward completion (classifier first, stem last) so buckets fill in
+  launch order and their all-reduce overlaps the rest of backward;
+* gradients are averaged by folding 1/world_size into the fused SGD kernel, BN statistics stay
+  per-rank (DistributedDataParallel semantics without --sync-bn).
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+_ALIGN = 64  # floats; keeps every parameter segment 256-byte aligned
+
+
+def _round_up(n, a):
+    return (n + a - 1) // a * a
+
+
+class _Slot(object):
+    __slots__ = ('name', 'param', 'offset', 'numel', 'bucket', 'module', 'is_filter')
+
+
+class ParamArena(object):
+    def __init__(self, model, device, bucket_mb=25.0):
+        from . import nn as cnn
+        self.device = torch.device(device)
+        filters, others = [], []
+        seen = set()
+        for mod_name, mod in model.named_modules():
+            for pname, p in mod.named_parameters(recurse=False):
+                if id(p) in seen:
+                    continue
+                seen.add(id(p))
+                full = (mod_name + '.' if mod_name else '') + pname
+                is_filter = isinstance(mod, (cnn.Conv2d, cnn.Linear)) and pname == 'weight'
+                (filters if is_filter else others).append((full, mod, pname, p, is_filter))
+        ordered = list(reversed(filters)) + list(reversed(others))
+        self.slots = []
+        off = 0
+        for full, mod, pname, p, is_filter in ordered:
+            s = _Slot()
+            s.name, s.param, s.module, s.is_filter = full, p, mod, is_filter
+            s.offset, s.numel = off, p.numel()
+            off += _round_up(p.numel(), _ALIGN)
+            self.slots.append(s)
+        self.n_filter = sum(_round_up(s.numel, _ALIGN) for s in self.slots if s.is_filter)
+        self.total = off
+        self.params = torch.zeros(max(off, _ALIGN), dtype=torch.float32, device=self.device)
+        self.grads = torch.zeros_like(self.params)
+        for s in self.slots:
+            p = s.param
+            seg = self.params[s.offset:s.offset + s.numel]
+            gseg = self.grads[s.offset:s.offset + s.numel]
+            src = p.detach().to(device=self.device, dtype=torch.float32)
+            if s.is_filter and p.dim() == 4:
+                O, I, R, S_ = p.shape
+                view = seg.view(O, R, S_, I).permute(0, 3, 1, 2)
+                gview = gseg.view(O, R, S_, I).permute(0, 3, 1, 2)
+            else:
+                view = seg.view(p.shape)
+                gview = gseg.view(p.shape)
+            view.copy_(src)
+            p.data = view
+            p.grad = gview
+            if hasattr(s.module, '_bind_arena'):
+                s.module._bind_arena(self, s)
+        # buckets: contiguous slot ranges of <= bucket_mb (reference DDP default 25 MB)
+        cap = int(bucket_mb * 1024 * 1024 / 4)
+        self.buckets = []
+        cur_start, cur_len, members = 0, 0, []
+        for s in self.slots:
+            seglen = _round_up(s.numel, _ALIGN)
+            if members and cur_len + seglen > cap:
+                self.buckets.append((cur_start, cur_len, members))
+                cur_start, cur_len, members = s.offset, 0, []
+            members.append(s)
+            cur_len += seglen
+        if members:
+            self.buckets.append((cur_start, cur_len, members))
+        self._owner_buckets = {}
+        for bi, (_, _, members) in enumerate(self.buckets):
+            for s in members:
+                s.bucket = bi
+        # modules that own several slots (BN weight+bias) notify once per backward
+        self._module_slots = {}
+        for s in self.slots:
+            self._module_slots.setdefault(id(s.module), []).append(s)
+        self.version = 0          # bumped whenever master weights change (optimizer step / load)
+        self.reducer = None
+
+    # -- gradient lifecycle ---------------------------------------------------------------
+    def zero_grad(self):
+        ops.fill_f32_(self.grads, 0.0)
+
+    def bump_version(self):
+        self.version += 1
+
+    def module_ready(self, mod):
+        if self.reducer is not None:
+            for s in self._module_slots.get(id(mod), ()):
+                self.reducer.slot_ready(s)
+
+
+class BucketReducer(object):
+    """Bucketed gradient all-reduce overlapped with backward (RCCL when the process group backend is
+    'nccl' on ROCm, gloo in the CPU tests).  Sums only; the 1/world_size average is folded into the
+    optimizer kernel (ParamArena consumers read `grad_divisor`)."""
+
+    def __init__(self, arena, process_group=None):
+        self.arena = arena
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group)
+        self.enabled = True
+        self._pending = None
+        self._works = []
+        self.reset()
+        arena.reducer = self
+
+    def reset(self):
+        self._pending = [len(members) for (_, _, members) in self.arena.buckets]
+        self._works = []
+
+    def broadcast_parameters(self, src=0):
+        dist.broadcast(self.arena.params, src=src, group=self.pg)
+        self.arena.bump_version()
+
+    def slot_ready(self, slot):
+        if not self.enabled:
+            return
+        b = slot.bucket
+        self._pending[b] -= 1
+        if self._pending[b] == 0:
+            start, length, _ = self.arena.buckets[b]
+            view = self.arena.grads[start:start + length]
+            self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def finish(self):
+        """Flush buckets that never filled (unused parameters) and wait for all reductions."""
+        if self.enabled:
+            for b, left in enumerate(self._pending):
+                if left > 0:
+                    start, length, _ = self.arena.buckets[b]
+                    view = self.arena.grads[start:start + length]
+                    self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            for w in self._works:
+                w.wait()
+        self.reset()
+
+
+def prepare(model, device, dtype=torch.float32, bucket_mb=25.0):
+    """Move `model` onto `device`, build its flat arenas and set the compute dtype.
+    Idempotent; returns the ParamArena (also stored as model._cn_arena)."""
+    arena = getattr(model, '_cn_arena', None)
+    if arena is not None and arena.device == torch.device(device) and getattr(model, '_cn_dtype', None) == dtype:
+        return arena
+    device = torch.device(device)
+    for name, buf in list(model.named_buffers()):
+        pass
+    # buffers (BN running stats) move with a plain .to(); parameters are re-homed into the arena
+    for mod in model.modules():
+        for bname, buf in list(mod._buffers.items()):
+            if buf is not None:
+                mod._buffers[bname] = buf.to(device)
+    arena = ParamArena(model, device, bucket_mb=bucket_mb)
+    for mod in model.modules():
+        if hasattr(mod, '_set_compute_dtype'):
+            mod._set_compute_dtype(dtype)
+    model._cn_arena = arena
+    model._cn_dtype = dtype
+    return arena

@@ -1,0 +1,268 @@
+"""Operator modules with the constructor signatures and ``state_dict`` layout of the torch.nn
+classes the reference instantiates (/root/reference models/resnet.py:75-78,126-135,226-242;
+models/mnist.py:10-33), backed by the HIP kernels instead of ATen.
+
+The reference's own operator plug-in mechanism is rebinding ``torch.nn.Conv2d`` etc. before model
+construction (models/resnet.py:387-399); here the model files construct these classes explicitly.
+
+Internal activation layout is NHWC in the compute dtype; `to_nhwc` / `Linear` are the only places
+where the reference's NCHW / [B, features] shapes appear.
+"""
+import math
+
+import torch
+import torch.nn as tnn
+from torch.nn import init
+
+from . import _lib, ops
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+class _ArenaModule(tnn.Module):
+    """Mixin: parameters live in a ParamArena once engine.prepare() ran."""
+
+    def __init__(self):
+        super().__init__()
+        self._arena = None
+        self._slots = {}
+        self.compute_dtype = torch.float32
+
+    def _bind_arena(self, arena, slot):
+        self._arena = arena
+        self._slots[slot.name.rsplit('.', 1)[-1]] = slot
+
+    def _set_compute_dtype(self, dtype):
+        self.compute_dtype = dtype
+
+    def _require_prepared(self):
+        if self._arena is None:
+            raise _lib.ConvNetHipError(
+                '%s used before engine.prepare(model, device, dtype): parameters are not on the device arena'
+                % type(self).__name__)
+
+    def grad_view(self, pname):
+        """Flat fp32 gradient segment of parameter `pname` in kernel (KRSC) memory order."""
+        s = self._slots[pname]
+        return self._arena.grads[s.offset:s.offset + s.numel]
+
+    def master_view(self, pname):
+        s = self._slots[pname]
+        return self._arena.params[s.offset:s.offset + s.numel]
+
+    def _notify_grad_ready(self):
+        self._arena.module_ready(self)
+
+
+class Conv2d(_ArenaModule):
+    """nn.Conv2d(in, out, kernel_size, stride, padding, dilation, groups, bias) - groups=1,
+    dilation=1 (all that models/resnet.py and models/mnist.py use)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 bias=True, padding_mode='zeros'):
+        super().__init__()
+        if groups != 1 or _pair(dilation) != (1, 1) or padding_mode != 'zeros':
+            raise NotImplementedError('HIP Conv2d supports groups=1, dilation=1, zero padding')
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = _pair(kernel_size), _pair(stride), _pair(padding)
+        self.dilation, self.groups = (1, 1), 1
+        self.out_f32 = False
+        # same RNG consumption as torch.nn.Conv2d.reset_parameters so that seeded model
+        # construction reproduces the reference's initial weights bit for bit
+        self.weight = tnn.Parameter(torch.empty(out_channels, in_channels, *self.kernel_size))
+        init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if bias:
+            self.bias = tnn.Parameter(torch.empty(out_channels))
+            fan_in = in_channels * self.kernel_size[0] * self.kernel_size[1]
+            bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
+            init.uniform_(self.bias, -bound, bound)
+        else:
+            self.register_parameter('bias', None)
+        self.w_krsc = None
+        self.w_crsk = None
+        self._prep_version = -1
+        self.needs_dgrad = True
+
+    def padded_in_channels(self):
+        ch = _lib.chunk_elems(self.compute_dtype)
+        return (self.in_channels + ch - 1) // ch * ch
+
+    def ensure_prepared(self):
+        """(Re)build the compute-dtype filter copies when the fp32 master changed."""
+        self._require_prepared()
+        if self._prep_version == self._arena.version and self.w_krsc is not None \
+                and self.w_krsc.dtype == self.compute_dtype:
+            return
+        taps = self.kernel_size[0] * self.kernel_size[1]
+        cpad = self.padded_in_channels()
+        dev = self._arena.device
+        if self.w_krsc is None or self.w_krsc.dtype != self.compute_dtype:
+            self.w_krsc = torch.empty(self.out_channels * taps * cpad, dtype=self.compute_dtype, device=dev)
+            self.w_crsk = None
+            if self.needs_dgrad and cpad == self.in_channels:
+                self.w_crsk = torch.empty(self.out_channels * taps * cpad, dtype=self.compute_dtype, device=dev)
+        ops.weight_prep(self.master_view('weight'), self.w_krsc, self.w_crsk, self.out_channels, taps,
+                        self.in_channels, cpad)
+        self._prep_version = self._arena.version
+
+    def forward(self, x):
+        self._require_prepared()
+        if x.shape[-1] != self.padded_in_channels():
+            raise _lib.ConvNetHipError('Conv2d expected %d (padded) NHWC channels, got %s'
+                                       % (self.padded_in_channels(), tuple(x.shape)))
+        return ops.Conv2dFunction.apply(x, self.weight, self.bias, self)
+
+    def extra_repr(self):
+        return '{}, {}, kernel_size={}, stride={}, padding={}, bias={}'.format(
+            self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding,
+            self.bias is not None)
+
+
+class Linear(_ArenaModule):
+    """nn.Linear(in_features, out_features, bias): a 1x1 convolution over a 1x1 image; returns fp32
+    [B, out_features] (the criterion consumes fp32 logits)."""
+
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.in_channels, self.out_channels = in_features, out_features
+        self.kernel_size, self.stride, self.padding = (1, 1), (1, 1), (0, 0)
+        self.out_f32 = True
+        self.weight = tnn.Parameter(torch.empty(out_features, in_features))
+        init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if bias:
+            self.bias = tnn.Parameter(torch.empty(out_features))
+            bound = 1 / math.sqrt(in_features) if in_features > 0 else 0
+            init.uniform_(self.bias, -bound, bound)
+        else:
+            self.register_parameter('bias', None)
+        self.w_krsc = None
+        self.w_crsk = None
+        self._prep_version = -1
+
+    def padded_in_channels(self):
+        return self.in_features
+
+    def ensure_prepared(self):
+        self._require_prepared()
+        if self._prep_version == self._arena.version and self.w_krsc is not None \
+                and self.w_krsc.dtype == self.compute_dtype:
+            return
+        dev = self._arena.device
+        n = self.out_features * self.in_features
+        if self.w_krsc is None or self.w_krsc.dtype != self.compute_dtype:
+            self.w_krsc = torch.empty(n, dtype=self.compute_dtype, device=dev)
+            self.w_crsk = torch.empty(n, dtype=self.compute_dtype, device=dev)
+        ops.weight_prep(self.master_view('weight'), self.w_krsc, self.w_crsk, self.out_features, 1,
+                        self.in_features, self.in_features)
+        self._prep_version = self._arena.version
+
+    def forward(self, x):
+        self._require_prepared()
+        B = x.shape[0]
+        y = ops.Conv2dFunction.apply(x.reshape(B, 1, 1, self.in_features), self.weight, self.bias, self)
+        return y.view(B, self.out_features)
+
+    def extra_repr(self):
+        return 'in_features={}, out_features={}, bias={}'.format(self.in_features, self.out_features,
+                                                                 self.bias is not None)
+
+
+class BatchNorm2d(_ArenaModule):
+    """nn.BatchNorm2d(num_features, eps, momentum, affine, track_running_stats) with optional fused
+    residual add + ReLU: ``bn(y, residual=None, relu=False)``."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True):
+        super().__init__()
+        if not affine:
+            raise NotImplementedError('HIP BatchNorm2d is affine')
+        self.num_features, self.eps, self.momentum = num_features, eps, momentum
+        self.affine, self.track_running_stats = affine, track_running_stats
+        self.weight = tnn.Parameter(torch.ones(num_features))
+        self.bias = tnn.Parameter(torch.zeros(num_features))
+        self.register_buffer('running_mean', torch.zeros(num_features))
+        self.register_buffer('running_var', torch.ones(num_features))
+        self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
+        self._host_batches = 0  # host mirror of num_batches_tracked (momentum=None averaging)
+
+    def reset_running_stats(self):
+        self.running_mean.zero_()
+        self.running_var.fill_(1)
+        self.num_batches_tracked.zero_()
+        self._host_batches = 0
+
+    def effective_momentum(self):
+        if self.momentum is None:  # cumulative moving average (trainer.calibrate_bn)
+            self._host_batches += 1
+            return 1.0 / float(self._host_batches)
+        return float(self.momentum)
+
+    def forward(self, y, residual=None, relu=False):
+        self._require_prepared()
+        if self.training or not self.track_running_stats:
+            if torch.is_grad_enabled():
+                return ops.BatchNormActFunction.apply(y, self.weight, self.bias, residual, self, relu)
+            with torch.no_grad():
+                return ops.BatchNormActFunction.apply(y, self.weight, self.bias, residual, self, relu)
+        return ops.batch_norm_infer(y, residual, self, relu)
+
+    def extra_repr(self):
+        return '{}, eps={}, momentum={}'.format(self.num_features, self.eps, self.momentum)
+
+
+class ReLU(tnn.Module):
+    def __init__(self, inplace=False):
+        super().__init__()
+        self.inplace = inplace  # accepted for signature parity; the HIP op is out-of-place
+
+    def forward(self, x):
+        return ops.ReLUFunction.apply(x)
+
+
+class MaxPool2d(tnn.Module):
+    def __init__(self, kernel_size, stride=None, padding=0):
+        super().__init__()
+        self.kernel_size = kernel_size
+        self.stride = stride if stride is not None else kernel_size
+        self.padding = padding
+
+    def forward(self, x):
+        return ops.MaxPool2dFunction.apply(x, self.kernel_size, self.stride, self.padding)
+
+
+class AdaptiveAvgPool2d(tnn.Module):
+    def __init__(self, output_size):
+        super().__init__()
+        if output_size not in (1, (1, 1)):
+            raise NotImplementedError('HIP AdaptiveAvgPool2d supports output_size=1')
+        self.output_size = output_size
+
+    def forward(self, x):
+        return ops.GlobalAvgPoolFunction.apply(x)
+
+
+class Dropout(tnn.Module):
+    """nn.Dropout(p): the reference's ResNet blocks only use p = 0 (identity)."""
+
+    def __init__(self, p=0.5, inplace=False):
+        super().__init__()
+        self.p = p
+
+    def forward(self, x):
+        if self.p == 0 or not self.training:
+            return x
+        raise NotImplementedError('HIP Dropout with p > 0 is outside the ResNet hot path')
+
+
+def fork(x):
+    """Duplicate an activation for two consumers; gradients are summed by our kernel."""
+    if torch.is_grad_enabled() and x.requires_grad:
+        return ops.ForkFunction.apply(x)
+    return x, x
+
+
+def to_nhwc(x_nchw, dtype, c_pad=None):
+    """The H2D boundary of trainer.py:116-117: fp32 NCHW -> NHWC compute dtype (zero-padded C)."""
+    return ops.nchw_to_nhwc(x_nchw, dtype, c_pad)

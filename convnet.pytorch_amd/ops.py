@@ -1,0 +1,349 @@
+"""Functional wrappers + autograd Functions over the HIP kernels (C ABI in include/convnet_hip.h).
+
+Tensor conventions of this layer (not of the user-facing modules, which keep the reference's
+NCHW / OIHW shapes at their boundary): activations are contiguous NHWC tensors in the compute dtype
+(bf16 or fp32), filters are KRSC, parameters / gradients / statistics are fp32.
+
+PyTorch is used here for allocation, stream handles and the autograd tape only; every arithmetic
+pass over tensor data is one of the `cn_*` kernels.
+"""
+import torch
+from torch.autograd import Function
+
+from . import _lib
+from ._lib import check, dtype_code, ptr, stream_of
+
+# ---------------------------------------------------------------------------------------------
+# workspaces: one grow-only scratch buffer per (device, tag); kernels on one stream are ordered,
+# so reuse across ops is safe.
+_WS = {}
+
+
+def workspace(nbytes, device, tag='main'):
+    key = (str(device), tag)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() * 4 < nbytes:
+        n = max(int(nbytes + 3) // 4, 1024)
+        buf = torch.empty(n, dtype=torch.float32, device=device)
+        _WS[key] = buf
+    return buf
+
+
+def reserve_workspace(nbytes, device, tag='main'):
+    """Pre-size a workspace (needed before HIP-graph capture: no allocation inside a capture)."""
+    workspace(nbytes, device, tag)
+
+
+def _L():
+    return _lib.load()
+
+
+def conv_out_hw(H, W, R, S, stride, pad):
+    return (H + 2 * pad[0] - R) // stride[0] + 1, (W + 2 * pad[1] - S) // stride[1] + 1
+
+
+# ---------------------------------------------------------------------------------------------
+# raw (non-autograd) kernel calls
+
+def conv2d_fwd(x, w_krsc, bias, K, R, S, stride, pad, out_f32=False, relu=False):
+    N, H, W, C = x.shape
+    P, Q = conv_out_hw(H, W, R, S, stride, pad)
+    y = torch.empty((N, P, Q, K), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+    check(_L().cn_conv2d_fwd(ptr(x), ptr(w_krsc), ptr(y), ptr(bias), N, H, W, C, K, R, S, stride[0], stride[1],
+                             pad[0], pad[1], dtype_code(x.dtype), int(out_f32), int(relu), stream_of(x)),
+          'cn_conv2d_fwd')
+    return y
+
+
+def conv2d_dgrad(dy, w_crsk, x_shape, K, R, S, stride, pad):
+    N, H, W, C = x_shape
+    dx = torch.empty((N, H, W, C), dtype=dy.dtype, device=dy.device)
+    check(_L().cn_conv2d_dgrad(ptr(dy), ptr(w_crsk), ptr(dx), N, H, W, C, K, R, S, stride[0], stride[1], pad[0],
+                               pad[1], dtype_code(dy.dtype), 0, stream_of(dy)), 'cn_conv2d_dgrad')
+    return dx
+
+
+def conv2d_wgrad(x, dy, dw_krsc, c_real, K, R, S, stride, pad, beta=1.0, scale=1.0):
+    """dw_krsc (fp32, [K][R][S][c_real] memory order) = beta*dw + scale*wgrad."""
+    N, H, W, C = x.shape
+    code = dtype_code(x.dtype)
+    L = _L()
+    need = L.cn_conv2d_wgrad_workspace(N, H, W, C, K, R, S, stride[0], stride[1], pad[0], pad[1], code)
+    ws = workspace(need, x.device)
+    check(L.cn_conv2d_wgrad(ptr(x), ptr(dy), ptr(dw_krsc), c_real, N, H, W, C, K, R, S, stride[0], stride[1],
+                            pad[0], pad[1], code, beta, scale, ptr(ws), ws.numel() * 4, stream_of(x)),
+          'cn_conv2d_wgrad')
+
+
+def weight_prep(w_master_krsc, w_krsc, w_crsk, Co, taps, c_real, c_pad):
+    check(_L().cn_weight_prep(ptr(w_master_krsc), ptr(w_krsc), ptr(w_crsk), Co, taps, c_real, c_pad,
+                              dtype_code(w_krsc.dtype), stream_of(w_krsc)), 'cn_weight_prep')
+
+
+def colsum(x2d, out, beta=1.0, scale=1.0):
+    M, C = x2d.shape
+    L = _L()
+    ws = workspace(L.cn_colsum_workspace(C), x2d.device, 'colsum')
+    check(L.cn_colsum(ptr(x2d), ptr(out), M, C, dtype_code(x2d.dtype), beta, scale, ptr(ws), stream_of(x2d)),
+          'cn_colsum')
+
+
+def nchw_to_nhwc(x_nchw, dtype, c_pad=None):
+    """fp32 NCHW (the loader / reference layout) -> NHWC compute dtype, channels zero-padded."""
+    N, C, H, W = x_nchw.shape
+    ch = _lib.chunk_elems(dtype)
+    if c_pad is None:
+        c_pad = (C + ch - 1) // ch * ch
+    x_nchw = x_nchw.contiguous()
+    if x_nchw.dtype != torch.float32:
+        raise _lib.ConvNetHipError('nchw_to_nhwc expects float32 input, got %s' % x_nchw.dtype)
+    y = torch.empty((N, H, W, c_pad), dtype=dtype, device=x_nchw.device)
+    check(_L().cn_nchw_to_nhwc(ptr(x_nchw), ptr(y), N, C, H, W, c_pad, dtype_code(dtype), stream_of(x_nchw)),
+          'cn_nchw_to_nhwc')
+    return y
+
+
+def nhwc_to_nchw(x_nhwc, C=None):
+    N, H, W, Cp = x_nhwc.shape
+    C = C or Cp
+    y = torch.empty((N, C, H, W), dtype=torch.float32, device=x_nhwc.device)
+    check(_L().cn_nhwc_to_nchw(ptr(x_nhwc), ptr(y), N, C, H, W, Cp, dtype_code(x_nhwc.dtype), stream_of(x_nhwc)),
+          'cn_nhwc_to_nchw')
+    return y
+
+
+def add_(a, b):
+    check(_L().cn_eltwise(0, ptr(a), ptr(b), None, a.numel(), dtype_code(a.dtype), stream_of(a)), 'cn_eltwise')
+    return a
+
+
+def cast_from_f32(x, dtype):
+    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    check(_L().cn_cast_from_f32(ptr(x), ptr(y), x.numel(), dtype_code(dtype), stream_of(x)), 'cn_cast_from_f32')
+    return y
+
+
+def fill_f32_(x, v=0.0):
+    check(_L().cn_fill_f32(ptr(x), x.numel(), float(v), stream_of(x)), 'cn_fill_f32')
+    return x
+
+
+# ---------------------------------------------------------------------------------------------
+# autograd Functions.  Parameter gradients are accumulated *by the kernels* straight into the flat
+# gradient arena (`mod.grad_view(name)`), so the Functions return None for parameters and autograd
+# never runs an accumulation kernel of its own; `mod._notify_grad_ready()` lets the data-parallel
+# bucket manager start the all-reduce of a finished bucket while backward continues.
+
+class Conv2dFunction(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, mod):
+        mod.ensure_prepared()
+        y = conv2d_fwd(x, mod.w_krsc, bias, mod.out_channels, mod.kernel_size[0], mod.kernel_size[1],
+                       mod.stride, mod.padding, out_f32=mod.out_f32)
+        ctx.mod = mod
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        mod = ctx.mod
+        dy = dy.contiguous()
+        if dy.dtype != x.dtype:  # fp32 logits gradient -> compute dtype
+            dy = cast_from_f32(dy, x.dtype)
+        R, S = mod.kernel_size
+        conv2d_wgrad(x, dy, mod.grad_view('weight'), mod.in_channels, mod.out_channels, R, S, mod.stride,
+                     mod.padding)
+        if ctx.has_bias:
+            colsum(dy.view(-1, mod.out_channels), mod.grad_view('bias'))
+        mod._notify_grad_ready()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = conv2d_dgrad(dy, mod.w_crsk, x.shape, mod.out_channels, R, S, mod.stride, mod.padding)
+        return dx, None, None, None
+
+
+class BatchNormActFunction(Function):
+    """z = act(BN(y) + residual), training mode (batch statistics)."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, residual, mod, relu):
+        N, H, W, C = y.shape
+        M = N * H * W
+        L = _L()
+        code = dtype_code(y.dtype)
+        ws = workspace(L.cn_bn_workspace(M, C, code), y.device)
+        z = torch.empty_like(y)
+        stats = torch.empty(4 * C, dtype=torch.float32, device=y.device)
+        momentum = mod.effective_momentum()
+        track = mod.track_running_stats
+        check(L.cn_bn_fwd_train(ptr(y), ptr(residual), ptr(z), ptr(gamma), ptr(beta),
+                                ptr(mod.running_mean) if track else None,
+                                ptr(mod.running_var) if track else None,
+                                ptr(mod.num_batches_tracked) if track else None,
+                                momentum, mod.eps, ptr(stats), M, C, int(relu), code, ptr(ws), ws.numel() * 4,
+                                stream_of(y)), 'cn_bn_fwd_train')
+        ctx.mod = mod
+        ctx.relu = relu
+        ctx.has_res = residual is not None
+        if relu and residual is not None:
+            ctx.save_for_backward(y, stats, z)
+        else:
+            ctx.save_for_backward(y, stats)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        saved = ctx.saved_tensors
+        y, stats = saved[0], saved[1]
+        zmask = saved[2] if len(saved) > 2 else None
+        mod = ctx.mod
+        N, H, W, C = y.shape
+        M = N * H * W
+        L = _L()
+        code = dtype_code(y.dtype)
+        dz = dz.contiguous()
+        ws = workspace(L.cn_bn_workspace(M, C, code), y.device)
+        dy = torch.empty_like(y)
+        want_res = ctx.has_res and ctx.needs_input_grad[3]
+        dres = torch.empty_like(y) if want_res else None
+        coef = torch.empty(3 * C, dtype=torch.float32, device=y.device)
+        check(L.cn_bn_bwd(ptr(dz), ptr(y), ptr(zmask), ptr(mod.weight), ptr(stats), ptr(dy), ptr(dres),
+                          ptr(mod.grad_view('weight')), ptr(mod.grad_view('bias')), 1.0, 1.0, ptr(coef), M, C,
+                          int(ctx.relu), code, ptr(ws), ws.numel() * 4, stream_of(y)), 'cn_bn_bwd')
+        mod._notify_grad_ready()
+        return dy, None, None, dres, None, None
+
+
+def batch_norm_infer(y, residual, mod, relu):
+    N, H, W, C = y.shape
+    z = torch.empty_like(y)
+    coeffs = torch.empty(2 * C, dtype=torch.float32, device=y.device)
+    check(_L().cn_bn_fwd_infer(ptr(y), ptr(residual), ptr(z), ptr(mod.weight), ptr(mod.bias),
+                               ptr(mod.running_mean), ptr(mod.running_var), mod.eps, ptr(coeffs), N * H * W, C,
+                               int(relu), dtype_code(y.dtype), stream_of(y)), 'cn_bn_fwd_infer')
+    return z
+
+
+class MaxPool2dFunction(Function):
+    @staticmethod
+    def forward(ctx, x, k, stride, pad):
+        N, H, W, C = x.shape
+        P, Q = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        y = torch.empty((N, P, Q, C), dtype=x.dtype, device=x.device)
+        idx = torch.empty((N, P, Q, C), dtype=torch.uint8, device=x.device)
+        check(_L().cn_maxpool_fwd(ptr(x), ptr(y), ptr(idx), N, H, W, C, k, stride, pad, dtype_code(x.dtype),
+                                  stream_of(x)), 'cn_maxpool_fwd')
+        ctx.cfg = (N, H, W, C, k, stride, pad)
+        ctx.save_for_backward(idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        N, H, W, C, k, stride, pad = ctx.cfg
+        dy = dy.contiguous()
+        dx = torch.empty((N, H, W, C), dtype=dy.dtype, device=dy.device)
+        check(_L().cn_maxpool_bwd(ptr(dy), ptr(idx), ptr(dx), N, H, W, C, k, stride, pad, dtype_code(dy.dtype),
+                                  stream_of(dy)), 'cn_maxpool_bwd')
+        return dx, None, None, None
+
+
+class GlobalAvgPoolFunction(Function):
+    @staticmethod
+    def forward(ctx, x):
+        N, H, W, C = x.shape
+        y = torch.empty((N, 1, 1, C), dtype=x.dtype, device=x.device)
+        check(_L().cn_avgpool_fwd(ptr(x), ptr(y), N, H * W, C, dtype_code(x.dtype), stream_of(x)),
+              'cn_avgpool_fwd')
+        ctx.shape = (N, H, W, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, H, W, C = ctx.shape
+        dy = dy.contiguous()
+        dx = torch.empty((N, H, W, C), dtype=dy.dtype, device=dy.device)
+        check(_L().cn_avgpool_bwd(ptr(dy), ptr(dx), N, H * W, C, dtype_code(dy.dtype), stream_of(dy)),
+              'cn_avgpool_bwd')
+        return dx
+
+
+class ReLUFunction(Function):
+    @staticmethod
+    def forward(ctx, x):
+        z = torch.empty_like(x)
+        check(_L().cn_eltwise(1, ptr(z), ptr(x), None, x.numel(), dtype_code(x.dtype), stream_of(x)), 'cn_eltwise')
+        ctx.save_for_backward(z)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        (z,) = ctx.saved_tensors
+        dz = dz.contiguous()
+        dx = torch.empty_like(dz)
+        check(_L().cn_eltwise(2, ptr(dx), ptr(dz), ptr(z), dz.numel(), dtype_code(dz.dtype), stream_of(dz)),
+              'cn_eltwise')
+        return dx
+
+
+class ForkFunction(Function):
+    """Two aliases of one activation (block input -> conv branch + residual branch).  Backward sums
+    the two incoming gradients with our own kernel, so autograd never launches its accumulate."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if ga is None:
+            return gb
+        if gb is None:
+            return ga
+        ga = ga.contiguous()
+        return add_(ga, gb.contiguous())
+
+
+class SoftmaxCrossEntropyFunction(Function):
+    """loss = mean_b CE(logits_b, target_b) (+ label smoothing); also accumulates the reference's
+    loss / prec@1 / prec@5 meters on the device (crit.meters) when a buffer is attached."""
+
+    @staticmethod
+    def forward(ctx, logits, target, crit):
+        B, K = logits.shape
+        logits = logits.contiguous()
+        if logits.dtype != torch.float32:
+            raise _lib.ConvNetHipError('criterion expects fp32 logits')
+        target = target.contiguous()
+        row = torch.empty(3 * B, dtype=torch.float32, device=logits.device)
+        step_out = torch.empty(3, dtype=torch.float32, device=logits.device)
+        check(_L().cn_softmax_ce(ptr(logits), ptr(target), None, _lib.F32, ptr(row), ptr(step_out),
+                                 ptr(crit.meters), B, K, 1.0, None, crit.smooth_eps, stream_of(logits)),
+              'cn_softmax_ce')
+        crit.last_step = step_out
+        ctx.crit = crit
+        ctx.save_for_backward(logits, target, row)
+        return step_out[0]
+
+    @staticmethod
+    def backward(ctx, go):
+        logits, target, row = ctx.saved_tensors
+        B, K = logits.shape
+        dlogits = torch.empty_like(logits)
+        go = go.contiguous().to(torch.float32)
+        check(_L().cn_softmax_ce(ptr(logits), ptr(target), ptr(dlogits), _lib.F32, ptr(row), None, None, B, K,
+                                 1.0 / B, ptr(go), ctx.crit.smooth_eps, stream_of(logits)), 'cn_softmax_ce')
+        return dlogits, None, None
+
+
+def accuracy_counts(logits, target):
+    """Returns a device tensor [mean CE loss, prec@1 (%), prec@5 (%)] of this batch."""
+    B, K = logits.shape
+    logits = logits.contiguous().float()
+    row = torch.empty(3 * B, dtype=torch.float32, device=logits.device)
+    out = torch.empty(3, dtype=torch.float32, device=logits.device)
+    check(_L().cn_softmax_ce(ptr(logits), ptr(target.contiguous()), None, _lib.F32, ptr(row), ptr(out), None, B, K,
+                             1.0, None, 0.0, stream_of(logits)), 'cn_softmax_ce')
+    return out

@@ -1,0 +1,265 @@
+"""Trainer: the step engine, with the class / method surface of /root/reference trainer.py:54-285
+(`Trainer(model, criterion, optimizer, device_ids, device, dtype, distributed, local_rank, ...)`,
+`.train / .validate / .forward / .calibrate_bn / ._step`, result keys step, data, loss, prec1,
+prec5, [grad], error1, error5; attributes `epoch`, `training_steps` poked by main.py:298,300).
+
+What is different by design (MI355X-first):
+* the model runs on the HIP kernels through a flat fp32 parameter arena (engine.prepare) instead
+  of ATen + DistributedDataParallel; data parallelism is a bucketed RCCL all-reduce of the flat
+  gradient arena overlapped with backward, with the 1/world average and the reference's
+  `p.grad.div_(loss_scale)` loop (trainer.py:165-169) folded into the fused SGD kernel;
+* no per-step device->host sync: the reference calls float(loss) / float(prec) every iteration
+  (trainer.py:153,225-229); here loss / prec@1 / prec@5 / grad-norm meters accumulate on the device
+  and are read back only when a report line is due (values at report points are identical).
+
+Out of the hot path (raise if requested): mixup / cutmix, duplicates + adapt_grad_norm,
+tensorwatch streams, nn.DataParallel.
+"""
+import logging
+import time
+
+import torch
+import torch.distributed as dist
+
+from . import _lib, engine, ops
+from ._lib import check, ptr, stream_of
+from .cross_entropy import CrossEntropyLoss
+from .meters import AverageMeter, accuracy
+
+
+class Trainer(object):
+
+    def __init__(self, model, criterion, optimizer=None,
+                 device_ids=[0], device='cuda', dtype=torch.float,
+                 distributed=False, local_rank=-1, adapt_grad_norm=None,
+                 mixup=None, cutmix=None, loss_scale=1., grad_clip=-1, print_freq=100,
+                 bucket_mb=25.0, process_group=None):
+        if mixup is not None or cutmix is not None or adapt_grad_norm is not None:
+            raise NotImplementedError('mixup / cutmix / adapt_grad_norm are outside the MI355X hot path')
+        if dtype in (torch.half, torch.float16):
+            raise NotImplementedError("compute dtype 'half' is not supported on the MI355X path; "
+                                      "use bfloat16 (same BN-in-fp32 / fp32-master policy)")
+        self._model = model
+        self.model = model
+        self.criterion = criterion
+        self.epoch = 0
+        self.training_steps = 0
+        self.optimizer = optimizer
+        if not isinstance(device, (str, torch.device)):
+            device = 'cuda'
+        self.device = torch.device(device)
+        if self.device.type == 'cuda' and self.device.index is None and device_ids:
+            self.device = torch.device('cuda', device_ids[0])
+        self.dtype = dtype
+        self.distributed = distributed
+        self.local_rank = local_rank
+        self.print_freq = print_freq
+        self.grad_clip = grad_clip
+        self.grad_scale = None
+        self.loss_scale = loss_scale
+        self.watcher = None
+        self.arena = engine.prepare(model, self.device, dtype, bucket_mb=bucket_mb)
+        self.reducer = None
+        self.world_size = 1
+        if distributed:
+            if not dist.is_initialized():
+                raise RuntimeError('Trainer(distributed=True) needs an initialised process group')
+            self.reducer = engine.BucketReducer(self.arena, process_group)
+            self.world_size = self.reducer.world
+            self.reducer.broadcast_parameters(0)   # DDP construction broadcast (trainer.py:80-82)
+            self._broadcast_buffers()
+        # device-side meters: [loss*B, prec1*B, prec5*B, B, gradnorm*w, w]
+        self._meters = torch.zeros(8, dtype=torch.float32, device=self.device)
+        self._norm_out = torch.zeros(2, dtype=torch.float32, device=self.device)
+        self._norm_ws = torch.zeros(_lib.load().cn_grad_norm_workspace() // 4, dtype=torch.float32,
+                                    device=self.device)
+
+    # ------------------------------------------------------------------------------------
+    def _broadcast_buffers(self):
+        if self.reducer is None:
+            return
+        for buf in self._model.buffers():
+            dist.broadcast(buf, src=0, group=self.reducer.pg)
+
+    def _to_device(self, inputs, target):
+        target = target.to(self.device, non_blocking=True)
+        inputs = inputs.to(self.device, dtype=torch.float32, non_blocking=True)
+        return inputs, target
+
+    def _step(self, inputs_batch, target_batch, training=False, average_output=False, chunk_batch=1):
+        if average_output:
+            raise NotImplementedError('average_output (duplicates) is outside the MI355X hot path')
+        outputs = []
+        total_loss = None
+        grad = None
+
+        if training:
+            self.optimizer.zero_grad()
+            self.optimizer.update(self.epoch, self.training_steps)
+            if self.reducer is not None:
+                self.reducer.reset()
+
+        in_chunks = inputs_batch.chunk(chunk_batch, dim=0)
+        tg_chunks = target_batch.chunk(chunk_batch, dim=0)
+        n_chunks = len(in_chunks)
+        for i, (inputs, target) in enumerate(zip(in_chunks, tg_chunks)):
+            inputs, target = self._to_device(inputs, target)
+            if training:
+                self.optimizer.pre_forward()
+
+            output = self.model(inputs)
+            loss = self.criterion(output, target)
+
+            if chunk_batch > 1:
+                loss = loss / chunk_batch
+            if isinstance(output, (list, tuple)):
+                output = output[0]
+            outputs.append(output.detach())
+            total_loss = loss.detach() if total_loss is None else total_loss + loss.detach()
+
+            if training:
+                if i == 0:
+                    self.optimizer.pre_backward()
+                if self.grad_scale is not None:
+                    loss = loss * self.grad_scale
+                if self.loss_scale is not None and self.loss_scale != 1:
+                    loss = loss * self.loss_scale
+                if self.reducer is not None:
+                    self.reducer.enabled = (i == n_chunks - 1)   # reduce once, after accumulation
+                loss.backward()
+
+        if training:
+            if self.reducer is not None:
+                self.reducer.finish()
+            gscale = 1.0 / float(self.world_size)
+            if self.loss_scale is not None:
+                gscale /= float(self.loss_scale)
+            clip_coef = None
+            if self.grad_clip > 0:
+                a = self.arena
+                check(_lib.load().cn_grad_norm_clip(ptr(a.grads), a.grads.numel(), gscale, float(self.grad_clip),
+                                                    ptr(self._norm_out), ptr(self._meters[4:]),
+                                                    float(inputs_batch.size(0)), ptr(self._norm_ws),
+                                                    stream_of(a.grads)), 'cn_grad_norm_clip')
+                grad = self._norm_out[0]
+                clip_coef = self._norm_out[1:2]
+            self.optimizer.grad_scale = gscale
+            self.optimizer.clip_coef = clip_coef
+            self.optimizer.step()
+            self.training_steps += 1
+
+        outputs = outputs[0] if len(outputs) == 1 else torch.cat(outputs, dim=0)
+        return outputs, total_loss, grad
+
+    # ------------------------------------------------------------------------------------
+    def forward(self, data_loader, num_steps=None, training=False, average_output=False, chunk_batch=1):
+        meters = {name: AverageMeter() for name in ['step', 'data', 'loss', 'prec1', 'prec5']}
+        if training and self.grad_clip > 0:
+            meters['grad'] = AverageMeter()
+
+        device_meters = isinstance(self.criterion, CrossEntropyLoss)
+        if device_meters:
+            ops.fill_f32_(self._meters, 0.0)
+            self.criterion.meters = self._meters
+        host_acc = None
+
+        def sync_meters(last_loss):
+            """One D2H of the device accumulators -> reference AverageMeter state."""
+            if device_meters:
+                m = self._meters.tolist()
+                last = self.criterion.last_step.tolist() if self.criterion.last_step is not None else [0, 0, 0]
+                cnt = m[3] if m[3] > 0 else 0
+                lv = float(last_loss) if last_loss is not None else last[0]
+                meters['loss'].set(lv, m[0], cnt)
+                meters['prec1'].set(last[1], m[1], cnt)
+                meters['prec5'].set(last[2], m[2], cnt)
+                if 'grad' in meters:
+                    meters['grad'].set(float(self._norm_out[0]), m[4], m[5])
+
+        def meter_results(meters):
+            results = {name: meter.avg for name, meter in meters.items()}
+            results['error1'] = 100. - results['prec1']
+            results['error5'] = 100. - results['prec5']
+            return results
+
+        end = time.time()
+        n_batches = len(data_loader)
+        try:
+            for i, (inputs, target) in enumerate(data_loader):
+                if inputs.dim() > 4:
+                    raise NotImplementedError('duplicates (B x D x C x H x W inputs) are outside the hot path')
+                meters['data'].update(time.time() - end)
+
+                output, loss, grad = self._step(inputs, target, training=training,
+                                                average_output=average_output, chunk_batch=chunk_batch)
+
+                if not device_meters:   # foreign criterion: reference behaviour, host meters
+                    tgt = target.to(self.device)
+                    prec1, prec5 = accuracy(output, tgt, topk=(1, 5))
+                    meters['loss'].update(float(loss), inputs.size(0))
+                    meters['prec1'].update(float(prec1), inputs.size(0))
+                    meters['prec5'].update(float(prec5), inputs.size(0))
+                    if grad is not None:
+                        meters['grad'].update(float(grad), inputs.size(0))
+
+                report = (i % self.print_freq == 0) or (i == n_batches - 1)
+                if report:
+                    sync_meters(loss)   # the only device->host sync of the loop
+                meters['step'].update(time.time() - end)
+                end = time.time()
+
+                if report:
+                    line = str('{phase} - Epoch: [{0}][{1}/{2}]\t'
+                               'Time {meters[step].val:.3f} ({meters[step].avg:.3f})\t'
+                               'Data {meters[data].val:.3f} ({meters[data].avg:.3f})\t'
+                               'Loss {meters[loss].val:.4f} ({meters[loss].avg:.4f})\t'
+                               'Prec@1 {meters[prec1].val:.3f} ({meters[prec1].avg:.3f})\t'
+                               'Prec@5 {meters[prec5].val:.3f} ({meters[prec5].avg:.3f})\t'
+                               .format(self.epoch, i, n_batches,
+                                       phase='TRAINING' if training else 'EVALUATING', meters=meters))
+                    if 'grad' in meters.keys():
+                        line += 'Grad {meters[grad].val:.3f} ({meters[grad].avg:.3f})'.format(meters=meters)
+                    logging.info(line)
+
+                if num_steps is not None and i >= num_steps:
+                    break
+            sync_meters(None)
+        finally:
+            if device_meters:
+                self.criterion.meters = None
+        return meter_results(meters)
+
+    def train(self, data_loader, average_output=False, chunk_batch=1):
+        self.model.train()
+        return self.forward(data_loader, training=True, average_output=average_output, chunk_batch=chunk_batch)
+
+    def validate(self, data_loader, average_output=False):
+        self.model.eval()
+        self._broadcast_buffers()   # DDP broadcast_buffers: every rank evaluates rank 0's statistics
+        with torch.no_grad():
+            return self.forward(data_loader, average_output=average_output, training=False)
+
+    def calibrate_bn(self, data_loader, num_steps=None):
+        from . import nn as cnn
+        for m in self.model.modules():
+            if isinstance(m, cnn.BatchNorm2d):
+                m.momentum = None
+                m.track_running_stats = True
+                m.reset_running_stats()
+        self.model.train()
+        with torch.no_grad():
+            return self.forward(data_loader, num_steps=num_steps, training=False)
+
+    # tensorwatch hooks of the reference (trainer.py:287-337) are observability extras; keep the
+    # call surface as no-ops so main.py-style drivers keep working.
+    def set_watcher(self, filename, port=0):
+        return False
+
+    def observe(self, **kwargs):
+        return False
+
+    def stream_meters(self, meters_dict, prefix=None):
+        return False
+
+    def write_stream(self, name, values):
+        return False

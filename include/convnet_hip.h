@@ -1,0 +1,125 @@
+/* convnet_hip.h -- C ABI of libconvnet_hip.so: the MI355X (gfx950 / CDNA4) kernels behind the
+ * data-parallel training hot path of eladhoffer/convNet.pytorch
+ * (trainer.Trainer.train/forward/_step over models/resnet.py).
+ *
+ * The reference is 100 % Python and has no FFI: every entry point below replaces a *PyTorch op*
+ * the reference calls (file:line citations are into the reference tree).  A maintainer binds the
+ * library with ctypes; `convnet.pytorch_amd/_lib.py` is that binding.
+ *
+ * Conventions
+ *   - Plain pointers and sizes only; every pointer is a DEVICE pointer unless stated otherwise.
+ *   - The caller owns every buffer including workspaces; the library never allocates or frees
+ *     device memory, keeps no global state, and never synchronises the device.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); calls are
+ *     asynchronous and re-entrant.
+ *   - Every function returns 0 (CN_OK) or a negative CN_E* code; cn_last_error() returns the
+ *     thread-local reason.
+ *   - Activations are NHWC, filters KRSC ([Co][kh][kw][Ci]); the channel count of every tensor a
+ *     kernel vector-loads must be a multiple of the 16-byte chunk (8 bf16 / 4 fp32 elements).
+ *   - dtype: CN_F32 = 0, CN_BF16 = 1 (bf16 storage, fp32 accumulation).
+ */
+#ifndef CONVNET_HIP_H
+#define CONVNET_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CN_OK 0
+#define CN_EINVAL (-1)
+#define CN_ESHAPE (-2)
+#define CN_EHIP (-3)
+#define CN_EWORKSPACE (-4)
+#define CN_F32 0
+#define CN_BF16 1
+
+const char* cn_last_error(void);
+const char* cn_build_info(void);
+int cn_is_emulator(void); /* 1 only in the TEST-ONLY CPU emulator build */
+
+/* ---- nn.Conv2d / nn.Linear (models/resnet.py:75-78,126-132,178-179,226-227,242) ------------- */
+/* y[N,P,Q,K] = conv(x[N,H,W,C], w[K,R,S,C]) (+bias[K]) (ReLU optional); out_f32 writes fp32
+ * regardless of dtype (used for the classifier logits).  Linear = 1x1 conv on a 1x1 image. */
+int cn_conv2d_fwd(const void* x, const void* w_krsc, void* y, const float* bias, int N, int H, int W, int C,
+                  int K, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w, int dtype,
+                  int out_f32, int relu, void* stream);
+/* dx[N,H,W,C] from dy[N,P,Q,K] and the transposed filter w_crsk[C][R][S][K]
+ * (written by cn_weight_prep).  Strided convs run one launch per output-parity class. */
+int cn_conv2d_dgrad(const void* dy, const void* w_crsk, void* dx, int N, int H, int W, int C, int K, int R,
+                    int S, int stride_h, int stride_w, int pad_h, int pad_w, int dtype, int out_f32,
+                    void* stream);
+/* dw[K,R,S,C_real] (fp32) = beta*dw + scale * sum_pixels dy (x) x ; split reduction through
+ * `workspace` (cn_conv2d_wgrad_workspace bytes), fixed summation order. */
+size_t cn_conv2d_wgrad_workspace(int N, int H, int W, int C, int K, int R, int S, int stride_h, int stride_w,
+                                 int pad_h, int pad_w, int dtype);
+int cn_conv2d_wgrad(const void* x, const void* dy, float* dw_krsc, int C_real, int N, int H, int W, int C,
+                    int K, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w, int dtype,
+                    float beta, float scale, void* workspace, size_t ws_bytes, void* stream);
+
+/* ---- nn.BatchNorm2d (+ fused residual add + ReLU) (models/resnet.py:128-134,141-165) -------- */
+size_t cn_bn_workspace(int M, int C, int dtype);
+/* stats_out: 4*C floats = [batch mean | 1/sqrt(var+eps) | scale | shift]; M = N*H*W rows. */
+int cn_bn_fwd_train(const void* y, const void* residual, void* z, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, long long* num_batches_tracked, float momentum,
+                    float eps, float* stats_out, int M, int C, int relu, int dtype, void* workspace,
+                    size_t ws_bytes, void* stream);
+int cn_bn_fwd_infer(const void* y, const void* residual, void* z, const float* gamma, const float* beta,
+                    const float* running_mean, const float* running_var, float eps, float* coeffs /*2C*/,
+                    int M, int C, int relu, int dtype, void* stream);
+/* zmask: saved block output (needed when a residual was added), NULL => ReLU mask recomputed from
+ * y.  dres (optional) receives the masked upstream gradient for the residual branch. */
+int cn_bn_bwd(const void* dz, const void* y, const void* zmask, const float* gamma, const float* stats,
+              void* dy, void* dres, float* dgamma, float* dbeta, float beta_acc, float gscale,
+              float* coef_scratch /*3C*/, int M, int C, int relu, int dtype, void* workspace,
+              size_t ws_bytes, void* stream);
+
+/* ---- nn.MaxPool2d / nn.AdaptiveAvgPool2d(1) (models/resnet.py:230,241) ---------------------- */
+int cn_maxpool_fwd(const void* x, void* y, unsigned char* argmax_tap, int N, int H, int W, int C, int k,
+                   int stride, int pad, int dtype, void* stream);
+int cn_maxpool_bwd(const void* dy, const unsigned char* argmax_tap, void* dx, int N, int H, int W, int C,
+                   int k, int stride, int pad, int dtype, void* stream);
+int cn_avgpool_fwd(const void* x, void* y, int N, int HW, int C, int dtype, void* stream);
+int cn_avgpool_bwd(const void* dy, void* dx, int N, int HW, int C, int dtype, void* stream);
+
+/* ---- host->device boundary and autograd fan-in (trainer.py:116-117; models/resnet.py:115,162) */
+int cn_nchw_to_nhwc(const float* x_nchw, void* y_nhwc, int N, int C, int H, int W, int Cpad, int dtype,
+                    void* stream);
+int cn_nhwc_to_nchw(const void* x_nhwc, float* y_nchw, int N, int C, int H, int W, int Cpad, int dtype,
+                    void* stream);
+/* op 0: a += b;  1: a = relu(b);  2: a = b * (c > 0).  n elements (multiple of the chunk). */
+int cn_eltwise(int op, void* a, const void* b, const void* c, long long n, int dtype, void* stream);
+
+/* ---- criterion + accuracy + meters (main.py:231-235; trainer.py:143,153,224-229) ------------ */
+/* logits fp32 [B][K], target int64 [B]; dlogits (optional, grad_dtype) = (softmax - smoothed
+ * one-hot) * gscale; row_scratch 3*B floats; step_out[0..2] = mean loss, prec@1, prec@5 (%)
+ * of this batch; meters[0..3] += {loss*B, prec1*B, prec5*B, B} (either may be NULL). */
+int cn_softmax_ce(const float* logits, const long long* target, void* dlogits, int grad_dtype,
+                  float* row_scratch, float* step_out, float* meters, int B, int K, float gscale,
+                  const float* gscale_dev /*optional device scalar folded into gscale*/, float smooth_eps,
+                  void* stream);
+
+/* ---- optimizer.step / grad clipping / filter preparation (trainer.py:165-173) --------------- */
+int cn_sgd_momentum(float* p, const float* g, float* buf, long long n, float lr, float momentum,
+                    float weight_decay, float gscale, const float* clip_coef, void* stream);
+size_t cn_grad_norm_workspace(void);
+/* out2[0] = ||g||_2 * gscale, out2[1] = min(1, max_norm/(norm+1e-6)) (1 when max_norm <= 0). */
+int cn_grad_norm_clip(const float* g, long long n, float gscale, float max_norm, float* out2, float* meters2,
+                      float meter_weight, float* workspace, void* stream);
+int cn_weight_prep(const float* w_master_krsc, void* w_krsc, void* w_crsk /*optional*/, int Co, int taps,
+                   int Creal, int Cpad, int dtype, void* stream);
+size_t cn_colsum_workspace(int C);
+int cn_colsum(const void* x, float* out, int M, int C, int dtype, float beta, float scale, float* workspace,
+              void* stream);
+int cn_cast_from_f32(const float* x, void* y, long long n, int dtype, void* stream);
+int cn_fill_f32(float* x, long long n, float v, void* stream);
+
+/* ---- hardware lane-map probes (tests only) -------------------------------------------------- */
+int cn_probe_mfma_bf16(const unsigned short* A /*32x16*/, const unsigned short* B /*16x32*/, float* D /*32x32*/,
+                       void* stream);
+int cn_probe_mfma_f32(const float* A /*32x2*/, const float* B /*2x32*/, float* D, void* stream);
+int cn_probe_tr16(const unsigned short* src /*256*/, unsigned short* out /*64x4*/, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CONVNET_HIP_H */

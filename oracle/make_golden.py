@@ -1,0 +1,128 @@
+"""Generate the golden fixtures under tests/golden/ by executing the REAL reference.
+
+Runs only in the build container (needs /root/reference, read-only).  The reference's own
+``models/`` and ``trainer.Trainer`` are imported unmodified through ``oracle/refshim`` (re-stated
+``utils.*`` + a torchvision stub, placed ahead of the reference on sys.path) and driven on CPU fp32
+with fixed seeds.  Output: small JSON / .pt files that the CPU tests use to pin
+``oracle/convnet_oracle.py`` and that the GPU tests compare the HIP path against.
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py
+"""
+import json
+import os
+import sys
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = '/root/reference'
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(HERE, 'refshim'))
+
+import torch  # noqa: E402
+
+torch.set_num_threads(8)
+
+import models as ref_models            # noqa: E402  (the reference's registry)
+from trainer import Trainer as RefTrainer  # noqa: E402  (the reference's step engine)
+from utils.optim import OptimRegime        # noqa: E402  (refshim restatement)
+from utils.cross_entropy import CrossEntropyLoss  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
+os.makedirs(OUT, exist_ok=True)
+
+SMALL = dict(width=[8, 16, 32, 64], inplanes=8, num_classes=16)
+
+
+def tensor_sums(sd):
+    return {k: [float(v.double().sum()), float(v.double().abs().sum())] for k, v in sd.items()}
+
+
+def batches(n, B, size, classes, seed):
+    g = torch.Generator().manual_seed(seed)
+    return [(torch.randn(B, 3, size, size, generator=g), torch.randint(0, classes, (B,), generator=g))
+            for _ in range(n)]
+
+
+def structure():
+    out = {}
+    for name, kw in [('resnet18', dict(depth=18)), ('resnet50', dict(depth=50)), ('resnet34', dict(depth=34)),
+                     ('resnet101', dict(depth=101))]:
+        torch.manual_seed(123)
+        m = ref_models.resnet(dataset='imagenet', **kw)
+        sd = m.state_dict()
+        out[name] = {'params': sum(p.numel() for p in m.parameters()),
+                     'keys': {k: list(v.shape) for k, v in sd.items()},
+                     'regime': [{k: v for k, v in r.items() if k != 'regularizer'} for r in m.regime]}
+        if name in ('resnet18', 'resnet50'):
+            out[name]['init_sums'] = tensor_sums({k: v for k, v in sd.items() if v.dtype.is_floating_point})
+    torch.manual_seed(123)
+    m = ref_models.mnist()
+    sd = m.state_dict()
+    out['mnist'] = {'params': sum(p.numel() for p in m.parameters()),
+                    'keys': {k: list(v.shape) for k, v in sd.items()},
+                    'init_sums': tensor_sums({k: v for k, v in sd.items() if v.dtype.is_floating_point})}
+    out['registry'] = sorted(n for n in ref_models.__dict__ if n.islower() and not n.startswith('__')
+                             and callable(ref_models.__dict__[n]))
+    with open(os.path.join(OUT, 'structure.json'), 'w') as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print('structure.json', {k: v.get('params') for k, v in out.items() if isinstance(v, dict)})
+
+
+def trajectory(tag, model_kw, B, size, classes, steps, seed, loss_scale=1.0, grad_clip=1e9, chunk_batch=1,
+               smooth=0.0):
+    """k training steps of the reference Trainer (one-batch loaders -> per-step meter values)."""
+    torch.manual_seed(123)
+    model = ref_models.resnet(dataset='imagenet', **model_kw)
+    init_sums = tensor_sums({k: v for k, v in model.state_dict().items() if v.dtype.is_floating_point})
+    crit = CrossEntropyLoss(smooth_eps=smooth) if smooth else CrossEntropyLoss()
+    opt = OptimRegime(model, model.regime)
+    tr = RefTrainer(model, crit, opt, device_ids=None, device='cpu', dtype=torch.float, distributed=False,
+                    loss_scale=loss_scale, grad_clip=grad_clip, print_freq=10 ** 9)
+    data = batches(steps, B, size, classes, seed)
+    recs = []
+    for x, t in data:
+        r = tr.train([(x, t)], chunk_batch=chunk_batch)
+        recs.append({k: float(r[k]) for k in ('loss', 'prec1', 'prec5', 'grad')})
+    val = tr.validate(data[:2])
+    sd = model.state_dict()
+    out = {'tag': tag, 'model_kw': model_kw, 'B': B, 'size': size, 'classes': classes, 'steps': steps,
+           'seed': seed, 'loss_scale': loss_scale, 'grad_clip': grad_clip, 'chunk_batch': chunk_batch,
+           'smooth_eps': smooth, 'records': recs,
+           'validate': {k: float(val[k]) for k in ('loss', 'prec1', 'prec5')},
+           'input_sums': [[float(x.double().sum()), float(t.sum())] for x, t in data],
+           'init_sums': init_sums,
+           'final_sums': tensor_sums({k: v for k, v in sd.items() if v.dtype.is_floating_point}),
+           'num_batches_tracked': int(sd['bn1.num_batches_tracked'])}
+    with open(os.path.join(OUT, 'traj_%s.json' % tag), 'w') as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    # a few full tensors for element-wise comparison
+    keep = ['conv1.weight', 'bn1.running_mean', 'bn1.running_var', 'layer1.0.conv1.weight',
+            'layer2.0.downsample.0.weight', 'layer4.1.bn2.weight', 'fc.weight', 'fc.bias']
+    if size > 64:   # full-size models: keep the fixture small
+        keep = ['conv1.weight', 'bn1.running_mean', 'bn1.running_var', 'layer1.0.conv1.weight', 'fc.bias']
+    torch.save({k: sd[k].clone() for k in keep if k in sd}, os.path.join(OUT, 'traj_%s_final.pt' % tag))
+    print(tag, recs[0], recs[-1], 'val', out['validate'])
+
+
+def mnist_eval():
+    torch.manual_seed(123)
+    m = ref_models.mnist()
+    m.eval()
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(4, 1, 28, 28, generator=g)
+    with torch.no_grad():
+        y = m(x)
+    torch.save({'x': x, 'logits': y}, os.path.join(OUT, 'mnist_eval.pt'))
+    print('mnist_eval', y[0, :4])
+
+
+if __name__ == '__main__':
+    structure()
+    trajectory('r50s', dict(depth=50, **SMALL), B=8, size=32, classes=16, steps=4, seed=11)
+    trajectory('r18s', dict(depth=18, **SMALL), B=8, size=32, classes=16, steps=4, seed=12)
+    trajectory('r50s_clip', dict(depth=50, **SMALL), B=8, size=32, classes=16, steps=3, seed=13, loss_scale=8.0,
+               grad_clip=0.5, chunk_batch=2, smooth=0.1)
+    trajectory('r18_full', dict(depth=18), B=4, size=224, classes=1000, steps=2, seed=21)
+    trajectory('r50_full', dict(depth=50), B=4, size=224, classes=1000, steps=2, seed=22)
+    mnist_eval()
+    assert not os.path.exists(os.path.join(REF, '__pycache__')), 'bytecode leaked into the reference tree'
