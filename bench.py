@@ -1,0 +1,166 @@
+#!/usr/bin/env python
+"""bench.py -- ResNet-50 bf16 training throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path (Trainer._step: NCHW fp32 -> NHWC bf16 conversion, forward,
+softmax-CE + accuracy meters, backward, [RCCL all-reduce], fused SGD+momentum) over one synthetic
+batch of 256 images 3x224x224 per GPU.  Inputs are resident in HBM when the timed region starts
+(a pool of pre-staged device batches is cycled; the reference's per-step H2D copy is excluded).
+Weak scaling: per-GPU batch fixed, value = images of all ranks / max-over-ranks time.
+
+Rank 0 prints ONE JSON line.  Extra objects:
+  roofline     : live HIP-event timing (a separate profiled pass after the timed region) of the
+                 dominant kernel family: algorithmic FLOPs (2*MACs of
+                 conv/fc fwd+dgrad+wgrad) or bytes per launch / measured launch time vs the
+                 gfx950 peak (MI355X_MICROARCH.md: 2.5 PFLOP/s dense bf16 MFMA, 8 TB/s HBM3E).
+  kernels      : the same figures for every kernel family of the step (time share per step).
+  cpu_baseline : the CPU oracle (oracle/convnet_oracle.py, kind "port") timed on this host's
+                 cores on a bounded sample (ResNet-50 fp32, batch 32, 1 warm-up + 2 steps).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+TRAIN_GFLOP_PER_IMG = {50: 24.2991, 18: 10.6484}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=256, help='per-GPU batch (BASELINE: 256)')
+    ap.add_argument('--depth', type=int, default=50)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--pool', type=int, default=4, help='distinct pre-staged device batches')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-profile', action='store_true')
+    args = ap.parse_args()
+
+    import convnet_amd as ca
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: there is no CPU fallback for the measured path')
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if distributed:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', init_method='env://', world_size=world, rank=rank)
+    assert not ca._lib.is_emulated()
+
+    dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    torch.manual_seed(123)
+    model = ca.models.resnet(dataset='imagenet', depth=args.depth)
+    crit = ca.CrossEntropyLoss()
+    opt = ca.OptimRegime(model, model.regime)
+    tr = ca.Trainer(model, crit, opt, device=str(device), dtype=dtype, distributed=distributed,
+                    local_rank=local_rank, print_freq=10 ** 9)
+
+    B = args.batch
+    g = torch.Generator().manual_seed(123 + rank)
+    pool = [(torch.randn(B, 3, 224, 224, generator=g).to(device),
+             torch.randint(0, 1000, (B,), generator=g).to(device)) for _ in range(args.pool)]
+
+    def loader(n):
+        return [pool[i % len(pool)] for i in range(n)]
+
+    def fence():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    tr.train(loader(args.warmup))          # W untimed warm-up steps
+    fence()
+    t0 = time.perf_counter()
+    res = tr.train(loader(args.steps))     # EXACTLY K timed steps
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- live per-kernel timing (separate profiled pass, HIP events on the launch stream) ----
+    kernels, roof = {}, None
+    if rank == 0 and not args.no_kernel_profile:
+        ca.ops.PROFILER.records = []
+        ca.ops.PROFILER.enabled = True
+        nprof = 2
+        tr.train(loader(nprof))
+        ca.ops.PROFILER.enabled = False
+        agg = ca.ops.PROFILER.summary()
+        total_ms = sum(a['ms'] for a in agg.values())
+        for name, a in sorted(agg.items(), key=lambda kv: -kv[1]['ms']):
+            sec = a['ms'] * 1e-3
+            kernels[name] = {
+                'ms_per_step': round(a['ms'] / nprof, 3),
+                'share': round(a['ms'] / total_ms, 4),
+                'launches_per_step': a['launches'] // nprof,
+                'avg_us_per_launch': round(a['ms'] * 1e3 / max(a['launches'], 1), 2),
+                'tflops': round(a['flops'] / sec / 1e12, 2) if a['flops'] else None,
+                'gbs': round(a['bytes'] / sec / 1e9, 1),
+            }
+        dom = next(iter(kernels))
+        k = kernels[dom]
+        if k['tflops'] and k['tflops'] / PEAK_TFLOPS[args.dtype] >= k['gbs'] / PEAK_HBM_GBS:
+            roof = {'kernel': dom, 'bound': 'mfma', 'achieved': k['tflops'], 'peak': PEAK_TFLOPS[args.dtype],
+                    'unit': 'TFLOP/s', 'frac': round(k['tflops'] / PEAK_TFLOPS[args.dtype], 4), 'traffic': None}
+        else:
+            roof = {'kernel': dom, 'bound': 'hbm', 'achieved': k['gbs'], 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                    'frac': round(k['gbs'] / PEAK_HBM_GBS, 4), 'traffic': None}
+        roof['avg_us_per_launch'] = k['avg_us_per_launch']
+        roof['launches_per_step'] = k['launches_per_step']
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import convnet_oracle as O
+        r = O.time_cpu_baseline(depth=args.depth, batch=32, steps=2, warmup=1, size=224,
+                                threads=os.cpu_count())
+        cpu = {'value': round(r['img_per_s'], 2), 'unit': 'images/sec', 'cores': r['cores'], 'kind': 'port',
+               'sample': 'oracle ResNet-%d fp32 CPU training, batch 32, 1 warm-up + 2 timed steps '
+                         '(%.2f s/step)' % (args.depth, r['s_per_step'])}
+
+    if rank == 0:
+        img_s = B * world * args.steps / elapsed
+        step_tflops = TRAIN_GFLOP_PER_IMG.get(args.depth, 0.0) * B * 1e-3
+        out = {
+            'metric': 'images/sec ResNet-%d %s 3x224x224 b=%d/GPU training (fwd+bwd+SGD)' % (
+                args.depth, args.dtype, B),
+            'value': round(img_s, 1), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
+            'data': 'synthetic',
+            'config': {'workload': 'ResNet-%d (depth:%d) synthetic 3x224x224 b=%d/GPU %s, SGD+momentum, '
+                                   '%s' % (args.depth, args.depth, B, args.dtype,
+                                           'dp%d RCCL all-reduce' % world if world > 1 else '1 MI355X'),
+                       'global_batch': B * world, 'final_loss': round(float(res['loss']), 4)},
+            'mfma_frac_whole_step': round(step_tflops / (elapsed / args.steps) / PEAK_TFLOPS[args.dtype], 4)
+            if step_tflops else None,
+            'roofline': roof, 'cpu_baseline': cpu, 'kernels': kernels,
+        }
+        print(json.dumps(out))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -35,7 +35,7 @@ struct IgemmParams {
   long long w_row;
   int out_f32, relu;
   int M, n_ntiles;
-  FastDiv div_hw, div_w;
+  FastDiv div_hw, div_w, div_cpt;
   int tap_dhdw[IG_MAX_TAPS];
   int tap_woff[IG_MAX_TAPS];
 };
@@ -142,8 +142,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     const bool kvalid = kc < p.nchunks;
     int tap = 0, cchunk = kc;
     if (p.ntaps > 1) {
-      tap = kvalid ? (kc >> p.cpt_shift) : 0;
-      cchunk = kc & (p.cpt - 1);
+      tap = kvalid ? (int)cn_fastdiv((unsigned)kc, p.div_cpt) : 0;
+      cchunk = kvalid ? kc - tap * p.cpt : 0;
     }
     const int dhdw = s_taps[2 * tap];
     const int woff = s_taps[2 * tap + 1];
@@ -305,10 +305,7 @@ static int ig_common(IgemmParams& p, int dtype, int Ci, int ntaps) {
   }
   p.cpt = Ci / CH;
   p.cpt_shift = ig_log2_exact(p.cpt);
-  if (ntaps > 1 && p.cpt_shift < 0) {
-    cn_set_error("igemm: multi-tap conv needs a power-of-two chunk count per tap (Ci=%d)", Ci);
-    return CN_ESHAPE;
-  }
+  p.div_cpt = cn_make_fastdiv((unsigned)p.cpt);
   p.ntaps = ntaps;
   p.nchunks = ntaps * p.cpt;
   p.M = p.N * p.Hg * p.Wg;

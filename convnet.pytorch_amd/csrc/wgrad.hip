@@ -27,7 +27,7 @@ struct WgradParams {
   int ntaps, cpt, cpt_shift, ncols;
   int M, m_per_split, nsplit;
   int n_itiles, n_jtiles;
-  FastDiv div_hw, div_w;
+  FastDiv div_hw, div_w, div_cpt;
   int tap_dhdw[WG_MAX_TAPS];
 };
 
@@ -72,8 +72,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   const bool validJ = jc < p.ntaps * p.cpt;
   int tap = 0, cchunk = jc;
   if (p.ntaps > 1) {
-    tap = validJ ? (jc >> p.cpt_shift) : 0;
-    cchunk = jc & (p.cpt - 1);
+    tap = validJ ? (int)cn_fastdiv((unsigned)jc, p.div_cpt) : 0;
+    cchunk = validJ ? jc - tap * p.cpt : 0;
   }
   const int dhdw = p.tap_dhdw[tap];
   const int dh = (int)(short)(dhdw & 0xffff), dw = dhdw >> 16;
@@ -277,11 +277,7 @@ extern "C" int cn_conv2d_wgrad(const void* x, const void* dy, float* dw_krsc, in
   p.stride_h = stride_h; p.stride_w = stride_w;
   p.ntaps = R * S; p.cpt = C / CH; p.ncols = pl.ncols;
   p.cpt_shift = 0;
-  while ((1 << p.cpt_shift) < p.cpt) ++p.cpt_shift;
-  if (p.ntaps > 1 && (1 << p.cpt_shift) != p.cpt) {
-    cn_set_error("conv2d_wgrad: multi-tap conv needs power-of-two C/chunk (C=%d)", C);
-    return CN_ESHAPE;
-  }
+  p.div_cpt = cn_make_fastdiv((unsigned)p.cpt);
   p.M = N * P * Q; p.m_per_split = pl.m_per_split; p.nsplit = pl.nsplit;
   p.n_itiles = pl.n_itiles; p.n_jtiles = pl.n_jtiles;
   p.div_hw = cn_make_fastdiv((unsigned)(P * Q));

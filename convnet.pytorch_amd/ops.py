@@ -38,6 +38,46 @@ def _L():
     return _lib.load()
 
 
+class KernelProfiler(object):
+    """Optional per-call HIP-event timing of the kernel wrappers (used by bench.py for the live
+    roofline numbers).  Events are recorded on torch's current stream, which is the stream every
+    kernel of this package is launched on.  Disabled by default: zero overhead in the hot loop."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []
+
+    def run(self, name, launches, flops, nbytes, fn, device):
+        if not self.enabled or device.type != 'cuda':
+            return fn()
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        out = fn()
+        e.record()
+        self.records.append((name, launches, flops, nbytes, s, e))
+        return out
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, launches, flops, nbytes, s, e in self.records:
+            a = agg.setdefault(name, {'calls': 0, 'launches': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0})
+            a['calls'] += 1
+            a['launches'] += launches
+            a['ms'] += s.elapsed_time(e)
+            a['flops'] += flops
+            a['bytes'] += nbytes
+        return agg
+
+
+PROFILER = KernelProfiler()
+
+
+def _esize(t):
+    return t.element_size()
+
+
 def conv_out_hw(H, W, R, S, stride, pad):
     return (H + 2 * pad[0] - R) // stride[0] + 1, (W + 2 * pad[1] - S) // stride[1] + 1
 
@@ -49,17 +89,26 @@ def conv2d_fwd(x, w_krsc, bias, K, R, S, stride, pad, out_f32=False, relu=False)
     N, H, W, C = x.shape
     P, Q = conv_out_hw(H, W, R, S, stride, pad)
     y = torch.empty((N, P, Q, K), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
-    check(_L().cn_conv2d_fwd(ptr(x), ptr(w_krsc), ptr(y), ptr(bias), N, H, W, C, K, R, S, stride[0], stride[1],
-                             pad[0], pad[1], dtype_code(x.dtype), int(out_f32), int(relu), stream_of(x)),
-          'cn_conv2d_fwd')
+    PROFILER.run('igemm_fwd_%s_%s' % ('bn64' if K <= 64 else 'bn128', 'bf16' if x.dtype == torch.bfloat16 else 'f32'),
+                 1, 2.0 * N * P * Q * K * C * R * S,
+                 x.numel() * _esize(x) + y.numel() * _esize(y) + K * R * S * C * _esize(x),
+                 lambda: check(_L().cn_conv2d_fwd(ptr(x), ptr(w_krsc), ptr(y), ptr(bias), N, H, W, C, K, R, S,
+                                                  stride[0], stride[1], pad[0], pad[1], dtype_code(x.dtype),
+                                                  int(out_f32), int(relu), stream_of(x)), 'cn_conv2d_fwd'),
+                 x.device)
     return y
 
 
 def conv2d_dgrad(dy, w_crsk, x_shape, K, R, S, stride, pad):
     N, H, W, C = x_shape
     dx = torch.empty((N, H, W, C), dtype=dy.dtype, device=dy.device)
-    check(_L().cn_conv2d_dgrad(ptr(dy), ptr(w_crsk), ptr(dx), N, H, W, C, K, R, S, stride[0], stride[1], pad[0],
-                               pad[1], dtype_code(dy.dtype), 0, stream_of(dy)), 'cn_conv2d_dgrad')
+    PROFILER.run('igemm_dgrad_%s_%s' % ('bn64' if C <= 64 else 'bn128', 'bf16' if dy.dtype == torch.bfloat16 else 'f32'),
+                 stride[0] * stride[1], 2.0 * dy.numel() * C * R * S,
+                 dy.numel() * _esize(dy) + dx.numel() * _esize(dx) + K * R * S * C * _esize(dy),
+                 lambda: check(_L().cn_conv2d_dgrad(ptr(dy), ptr(w_crsk), ptr(dx), N, H, W, C, K, R, S, stride[0],
+                                                    stride[1], pad[0], pad[1], dtype_code(dy.dtype), 0,
+                                                    stream_of(dy)), 'cn_conv2d_dgrad'),
+                 dy.device)
     return dx
 
 
@@ -70,14 +119,20 @@ def conv2d_wgrad(x, dy, dw_krsc, c_real, K, R, S, stride, pad, beta=1.0, scale=1
     L = _L()
     need = L.cn_conv2d_wgrad_workspace(N, H, W, C, K, R, S, stride[0], stride[1], pad[0], pad[1], code)
     ws = workspace(need, x.device)
-    check(L.cn_conv2d_wgrad(ptr(x), ptr(dy), ptr(dw_krsc), c_real, N, H, W, C, K, R, S, stride[0], stride[1],
-                            pad[0], pad[1], code, beta, scale, ptr(ws), ws.numel() * 4, stream_of(x)),
-          'cn_conv2d_wgrad')
+    PROFILER.run('wgrad_%s_%s' % ('bi64' if K <= 64 else 'bi128', 'bf16' if x.dtype == torch.bfloat16 else 'f32'),
+                 2, 2.0 * dy.numel() * C * R * S,
+                 x.numel() * _esize(x) + dy.numel() * _esize(dy) + K * R * S * C * 4,
+                 lambda: check(L.cn_conv2d_wgrad(ptr(x), ptr(dy), ptr(dw_krsc), c_real, N, H, W, C, K, R, S,
+                                                 stride[0], stride[1], pad[0], pad[1], code, beta, scale, ptr(ws),
+                                                 ws.numel() * 4, stream_of(x)), 'cn_conv2d_wgrad'),
+                 x.device)
 
 
 def weight_prep(w_master_krsc, w_krsc, w_crsk, Co, taps, c_real, c_pad):
-    check(_L().cn_weight_prep(ptr(w_master_krsc), ptr(w_krsc), ptr(w_crsk), Co, taps, c_real, c_pad,
-                              dtype_code(w_krsc.dtype), stream_of(w_krsc)), 'cn_weight_prep')
+    PROFILER.run('weight_prep', 1, 0.0, Co * taps * c_real * 4 + Co * taps * c_pad * _esize(w_krsc) * (2 if w_crsk is not None else 1),
+                 lambda: check(_L().cn_weight_prep(ptr(w_master_krsc), ptr(w_krsc), ptr(w_crsk), Co, taps, c_real,
+                                                   c_pad, dtype_code(w_krsc.dtype), stream_of(w_krsc)),
+                               'cn_weight_prep'), w_krsc.device)
 
 
 def colsum(x2d, out, beta=1.0, scale=1.0):
@@ -98,8 +153,9 @@ def nchw_to_nhwc(x_nchw, dtype, c_pad=None):
     if x_nchw.dtype != torch.float32:
         raise _lib.ConvNetHipError('nchw_to_nhwc expects float32 input, got %s' % x_nchw.dtype)
     y = torch.empty((N, H, W, c_pad), dtype=dtype, device=x_nchw.device)
-    check(_L().cn_nchw_to_nhwc(ptr(x_nchw), ptr(y), N, C, H, W, c_pad, dtype_code(dtype), stream_of(x_nchw)),
-          'cn_nchw_to_nhwc')
+    PROFILER.run('nchw_to_nhwc', 1, 0.0, x_nchw.numel() * 4 + y.numel() * _esize(y),
+                 lambda: check(_L().cn_nchw_to_nhwc(ptr(x_nchw), ptr(y), N, C, H, W, c_pad, dtype_code(dtype),
+                                                    stream_of(x_nchw)), 'cn_nchw_to_nhwc'), x_nchw.device)
     return y
 
 
@@ -113,7 +169,9 @@ def nhwc_to_nchw(x_nhwc, C=None):
 
 
 def add_(a, b):
-    check(_L().cn_eltwise(0, ptr(a), ptr(b), None, a.numel(), dtype_code(a.dtype), stream_of(a)), 'cn_eltwise')
+    PROFILER.run('eltwise_add', 1, 0.0, 3 * a.numel() * _esize(a),
+                 lambda: check(_L().cn_eltwise(0, ptr(a), ptr(b), None, a.numel(), dtype_code(a.dtype),
+                                               stream_of(a)), 'cn_eltwise'), a.device)
     return a
 
 
@@ -178,12 +236,15 @@ class BatchNormActFunction(Function):
         stats = torch.empty(4 * C, dtype=torch.float32, device=y.device)
         momentum = mod.effective_momentum()
         track = mod.track_running_stats
-        check(L.cn_bn_fwd_train(ptr(y), ptr(residual), ptr(z), ptr(gamma), ptr(beta),
-                                ptr(mod.running_mean) if track else None,
-                                ptr(mod.running_var) if track else None,
-                                ptr(mod.num_batches_tracked) if track else None,
-                                momentum, mod.eps, ptr(stats), M, C, int(relu), code, ptr(ws), ws.numel() * 4,
-                                stream_of(y)), 'cn_bn_fwd_train')
+        nb = y.numel() * _esize(y)
+        PROFILER.run('bn_fwd_train', 3, 0.0, nb * (4 if residual is not None else 3),
+                     lambda: check(L.cn_bn_fwd_train(ptr(y), ptr(residual), ptr(z), ptr(gamma), ptr(beta),
+                                                     ptr(mod.running_mean) if track else None,
+                                                     ptr(mod.running_var) if track else None,
+                                                     ptr(mod.num_batches_tracked) if track else None,
+                                                     momentum, mod.eps, ptr(stats), M, C, int(relu), code, ptr(ws),
+                                                     ws.numel() * 4, stream_of(y)), 'cn_bn_fwd_train'),
+                     y.device)
         ctx.mod = mod
         ctx.relu = relu
         ctx.has_res = residual is not None
@@ -209,9 +270,13 @@ class BatchNormActFunction(Function):
         want_res = ctx.has_res and ctx.needs_input_grad[3]
         dres = torch.empty_like(y) if want_res else None
         coef = torch.empty(3 * C, dtype=torch.float32, device=y.device)
-        check(L.cn_bn_bwd(ptr(dz), ptr(y), ptr(zmask), ptr(mod.weight), ptr(stats), ptr(dy), ptr(dres),
-                          ptr(mod.grad_view('weight')), ptr(mod.grad_view('bias')), 1.0, 1.0, ptr(coef), M, C,
-                          int(ctx.relu), code, ptr(ws), ws.numel() * 4, stream_of(y)), 'cn_bn_bwd')
+        nb = y.numel() * _esize(y)
+        PROFILER.run('bn_bwd', 3, 0.0, nb * (5 + (2 if zmask is not None else 0) + (1 if dres is not None else 0)),
+                     lambda: check(L.cn_bn_bwd(ptr(dz), ptr(y), ptr(zmask), ptr(mod.weight), ptr(stats), ptr(dy),
+                                               ptr(dres), ptr(mod.grad_view('weight')), ptr(mod.grad_view('bias')),
+                                               1.0, 1.0, ptr(coef), M, C, int(ctx.relu), code, ptr(ws),
+                                               ws.numel() * 4, stream_of(y)), 'cn_bn_bwd'),
+                     y.device)
         mod._notify_grad_ready()
         return dy, None, None, dres, None, None
 
@@ -233,8 +298,10 @@ class MaxPool2dFunction(Function):
         P, Q = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
         y = torch.empty((N, P, Q, C), dtype=x.dtype, device=x.device)
         idx = torch.empty((N, P, Q, C), dtype=torch.uint8, device=x.device)
-        check(_L().cn_maxpool_fwd(ptr(x), ptr(y), ptr(idx), N, H, W, C, k, stride, pad, dtype_code(x.dtype),
-                                  stream_of(x)), 'cn_maxpool_fwd')
+        PROFILER.run('maxpool_fwd', 1, 0.0, x.numel() * _esize(x) + y.numel() * (_esize(y) + 1),
+                     lambda: check(_L().cn_maxpool_fwd(ptr(x), ptr(y), ptr(idx), N, H, W, C, k, stride, pad,
+                                                       dtype_code(x.dtype), stream_of(x)), 'cn_maxpool_fwd'),
+                     x.device)
         ctx.cfg = (N, H, W, C, k, stride, pad)
         ctx.save_for_backward(idx)
         return y
@@ -245,8 +312,10 @@ class MaxPool2dFunction(Function):
         N, H, W, C, k, stride, pad = ctx.cfg
         dy = dy.contiguous()
         dx = torch.empty((N, H, W, C), dtype=dy.dtype, device=dy.device)
-        check(_L().cn_maxpool_bwd(ptr(dy), ptr(idx), ptr(dx), N, H, W, C, k, stride, pad, dtype_code(dy.dtype),
-                                  stream_of(dy)), 'cn_maxpool_bwd')
+        PROFILER.run('maxpool_bwd', 1, 0.0, dx.numel() * _esize(dx) + dy.numel() * (_esize(dy) + 1),
+                     lambda: check(_L().cn_maxpool_bwd(ptr(dy), ptr(idx), ptr(dx), N, H, W, C, k, stride, pad,
+                                                       dtype_code(dy.dtype), stream_of(dy)), 'cn_maxpool_bwd'),
+                     dy.device)
         return dx, None, None, None
 
 

@@ -185,9 +185,12 @@ class OptimRegime(Regime):
         lr, mu = float(self.hyper['lr']), float(self.hyper['momentum'])
         for start, end, wd in self._runs:
             n = end - start
-            check(L.cn_sgd_momentum(ptr(a.params[start:]), ptr(a.grads[start:]), ptr(self.momentum_buf[start:]), n,
-                                    lr, mu, float(wd), float(self.grad_scale), ptr(self.clip_coef),
-                                    stream_of(a.params)), 'cn_sgd_momentum')
+            ops.PROFILER.run('sgd_momentum', 1, 0.0, 20.0 * n,
+                             lambda: check(L.cn_sgd_momentum(ptr(a.params[start:]), ptr(a.grads[start:]),
+                                                             ptr(self.momentum_buf[start:]), n, lr, mu, float(wd),
+                                                             float(self.grad_scale), ptr(self.clip_coef),
+                                                             stream_of(a.params)), 'cn_sgd_momentum'),
+                             a.device)
         a.bump_version()
 
     def get_value(self, key):

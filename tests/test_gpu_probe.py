@@ -1,0 +1,60 @@
+"""Pins the gfx950 lane maps the kernels assume (cn_common.h): MFMA 32x32x16 bf16 / 32x32x2 f32
+operand + accumulator layout and the ds_read_b64_tr_b16 shuffle.  On the emulator this only checks
+the harness; on the GPU it checks the hardware."""
+import pytest
+import torch
+
+from conftest import HAS_GPU
+
+MODES = [pytest.param('emul'), pytest.param('gpu', marks=pytest.mark.gpu)]
+
+
+def _setup(mode):
+    if mode == 'emul' and HAS_GPU:
+        pytest.skip('emulator mode is for GPU-less hosts')
+    if mode == 'gpu' and not HAS_GPU:
+        pytest.skip('no GPU')
+    import convnet_amd as ca
+    dev = torch.device('cuda', 0) if mode == 'gpu' else torch.device('cpu')
+    stream = torch.cuda.current_stream().cuda_stream if mode == 'gpu' else None
+    return ca, dev, stream
+
+
+@pytest.mark.parametrize('mode', MODES)
+def test_mfma_bf16_lane_map(mode):
+    ca, dev, stream = _setup(mode)
+    g = torch.Generator().manual_seed(0)
+    A = torch.randint(-4, 5, (32, 16), generator=g).float()     # asymmetric, exactly representable
+    B = torch.randint(-4, 5, (16, 32), generator=g).float()
+    Ab = A.to(torch.bfloat16).view(torch.int16).to(dev)
+    Bb = B.to(torch.bfloat16).view(torch.int16).to(dev)
+    D = torch.zeros(32, 32, device=dev)
+    ca._lib.check(ca._lib.load().cn_probe_mfma_bf16(Ab.data_ptr(), Bb.data_ptr(), D.data_ptr(), stream))
+    assert torch.equal(D.cpu(), A @ B)
+
+
+@pytest.mark.parametrize('mode', MODES)
+def test_mfma_f32_lane_map(mode):
+    ca, dev, stream = _setup(mode)
+    g = torch.Generator().manual_seed(1)
+    A = torch.randint(-4, 5, (32, 2), generator=g).float()
+    B = torch.randint(-4, 5, (2, 32), generator=g).float()
+    D = torch.zeros(32, 32, device=dev)
+    ca._lib.check(ca._lib.load().cn_probe_mfma_f32(A.to(dev).data_ptr(), B.to(dev).data_ptr(), D.data_ptr(), stream))
+    assert torch.equal(D.cpu(), A @ B)
+
+
+@pytest.mark.parametrize('mode', MODES)
+def test_lds_transpose_read_map(mode):
+    ca, dev, stream = _setup(mode)
+    src = torch.arange(256, dtype=torch.int16).to(dev)
+    out = torch.zeros(64, 4, dtype=torch.int16, device=dev)
+    ca._lib.check(ca._lib.load().cn_probe_tr16(src.data_ptr(), out.data_ptr(), stream))
+    exp = torch.zeros(64, 4, dtype=torch.int16)
+    for l in range(64):
+        g0, i = l & ~15, l & 15
+        for j in range(4):
+            src_lane = g0 + 4 * j + (i >> 2)        # in[L][e] = 4*L + e for the linear 8-byte/lane image
+            exp[l, j] = 4 * src_lane + (i & 3)
+    got = out.cpu()
+    assert torch.equal(got, exp), 'ds_read_b64_tr_b16 map differs:\n%s' % got[:16].tolist()

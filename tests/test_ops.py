@@ -1,0 +1,316 @@
+"""Per-operator parity: every HIP kernel against the PyTorch CPU fp32 op the reference executes
+(level T1).  Each case runs in two modes:
+  * emul : the same kernel source through the TEST-ONLY SIMT emulator, tiny shapes (build container)
+  * gpu  : libconvnet_hip.so on a real MI355X, shapes up to the ResNet-50 layer inventory
+Tolerances (rel-L2 unless noted): fp32 <= 1e-5 forward / 1e-4 gradients; bf16 storage with fp32
+accumulation <= 1e-2 (inputs are pre-rounded to bf16 so only output rounding + summation order
+differ)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import HAS_GPU
+from helpers import rel_l2
+
+MODES = [pytest.param('emul'), pytest.param('gpu', marks=pytest.mark.gpu)]
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _dev(mode):
+    if mode == 'emul' and HAS_GPU:
+        pytest.skip('emulator mode is for GPU-less hosts')
+    if mode == 'gpu' and not HAS_GPU:
+        pytest.skip('no GPU')
+    import convnet_amd as ca
+    assert ca._lib.is_emulated() == (mode == 'emul')
+    return torch.device('cuda', 0) if mode == 'gpu' else torch.device('cpu')
+
+
+def _tol(dtype, grad=False):
+    if dtype == torch.bfloat16:
+        return 1e-2
+    return 1e-4 if grad else 1e-5
+
+
+def _q(t, dtype):
+    """round test data to the compute dtype (so the fp32 reference sees the same values)"""
+    return t.to(dtype).float()
+
+
+def _nhwc(t, dtype, dev):
+    return t.permute(0, 2, 3, 1).contiguous().to(dtype).to(dev)
+
+
+# (N, H, W, C, K, R, stride, pad)
+CONV_EMUL = [(2, 8, 8, 16, 64, 3, 1, 1), (1, 9, 7, 16, 72, 3, 2, 1), (2, 6, 6, 8, 64, 7, 2, 3),
+             (3, 5, 5, 64, 136, 1, 1, 0), (1, 8, 8, 32, 40, 1, 2, 0)]
+# the 23 distinct ResNet-50 conv configs at N=2 plus ResNet-18's extra ones
+CONV_GPU = [(2, 224, 224, 8, 64, 7, 2, 3), (2, 56, 56, 64, 64, 1, 1, 0), (2, 56, 56, 64, 64, 3, 1, 1),
+            (2, 56, 56, 64, 256, 1, 1, 0), (2, 56, 56, 256, 64, 1, 1, 0), (2, 56, 56, 256, 128, 1, 1, 0),
+            (2, 56, 56, 128, 128, 3, 2, 1), (2, 28, 28, 128, 512, 1, 1, 0), (2, 56, 56, 256, 512, 1, 2, 0),
+            (2, 28, 28, 512, 128, 1, 1, 0), (2, 28, 28, 128, 128, 3, 1, 1), (2, 28, 28, 512, 256, 1, 1, 0),
+            (2, 28, 28, 256, 256, 3, 2, 1), (2, 14, 14, 256, 1024, 1, 1, 0), (2, 28, 28, 512, 1024, 1, 2, 0),
+            (2, 14, 14, 1024, 256, 1, 1, 0), (2, 14, 14, 256, 256, 3, 1, 1), (2, 14, 14, 1024, 512, 1, 1, 0),
+            (2, 14, 14, 512, 512, 3, 2, 1), (2, 7, 7, 512, 2048, 1, 1, 0), (2, 14, 14, 1024, 2048, 1, 2, 0),
+            (2, 7, 7, 2048, 512, 1, 1, 0), (2, 7, 7, 512, 512, 3, 1, 1),
+            (2, 56, 56, 64, 128, 3, 2, 1), (2, 56, 56, 64, 128, 1, 2, 0), (3, 17, 13, 64, 72, 3, 2, 1)]
+
+
+def _conv_case(cfg, dtype, dev, seed=0):
+    import convnet_amd as ca
+    ops = ca.ops
+    N, H, W, C, K, R, st, pad = cfg
+    g = torch.Generator().manual_seed(seed)
+    x = _q(torch.randn(N, C, H, W, generator=g), dtype)
+    w = _q(torch.randn(K, C, R, R, generator=g) * (2.0 / (C * R * R)) ** 0.5, dtype)
+    x.requires_grad_(True)
+    w.requires_grad_(True)
+    y_ref = F.conv2d(x, w, stride=st, padding=pad)
+    dy = _q(torch.randn(y_ref.shape, generator=g), dtype)
+    y_ref.backward(dy)
+    xh = _nhwc(x.detach(), dtype, dev)
+    wk = w.detach().permute(0, 2, 3, 1).contiguous().to(dtype).to(dev)
+    wc = w.detach().permute(1, 2, 3, 0).contiguous().to(dtype).to(dev)
+    dyh = _nhwc(dy, dtype, dev)
+    y = ops.conv2d_fwd(xh, wk, None, K, R, R, (st, st), (pad, pad))
+    dx = ops.conv2d_dgrad(dyh, wc, xh.shape, K, R, R, (st, st), (pad, pad))
+    dw = torch.zeros(K, R, R, C, dtype=torch.float32, device=dev)
+    ops.conv2d_wgrad(xh, dyh, dw, C, K, R, R, (st, st), (pad, pad), beta=0.0)
+    return (rel_l2(y.float().cpu().permute(0, 3, 1, 2), y_ref.detach()),
+            rel_l2(dx.float().cpu().permute(0, 3, 1, 2), x.grad),
+            rel_l2(dw.cpu().permute(0, 3, 1, 2), w.grad))
+
+
+@pytest.mark.parametrize('mode', MODES)
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_conv2d_fwd_dgrad_wgrad(mode, dtype):
+    dev = _dev(mode)
+    cases = CONV_EMUL if mode == 'emul' else CONV_GPU
+    bad = []
+    for cfg in cases:
+        if dtype == torch.bfloat16 and cfg[3] % 8:
+            continue
+        ef, ed, ew = _conv_case(cfg, dtype, dev)
+        if ef > _tol(dtype) or ed > _tol(dtype, True) or ew > _tol(dtype, True):
+            bad.append((cfg, ef, ed, ew))
+    assert not bad, 'conv mismatches (cfg, fwd, dgrad, wgrad rel-L2): %s' % bad
+
+
+@pytest.mark.parametrize('mode', MODES)
+def test_wgrad_accumulates_and_scales(mode):
+    dev = _dev(mode)
+    import convnet_amd as ca
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 6, 6, 8, generator=g).to(dev)
+    dy = torch.randn(2, 6, 6, 64, generator=g).to(dev)
+    a = torch.zeros(64, 3, 3, 8, device=dev)
+    ca.ops.conv2d_wgrad(x, dy, a, 8, 64, 3, 3, (1, 1), (1, 1), beta=0.0)
+    b = a.clone()
+    ca.ops.conv2d_wgrad(x, dy, b, 8, 64, 3, 3, (1, 1), (1, 1), beta=1.0, scale=0.5)
+    assert rel_l2(b.cpu(), 1.5 * a.cpu()) < 1e-6
+    c = torch.zeros_like(a)
+    ca.ops.conv2d_wgrad(x, dy, c, 8, 64, 3, 3, (1, 1), (1, 1), beta=0.0)
+    assert torch.equal(a, c), 'split reduction must be run-to-run deterministic'
+
+
+@pytest.mark.parametrize('mode', MODES)
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_linear_with_bias_fp32_logits(mode, dtype):
+    dev = _dev(mode)
+    import convnet_amd as ca
+    g = torch.Generator().manual_seed(1)
+    B, C, K = (5, 64, 1000) if mode == 'emul' else (256, 2048, 1000)
+    x = _q(torch.randn(B, C, generator=g), dtype)
+    w = _q(torch.randn(K, C, generator=g) * 0.05, dtype)
+    b = torch.randn(K, generator=g)
+    y_ref = F.linear(x, w, b)
+    y = ca.ops.conv2d_fwd(x.view(B, 1, 1, C).to(dtype).to(dev), w.to(dtype).to(dev), b.to(dev), K, 1, 1, (1, 1),
+                          (0, 0), out_f32=True)
+    assert y.dtype == torch.float32
+    assert rel_l2(y.cpu().view(B, K), y_ref) < (1e-5 if dtype == torch.float32 else 2e-3)
+
+
+def _bn_ref(y, gamma, beta, res, relu, eps=1e-5, momentum=0.1):
+    y = y.clone().requires_grad_(True)
+    gamma = gamma.clone().requires_grad_(True)
+    beta = beta.clone().requires_grad_(True)
+    rm, rv = torch.zeros(y.shape[1]), torch.ones(y.shape[1])
+    z = F.batch_norm(y, rm, rv, gamma, beta, True, momentum, eps)
+    r = None
+    if res is not None:
+        r = res.clone().requires_grad_(True)
+        z = z + r
+    if relu:
+        z = F.relu(z)
+    return y, gamma, beta, r, z, rm, rv
+
+
+@pytest.mark.parametrize('mode', MODES)
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('relu,use_res', [(False, False), (True, False), (True, True)])
+def test_batchnorm_train_fwd_bwd(mode, dtype, relu, use_res):
+    dev = _dev(mode)
+    import convnet_amd as ca
+    shapes = [(4, 16, 5, 5), (2, 72, 3, 7)] if mode == 'emul' else [(8, 64, 56, 56), (4, 2048, 7, 7), (3, 136, 9, 5)]
+    for (N, C, H, W) in shapes:
+        g = torch.Generator().manual_seed(N + C)
+        y0 = _q(torch.randn(N, C, H, W, generator=g) * 2 + 0.5, dtype)
+        res0 = _q(torch.randn(N, C, H, W, generator=g), dtype) if use_res else None
+        gamma0, beta0 = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+        dz = _q(torch.randn(N, C, H, W, generator=g), dtype)
+        y, gamma, beta, r, z, rm, rv = _bn_ref(y0, gamma0, beta0, res0, relu)
+        z.backward(dz)
+
+        class Holder:   # minimal stand-in for nn.BatchNorm2d's attributes used by the Function
+            pass
+        bn = ca.nn.BatchNorm2d(C)
+        model = torch.nn.Sequential(bn)
+        ca.engine.prepare(model, dev, dtype)
+        bn.weight.data.copy_(gamma0.to(dev))
+        bn.bias.data.copy_(beta0.to(dev))
+        bn.train()
+        yh = _nhwc(y0, dtype, dev).requires_grad_(True)
+        rh = _nhwc(res0, dtype, dev).requires_grad_(True) if use_res else None
+        zh = bn(yh, residual=rh, relu=relu)
+        model._cn_arena.zero_grad()
+        zh.backward(_nhwc(dz, dtype, dev))
+        t = _tol(dtype)
+        assert rel_l2(zh.detach().float().cpu().permute(0, 3, 1, 2), z.detach()) < t
+        assert rel_l2(bn.running_mean.cpu(), rm) < 1e-4 and rel_l2(bn.running_var.cpu(), rv) < 1e-4
+        assert int(bn.num_batches_tracked) == 1
+        tg = _tol(dtype, True) if dtype == torch.float32 else 1.5e-2
+        assert rel_l2(yh.grad.float().cpu().permute(0, 3, 1, 2), y.grad) < tg
+        assert rel_l2(bn.weight.grad.cpu(), gamma.grad) < max(tg, 2e-4)
+        assert rel_l2(bn.bias.grad.cpu(), beta.grad) < max(tg, 2e-4)
+        if use_res:
+            assert rel_l2(rh.grad.float().cpu().permute(0, 3, 1, 2), r.grad) < tg
+        # inference path from the running statistics
+        bn.eval()
+        with torch.no_grad():
+            ze = bn(yh.detach(), residual=rh.detach() if use_res else None, relu=relu)
+        z_ref = F.batch_norm(y0, rm, rv, gamma0, beta0, False, 0.1, 1e-5)
+        if use_res:
+            z_ref = z_ref + res0
+        if relu:
+            z_ref = F.relu(z_ref)
+        assert rel_l2(ze.float().cpu().permute(0, 3, 1, 2), z_ref) < t
+
+
+@pytest.mark.parametrize('mode', MODES)
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_maxpool_fwd_bwd_with_ties(mode, dtype):
+    dev = _dev(mode)
+    import convnet_amd as ca
+    shapes = [(2, 8, 9, 9, 3, 2, 1), (1, 16, 8, 8, 2, 2, 0)] if mode == 'emul' else \
+        [(4, 64, 112, 112, 3, 2, 1), (2, 32, 26, 26, 2, 2, 0), (3, 8, 13, 13, 2, 2, 0)]
+    for (N, C, H, W, k, st, pad) in shapes:
+        g = torch.Generator().manual_seed(C)
+        x0 = F.relu(_q(torch.randn(N, C, H, W, generator=g), dtype))   # post-ReLU: many exact ties at 0
+        x = x0.clone().requires_grad_(True)
+        y = F.max_pool2d(x, k, st, pad)
+        dy = _q(torch.randn(y.shape, generator=g), dtype)
+        y.backward(dy)
+        xh = _nhwc(x0, dtype, dev).requires_grad_(True)
+        yh = ca.ops.MaxPool2dFunction.apply(xh, k, st, pad)
+        yh.backward(_nhwc(dy, dtype, dev))
+        assert torch.equal(yh.detach().float().cpu().permute(0, 3, 1, 2), y.detach())
+        assert rel_l2(xh.grad.float().cpu().permute(0, 3, 1, 2), x.grad) < (1e-6 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize('mode', MODES)
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_global_avgpool_and_fork_and_relu(mode, dtype):
+    dev = _dev(mode)
+    import convnet_amd as ca
+    N, C, H, W = (2, 16, 7, 7) if mode == 'emul' else (8, 2048, 7, 7)
+    g = torch.Generator().manual_seed(5)
+    x0 = _q(torch.randn(N, C, H, W, generator=g), dtype)
+    x = x0.clone().requires_grad_(True)
+    a, b = x, x
+    out = F.adaptive_avg_pool2d(F.relu(a), 1).flatten(1).sum() * 2 + (b * b).sum()
+    out.backward()
+    xh = _nhwc(x0, dtype, dev).requires_grad_(True)
+    xa, xb = ca.nn.fork(xh)
+    p = ca.ops.GlobalAvgPoolFunction.apply(ca.ops.ReLUFunction.apply(xa))
+    assert rel_l2(p.detach().float().cpu().view(N, C), F.adaptive_avg_pool2d(F.relu(x0), 1).flatten(1)) < _tol(dtype)
+    # hand the two branch gradients to autograd: d/dxa = relu'(x) * 2/(HW), d/dxb = 2x
+    gp = torch.full(p.shape, 2.0, dtype=dtype, device=dev)
+    torch.autograd.backward([p, xb], [gp, (2 * xh.detach().float()).to(dtype)])
+    assert rel_l2(xh.grad.float().cpu().permute(0, 3, 1, 2), x.grad) < (1e-5 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize('mode', MODES)
+@pytest.mark.parametrize('smooth', [0.0, 0.1])
+def test_softmax_cross_entropy_and_accuracy(mode, smooth):
+    dev = _dev(mode)
+    import convnet_amd as ca
+    from oracle import convnet_oracle as O
+    B, K = (8, 16) if mode == 'emul' else (256, 1000)
+    g = torch.Generator().manual_seed(9)
+    logits0 = torch.randn(B, K, generator=g) * 3
+    target = torch.randint(0, K, (B,), generator=g)
+    logits0[0, target[0]] = logits0[0].max() + 1   # at least one top-1 hit
+    lr = logits0.clone().requires_grad_(True)
+    loss_ref = O.oracle_cross_entropy(lr, target, smooth)
+    (loss_ref * 3.0).backward()
+    crit = ca.CrossEntropyLoss(smooth_eps=smooth)
+    meters = torch.zeros(8, device=dev)
+    crit.meters = meters
+    lh = logits0.to(dev).requires_grad_(True)
+    loss = crit(lh, target.to(dev))
+    (loss * 3.0).backward()
+    assert float(loss) == pytest.approx(float(loss_ref), rel=2e-6)
+    assert rel_l2(lh.grad.cpu(), lr.grad) < 1e-5
+    p1, p5 = O.oracle_accuracy(logits0, target, (1, 5))
+    m = meters.cpu().tolist()
+    assert m[3] == B and m[1] / B == pytest.approx(p1) and m[2] / B == pytest.approx(p5)
+    assert m[0] / B == pytest.approx(float(loss_ref), rel=2e-6)
+    a1, a5 = ca.accuracy(logits0.to(dev), target.to(dev), (1, 5))
+    assert float(a1) == pytest.approx(p1) and float(a5) == pytest.approx(p5)
+
+
+@pytest.mark.parametrize('mode', MODES)
+def test_sgd_momentum_weight_decay_clip(mode):
+    dev = _dev(mode)
+    import convnet_amd as ca
+    from convnet_amd._lib import check, load, ptr
+    n = 1000 + 3 if mode == 'emul' else 1_000_003   # odd tail exercised
+    g = torch.Generator().manual_seed(2)
+    p0, g0 = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.SGD([pr], lr=0.1, momentum=0.9)
+    npad = (n + 3) // 4 * 4
+    p = torch.zeros(npad, device=dev); p[:n] = p0.to(dev)
+    gr = torch.zeros(npad, device=dev)
+    buf = torch.zeros(npad, device=dev)
+    norm_out = torch.zeros(2, device=dev)
+    ws = torch.zeros(load().cn_grad_norm_workspace() // 4, device=dev)
+    for step in range(3):
+        gs = g0 * (step + 1)
+        pr.grad = (gs / 8.0).clone()                       # reference: p.grad.div_(loss_scale)
+        total = torch.nn.utils.clip_grad_norm_([pr], 5.0)   # then clip (trainer.py:171-172)
+        pr.grad.add_(pr.detach(), alpha=1e-4)               # WeightDecay regulariser, then SGD
+        opt.step()
+        gr[:n] = gs.to(dev)
+        check(load().cn_grad_norm_clip(ptr(gr), npad, 1.0 / 8.0, 5.0, ptr(norm_out), None, 0.0, ptr(ws), None
+                                       if dev.type == 'cpu' else torch.cuda.current_stream().cuda_stream))
+        check(load().cn_sgd_momentum(ptr(p), ptr(gr), ptr(buf), n, 0.1, 0.9, 1e-4, 1.0 / 8.0, ptr(norm_out[1:]),
+                                     None if dev.type == 'cpu' else torch.cuda.current_stream().cuda_stream))
+        assert float(norm_out[0]) == pytest.approx(float(total), rel=1e-5)
+        assert rel_l2(p[:n].cpu(), pr.detach()) < 1e-6
+
+
+@pytest.mark.parametrize('mode', MODES)
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_layout_conversion_roundtrip(mode, dtype):
+    dev = _dev(mode)
+    import convnet_amd as ca
+    N, C, H, W = (2, 3, 6, 5) if mode == 'emul' else (16, 3, 224, 224)
+    x = torch.randn(N, C, H, W)
+    xh = ca.ops.nchw_to_nhwc(x.to(dev), dtype)
+    cp = xh.shape[-1]
+    assert cp % (4 if dtype == torch.float32 else 8) == 0 and cp >= C
+    assert torch.equal(xh[..., :C].float().cpu(), x.permute(0, 2, 3, 1).to(dtype).float())
+    assert float(xh[..., C:].float().abs().sum()) == 0.0
+    back = ca.ops.nhwc_to_nchw(xh, C)
+    assert torch.equal(back.cpu(), x.to(dtype).float())

@@ -1,0 +1,24 @@
+#!/bin/bash
+# One gpurun call: environment facts, lane-map probes, GPU parity tests, bench line, rocprof summary.
+# Everything lands under gpurun_out/ (merged back by gpurun).
+export TMPDIR=/tmp
+OUT=gpurun_out/${1:-r1}
+mkdir -p $OUT
+{
+  echo "== env"; date
+  python -c "import torch;print('torch',torch.__version__,'devices',torch.cuda.device_count(),torch.cuda.get_device_name(0))"
+  /opt/rocm/bin/rocminfo | grep -E "Marketing Name|Compute Unit|Max Clock Freq|gfx" | head -12
+  nproc; grep -m1 "model name" /proc/cpuinfo; free -g | head -2
+} > $OUT/env.txt 2>&1
+echo "== probes" ; timeout 600 python -m pytest tests/test_gpu_probe.py -m gpu -q --tb=short 2>&1 | tail -30 | tee $OUT/probe.txt
+echo "== gpu tests"; timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider 2>&1 | tail -120 | tee $OUT/pytest_gpu.txt
+echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -15 | tee $OUT/smoke.txt
+echo "== bench"; timeout 900 python bench.py --steps ${BENCH_STEPS:-10} --warmup 3 2>&1 | tail -5 | tee $OUT/bench.txt
+echo "== rocprof"
+timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o r50 -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-profile > $OUT/rocprof.log 2>&1
+ls -R $OUT/prof | head -30
+STATS=$(find $OUT/prof -name "*kernel_stats.csv" | head -1)
+[ -n "$STATS" ] && head -40 "$STATS" | tee $OUT/kernel_stats_head.csv
+# keep only the small summaries (the raw trace can be large)
+find $OUT/prof -name "*kernel_trace.csv" -size +20M -delete
+echo "== done"; date
