@@ -133,8 +133,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import convnet_oracle as O
-        r = O.time_cpu_baseline(depth=args.depth, batch=32, steps=2, warmup=1, size=224,
-                                threads=os.cpu_count())
+        r = O.time_cpu_baseline(depth=args.depth, batch=32, steps=2, warmup=1, size=224)
         cpu = {'value': round(r['img_per_s'], 2), 'unit': 'images/sec', 'cores': r['cores'], 'kind': 'port',
                'sample': 'oracle ResNet-%d fp32 CPU training, batch 32, 1 warm-up + 2 timed steps '
                          '(%.2f s/step)' % (args.depth, r['s_per_step'])}

@@ -31,6 +31,7 @@ _SIGNATURES = {
     'cn_last_error': (ctypes.c_char_p, []),
     'cn_build_info': (ctypes.c_char_p, []),
     'cn_is_emulator': (c_i, []),
+    'cn_set_option': (c_i, [ctypes.c_char_p, c_i]),
     'cn_conv2d_fwd': (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 11 + [c_i, c_i, c_i, c_p]),
     'cn_conv2d_dgrad': (c_i, [c_p, c_p, c_p] + [c_i] * 11 + [c_i, c_i, c_p]),
     'cn_conv2d_wgrad_workspace': (c_sz, [c_i] * 12),

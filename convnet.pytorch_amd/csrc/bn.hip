@@ -63,11 +63,23 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const char* y, float* par
   for (int e = 0; e < CH; ++e) { s[e] = 0.f; q[e] = 0.f; }
   if (col < cpr) {
     const int step = gridDim.x * rpp;
-#pragma unroll 4
-    for (int row = blockIdx.x * rpp + rsub; row < M; row += step) {
-      u32x4 v = cn_ld16(y + ((size_t)row * C + (size_t)col * CH) * EB);
+    const size_t cb = (size_t)col * CH * EB, rb = (size_t)C * EB;
+    int row = blockIdx.x * rpp + rsub;
+    for (; row + 3 * step < M; row += 4 * step) {   // 4 independent 16-byte loads in flight per lane
+      u32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = cn_ld16(y + (size_t)(row + u * step) * rb + cb);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float f[CH];
+        Chunk<T>::unpack(v[u], f);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) { s[e] += f[e]; q[e] = fmaf(f[e], f[e], q[e]); }
+      }
+    }
+    for (; row < M; row += step) {
       float f[CH];
-      Chunk<T>::unpack(v, f);
+      Chunk<T>::unpack(cn_ld16(y + (size_t)row * rb + cb), f);
 #pragma unroll
       for (int e = 0; e < CH; ++e) { s[e] += f[e]; q[e] = fmaf(f[e], f[e], q[e]); }
     }
@@ -87,22 +99,55 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const char* y, float* par
   }
 }
 
-// One thread per channel: fixed-order sum of the partials, statistics, running-stat update and the
-// fused scale/shift the apply kernel consumes.
+// Fixed-order, latency-tolerant reduction of the per-workgroup partials: 32 channels per workgroup,
+// 8 threads per channel each summing every 8th partial with 4 independent loads in flight, then a
+// fixed-order LDS combine.  (A single thread walking all partials is a chain of dependent L2
+// round trips: measured 0.5 ms per launch at 2048 partials.)
+__device__ __forceinline__ void bn_sum_partials(const float* partial, int nrb, int C, int c, int part,
+                                                double* red /*[2][8][32]*/, double& s_out, double& q_out) {
+  double s = 0.0, q = 0.0;
+  if (c < C) {
+    int r = part;
+    for (; r + 24 < nrb; r += 32) {
+      const float a0 = partial[(size_t)r * 2 * C + c], b0 = partial[(size_t)r * 2 * C + C + c];
+      const float a1 = partial[(size_t)(r + 8) * 2 * C + c], b1 = partial[(size_t)(r + 8) * 2 * C + C + c];
+      const float a2 = partial[(size_t)(r + 16) * 2 * C + c], b2 = partial[(size_t)(r + 16) * 2 * C + C + c];
+      const float a3 = partial[(size_t)(r + 24) * 2 * C + c], b3 = partial[(size_t)(r + 24) * 2 * C + C + c];
+      s += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+      q += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+    }
+    for (; r < nrb; r += 8) {
+      s += (double)partial[(size_t)r * 2 * C + c];
+      q += (double)partial[(size_t)r * 2 * C + C + c];
+    }
+  }
+  const int lc = threadIdx.x & 31;
+  red[part * 32 + lc] = s;
+  red[256 + part * 32 + lc] = q;
+  __syncthreads();
+  s = 0.0;
+  q = 0.0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { s += red[k * 32 + lc]; q += red[256 + k * 32 + lc]; }
+  s_out = s;
+  q_out = q;
+}
+
+// 32 channels per workgroup: statistics, running-stat update and the fused scale/shift the apply
+// kernel consumes.
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* partial, int nrb, int M, int C,
                                                          const float* gamma, const float* beta,
                                                          float* running_mean, float* running_var,
                                                          long long* num_batches_tracked, float momentum,
                                                          float eps, float* save_mean, float* save_invstd,
                                                          float* scale, float* shift) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c == 0 && num_batches_tracked != nullptr) *num_batches_tracked += 1;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int r = 0; r < nrb; ++r) {
-    s += (double)partial[(size_t)r * 2 * C + c];
-    q += (double)partial[(size_t)r * 2 * C + C + c];
-  }
+  __shared__ double red[512];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int part = threadIdx.x >> 5;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked != nullptr) *num_batches_tracked += 1;
+  double s, q;
+  bn_sum_partials(partial, nrb, C, c, part, red, s, q);
+  if (c >= C || part != 0) return;
   const double mean = s / (double)M;
   double var = q / (double)M - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -248,13 +293,12 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* parti
                                                              const float* invstd, float* dgamma,
                                                              float* dbeta, float beta_acc, float gscale,
                                                              float* coef) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int r = 0; r < nrb; ++r) {
-    s1 += (double)partial[(size_t)r * 2 * C + c];
-    s2 += (double)partial[(size_t)r * 2 * C + C + c];
-  }
+  __shared__ double red[512];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int part = threadIdx.x >> 5;
+  double s1, s2;
+  bn_sum_partials(partial, nrb, C, c, part, red, s1, s2);
+  if (c >= C || part != 0) return;
   const float g = gamma != nullptr ? gamma[c] : 1.f;
   if (dgamma != nullptr) dgamma[c] = (beta_acc != 0.f ? beta_acc * dgamma[c] : 0.f) + (float)s2 * gscale;
   if (dbeta != nullptr) dbeta[c] = (beta_acc != 0.f ? beta_acc * dbeta[c] : 0.f) + (float)s1 * gscale;
@@ -315,7 +359,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char* dz, const
 // Inference-mode backward is not part of the reference hot path (validate() runs under no_grad).
 
 // ------------------------------------------------------------------------------------------------
-#define BN_TARGET_BLOCKS 2048
+#define BN_TARGET_BLOCKS 512   /* reduction kernels: partial rows per channel (kept small) */
+#define BN_APPLY_BLOCKS 2048   /* pure streaming kernels */
 
 extern "C" size_t cn_bn_workspace(int M, int C, int dtype) {
   const int CH = dtype == CN_BF16 ? 8 : 4;
@@ -357,10 +402,10 @@ extern "C" int cn_bn_fwd_train(const void* y, const void* residual, void* z, con
     CN_LAUNCH(bn_stats_kernel<bf16_t>, grid, dim3(256), stream, (const char*)y, partial, M, C, m.tpr_log2);
   else
     CN_LAUNCH(bn_stats_kernel<float>, grid, dim3(256), stream, (const char*)y, partial, M, C, m.tpr_log2);
-  CN_LAUNCH(bn_finalize_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), stream, (const float*)partial, nrb,
+  CN_LAUNCH(bn_finalize_kernel, dim3((unsigned)((C + 31) / 32)), dim3(256), stream, (const float*)partial, nrb,
             M, C, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, stats_out,
             stats_out + C, stats_out + 2 * C, stats_out + 3 * C);
-  int nab = bn_row_blocks(M, m, BN_TARGET_BLOCKS * 2);
+  int nab = bn_row_blocks(M, m, BN_APPLY_BLOCKS);
   dim3 agrid((unsigned)nab, (unsigned)m.gy);
   if (dtype == CN_BF16)
     CN_LAUNCH(bn_apply_kernel<bf16_t>, agrid, dim3(256), stream, (const char*)y, (const char*)residual,
@@ -383,7 +428,7 @@ extern "C" int cn_bn_fwd_infer(const void* y, const void* residual, void* z, con
   BnMap m = bn_map(C / CH);
   CN_LAUNCH(bn_infer_coeffs_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), stream, C, gamma, beta,
             running_mean, running_var, eps, coeffs, coeffs + C);
-  int nab = bn_row_blocks(M, m, BN_TARGET_BLOCKS * 2);
+  int nab = bn_row_blocks(M, m, BN_APPLY_BLOCKS);
   dim3 agrid((unsigned)nab, (unsigned)m.gy);
   if (dtype == CN_BF16)
     CN_LAUNCH(bn_apply_kernel<bf16_t>, agrid, dim3(256), stream, (const char*)y, (const char*)residual,
@@ -423,9 +468,9 @@ extern "C" int cn_bn_bwd(const void* dz, const void* y, const void* zmask, const
   else
     CN_LAUNCH(bn_bwd_reduce_kernel<float>, grid, dim3(256), stream, (const char*)dz, (const char*)y,
               (const char*)zmask, mean, invstd, scale, shift, partial, M, C, relu, m.tpr_log2);
-  CN_LAUNCH(bn_bwd_finalize_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), stream, (const float*)partial,
+  CN_LAUNCH(bn_bwd_finalize_kernel, dim3((unsigned)((C + 31) / 32)), dim3(256), stream, (const float*)partial,
             nrb, M, C, gamma, mean, invstd, dgamma, dbeta, beta_acc, gscale, coef_scratch);
-  int nab = bn_row_blocks(M, m, BN_TARGET_BLOCKS * 2);
+  int nab = bn_row_blocks(M, m, BN_APPLY_BLOCKS);
   dim3 agrid((unsigned)nab, (unsigned)m.gy);
   if (dtype == CN_BF16)
     CN_LAUNCH(bn_bwd_apply_kernel<bf16_t>, agrid, dim3(256), stream, (const char*)dz, (const char*)y,

@@ -27,6 +27,7 @@
 
 void cn_set_error(const char* fmt, ...);
 int cn_check_launch(const char* what);
+int cn_get_option(const char* name, int dflt);
 
 // ---------------------------------------------------------------- launch macro
 #ifdef CN_EMULATE

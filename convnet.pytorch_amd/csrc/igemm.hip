@@ -61,7 +61,11 @@ __device__ __forceinline__ int ig_slot(int row, int chunk) {
   return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
-template <typename T, int WC, int WP, int TI, int TJ>
+// STAGES = 2: double-buffered LDS staging (one barrier per K tile, 2 workgroups/CU at 128x128);
+// STAGES = 1: single staging buffer + register prefetch (two barriers per K tile, but half the LDS
+//             so 4 workgroups/CU hide the global-load latency of short reductions, e.g. 1x1 convs).
+// OUTF32 sizes the LDS output tile for fp32 results (fp32 compute or fp32 logits).
+template <typename T, int WC, int WP, int TI, int TJ, int STAGES, bool OUTF32>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   constexpr int BN = WC * TI * 32;  // output channels per block
   constexpr int BM = WP * TJ * 32;  // pixels per block
@@ -71,8 +75,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   constexpr int NPR = BM / 32;  // pixel rows staged per thread
   constexpr int NWR = BN / 32;  // filter rows staged per thread
   constexpr int STAGE = (BM + BN) * 128;
-  constexpr int OUT_MAX = BM * (BN * 4 + 16);
-  constexpr int MAIN = (2 * STAGE > OUT_MAX) ? 2 * STAGE : OUT_MAX;
+  constexpr int OUT_MAX = BM * (BN * (OUTF32 ? 4 : EB) + 16);
+  constexpr int MAIN = (STAGES * STAGE > OUT_MAX) ? STAGES * STAGE : OUT_MAX;
   constexpr int LDS_BYTES = MAIN + IG_MAX_TAPS * 8 + BM * 4;
   __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
   int* s_taps = (int*)(lds + MAIN);
@@ -199,16 +203,26 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     store_tile(0);
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
-      const int buf = kt & 1;
-      if (kt + 1 < nkt) load_tile(kt + 1);
-      compute(buf);
-      if (kt + 1 < nkt) store_tile(buf ^ 1);
-      __syncthreads();
+      if (STAGES == 2) {
+        const int buf = kt & 1;
+        if (kt + 1 < nkt) load_tile(kt + 1);
+        compute(buf);
+        if (kt + 1 < nkt) store_tile(buf ^ 1);
+        __syncthreads();
+      } else {
+        if (kt + 1 < nkt) load_tile(kt + 1);
+        compute(0);
+        __syncthreads();
+        if (kt + 1 < nkt) {
+          store_tile(0);
+          __syncthreads();
+        }
+      }
     }
   }
 
   // ---- epilogue: accumulators -> LDS out tile [BM pixels][BN channels] -> coalesced global store
-  const int OEB = p.out_f32 ? 4 : EB;
+  const int OEB = OUTF32 ? 4 : EB;
   const int pitch = BN * OEB + 16;
 #pragma unroll
   for (int a = 0; a < TI; ++a)
@@ -267,28 +281,29 @@ static int ig_log2_exact(int v) {
   return ((1 << s) == v) ? s : -1;
 }
 
-template <typename T>
+template <typename T, bool OUTF32>
 static int ig_launch(IgemmParams& p, hipStream_t stream) {
+  const int nkt = (p.nchunks + 7) / 8;
+  int stages = cn_get_option("igemm_stages", 0);
+  if (stages != 1 && stages != 2) stages = nkt <= 8 ? 1 : 2;   // short reductions want occupancy
+  const int BM = 128, BN = p.Co <= 64 ? 64 : 128;
+  p.n_ntiles = (p.Co + BN - 1) / BN;
+  const int n_mtiles = (p.M + BM - 1) / BM;
+  dim3 grid((unsigned)(p.n_ntiles * n_mtiles));
   if (p.Co <= 64) {
-    constexpr int BN = 64, BM = 128;
-    p.n_ntiles = (p.Co + BN - 1) / BN;
-    int n_mtiles = (p.M + BM - 1) / BM;
-    dim3 grid((unsigned)(p.n_ntiles * n_mtiles));
-    CN_LAUNCH((igemm_kernel<T, 1, 4, 2, 1>), grid, dim3(256), stream, p);
+    if (stages == 1) CN_LAUNCH((igemm_kernel<T, 1, 4, 2, 1, 1, OUTF32>), grid, dim3(256), stream, p);
+    else CN_LAUNCH((igemm_kernel<T, 1, 4, 2, 1, 2, OUTF32>), grid, dim3(256), stream, p);
   } else {
-    constexpr int BN = 128, BM = 128;
-    p.n_ntiles = (p.Co + BN - 1) / BN;
-    int n_mtiles = (p.M + BM - 1) / BM;
-    dim3 grid((unsigned)(p.n_ntiles * n_mtiles));
-    CN_LAUNCH((igemm_kernel<T, 2, 2, 2, 2>), grid, dim3(256), stream, p);
+    if (stages == 1) CN_LAUNCH((igemm_kernel<T, 2, 2, 2, 2, 1, OUTF32>), grid, dim3(256), stream, p);
+    else CN_LAUNCH((igemm_kernel<T, 2, 2, 2, 2, 2, OUTF32>), grid, dim3(256), stream, p);
   }
   return cn_check_launch("igemm");
 }
 
 static int ig_dispatch(IgemmParams& p, int dtype, hipStream_t stream) {
   if (p.M <= 0 || p.Co <= 0) return CN_OK;
-  if (dtype == CN_BF16) return ig_launch<bf16_t>(p, stream);
-  if (dtype == CN_F32) return ig_launch<float>(p, stream);
+  if (dtype == CN_BF16) return p.out_f32 ? ig_launch<bf16_t, true>(p, stream) : ig_launch<bf16_t, false>(p, stream);
+  if (dtype == CN_F32) { p.out_f32 = 1; return ig_launch<float, true>(p, stream); }
   cn_set_error("igemm: bad dtype %d", dtype);
   return CN_EINVAL;
 }

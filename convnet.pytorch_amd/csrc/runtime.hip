@@ -31,6 +31,26 @@ int cn_check_launch(const char* what) {
 
 extern "C" const char* cn_last_error(void) { return g_err; }
 
+// Tuning knobs (kernel variant selection for A/B measurements; never change results).
+#include <string.h>
+#define CN_MAX_OPTS 16
+static char g_opt_name[CN_MAX_OPTS][32];
+static int g_opt_val[CN_MAX_OPTS];
+static int g_nopts = 0;
+extern "C" int cn_set_option(const char* name, int value) {
+  for (int i = 0; i < g_nopts; ++i)
+    if (strcmp(g_opt_name[i], name) == 0) { g_opt_val[i] = value; return CN_OK; }
+  if (g_nopts >= CN_MAX_OPTS || strlen(name) >= 32) { cn_set_error("set_option: table full / name too long"); return CN_EINVAL; }
+  strcpy(g_opt_name[g_nopts], name);
+  g_opt_val[g_nopts++] = value;
+  return CN_OK;
+}
+int cn_get_option(const char* name, int dflt) {
+  for (int i = 0; i < g_nopts; ++i)
+    if (strcmp(g_opt_name[i], name) == 0) return g_opt_val[i];
+  return dflt;
+}
+
 extern "C" int cn_is_emulator(void) {
 #ifdef CN_EMULATE
   return 1;

@@ -200,9 +200,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, fl
     int c = (int)(idx % Creal);
     long long rest = idx / Creal;  // co*ntaps + t
     const float* src = part + rest * Ci + c;
-    float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += src[(long long)k * stride_split];
-    s *= scale;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // 8 loads in flight; summation order is fixed
+    int k = 0;
+    for (; k + 7 < nsplit; k += 8) {
+      const float v0 = src[(long long)(k + 0) * stride_split], v1 = src[(long long)(k + 1) * stride_split];
+      const float v2 = src[(long long)(k + 2) * stride_split], v3 = src[(long long)(k + 3) * stride_split];
+      const float v4 = src[(long long)(k + 4) * stride_split], v5 = src[(long long)(k + 5) * stride_split];
+      const float v6 = src[(long long)(k + 6) * stride_split], v7 = src[(long long)(k + 7) * stride_split];
+      s0 += v0 + v4; s1 += v1 + v5; s2 += v2 + v6; s3 += v3 + v7;
+    }
+    for (; k < nsplit; ++k) s0 += src[(long long)k * stride_split];
+    float s = ((s0 + s1) + (s2 + s3)) * scale;
     dw[idx] = beta != 0.f ? beta * dw[idx] + s : s;
   }
 }
@@ -222,7 +230,7 @@ static WgradPlan wg_plan(int M, int Co, int ntaps, int Ci, int dtype) {
   pl.n_jtiles = (pl.ncols + pl.BJ - 1) / pl.BJ;
   int tiles = pl.n_itiles * pl.n_jtiles;
   int stages = (M + pl.BKP - 1) / pl.BKP;
-  int want = (1024 + tiles - 1) / tiles;          // aim for ~4 workgroups per CU
+  int want = (768 + tiles - 1) / tiles;           // aim for ~3 workgroups per CU
   int max_split = (stages + 7) / 8;               // at least 8 stages per split
   if (max_split < 1) max_split = 1;
   int nsplit = want < max_split ? want : max_split;
@@ -290,7 +298,7 @@ extern "C" int cn_conv2d_wgrad(const void* x, const void* dy, float* dw_krsc, in
   if (rc) return rc;
   long long total = (long long)K * R * S * C_real;
   unsigned nb = (unsigned)((total + 255) / 256);
-  if (nb > 4096) nb = 4096;
+  if (nb > 8192) nb = 8192;
   CN_LAUNCH(wgrad_reduce_kernel, dim3(nb), dim3(256), (hipStream_t)stream, (const float*)workspace, dw_krsc,
             pl.nsplit, K, R * S, C, C_real, beta, scale);
   return cn_check_launch("wgrad_reduce");

@@ -36,6 +36,8 @@ extern "C" {
 const char* cn_last_error(void);
 const char* cn_build_info(void);
 int cn_is_emulator(void); /* 1 only in the TEST-ONLY CPU emulator build */
+/* kernel-variant tuning knobs for A/B measurement (e.g. "igemm_stages" = 1|2); results never change */
+int cn_set_option(const char* name, int value);
 
 /* ---- nn.Conv2d / nn.Linear (models/resnet.py:75-78,126-132,178-179,226-227,242) ------------- */
 /* y[N,P,Q,K] = conv(x[N,H,W,C], w[K,R,S,C]) (+bias[K]) (ReLU optional); out_f32 writes fp32

@@ -251,10 +251,23 @@ def synthetic_batches(n_batches, batch, size=224, classes=1000, seed=123, channe
              torch.randint(0, classes, (batch,), generator=g)) for _ in range(n_batches)]
 
 
+def usable_cpus():
+    """Cores this process may really use: affinity mask, capped by the cgroup CPU quota."""
+    import os
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = max(1, min(n, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return n
+
+
 def time_cpu_baseline(depth=50, batch=32, steps=2, warmup=1, size=224, threads=None):
     """Reported CPU baseline (kind='port'): this oracle's training step timed on the host cores."""
-    if threads:
-        torch.set_num_threads(threads)
+    threads = threads or min(usable_cpus(), 64)   # oneDNN stops scaling (and starts thrashing) far below 256
+    torch.set_num_threads(threads)
     torch.manual_seed(123)
     model = OracleResNet(depth)
     batches = synthetic_batches(warmup + steps, batch, size)

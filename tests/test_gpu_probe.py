@@ -40,7 +40,8 @@ def test_mfma_f32_lane_map(mode):
     A = torch.randint(-4, 5, (32, 2), generator=g).float()
     B = torch.randint(-4, 5, (2, 32), generator=g).float()
     D = torch.zeros(32, 32, device=dev)
-    ca._lib.check(ca._lib.load().cn_probe_mfma_f32(A.to(dev).data_ptr(), B.to(dev).data_ptr(), D.data_ptr(), stream))
+    Ad, Bd = A.to(dev), B.to(dev)   # keep the device copies alive across the launch
+    ca._lib.check(ca._lib.load().cn_probe_mfma_f32(Ad.data_ptr(), Bd.data_ptr(), D.data_ptr(), stream))
     assert torch.equal(D.cpu(), A @ B)
 
 

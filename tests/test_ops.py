@@ -296,7 +296,7 @@ def test_sgd_momentum_weight_decay_clip(mode):
                                        if dev.type == 'cpu' else torch.cuda.current_stream().cuda_stream))
         check(load().cn_sgd_momentum(ptr(p), ptr(gr), ptr(buf), n, 0.1, 0.9, 1e-4, 1.0 / 8.0, ptr(norm_out[1:]),
                                      None if dev.type == 'cpu' else torch.cuda.current_stream().cuda_stream))
-        assert float(norm_out[0]) == pytest.approx(float(total), rel=1e-5)
+        assert float(norm_out[0]) == pytest.approx(float(total), rel=1e-4)   # fp32 vs double summation
         assert rel_l2(p[:n].cpu(), pr.detach()) < 1e-6
 
 

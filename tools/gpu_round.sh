@@ -8,14 +8,16 @@ mkdir -p $OUT
   echo "== env"; date
   python -c "import torch;print('torch',torch.__version__,'devices',torch.cuda.device_count(),torch.cuda.get_device_name(0))"
   /opt/rocm/bin/rocminfo | grep -E "Marketing Name|Compute Unit|Max Clock Freq|gfx" | head -12
+  python -c "import sys;sys.path.insert(0,'.');from oracle.convnet_oracle import usable_cpus;print('usable cpus',usable_cpus())"; cat /sys/fs/cgroup/cpu.max
   nproc; grep -m1 "model name" /proc/cpuinfo; free -g | head -2
 } > $OUT/env.txt 2>&1
 echo "== probes" ; timeout 600 python -m pytest tests/test_gpu_probe.py -m gpu -q --tb=short 2>&1 | tail -30 | tee $OUT/probe.txt
 echo "== gpu tests"; timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider 2>&1 | tail -120 | tee $OUT/pytest_gpu.txt
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -15 | tee $OUT/smoke.txt
+echo "== layers"; timeout 600 python tools/bench_layers.py 2>&1 | tail -30 | tee $OUT/layers.txt
 echo "== bench"; timeout 900 python bench.py --steps ${BENCH_STEPS:-10} --warmup 3 2>&1 | tail -5 | tee $OUT/bench.txt
 echo "== rocprof"
-timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o r50 -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-profile > $OUT/rocprof.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o r50 -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-profile > $OUT/rocprof.log 2>&1
 ls -R $OUT/prof | head -30
 STATS=$(find $OUT/prof -name "*kernel_stats.csv" | head -1)
 [ -n "$STATS" ] && head -40 "$STATS" | tee $OUT/kernel_stats_head.csv
