@@ -1,0 +1,121 @@
+"""Host-logic tests that run without a GPU (kernel sources through the TEST-ONLY emulator):
+the main.py CLI surface + checkpoint round trip, and the data-parallel path on 2 gloo ranks
+against an oracle-side restatement of DistributedDataParallel semantics (per-rank BN statistics,
+gradients averaged over ranks, SURVEY.md section 8e / level T4)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import HAS_GPU
+from helpers import ROOT, rel_l2
+
+pytestmark = pytest.mark.skipif(HAS_GPU, reason='emulator-mode host tests')
+
+SMALL = "{'depth': 18, 'width': [8, 16, 32, 64], 'inplanes': 8, 'num_classes': 16}"
+
+
+def test_cli_train_checkpoint_resume(tmp_path):
+    import convnet_amd as ca
+    from convnet_amd.main import main
+    common = ['--model', 'resnet', '--model-config', SMALL, '--input-size', '32', '-b', '4',
+              '--steps-per-epoch', '2', '--val-steps', '1', '--results-dir', str(tmp_path), '--print-freq', '1']
+    out = main(common + ['--save', 'run', '--epochs', '1'])
+    run = tmp_path / 'run'
+    for f in ('config.json', 'log.txt', 'results.csv', 'checkpoint.pth.tar'):   # model_best only when prec1 improves
+        assert (run / f).exists(), f
+    ck = torch.load(run / 'checkpoint.pth.tar', map_location='cpu')
+    assert set(ck) == {'epoch', 'model', 'config', 'state_dict', 'optim_state_dict', 'best_prec1'}
+    assert ck['epoch'] == 1 and ck['model'] == 'resnet'
+    assert ck['state_dict']['conv1.weight'].shape == (8, 3, 7, 7)          # reference OIHW shape
+    assert ck['state_dict']['layer1.0.conv1.weight'].shape == (8, 8, 3, 3)
+    assert set(out['train']) >= {'step', 'data', 'loss', 'prec1', 'prec5', 'error1', 'error5'}
+    # the checkpoint loads into the ORACLE model (reference state_dict layout) and evaluates equally
+    from oracle import convnet_oracle as O
+    oracle = O.OracleResNet(18, 16, 8, (8, 16, 32, 64))
+    oracle.load_state_dict(ck['state_dict'])
+    val = main(common + ['--save', 'ev', '-e', str(run / 'checkpoint.pth.tar')])
+    from convnet_amd.main import SyntheticLoader
+    data = list(SyntheticLoader(1, 4, 32, 16, 3, 123 + 10000))
+    ref = O.oracle_validate(oracle, data)
+    assert val['loss'] == pytest.approx(ref['loss'], rel=1e-4) and val['prec1'] == ref['prec1']
+    # resume continues from the saved epoch with the optimizer state
+    out2 = main(common + ['--save', 'run2', '--epochs', '2', '--resume', str(run / 'checkpoint.pth.tar')])
+    ck2 = torch.load(tmp_path / 'run2' / 'checkpoint.pth.tar', map_location='cpu')
+    assert ck2['epoch'] == 2
+
+
+DP_WORKER = r'''
+import os, sys, json, torch, torch.distributed as dist
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, 'tests'))
+os.environ['CONVNET_AMD_EMULATE'] = '1'
+import convnet_amd as ca
+rank = int(os.environ['RANK'])
+dist.init_process_group('gloo', init_method='env://')
+torch.manual_seed(123 + 7 * rank)          # different initial weights per rank: the broadcast must fix that
+model = ca.models.resnet(depth=18, width=(8, 16, 32, 64), inplanes=8, num_classes=16)
+tr = ca.Trainer(model, ca.CrossEntropyLoss(), ca.OptimRegime(model, model.regime), device='cpu',
+                dtype=torch.float32, distributed=True, local_rank=rank, grad_clip=1e9, print_freq=10**9,
+                bucket_mb=0.05)
+g = torch.Generator().manual_seed(77)
+data = [(torch.randn(8, 3, 32, 32, generator=g), torch.randint(0, 16, (8,), generator=g)) for _ in range(2)]
+recs = []
+for x, t in data:
+    r = tr.train([(x[rank * 4:(rank + 1) * 4], t[rank * 4:(rank + 1) * 4])])
+    recs.append({k: float(r[k]) for k in ('loss', 'grad')})
+sd = {k: v.float().cpu() for k, v in model.state_dict().items() if v.dtype.is_floating_point}
+torch.save({'recs': recs, 'sd': sd, 'nbuckets': len(tr.arena.buckets)}, %(out)r %% rank)
+dist.destroy_process_group()
+'''
+
+
+def test_data_parallel_two_ranks_gloo(tmp_path):
+    script = tmp_path / 'dp_worker.py'
+    out_pat = str(tmp_path / 'rank%d.pt')
+    script.write_text(DP_WORKER % {'root': ROOT, 'out': out_pat})
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29531', WORLD_SIZE='2',
+               CONVNET_AMD_EMULATE='1', OMP_NUM_THREADS='2')
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)))
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=900) == 0
+    outs = [torch.load(out_pat % r) for r in range(2)]
+    assert outs[0]['nbuckets'] > 1, 'the tiny bucket size must exercise multi-bucket overlap'
+    # replicas stay bit-identical (same broadcast weights, same reduced gradients)
+    for k in outs[0]['sd']:
+        if 'running' in k or 'num_batches' in k:
+            continue
+        assert torch.equal(outs[0]['sd'][k], outs[1]['sd'][k]), k
+    # oracle-side DDP semantics: rank-0 initial weights everywhere, per-rank BN statistics,
+    # gradients averaged over the 2 ranks, one SGD step per iteration
+    from oracle import convnet_oracle as O
+    torch.manual_seed(123)
+    replicas = [O.OracleResNet(18, 16, 8, (8, 16, 32, 64)) for _ in range(2)]
+    replicas[1].load_state_dict(replicas[0].state_dict())
+    opts = [O.OracleSGD(m) for m in replicas]
+    g = torch.Generator().manual_seed(77)
+    data = [(torch.randn(8, 3, 32, 32, generator=g), torch.randint(0, 16, (8,), generator=g)) for _ in range(2)]
+    for step, (x, t) in enumerate(data):
+        losses = []
+        for r, m in enumerate(replicas):
+            m.train()
+            opts[r].zero_grad()
+            loss = O.oracle_cross_entropy(m(x[r * 4:(r + 1) * 4]), t[r * 4:(r + 1) * 4])
+            loss.backward()
+            losses.append(float(loss))
+        for p0, p1 in zip(replicas[0].parameters(), replicas[1].parameters()):
+            avg = (p0.grad + p1.grad) / 2
+            p0.grad.copy_(avg)
+            p1.grad.copy_(avg)
+        gnorm = torch.norm(torch.stack([p.grad.norm(2) for p in replicas[0].parameters()]), 2).item()
+        for o in opts:
+            o.step()
+        for r in range(2):
+            assert outs[r]['recs'][step]['loss'] == pytest.approx(losses[r], abs=1e-4)
+            assert outs[r]['recs'][step]['grad'] == pytest.approx(gnorm, rel=1e-3)
+    ref_sd = replicas[0].state_dict()
+    for k in ('conv1.weight', 'layer2.0.downsample.0.weight', 'fc.weight', 'layer4.1.bn2.bias'):
+        assert rel_l2(outs[0]['sd'][k], ref_sd[k]) < 1e-4, k
