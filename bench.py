@@ -56,11 +56,12 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    distributed = world > 1
+    distributed = world > 1 or os.environ.get('BENCH_FORCE_DIST') == '1'   # world-1 RCCL smoke test
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if distributed:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29517')
         dist.init_process_group(backend='nccl', init_method='env://', world_size=world, rank=rank)
     assert not ca._lib.is_emulated()
 

@@ -180,11 +180,14 @@ __global__ __launch_bounds__(256) void bn_infer_coeffs_kernel(int C, const float
   shift[c] = b - running_mean[c] * g * invstd;
 }
 
-// z = act(y*scale[c] + shift[c] (+ residual))
+// z = act(y*scale[c] + shift[c] (+ residual)).  When `mask` is given (ReLU after a residual add) one
+// byte per 16-byte chunk records which outputs were positive, so backward reads M*C/CH bytes instead
+// of re-reading z (the mask cannot be recomputed from y alone once a residual was added).
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const char* y, const char* res, char* z,
-                                                      const float* scale, const float* shift, int M, int C,
-                                                      int relu, int tpr_log2) {
+                                                      unsigned char* mask, const float* scale,
+                                                      const float* shift, int M, int C, int relu,
+                                                      int tpr_log2) {
   constexpr int CH = ElemTraits<T>::kChunk;
   constexpr int EB = ElemTraits<T>::kBytes;
   const int tid = threadIdx.x;
@@ -210,18 +213,23 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const char* y, const char
       for (int e = 0; e < CH; ++e) f[e] += r[e];
     }
     if (relu) {
+      unsigned int bits = 0;
 #pragma unroll
-      for (int e = 0; e < CH; ++e) f[e] = f[e] > 0.f ? f[e] : 0.f;
+      for (int e = 0; e < CH; ++e) {
+        bits |= (f[e] > 0.f ? 1u : 0u) << e;
+        f[e] = f[e] > 0.f ? f[e] : 0.f;
+      }
+      if (mask != nullptr) mask[(size_t)row * cpr + col] = (unsigned char)bits;
     }
     cn_st16(z + off, Chunk<T>::pack(f));
   }
 }
 
 // Per-channel sum(g) and sum(g * xhat), g = dz * relu_mask.
-//   mask source: zmask (the saved activation output, needed when a residual was added) or, when
-//   zmask == nullptr and relu != 0, recomputed from y*scale+shift > 0.
+//   mask source: the byte mask written by bn_apply (needed when a residual was added) or, when
+//   mask == nullptr and relu != 0, recomputed from y*scale+shift > 0.
 template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const char* dz, const char* y, const char* zmask,
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const char* dz, const char* y, const unsigned char* zmask,
                                                            const float* mean, const float* invstd,
                                                            const float* scale, const float* shift,
                                                            float* partial, int M, int C, int relu,
@@ -255,10 +263,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const char* dz, cons
       Chunk<T>::unpack(cn_ld16(y + off), v);
       if (relu) {
         if (zmask != nullptr) {
-          float zz[CH];
-          Chunk<T>::unpack(cn_ld16(zmask + off), zz);
+          const unsigned int bits = zmask[(size_t)row * cpr + col];
 #pragma unroll
-          for (int e = 0; e < CH; ++e) g[e] = zz[e] > 0.f ? g[e] : 0.f;
+          for (int e = 0; e < CH; ++e) g[e] = ((bits >> e) & 1u) ? g[e] : 0.f;
         } else {
 #pragma unroll
           for (int e = 0; e < CH; ++e) g[e] = fmaf(v[e], sc[e], sh[e]) > 0.f ? g[e] : 0.f;
@@ -310,7 +317,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* parti
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char* dz, const char* y, const char* zmask,
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char* dz, const char* y, const unsigned char* zmask,
                                                           const float* scale, const float* shift,
                                                           const float* coef, char* dy, char* dres, int M,
                                                           int C, int relu, int tpr_log2) {
@@ -339,10 +346,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char* dz, const
     Chunk<T>::unpack(cn_ld16(y + off), v);
     if (relu) {
       if (zmask != nullptr) {
-        float zz[CH];
-        Chunk<T>::unpack(cn_ld16(zmask + off), zz);
+        const unsigned int bits = zmask[(size_t)row * cpr + col];
 #pragma unroll
-        for (int e = 0; e < CH; ++e) g[e] = zz[e] > 0.f ? g[e] : 0.f;
+        for (int e = 0; e < CH; ++e) g[e] = ((bits >> e) & 1u) ? g[e] : 0.f;
       } else {
 #pragma unroll
         for (int e = 0; e < CH; ++e) g[e] = fmaf(v[e], sc[e], sh[e]) > 0.f ? g[e] : 0.f;
@@ -381,7 +387,8 @@ static int bn_check(const char* who, int M, int C, int dtype) {
 }
 
 // Training forward.  stats_out = [save_mean | save_invstd | scale | shift] (4*C floats).
-extern "C" int cn_bn_fwd_train(const void* y, const void* residual, void* z, const float* gamma,
+extern "C" int cn_bn_fwd_train(const void* y, const void* residual, void* z, unsigned char* relu_mask,
+                               const float* gamma,
                                const float* beta, float* running_mean, float* running_var,
                                long long* num_batches_tracked, float momentum, float eps, float* stats_out,
                                int M, int C, int relu, int dtype, void* workspace, size_t ws_bytes,
@@ -409,11 +416,12 @@ extern "C" int cn_bn_fwd_train(const void* y, const void* residual, void* z, con
   dim3 agrid((unsigned)nab, (unsigned)m.gy);
   if (dtype == CN_BF16)
     CN_LAUNCH(bn_apply_kernel<bf16_t>, agrid, dim3(256), stream, (const char*)y, (const char*)residual,
-              (char*)z, (const float*)(stats_out + 2 * C), (const float*)(stats_out + 3 * C), M, C, relu,
-              m.tpr_log2);
+              (char*)z, relu_mask, (const float*)(stats_out + 2 * C), (const float*)(stats_out + 3 * C), M, C,
+              relu, m.tpr_log2);
   else
     CN_LAUNCH(bn_apply_kernel<float>, agrid, dim3(256), stream, (const char*)y, (const char*)residual, (char*)z,
-              (const float*)(stats_out + 2 * C), (const float*)(stats_out + 3 * C), M, C, relu, m.tpr_log2);
+              relu_mask, (const float*)(stats_out + 2 * C), (const float*)(stats_out + 3 * C), M, C, relu,
+              m.tpr_log2);
   return cn_check_launch("bn_fwd_train");
 }
 
@@ -432,17 +440,18 @@ extern "C" int cn_bn_fwd_infer(const void* y, const void* residual, void* z, con
   dim3 agrid((unsigned)nab, (unsigned)m.gy);
   if (dtype == CN_BF16)
     CN_LAUNCH(bn_apply_kernel<bf16_t>, agrid, dim3(256), stream, (const char*)y, (const char*)residual,
-              (char*)z, (const float*)coeffs, (const float*)(coeffs + C), M, C, relu, m.tpr_log2);
+              (char*)z, (unsigned char*)nullptr, (const float*)coeffs, (const float*)(coeffs + C), M, C, relu,
+              m.tpr_log2);
   else
     CN_LAUNCH(bn_apply_kernel<float>, agrid, dim3(256), stream, (const char*)y, (const char*)residual, (char*)z,
-              (const float*)coeffs, (const float*)(coeffs + C), M, C, relu, m.tpr_log2);
+              (unsigned char*)nullptr, (const float*)coeffs, (const float*)(coeffs + C), M, C, relu, m.tpr_log2);
   return cn_check_launch("bn_fwd_infer");
 }
 
 // Training backward.  stats = the 4*C floats written by cn_bn_fwd_train; coef_scratch = 3*C floats.
 // dgamma/dbeta are written (beta_acc = 0) or accumulated (beta_acc = 1).  dres (optional) receives
 // the masked upstream gradient for the residual branch.
-extern "C" int cn_bn_bwd(const void* dz, const void* y, const void* zmask, const float* gamma,
+extern "C" int cn_bn_bwd(const void* dz, const void* y, const unsigned char* relu_mask, const float* gamma,
                          const float* stats, void* dy, void* dres, float* dgamma, float* dbeta,
                          float beta_acc, float gscale, float* coef_scratch, int M, int C, int relu, int dtype,
                          void* workspace, size_t ws_bytes, void* stream_) {
@@ -464,21 +473,21 @@ extern "C" int cn_bn_bwd(const void* dz, const void* y, const void* zmask, const
   dim3 grid((unsigned)nrb, (unsigned)m.gy);
   if (dtype == CN_BF16)
     CN_LAUNCH(bn_bwd_reduce_kernel<bf16_t>, grid, dim3(256), stream, (const char*)dz, (const char*)y,
-              (const char*)zmask, mean, invstd, scale, shift, partial, M, C, relu, m.tpr_log2);
+              relu_mask, mean, invstd, scale, shift, partial, M, C, relu, m.tpr_log2);
   else
     CN_LAUNCH(bn_bwd_reduce_kernel<float>, grid, dim3(256), stream, (const char*)dz, (const char*)y,
-              (const char*)zmask, mean, invstd, scale, shift, partial, M, C, relu, m.tpr_log2);
+              relu_mask, mean, invstd, scale, shift, partial, M, C, relu, m.tpr_log2);
   CN_LAUNCH(bn_bwd_finalize_kernel, dim3((unsigned)((C + 31) / 32)), dim3(256), stream, (const float*)partial,
             nrb, M, C, gamma, mean, invstd, dgamma, dbeta, beta_acc, gscale, coef_scratch);
   int nab = bn_row_blocks(M, m, BN_APPLY_BLOCKS);
   dim3 agrid((unsigned)nab, (unsigned)m.gy);
   if (dtype == CN_BF16)
     CN_LAUNCH(bn_bwd_apply_kernel<bf16_t>, agrid, dim3(256), stream, (const char*)dz, (const char*)y,
-              (const char*)zmask, scale, shift, (const float*)coef_scratch, (char*)dy, (char*)dres, M, C, relu,
+              relu_mask, scale, shift, (const float*)coef_scratch, (char*)dy, (char*)dres, M, C, relu,
               m.tpr_log2);
   else
     CN_LAUNCH(bn_bwd_apply_kernel<float>, agrid, dim3(256), stream, (const char*)dz, (const char*)y,
-              (const char*)zmask, scale, shift, (const float*)coef_scratch, (char*)dy, (char*)dres, M, C, relu,
+              relu_mask, scale, shift, (const float*)coef_scratch, (char*)dy, (char*)dres, M, C, relu,
               m.tpr_log2);
   return cn_check_launch("bn_bwd");
 }

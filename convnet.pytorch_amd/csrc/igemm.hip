@@ -26,6 +26,7 @@ struct IgemmParams {
   const char* x;
   const char* w;
   char* y;
+  const char* addend;   // optional tensor added to the output (same layout / dtype as y)
   const float* bias;
   int N, Hi, Wi, Ci;
   int Hg, Wg, a_h, a_w;
@@ -263,12 +264,39 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     if (c_first >= p.Co) continue;
     const char* src = lds + row * pitch + col * 16;
     char* dst = p.y + ((size_t)pix * (size_t)p.Co + (size_t)c_first) * OEB;
+    const size_t goff = ((size_t)pix * (size_t)p.Co + (size_t)c_first) * OEB;
     if (vec_ok && c_first + epc <= p.Co) {
-      cn_st16(dst, cn_ld16(src));
+      u32x4 v = cn_ld16(src);
+      if (p.addend != nullptr) {   // e.g. the residual-branch gradient folded into dgrad
+        const u32x4 a = cn_ld16(p.addend + goff);
+        if (OEB == 4) {
+          float fv[4], fa[4];
+          Chunk<float>::unpack(v, fv);
+          Chunk<float>::unpack(a, fa);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) fv[e] += fa[e];
+          v = Chunk<float>::pack(fv);
+        } else {
+          float fv[8], fa[8];
+          Chunk<bf16_t>::unpack(v, fv);
+          Chunk<bf16_t>::unpack(a, fa);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) fv[e] += fa[e];
+          v = Chunk<bf16_t>::pack(fv);
+        }
+      }
+      cn_st16(dst, v);
     } else {
       for (int e = 0; e < epc && c_first + e < p.Co; ++e) {
-        if (OEB == 4) ((float*)dst)[e] = ((const float*)src)[e];
-        else ((unsigned short*)dst)[e] = ((const unsigned short*)src)[e];
+        if (OEB == 4) {
+          float f = ((const float*)src)[e];
+          if (p.addend != nullptr) f += ((const float*)(p.addend + goff))[e];
+          ((float*)dst)[e] = f;
+        } else {
+          float f = cn_bf16_to_f32(((const unsigned short*)src)[e]);
+          if (p.addend != nullptr) f += cn_bf16_to_f32(((const unsigned short*)(p.addend + goff))[e]);
+          ((unsigned short*)dst)[e] = cn_f32_to_bf16(f);
+        }
       }
     }
   }
@@ -285,7 +313,7 @@ template <typename T, bool OUTF32>
 static int ig_launch(IgemmParams& p, hipStream_t stream) {
   const int nkt = (p.nchunks + 7) / 8;
   int stages = cn_get_option("igemm_stages", 0);
-  if (stages != 1 && stages != 2) stages = nkt <= 8 ? 1 : 2;   // short reductions want occupancy
+  if (stages != 1 && stages != 2) stages = nkt <= 24 ? 1 : 2;   // measured crossover (profiles/r01_conv_layers)
   const int BM = 128, BN = p.Co <= 64 ? 64 : 128;
   p.n_ntiles = (p.Co + BN - 1) / BN;
   const int n_mtiles = (p.M + BM - 1) / BM;
@@ -355,9 +383,9 @@ extern "C" int cn_conv2d_fwd(const void* x, const void* w_krsc, void* y, const f
   return ig_dispatch(p, dtype, (hipStream_t)stream);
 }
 
-extern "C" int cn_conv2d_dgrad(const void* dy, const void* w_crsk, void* dx, int N, int H, int W, int C,
-                               int K, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w,
-                               int dtype, int out_f32, void* stream) {
+extern "C" int cn_conv2d_dgrad(const void* dy, const void* w_crsk, void* dx, const void* addend, int N, int H,
+                               int W, int C, int K, int R, int S, int stride_h, int stride_w, int pad_h,
+                               int pad_w, int dtype, int out_f32, void* stream) {
   const int P = (H + 2 * pad_h - R) / stride_h + 1;
   const int Q = (W + 2 * pad_w - S) / stride_w + 1;
   if (P <= 0 || Q <= 0 || N <= 0) { cn_set_error("conv2d_dgrad: empty output"); return CN_ESHAPE; }
@@ -368,6 +396,7 @@ extern "C" int cn_conv2d_dgrad(const void* dy, const void* w_crsk, void* dx, int
       IgemmParams p;
       memset(&p, 0, sizeof(p));
       p.x = (const char*)dy; p.w = (const char*)w_crsk; p.y = (char*)dx; p.bias = nullptr;
+      p.addend = (const char*)addend;
       p.N = N; p.Hi = P; p.Wi = Q; p.Ci = K;
       p.Hg = (H - ph + stride_h - 1) / stride_h;
       p.Wg = (W - pw + stride_w - 1) / stride_w;

@@ -86,6 +86,31 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const float* w, T* krs
   }
 }
 
+// Multi-tensor form: every filter of the model in ONE launch.  desc rows (int64 x 8):
+//   [src_off (floats into the master arena), start (prefix sum of Co*taps*Cpad), krsc_off, crsk_off
+//    (element offsets into the compute-dtype weight buffer, crsk_off < 0: none), Co, taps, Creal, Cpad]
+template <typename T>
+__global__ __launch_bounds__(256) void weight_prep_multi_kernel(const float* master, T* wbuf, const long long* desc,
+                                                               int nd, long long total) {
+  for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
+    int lo = 0, hi = nd - 1;
+    while (lo < hi) {   // last descriptor with start <= id
+      const int mid = (lo + hi + 1) >> 1;
+      if (desc[(size_t)mid * 8 + 1] <= id) lo = mid; else hi = mid - 1;
+    }
+    const long long* d = desc + (size_t)lo * 8;
+    const long long local = id - d[1];
+    const int Co = (int)d[4], taps = (int)d[5], Creal = (int)d[6], Cpad = (int)d[7];
+    const int c = (int)(local % Cpad);
+    const long long rest = local / Cpad;
+    const int t = (int)(rest % taps);
+    const int co = (int)(rest / taps);
+    const float v = c < Creal ? master[d[0] + rest * Creal + c] : 0.f;
+    cn_store_elem<T>(wbuf + d[2] + local, v);
+    if (d[3] >= 0) cn_store_elem<T>(wbuf + d[3] + ((size_t)c * taps + t) * Co + co, v);
+  }
+}
+
 // out[c] (+)= sum_m x[m][c], x fp32 or bf16 row-major [M][C]; one thread per column, rows strided
 // over gridDim.y with a fixed-order second stage.
 template <typename T>
@@ -165,6 +190,19 @@ extern "C" int cn_weight_prep(const float* w_master, void* w_krsc, void* w_crsk,
               taps, Creal, Cpad);
   else { cn_set_error("weight_prep: bad dtype"); return CN_EINVAL; }
   return cn_check_launch("weight_prep");
+}
+
+extern "C" int cn_weight_prep_multi(const float* master, void* wbuf, const long long* desc, int nd, long long total,
+                                    int dtype, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (nd <= 0 || total <= 0) return CN_OK;
+  dim3 grid(opt_grid(total, 8192));
+  if (dtype == CN_BF16)
+    CN_LAUNCH(weight_prep_multi_kernel<bf16_t>, grid, dim3(256), stream, master, (bf16_t*)wbuf, desc, nd, total);
+  else if (dtype == CN_F32)
+    CN_LAUNCH(weight_prep_multi_kernel<float>, grid, dim3(256), stream, master, (float*)wbuf, desc, nd, total);
+  else { cn_set_error("weight_prep_multi: bad dtype"); return CN_EINVAL; }
+  return cn_check_launch("weight_prep_multi");
 }
 
 #define CN_COLSUM_PARTS 64

@@ -96,6 +96,57 @@ class ParamArena(object):
             self._module_slots.setdefault(id(s.module), []).append(s)
         self.version = 0          # bumped whenever master weights change (optimizer step / load)
         self.reducer = None
+        self.wbuf = None          # compute-dtype filter copies of every conv / linear (one buffer)
+        self._wdesc = None
+        self._wtotal = 0
+        self._wversion = -1
+
+    # -- compute-dtype filter copies ------------------------------------------------------
+    def build_weight_plan(self, dtype):
+        """Lay out the KRSC (+ CRSK for layers that need dgrad) compute-dtype copies of all filters in
+        one buffer and build the device descriptor table of cn_weight_prep_multi."""
+        from . import nn as cnn
+        rows, off, start = [], 0, 0
+        mods = []
+        for s in self.slots:
+            mod = s.module
+            if not s.is_filter or not isinstance(mod, (cnn.Conv2d, cnn.Linear)):
+                continue
+            taps = mod.kernel_size[0] * mod.kernel_size[1]
+            co, creal = mod.out_channels, mod.in_channels
+            ch = 4 if dtype == torch.float32 else 8
+            cpad = _round_up(creal, ch) if isinstance(mod, cnn.Conv2d) else creal
+            n = co * taps * cpad
+            krsc_off = off
+            off += _round_up(n, _ALIGN)
+            want_crsk = isinstance(mod, cnn.Linear) or (getattr(mod, 'needs_dgrad', True) and cpad == creal)
+            crsk_off = -1
+            if want_crsk:
+                crsk_off = off
+                off += _round_up(n, _ALIGN)
+            rows.append([s.offset, start, krsc_off, crsk_off, co, taps, creal, cpad])
+            start += n
+            mods.append((mod, krsc_off, crsk_off, n))
+        self.wbuf = torch.zeros(max(off, _ALIGN), dtype=dtype, device=self.device)
+        self._wdesc = torch.tensor(rows, dtype=torch.int64, device=self.device) if rows else None
+        self._wtotal = start
+        self._wversion = -1
+        for mod, krsc_off, crsk_off, n in mods:
+            mod.w_krsc = self.wbuf[krsc_off:krsc_off + n]
+            mod.w_crsk = self.wbuf[crsk_off:crsk_off + n] if crsk_off >= 0 else None
+
+    def prepare_weights(self):
+        if self._wversion == self.version or self._wdesc is None:
+            return
+        from . import _lib
+        L = _lib.load()
+        ops.PROFILER.run('weight_prep', 1, 0.0, 8.0 * self._wtotal,
+                         lambda: _lib.check(L.cn_weight_prep_multi(self.params.data_ptr(), self.wbuf.data_ptr(),
+                                                                   self._wdesc.data_ptr(), self._wdesc.shape[0],
+                                                                   self._wtotal, _lib.dtype_code(self.wbuf.dtype),
+                                                                   _lib.stream_of(self.params)),
+                                            'cn_weight_prep_multi'), self.device)
+        self._wversion = self.version
 
     # -- gradient lifecycle ---------------------------------------------------------------
     def zero_grad(self):
@@ -174,6 +225,9 @@ def prepare(model, device, dtype=torch.float32, bucket_mb=25.0):
     for mod in model.modules():
         if hasattr(mod, '_set_compute_dtype'):
             mod._set_compute_dtype(dtype)
+    arena.build_weight_plan(dtype)
+    # masters change behind our back when a checkpoint is loaded: refresh the compute copies
+    model.register_load_state_dict_post_hook(lambda module, incompatible: arena.bump_version())
     model._cn_arena = arena
     model._cn_dtype = dtype
     return arena

@@ -74,12 +74,18 @@ class ResidualBlock(tnn.Module):
             self.dropout = cnn.Dropout(0)
         self.stride = stride
         self.expansion = expansion
+        self._holder = None
+        if downsample is None:   # identity block: fold the residual gradient into conv1's dgrad epilogue
+            from ..ops import ResGradHolder
+            self._holder = ResGradHolder()
+            self.conv1._res_holder = self._holder
+            self.last_bn()._res_holder = self._holder
 
     def last_bn(self):
         return getattr(self, 'bn%d' % self.n_convs)
 
     def forward(self, x):
-        xa, xb = cnn.fork(x)
+        xa, xb = cnn.fork(x, self._holder)
         out = xa
         for i in range(1, self.n_convs):
             out = getattr(self, 'conv%d' % i)(out)

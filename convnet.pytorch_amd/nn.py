@@ -90,22 +90,10 @@ class Conv2d(_ArenaModule):
         return (self.in_channels + ch - 1) // ch * ch
 
     def ensure_prepared(self):
-        """(Re)build the compute-dtype filter copies when the fp32 master changed."""
+        """Compute-dtype filter copies (KRSC + CRSK) are refreshed for the whole model in one launch
+        whenever the fp32 masters changed (engine.ParamArena.prepare_weights)."""
         self._require_prepared()
-        if self._prep_version == self._arena.version and self.w_krsc is not None \
-                and self.w_krsc.dtype == self.compute_dtype:
-            return
-        taps = self.kernel_size[0] * self.kernel_size[1]
-        cpad = self.padded_in_channels()
-        dev = self._arena.device
-        if self.w_krsc is None or self.w_krsc.dtype != self.compute_dtype:
-            self.w_krsc = torch.empty(self.out_channels * taps * cpad, dtype=self.compute_dtype, device=dev)
-            self.w_crsk = None
-            if self.needs_dgrad and cpad == self.in_channels:
-                self.w_crsk = torch.empty(self.out_channels * taps * cpad, dtype=self.compute_dtype, device=dev)
-        ops.weight_prep(self.master_view('weight'), self.w_krsc, self.w_crsk, self.out_channels, taps,
-                        self.in_channels, cpad)
-        self._prep_version = self._arena.version
+        self._arena.prepare_weights()
 
     def forward(self, x):
         self._require_prepared()
@@ -147,17 +135,7 @@ class Linear(_ArenaModule):
 
     def ensure_prepared(self):
         self._require_prepared()
-        if self._prep_version == self._arena.version and self.w_krsc is not None \
-                and self.w_krsc.dtype == self.compute_dtype:
-            return
-        dev = self._arena.device
-        n = self.out_features * self.in_features
-        if self.w_krsc is None or self.w_krsc.dtype != self.compute_dtype:
-            self.w_krsc = torch.empty(n, dtype=self.compute_dtype, device=dev)
-            self.w_crsk = torch.empty(n, dtype=self.compute_dtype, device=dev)
-        ops.weight_prep(self.master_view('weight'), self.w_krsc, self.w_crsk, self.out_features, 1,
-                        self.in_features, self.in_features)
-        self._prep_version = self._arena.version
+        self._arena.prepare_weights()
 
     def forward(self, x):
         self._require_prepared()
@@ -256,10 +234,11 @@ class Dropout(tnn.Module):
         raise NotImplementedError('HIP Dropout with p > 0 is outside the ResNet hot path')
 
 
-def fork(x):
-    """Duplicate an activation for two consumers; gradients are summed by our kernel."""
+def fork(x, holder=None):
+    """Duplicate an activation for two consumers; gradients are summed by our kernel (or, with a
+    ResGradHolder, inside the conv-branch dgrad epilogue)."""
     if torch.is_grad_enabled() and x.requires_grad:
-        return ops.ForkFunction.apply(x)
+        return ops.ForkFunction.apply(x, holder)
     return x, x
 
 

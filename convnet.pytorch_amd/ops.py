@@ -99,13 +99,14 @@ def conv2d_fwd(x, w_krsc, bias, K, R, S, stride, pad, out_f32=False, relu=False)
     return y
 
 
-def conv2d_dgrad(dy, w_crsk, x_shape, K, R, S, stride, pad):
+def conv2d_dgrad(dy, w_crsk, x_shape, K, R, S, stride, pad, addend=None):
     N, H, W, C = x_shape
     dx = torch.empty((N, H, W, C), dtype=dy.dtype, device=dy.device)
     PROFILER.run('igemm_dgrad_%s_%s' % ('bn64' if C <= 64 else 'bn128', 'bf16' if dy.dtype == torch.bfloat16 else 'f32'),
                  stride[0] * stride[1], 2.0 * dy.numel() * C * R * S,
-                 dy.numel() * _esize(dy) + dx.numel() * _esize(dx) + K * R * S * C * _esize(dy),
-                 lambda: check(_L().cn_conv2d_dgrad(ptr(dy), ptr(w_crsk), ptr(dx), N, H, W, C, K, R, S, stride[0],
+                 dy.numel() * _esize(dy) + dx.numel() * _esize(dx) * (2 if addend is not None else 1)
+                 + K * R * S * C * _esize(dy),
+                 lambda: check(_L().cn_conv2d_dgrad(ptr(dy), ptr(w_crsk), ptr(dx), ptr(addend), N, H, W, C, K, R, S, stride[0],
                                                     stride[1], pad[0], pad[1], dtype_code(dy.dtype), 0,
                                                     stream_of(dy)), 'cn_conv2d_dgrad'),
                  dy.device)
@@ -218,7 +219,13 @@ class Conv2dFunction(Function):
         mod._notify_grad_ready()
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = conv2d_dgrad(dy, mod.w_crsk, x.shape, mod.out_channels, R, S, mod.stride, mod.padding)
+            addend = None
+            holder = getattr(mod, '_res_holder', None)
+            if holder is not None and holder.dres is not None and holder.dres.shape == x.shape:
+                addend = holder.dres          # residual-branch gradient folded into the dgrad epilogue
+                holder.fused = True
+            dx = conv2d_dgrad(dy, mod.w_crsk, x.shape, mod.out_channels, R, S, mod.stride, mod.padding,
+                              addend=addend)
         return dx, None, None, None
 
 
@@ -234,11 +241,14 @@ class BatchNormActFunction(Function):
         ws = workspace(L.cn_bn_workspace(M, C, code), y.device)
         z = torch.empty_like(y)
         stats = torch.empty(4 * C, dtype=torch.float32, device=y.device)
+        mask = None
+        if relu and residual is not None:   # 1 bit per output instead of re-reading z in backward
+            mask = torch.empty(M * (C // _lib.chunk_elems(y.dtype)), dtype=torch.uint8, device=y.device)
         momentum = mod.effective_momentum()
         track = mod.track_running_stats
         nb = y.numel() * _esize(y)
-        PROFILER.run('bn_fwd_train', 3, 0.0, nb * (4 if residual is not None else 3),
-                     lambda: check(L.cn_bn_fwd_train(ptr(y), ptr(residual), ptr(z), ptr(gamma), ptr(beta),
+        PROFILER.run('bn_fwd_train', 3, 0.0, nb * (4 if residual is not None else 3) + (mask.numel() if mask is not None else 0),
+                     lambda: check(L.cn_bn_fwd_train(ptr(y), ptr(residual), ptr(z), ptr(mask), ptr(gamma), ptr(beta),
                                                      ptr(mod.running_mean) if track else None,
                                                      ptr(mod.running_var) if track else None,
                                                      ptr(mod.num_batches_tracked) if track else None,
@@ -248,8 +258,8 @@ class BatchNormActFunction(Function):
         ctx.mod = mod
         ctx.relu = relu
         ctx.has_res = residual is not None
-        if relu and residual is not None:
-            ctx.save_for_backward(y, stats, z)
+        if mask is not None:
+            ctx.save_for_backward(y, stats, mask)
         else:
             ctx.save_for_backward(y, stats)
         return z
@@ -271,13 +281,17 @@ class BatchNormActFunction(Function):
         dres = torch.empty_like(y) if want_res else None
         coef = torch.empty(3 * C, dtype=torch.float32, device=y.device)
         nb = y.numel() * _esize(y)
-        PROFILER.run('bn_bwd', 3, 0.0, nb * (5 + (2 if zmask is not None else 0) + (1 if dres is not None else 0)),
+        PROFILER.run('bn_bwd', 3, 0.0, nb * (5 + (1 if dres is not None else 0)) + (2 * zmask.numel() if zmask is not None else 0),
                      lambda: check(L.cn_bn_bwd(ptr(dz), ptr(y), ptr(zmask), ptr(mod.weight), ptr(stats), ptr(dy),
                                                ptr(dres), ptr(mod.grad_view('weight')), ptr(mod.grad_view('bias')),
                                                1.0, 1.0, ptr(coef), M, C, int(ctx.relu), code, ptr(ws),
                                                ws.numel() * 4, stream_of(y)), 'cn_bn_bwd'),
                      y.device)
         mod._notify_grad_ready()
+        holder = getattr(mod, '_res_holder', None)
+        if holder is not None:
+            holder.dres = dres
+            holder.fused = False
         return dy, None, None, dres, None, None
 
 
@@ -362,17 +376,31 @@ class ForkFunction(Function):
     the two incoming gradients with our own kernel, so autograd never launches its accumulate."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, holder=None):
+        ctx.holder = holder
         return x.view_as(x), x.view_as(x)
 
     @staticmethod
     def backward(ctx, ga, gb):
+        holder = ctx.holder
+        fused = holder is not None and holder.fused
+        if holder is not None:
+            holder.dres, holder.fused = None, False
         if ga is None:
-            return gb
-        if gb is None:
-            return ga
+            return gb, None
+        if gb is None or fused:      # the conv-branch dgrad already added the residual-branch gradient
+            return ga, None
         ga = ga.contiguous()
-        return add_(ga, gb.contiguous())
+        return add_(ga, gb.contiguous()), None
+
+
+class ResGradHolder(object):
+    """Per-block mailbox: the last BN's backward leaves the residual-branch gradient here so that the
+    first conv's dgrad can add it in its epilogue (one pass instead of a separate add kernel)."""
+    __slots__ = ('dres', 'fused')
+
+    def __init__(self):
+        self.dres, self.fused = None, False
 
 
 class SoftmaxCrossEntropyFunction(Function):

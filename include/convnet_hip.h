@@ -47,9 +47,10 @@ int cn_conv2d_fwd(const void* x, const void* w_krsc, void* y, const float* bias,
                   int out_f32, int relu, void* stream);
 /* dx[N,H,W,C] from dy[N,P,Q,K] and the transposed filter w_crsk[C][R][S][K]
  * (written by cn_weight_prep).  Strided convs run one launch per output-parity class. */
-int cn_conv2d_dgrad(const void* dy, const void* w_crsk, void* dx, int N, int H, int W, int C, int K, int R,
-                    int S, int stride_h, int stride_w, int pad_h, int pad_w, int dtype, int out_f32,
-                    void* stream);
+int cn_conv2d_dgrad(const void* dy, const void* w_crsk, void* dx, const void* addend /*optional: dx += addend,
+                    the residual-branch gradient of models/resnet.py:162 folded into the epilogue*/, int N, int H,
+                    int W, int C, int K, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w,
+                    int dtype, int out_f32, void* stream);
 /* dw[K,R,S,C_real] (fp32) = beta*dw + scale * sum_pixels dy (x) x ; split reduction through
  * `workspace` (cn_conv2d_wgrad_workspace bytes), fixed summation order. */
 size_t cn_conv2d_wgrad_workspace(int N, int H, int W, int C, int K, int R, int S, int stride_h, int stride_w,
@@ -61,16 +62,19 @@ int cn_conv2d_wgrad(const void* x, const void* dy, float* dw_krsc, int C_real, i
 /* ---- nn.BatchNorm2d (+ fused residual add + ReLU) (models/resnet.py:128-134,141-165) -------- */
 size_t cn_bn_workspace(int M, int C, int dtype);
 /* stats_out: 4*C floats = [batch mean | 1/sqrt(var+eps) | scale | shift]; M = N*H*W rows. */
-int cn_bn_fwd_train(const void* y, const void* residual, void* z, const float* gamma, const float* beta,
+/* relu_mask (optional, M*C/chunk bytes): one bit per output recording z > 0, written when a residual is
+ * added before the ReLU so that backward need not re-read z. */
+int cn_bn_fwd_train(const void* y, const void* residual, void* z, unsigned char* relu_mask, const float* gamma,
+                    const float* beta,
                     float* running_mean, float* running_var, long long* num_batches_tracked, float momentum,
                     float eps, float* stats_out, int M, int C, int relu, int dtype, void* workspace,
                     size_t ws_bytes, void* stream);
 int cn_bn_fwd_infer(const void* y, const void* residual, void* z, const float* gamma, const float* beta,
                     const float* running_mean, const float* running_var, float eps, float* coeffs /*2C*/,
                     int M, int C, int relu, int dtype, void* stream);
-/* zmask: saved block output (needed when a residual was added), NULL => ReLU mask recomputed from
- * y.  dres (optional) receives the masked upstream gradient for the residual branch. */
-int cn_bn_bwd(const void* dz, const void* y, const void* zmask, const float* gamma, const float* stats,
+/* relu_mask: the byte mask of cn_bn_fwd_train (needed when a residual was added), NULL => ReLU mask
+ * recomputed from y.  dres (optional) receives the masked upstream gradient for the residual branch. */
+int cn_bn_bwd(const void* dz, const void* y, const unsigned char* relu_mask, const float* gamma, const float* stats,
               void* dy, void* dres, float* dgamma, float* dbeta, float beta_acc, float gscale,
               float* coef_scratch /*3C*/, int M, int C, int relu, int dtype, void* workspace,
               size_t ws_bytes, void* stream);
@@ -109,6 +113,10 @@ int cn_grad_norm_clip(const float* g, long long n, float gscale, float max_norm,
                       float meter_weight, float* workspace, void* stream);
 int cn_weight_prep(const float* w_master_krsc, void* w_krsc, void* w_crsk /*optional*/, int Co, int taps,
                    int Creal, int Cpad, int dtype, void* stream);
+/* all filters of a model in one launch; desc = int64[nd][8] on the device:
+ * {src_off, start, krsc_off, crsk_off (<0: none), Co, taps, Creal, Cpad} */
+int cn_weight_prep_multi(const float* master_arena, void* wbuf, const long long* desc, int nd, long long total,
+                         int dtype, void* stream);
 size_t cn_colsum_workspace(int C);
 int cn_colsum(const void* x, float* out, int M, int C, int dtype, float beta, float scale, float* workspace,
               void* stream);
