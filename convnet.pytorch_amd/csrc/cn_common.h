@@ -247,6 +247,31 @@ static inline int cn_shfl_xor_i(int v, int mask) {
 }
 #endif
 
+// ---------------------------------------------------------------- bounds-checked buffer loads
+// A raw buffer descriptor over [p, p+nbytes): 16-byte loads at a 32-bit byte offset return zeros
+// when the offset is out of range, which gives the im2col zero padding / tile tails for free
+// (offset CN_OOB = "invalid") and keeps all address arithmetic in 32 bits.
+#define CN_OOB 0x80000000u
+#ifndef CN_EMULATE
+typedef __amdgpu_buffer_rsrc_t cn_buf_t;
+__device__ __forceinline__ cn_buf_t cn_make_buf(const void* p, unsigned int nbytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)nbytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4 cn_buf_ld16(cn_buf_t b, unsigned int off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(b, (int)off, 0, 0);
+}
+#else
+struct cn_buf_t { const char* p; unsigned int n; };
+static inline cn_buf_t cn_make_buf(const void* p, unsigned int nbytes) {
+  cn_buf_t b; b.p = (const char*)p; b.n = nbytes; return b;
+}
+static inline u32x4 cn_buf_ld16(cn_buf_t b, unsigned int off) {
+  u32x4 z = {0u, 0u, 0u, 0u};
+  if ((unsigned long long)off + 16ull <= (unsigned long long)b.n) return *(const u32x4*)(b.p + off);
+  return z;
+}
+#endif
+
 // 16-byte global / LDS accessors
 __host__ __device__ __forceinline__ u32x4 cn_ld16(const void* p) { return *(const u32x4*)p; }
 __host__ __device__ __forceinline__ void cn_st16(void* p, const u32x4& v) { *(u32x4*)p = v; }

@@ -36,6 +36,8 @@ struct IgemmParams {
   long long w_row;
   int out_f32, relu;
   int M, n_ntiles;
+  unsigned int x_bytes, w_bytes;   // extents of the gather source / filter tensors (buffer descriptors)
+  int simple;                      // 1: no tap of a valid row ever leaves the image (skip bounds tests)
   FastDiv div_hw, div_w, div_cpt;
   int tap_dhdw[IG_MAX_TAPS];
   int tap_woff[IG_MAX_TAPS];
@@ -66,22 +68,26 @@ __device__ __forceinline__ int ig_slot(int row, int chunk) {
 // STAGES = 1: single staging buffer + register prefetch (two barriers per K tile, but half the LDS
 //             so 4 workgroups/CU hide the global-load latency of short reductions, e.g. 1x1 convs).
 // OUTF32 sizes the LDS output tile for fp32 results (fp32 compute or fp32 logits).
+//
+// The reduction loop is kept lean in VALU work (a first version spent 23 VALU instructions per MFMA
+// on 64-bit im2col address math, see profiles/r01_pmc_*): operands come in through bounds-checked
+// buffer loads (zero fill = offset CN_OOB), every row's byte offset is computed once, a tap only
+// adds a per-tap byte delta read from an LDS table, and all LDS addresses are loop invariant.
 template <typename T, int WC, int WP, int TI, int TJ, int STAGES, bool OUTF32>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   constexpr int BN = WC * TI * 32;  // output channels per block
   constexpr int BM = WP * TJ * 32;  // pixels per block
   static_assert(WC * WP == 4, "4 waves");
   constexpr int EB = ElemTraits<T>::kBytes;
-  constexpr int CH = ElemTraits<T>::kChunk;
   constexpr int NPR = BM / 32;  // pixel rows staged per thread
   constexpr int NWR = BN / 32;  // filter rows staged per thread
   constexpr int STAGE = (BM + BN) * 128;
   constexpr int OUT_MAX = BM * (BN * (OUTF32 ? 4 : EB) + 16);
   constexpr int MAIN = (STAGES * STAGE > OUT_MAX) ? STAGES * STAGE : OUT_MAX;
-  constexpr int LDS_BYTES = MAIN + IG_MAX_TAPS * 8 + BM * 4;
+  constexpr int LDS_BYTES = MAIN + IG_MAX_TAPS * 16 + BM * 4;
   __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
-  int* s_taps = (int*)(lds + MAIN);
-  int* s_outpix = (int*)(lds + MAIN + IG_MAX_TAPS * 8);
+  int* s_taps = (int*)(lds + MAIN);                       // per tap: {dhdw, woff bytes, x delta bytes, 0}
+  int* s_outpix = (int*)(lds + MAIN + IG_MAX_TAPS * 16);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -94,9 +100,18 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   const int HgWg = p.Hg * p.Wg;
 
   if (tid < IG_MAX_TAPS) {
-    int t = tid < p.ntaps ? tid : 0;
-    s_taps[2 * tid] = p.ntaps > 0 ? p.tap_dhdw[t] : 0;
-    s_taps[2 * tid + 1] = p.ntaps > 0 ? p.tap_woff[t] : 0;
+    const int t = tid < p.ntaps ? tid : 0;
+    int dhdw = 0, woffb = 0, delta = 0;
+    if (p.ntaps > 0) {
+      dhdw = p.tap_dhdw[t];
+      woffb = p.tap_woff[t] * EB;
+      const int dh = (int)(short)(dhdw & 0xffff), dw = dhdw >> 16;
+      delta = (dh * p.Wi + dw) * p.Ci * EB;
+    }
+    s_taps[4 * tid] = dhdw;
+    s_taps[4 * tid + 1] = woffb;
+    s_taps[4 * tid + 2] = delta;
+    s_taps[4 * tid + 3] = 0;
   }
   if (tid < BM) {
     int m = m0 + tid;
@@ -114,21 +129,39 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   // per-thread staging coordinates (fixed for the whole reduction loop)
   const int cc = tid & 7;
   const int r0 = tid >> 3;
-  int pbase[NPR], phin[NPR], pwin[NPR];
-  bool pvalid[NPR];
+  const cn_buf_t xbuf = cn_make_buf(p.x, p.x_bytes);
+  const cn_buf_t wbuf = cn_make_buf(p.w, p.w_bytes);
+  int phin[NPR], pwin[NPR];
+  unsigned int prow[NPR], wrow[NWR];   // byte offsets of the row starts (CN_OOB = row not valid)
 #pragma unroll
   for (int i = 0; i < NPR; ++i) {
     int m = m0 + r0 + 32 * i;
-    pvalid[i] = m < p.M;
-    int mm = pvalid[i] ? m : 0;
+    const bool valid = m < p.M;
+    int mm = valid ? m : 0;
     int n = (int)cn_fastdiv((unsigned)mm, p.div_hw);
     int rem = mm - n * HgWg;
     int hg = (int)cn_fastdiv((unsigned)rem, p.div_w);
     int wg = rem - hg * p.Wg;
-    pbase[i] = n * p.Hi * p.Wi;
-    phin[i] = hg * p.a_h;
+    phin[i] = valid ? hg * p.a_h : -0x4000;   // invalid rows fail every bounds test below
     pwin[i] = wg * p.a_w;
+    prow[i] = valid ? (unsigned int)(((n * p.Hi + hg * p.a_h) * p.Wi + wg * p.a_w) * p.Ci * EB) : CN_OOB;
   }
+#pragma unroll
+  for (int i = 0; i < NWR; ++i) {
+    const int co = n0 + r0 + 32 * i;
+    wrow[i] = co < p.Co ? (unsigned int)(co * (int)p.w_row * EB) : CN_OOB;
+  }
+  // loop-invariant LDS addresses: staging stores and fragment reads
+  const int st0 = ig_slot(r0, cc);   // rows r0 + 32*i share the swizzle: slot(i) = st0 + i*32*128
+  const int wc = wave % WC;
+  const int wp = wave / WC;
+  const int lrow = lane & 31;
+  const int swz = (lrow >> 1) & 7;   // tile bases are multiples of 32 rows: the swizzle is per lane
+  int koff[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) koff[kk] = lrow * 128 + (((kk * 2 + (lane >> 5)) ^ swz) << 4);
+  const int rd_w = wc * TI * 32 * 128;
+  const int rd_p = BN * 128 + wp * TJ * 32 * 128;
   __syncthreads();
 
   f32x16 acc[TI][TJ];
@@ -141,6 +174,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 
   u32x4 preg[NPR], wreg[NWR];
   const int nkt = (p.nchunks + 7) >> 3;
+  const bool simple = p.simple != 0;   // every tap of every valid row is inside the image
 
   auto load_tile = [&](int kt) {
     const int kc = kt * 8 + cc;
@@ -148,50 +182,45 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     int tap = 0, cchunk = kc;
     if (p.ntaps > 1) {
       tap = kvalid ? (int)cn_fastdiv((unsigned)kc, p.div_cpt) : 0;
-      cchunk = kvalid ? kc - tap * p.cpt : 0;
+      cchunk = kc - tap * p.cpt;
     }
-    const int dhdw = s_taps[2 * tap];
-    const int woff = s_taps[2 * tap + 1];
-    const int dh = (int)(short)(dhdw & 0xffff);
-    const int dw = dhdw >> 16;
-    const int coff = cchunk * CH;
+    const int dhdw = s_taps[4 * tap];
+    const unsigned int kb = kvalid ? (unsigned int)(cchunk * 16) : CN_OOB;   // 16 bytes per chunk
+    const unsigned int wofs = (unsigned int)s_taps[4 * tap + 1] + kb;
+    const unsigned int xofs = (unsigned int)s_taps[4 * tap + 2] + kb;
+    if (simple) {
 #pragma unroll
-    for (int i = 0; i < NPR; ++i) {
-      int hi = phin[i] + dh, wi = pwin[i] + dw;
-      bool ok = kvalid && pvalid[i] && (unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi;
-      size_t off = ((size_t)(pbase[i] + hi * p.Wi + wi) * (size_t)p.Ci + (size_t)coff) * EB;
-      preg[i] = ok ? cn_ld16(p.x + off) : cn_zero16();
+      for (int i = 0; i < NPR; ++i) preg[i] = cn_buf_ld16(xbuf, (prow[i] | kb) >= CN_OOB ? CN_OOB : prow[i] + xofs);
+    } else {
+      const int dh = (int)(short)(dhdw & 0xffff);
+      const int dw = dhdw >> 16;
+#pragma unroll
+      for (int i = 0; i < NPR; ++i) {
+        const bool ok = (unsigned)(phin[i] + dh) < (unsigned)p.Hi && (unsigned)(pwin[i] + dw) < (unsigned)p.Wi &&
+                        kb < CN_OOB;
+        preg[i] = cn_buf_ld16(xbuf, ok ? prow[i] + xofs : CN_OOB);
+      }
     }
 #pragma unroll
-    for (int i = 0; i < NWR; ++i) {
-      int co = n0 + r0 + 32 * i;
-      bool ok = kvalid && co < p.Co;
-      size_t off = ((size_t)co * (size_t)p.w_row + (size_t)(woff + coff)) * EB;
-      wreg[i] = ok ? cn_ld16(p.w + off) : cn_zero16();
-    }
+    for (int i = 0; i < NWR; ++i) wreg[i] = cn_buf_ld16(wbuf, (wrow[i] | kb) >= CN_OOB ? CN_OOB : wrow[i] + wofs);
   };
   auto store_tile = [&](int buf) {
-    char* wt = lds + buf * STAGE;
-    char* pt = wt + BN * 128;
+    char* base = lds + buf * STAGE;
 #pragma unroll
-    for (int i = 0; i < NWR; ++i) cn_st16(wt + ig_slot(r0 + 32 * i, cc), wreg[i]);
+    for (int i = 0; i < NWR; ++i) cn_st16(base + st0 + i * 32 * 128, wreg[i]);
 #pragma unroll
-    for (int i = 0; i < NPR; ++i) cn_st16(pt + ig_slot(r0 + 32 * i, cc), preg[i]);
+    for (int i = 0; i < NPR; ++i) cn_st16(base + st0 + BN * 128 + i * 32 * 128, preg[i]);
   };
-
-  const int wc = wave % WC;
-  const int wp = wave / WC;
   auto compute = [&](int buf) {
-    const char* wt = lds + buf * STAGE;
-    const char* pt = wt + BN * 128;
+    const char* wt = lds + buf * STAGE + rd_w;
+    const char* pt = lds + buf * STAGE + rd_p;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      const int chunk = kk * 2 + (lane >> 5);
       u32x4 af[TI], bfr[TJ];
 #pragma unroll
-      for (int a = 0; a < TI; ++a) af[a] = cn_ld16(wt + ig_slot((wc * TI + a) * 32 + (lane & 31), chunk));
+      for (int a = 0; a < TI; ++a) af[a] = cn_ld16(wt + koff[kk] + a * 32 * 128);
 #pragma unroll
-      for (int b = 0; b < TJ; ++b) bfr[b] = cn_ld16(pt + ig_slot((wp * TJ + b) * 32 + (lane & 31), chunk));
+      for (int b = 0; b < TJ; ++b) bfr[b] = cn_ld16(pt + koff[kk] + b * 32 * 128);
 #pragma unroll
       for (int a = 0; a < TI; ++a)
 #pragma unroll
@@ -222,32 +251,55 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     }
   }
 
-  // ---- epilogue: accumulators -> LDS out tile [BM pixels][BN channels] -> coalesced global store
+  // ---- epilogue: (bias, ReLU) -> LDS out tile [BM pixels][BN channels] -> coalesced global store
+  if (p.bias != nullptr) {   // uniform branch; a lane's 4 consecutive channels = one 16-byte bias load
+#pragma unroll
+    for (int a = 0; a < TI; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = n0 + (wc * TI + a) * 32 + 8 * q + 4 * (lane >> 5);
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (c + 3 < p.Co) {
+          const f32x4 t = *(const f32x4*)(p.bias + c);
+          bv[0] = t[0]; bv[1] = t[1]; bv[2] = t[2]; bv[3] = t[3];
+        } else {
+          for (int e = 0; e < 4; ++e)
+            if (c + e < p.Co) bv[e] = p.bias[c + e];
+        }
+#pragma unroll
+        for (int b = 0; b < TJ; ++b)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[a][b][q * 4 + e] += bv[e];
+      }
+  }
+  if (p.relu) {
+#pragma unroll
+    for (int a = 0; a < TI; ++a)
+#pragma unroll
+      for (int b = 0; b < TJ; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = acc[a][b][r] > 0.f ? acc[a][b][r] : 0.f;
+  }
   const int OEB = OUTF32 ? 4 : EB;
   const int pitch = BN * OEB + 16;
 #pragma unroll
   for (int a = 0; a < TI; ++a)
 #pragma unroll
     for (int b = 0; b < TJ; ++b) {
-      const int prow = (wp * TJ + b) * 32 + (lane & 31);
+      const int prow_l = (wp * TJ + b) * 32 + (lane & 31);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int c = (wc * TI + a) * 32 + 8 * q + 4 * (lane >> 5);
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float f = acc[a][b][q * 4 + e];
-          if (p.bias != nullptr && n0 + c + e < p.Co) f += p.bias[n0 + c + e];
-          if (p.relu) f = f > 0.f ? f : 0.f;
-          v[e] = f;
-        }
-        char* dst = lds + prow * pitch + c * OEB;
+        char* dst = lds + prow_l * pitch + c * OEB;
         if (OEB == 4) {
-          cn_st16(dst, Chunk<float>::pack(v));
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[a][b][q * 4 + e];
+          *(f32x4*)dst = v;
         } else {
           u32x2 pk;
-          pk[0] = cn_pack_bf16x2(v[0], v[1]);
-          pk[1] = cn_pack_bf16x2(v[2], v[3]);
+          pk[0] = cn_pack_bf16x2(acc[a][b][q * 4], acc[a][b][q * 4 + 1]);
+          pk[1] = cn_pack_bf16x2(acc[a][b][q * 4 + 2], acc[a][b][q * 4 + 3]);
           *(u32x2*)dst = pk;
         }
       }
@@ -354,7 +406,26 @@ static int ig_common(IgemmParams& p, int dtype, int Ci, int ntaps) {
   p.M = p.N * p.Hg * p.Wg;
   p.div_hw = cn_make_fastdiv((unsigned)(p.Hg * p.Wg));
   p.div_w = cn_make_fastdiv((unsigned)p.Wg);
+  const int EB = dtype == CN_BF16 ? 2 : 4;
+  const long long xb = (long long)p.N * p.Hi * p.Wi * p.Ci * EB;
+  const long long wb = (long long)p.Co * p.w_row * EB;
+  if (xb >= (1ll << 31) || wb >= (1ll << 31)) {
+    cn_set_error("igemm: operand of %lld bytes exceeds the 2 GiB buffer-descriptor window", xb > wb ? xb : wb);
+    return CN_ESHAPE;
+  }
+  p.x_bytes = (unsigned int)xb;
+  p.w_bytes = (unsigned int)wb;
   return CN_OK;
+}
+
+// 1 when every tap of every enumerated output position reads inside the source image
+static int ig_is_simple(const IgemmParams& p, const int* dhdw, int ntaps) {
+  for (int t = 0; t < ntaps; ++t) {
+    const int dh = (int)(short)(dhdw[t] & 0xffff), dw = dhdw[t] >> 16;
+    if (dh < 0 || dw < 0) return 0;
+    if ((p.Hg - 1) * p.a_h + dh >= p.Hi || (p.Wg - 1) * p.a_w + dw >= p.Wi) return 0;
+  }
+  return 1;
 }
 
 extern "C" int cn_conv2d_fwd(const void* x, const void* w_krsc, void* y, const float* bias, int N, int H,
@@ -380,6 +451,7 @@ extern "C" int cn_conv2d_fwd(const void* x, const void* w_krsc, void* y, const f
       p.tap_dhdw[t] = ((r - pad_h) & 0xffff) | ((s - pad_w) << 16);
       p.tap_woff[t] = t * C;
     }
+  p.simple = ig_is_simple(p, p.tap_dhdw, R * S);
   return ig_dispatch(p, dtype, (hipStream_t)stream);
 }
 
@@ -424,6 +496,7 @@ extern "C" int cn_conv2d_dgrad(const void* dy, const void* w_crsk, void* dx, con
       int rc = ig_common(p, dtype, K, nt);
       if (rc) return rc;
       for (int t = 0; t < nt; ++t) { p.tap_dhdw[t] = dhdw[t]; p.tap_woff[t] = woff[t]; }
+      p.simple = ig_is_simple(p, dhdw, nt);
       rc = ig_dispatch(p, dtype, (hipStream_t)stream);
       if (rc) return rc;
     }

@@ -38,6 +38,7 @@ def main():
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--variants', default='0,1,2', help='igemm_stages values to A/B (0 = auto)')
+    ap.add_argument('--only', default='', help='comma-separated layer indices (default: all)')
     args = ap.parse_args()
     dev = torch.device('cuda', 0)
     dt = torch.bfloat16
@@ -49,7 +50,8 @@ def main():
     print('%-34s %5s | %s | %s | %s' % ('layer (n x C,H -> K, RxR/s)', 'GF',
                                         ' '.join('fwd[s=%d] ms  TF/s  GB/s' % v for v in variants),
                                         ' '.join('dgrad[s=%d] ms TF/s' % v for v in variants), 'wgrad ms TF/s GB/s'))
-    for cnt, C, H, K, R, st, pad in R50:
+    sel = [int(i) for i in args.only.split(',')] if args.only else range(len(R50))
+    for cnt, C, H, K, R, st, pad in [R50[i] for i in sel]:
         N = args.batch
         P = (H + 2 * pad - R) // st + 1
         x = torch.randn(N, H, H, C, device=dev).to(dt)
