@@ -272,6 +272,20 @@ static inline u32x4 cn_buf_ld16(cn_buf_t b, unsigned int off) {
 }
 #endif
 
+// Direct-to-LDS DMA form (buffer_load_dwordx4 ... lds): the 64 lanes of the wave write one
+// contiguous KiB at `lds_wave_base` (wave-uniform) + lane*16; no VGPR round trip, no ds_write.
+// Completion is tracked by vmcnt; hipcc waits for it at the next __syncthreads().
+#ifndef CN_EMULATE
+__device__ __forceinline__ void cn_buf_ld16_lds(cn_buf_t b, unsigned int off, void* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(b, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)off,
+                                           0, 0, 0);
+}
+#else
+static inline void cn_buf_ld16_lds(cn_buf_t b, unsigned int off, void* lds_wave_base) {
+  *(u32x4*)((char*)lds_wave_base + cn_emul::lane() * 16) = cn_buf_ld16(b, off);
+}
+#endif
+
 // 16-byte global / LDS accessors
 __host__ __device__ __forceinline__ u32x4 cn_ld16(const void* p) { return *(const u32x4*)p; }
 __host__ __device__ __forceinline__ void cn_st16(void* p, const u32x4& v) { *(u32x4*)p = v; }

@@ -73,8 +73,12 @@ __device__ __forceinline__ int ig_slot(int row, int chunk) {
 // on 64-bit im2col address math, see profiles/r01_pmc_*): operands come in through bounds-checked
 // buffer loads (zero fill = offset CN_OOB), every row's byte offset is computed once, a tap only
 // adds a per-tap byte delta read from an LDS table, and all LDS addresses are loop invariant.
-template <typename T, int WC, int WP, int TI, int TJ, int STAGES, bool OUTF32>
+// GLDS: operands are DMA'd straight into the (source-permuted, hence still XOR-swizzled) LDS tiles
+//       with `buffer_load ... lds`: no prefetch registers, no ds_write pass (the register-staged
+//       variant spends ~416 LDS cycles per K tile on ds_write_b128 against 512 MFMA cycles).
+template <typename T, int WC, int WP, int TI, int TJ, int STAGES, bool OUTF32, bool GLDS>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
+  static_assert(!GLDS || STAGES == 2, "LDS-DMA needs the double-buffered tile");
   constexpr int BN = WC * TI * 32;  // output channels per block
   constexpr int BM = WP * TJ * 32;  // pixels per block
   static_assert(WC * WP == 4, "4 waves");
@@ -129,6 +133,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   // per-thread staging coordinates (fixed for the whole reduction loop)
   const int cc = tid & 7;
   const int r0 = tid >> 3;
+  // LDS slot cc of row r0 holds chunk cc ^ swizzle(row): with DMA the lane must FETCH that chunk
+  const int cg = GLDS ? (cc ^ ((r0 >> 1) & 7)) : cc;
   const cn_buf_t xbuf = cn_make_buf(p.x, p.x_bytes);
   const cn_buf_t wbuf = cn_make_buf(p.w, p.w_bytes);
   int phin[NPR], pwin[NPR];
@@ -176,8 +182,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   const int nkt = (p.nchunks + 7) >> 3;
   const bool simple = p.simple != 0;   // every tap of every valid row is inside the image
 
-  auto load_tile = [&](int kt) {
-    const int kc = kt * 8 + cc;
+  auto load_tile = [&](int kt, int buf) {
+    const int kc = kt * 8 + cg;
+    char* dw_ = lds + buf * STAGE + (8 * wave) * 128;             // this wave's KiB of filter rows
+    char* dp_ = lds + buf * STAGE + BN * 128 + (8 * wave) * 128;  // ... and of pixel rows
     const bool kvalid = kc < p.nchunks;
     int tap = 0, cchunk = kc;
     if (p.ntaps > 1) {
@@ -190,7 +198,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     const unsigned int xofs = (unsigned int)s_taps[4 * tap + 2] + kb;
     if (simple) {
 #pragma unroll
-      for (int i = 0; i < NPR; ++i) preg[i] = cn_buf_ld16(xbuf, (prow[i] | kb) >= CN_OOB ? CN_OOB : prow[i] + xofs);
+      for (int i = 0; i < NPR; ++i) {
+        const unsigned int o = (prow[i] | kb) >= CN_OOB ? CN_OOB : prow[i] + xofs;
+        if (GLDS) cn_buf_ld16_lds(xbuf, o, dp_ + i * 32 * 128);
+        else preg[i] = cn_buf_ld16(xbuf, o);
+      }
     } else {
       const int dh = (int)(short)(dhdw & 0xffff);
       const int dw = dhdw >> 16;
@@ -198,11 +210,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
       for (int i = 0; i < NPR; ++i) {
         const bool ok = (unsigned)(phin[i] + dh) < (unsigned)p.Hi && (unsigned)(pwin[i] + dw) < (unsigned)p.Wi &&
                         kb < CN_OOB;
-        preg[i] = cn_buf_ld16(xbuf, ok ? prow[i] + xofs : CN_OOB);
+        const unsigned int o = ok ? prow[i] + xofs : CN_OOB;
+        if (GLDS) cn_buf_ld16_lds(xbuf, o, dp_ + i * 32 * 128);
+        else preg[i] = cn_buf_ld16(xbuf, o);
       }
     }
 #pragma unroll
-    for (int i = 0; i < NWR; ++i) wreg[i] = cn_buf_ld16(wbuf, (wrow[i] | kb) >= CN_OOB ? CN_OOB : wrow[i] + wofs);
+    for (int i = 0; i < NWR; ++i) {
+      const unsigned int o = (wrow[i] | kb) >= CN_OOB ? CN_OOB : wrow[i] + wofs;
+      if (GLDS) cn_buf_ld16_lds(wbuf, o, dw_ + i * 32 * 128);
+      else wreg[i] = cn_buf_ld16(wbuf, o);
+    }
   };
   auto store_tile = [&](int buf) {
     char* base = lds + buf * STAGE;
@@ -229,18 +247,23 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   };
 
   if (nkt > 0) {
-    load_tile(0);
-    store_tile(0);
+    load_tile(0, 0);
+    if (!GLDS) store_tile(0);
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
-      if (STAGES == 2) {
+      if (GLDS) {
         const int buf = kt & 1;
-        if (kt + 1 < nkt) load_tile(kt + 1);
+        if (kt + 1 < nkt) load_tile(kt + 1, buf ^ 1);   // DMA into the other buffer while we compute
+        compute(buf);
+        __syncthreads();                                // (hipcc drains vmcnt before the barrier)
+      } else if (STAGES == 2) {
+        const int buf = kt & 1;
+        if (kt + 1 < nkt) load_tile(kt + 1, 0);
         compute(buf);
         if (kt + 1 < nkt) store_tile(buf ^ 1);
         __syncthreads();
       } else {
-        if (kt + 1 < nkt) load_tile(kt + 1);
+        if (kt + 1 < nkt) load_tile(kt + 1, 0);
         compute(0);
         __syncthreads();
         if (kt + 1 < nkt) {
@@ -364,19 +387,23 @@ static int ig_log2_exact(int v) {
 template <typename T, bool OUTF32>
 static int ig_launch(IgemmParams& p, hipStream_t stream) {
   const int nkt = (p.nchunks + 7) / 8;
-  int stages = cn_get_option("igemm_stages", 0);
-  if (stages != 1 && stages != 2) stages = nkt <= 24 ? 1 : 2;   // measured crossover (profiles/r01_conv_layers)
+  // variant: 1 = register-staged single buffer, 2 = register-staged double buffer, 3 = LDS-DMA double
+  // buffer; 0 / unset = heuristic (tuning knob "igemm_variant", profiles/r01_conv_layers*)
+  int variant = cn_get_option("igemm_variant", 0);
+  if (variant < 1 || variant > 3) variant = cn_get_option("igemm_default_variant", nkt <= 2 ? 1 : 3);
   const int BM = 128, BN = p.Co <= 64 ? 64 : 128;
   p.n_ntiles = (p.Co + BN - 1) / BN;
   const int n_mtiles = (p.M + BM - 1) / BM;
   dim3 grid((unsigned)(p.n_ntiles * n_mtiles));
-  if (p.Co <= 64) {
-    if (stages == 1) CN_LAUNCH((igemm_kernel<T, 1, 4, 2, 1, 1, OUTF32>), grid, dim3(256), stream, p);
-    else CN_LAUNCH((igemm_kernel<T, 1, 4, 2, 1, 2, OUTF32>), grid, dim3(256), stream, p);
-  } else {
-    if (stages == 1) CN_LAUNCH((igemm_kernel<T, 2, 2, 2, 2, 1, OUTF32>), grid, dim3(256), stream, p);
-    else CN_LAUNCH((igemm_kernel<T, 2, 2, 2, 2, 2, OUTF32>), grid, dim3(256), stream, p);
-  }
+#define IG_GO(WC, WP, TI, TJ)                                                                                  \
+  do {                                                                                                         \
+    if (variant == 1) CN_LAUNCH((igemm_kernel<T, WC, WP, TI, TJ, 1, OUTF32, false>), grid, dim3(256), stream, p); \
+    else if (variant == 2) CN_LAUNCH((igemm_kernel<T, WC, WP, TI, TJ, 2, OUTF32, false>), grid, dim3(256), stream, p); \
+    else CN_LAUNCH((igemm_kernel<T, WC, WP, TI, TJ, 2, OUTF32, true>), grid, dim3(256), stream, p);             \
+  } while (0)
+  if (p.Co <= 64) IG_GO(1, 4, 2, 1);
+  else IG_GO(2, 2, 2, 2);
+#undef IG_GO
   return cn_check_launch("igemm");
 }
 

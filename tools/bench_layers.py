@@ -37,7 +37,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--iters', type=int, default=5)
-    ap.add_argument('--variants', default='0,1,2', help='igemm_stages values to A/B (0 = auto)')
+    ap.add_argument('--variants', default='0,1,2,3', help='igemm_variant values to A/B (0 = heuristic, 1 = reg-staged 1 buf, 2 = reg-staged 2 buf, 3 = LDS-DMA)')
     ap.add_argument('--only', default='', help='comma-separated layer indices (default: all)')
     args = ap.parse_args()
     dev = torch.device('cuda', 0)
@@ -48,8 +48,8 @@ def main():
     tot.update({('dgrad', v): 0.0 for v in variants})
     tot['wgrad'] = 0.0
     print('%-34s %5s | %s | %s | %s' % ('layer (n x C,H -> K, RxR/s)', 'GF',
-                                        ' '.join('fwd[s=%d] ms  TF/s  GB/s' % v for v in variants),
-                                        ' '.join('dgrad[s=%d] ms TF/s' % v for v in variants), 'wgrad ms TF/s GB/s'))
+                                        ' '.join('fwd[v=%d] ms  TF/s  GB/s' % v for v in variants),
+                                        ' '.join('dgrad[v=%d] ms TF/s' % v for v in variants), 'wgrad ms TF/s GB/s'))
     sel = [int(i) for i in args.only.split(',')] if args.only else range(len(R50))
     for cnt, C, H, K, R, st, pad in [R50[i] for i in sel]:
         N = args.batch
@@ -63,20 +63,20 @@ def main():
         by_f = (x.numel() + N * P * P * K + w.numel()) * 2 / 1e9
         cols = []
         for v in variants:
-            L.cn_set_option(b'igemm_stages', v)
+            L.cn_set_option(b'igemm_variant', v)
             ms = timeit(lambda: ca.ops.conv2d_fwd(x, w, None, K, R, R, (st, st), (pad, pad)), args.iters)
             tot[('fwd', v)] += ms * cnt
             cols.append('%8.3f %6.0f %5.0f' % (ms, gf / ms, by_f / ms * 1e3))
         cols_d = []
         for v in variants:
-            L.cn_set_option(b'igemm_stages', v)
+            L.cn_set_option(b'igemm_variant', v)
             if C == 8:
                 cols_d.append('%8s %6s' % ('-', '-'))
                 continue
             ms = timeit(lambda: ca.ops.conv2d_dgrad(dy, wc, x.shape, K, R, R, (st, st), (pad, pad)), args.iters)
             tot[('dgrad', v)] += ms * cnt
             cols_d.append('%8.3f %6.0f' % (ms, gf / ms))
-        L.cn_set_option(b'igemm_stages', 0)
+        L.cn_set_option(b'igemm_variant', 0)
         msw = timeit(lambda: ca.ops.conv2d_wgrad(x, dy, dw, C, K, R, R, (st, st), (pad, pad), beta=0.0), args.iters)
         tot['wgrad'] += msw * cnt
         print('%dx %4d,%3d -> %4d, %dx%d/%d %12s %5.0f | %s | %s | %8.3f %6.0f %5.0f' % (
