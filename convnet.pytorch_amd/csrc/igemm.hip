@@ -390,7 +390,7 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
   // variant: 1 = register-staged single buffer, 2 = register-staged double buffer, 3 = LDS-DMA double
   // buffer; 0 / unset = heuristic (tuning knob "igemm_variant", profiles/r01_conv_layers*)
   int variant = cn_get_option("igemm_variant", 0);
-  if (variant < 1 || variant > 3) variant = cn_get_option("igemm_default_variant", nkt <= 2 ? 1 : 3);
+  if (variant < 1 || variant > 3) variant = cn_get_option("igemm_default_variant", nkt < 24 ? 1 : 3);
   const int BM = 128, BN = p.Co <= 64 ? 64 : 128;
   p.n_ntiles = (p.Co + BN - 1) / BN;
   const int n_mtiles = (p.M + BM - 1) / BM;

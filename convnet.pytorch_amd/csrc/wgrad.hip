@@ -27,6 +27,8 @@ struct WgradParams {
   int ntaps, cpt, cpt_shift, ncols;
   int M, m_per_split, nsplit;
   int n_itiles, n_jtiles;
+  unsigned int x_bytes, dy_bytes;
+  int simple;   // 1x1, stride 1, no padding: the gather is the identity (row m of x)
   FastDiv div_hw, div_w, div_cpt;
   int tap_dhdw[WG_MAX_TAPS];
 };
@@ -64,7 +66,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   if (m_end > p.M) m_end = p.M;
   const int HoWo = p.Ho * p.Wo;
 
-  // fixed per-thread columns
+  // fixed per-thread columns; all global addressing is 32-bit through bounds-checked buffer loads
+  // (out-of-range / padded elements arrive as zeros: offset CN_OOB)
+  const cn_buf_t xbuf = cn_make_buf(p.x, p.x_bytes);
+  const cn_buf_t dybuf = cn_make_buf(p.dy, p.dy_bytes);
   const int colI = tid % CI_, rowI0 = tid / CI_;
   const int colJ = tid % CJ_, rowJ0 = tid / CJ_;
   const bool validI = i0 + colI * CH < p.Co;
@@ -77,6 +82,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   }
   const int dhdw = p.tap_dhdw[tap];
   const int dh = (int)(short)(dhdw & 0xffff), dw = dhdw >> 16;
+  const unsigned int colI_b = validI ? (unsigned int)((i0 + colI * CH) * EB) : CN_OOB;
+  const unsigned int colJ_b = validJ ? (unsigned int)(cchunk * 16) : CN_OOB;
+  const unsigned int rowI_pitch = (unsigned int)(p.Co * EB), rowJ_pitch = (unsigned int)(p.Ci * EB);
 
   f32x16 acc[TI][TJ];
 #pragma unroll
@@ -90,24 +98,31 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   auto load_stage = [&](int mb) {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      int m = mb + rowI0 + i * RI;
-      bool ok = validI && m < m_end;
-      size_t off = ((size_t)m * (size_t)p.Co + (size_t)(i0 + colI * CH)) * EB;
-      regI[i] = ok ? cn_ld16(p.dy + off) : cn_zero16();
+      const int m = mb + rowI0 + i * RI;
+      const bool ok = m < m_end && colI_b < CN_OOB;
+      regI[i] = cn_buf_ld16(dybuf, ok ? (unsigned int)m * rowI_pitch + colI_b : CN_OOB);
     }
+    if (p.simple) {
 #pragma unroll
-    for (int i = 0; i < NJ; ++i) {
-      int m = mb + rowJ0 + i * RJ;
-      bool ok = validJ && m < m_end;
-      int mm = ok ? m : 0;
-      int n = (int)cn_fastdiv((unsigned)mm, p.div_hw);
-      int rem = mm - n * HoWo;
-      int ho = (int)cn_fastdiv((unsigned)rem, p.div_w);
-      int wo = rem - ho * p.Wo;
-      int hi = ho * p.stride_h + dh, wq = wo * p.stride_w + dw;
-      ok = ok && (unsigned)hi < (unsigned)p.Hi && (unsigned)wq < (unsigned)p.Wi;
-      size_t off = ((size_t)((n * p.Hi + hi) * p.Wi + wq) * (size_t)p.Ci + (size_t)(cchunk * CH)) * EB;
-      regJ[i] = ok ? cn_ld16(p.x + off) : cn_zero16();
+      for (int i = 0; i < NJ; ++i) {
+        const int m = mb + rowJ0 + i * RJ;
+        const bool ok = m < m_end && colJ_b < CN_OOB;
+        regJ[i] = cn_buf_ld16(xbuf, ok ? (unsigned int)m * rowJ_pitch + colJ_b : CN_OOB);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NJ; ++i) {
+        const int m = mb + rowJ0 + i * RJ;
+        bool ok = m < m_end && colJ_b < CN_OOB;
+        const int mm = ok ? m : 0;
+        const int n = (int)cn_fastdiv((unsigned)mm, p.div_hw);
+        const int rem = mm - n * HoWo;
+        const int ho = (int)cn_fastdiv((unsigned)rem, p.div_w);
+        const int wo = rem - ho * p.Wo;
+        const int hi = ho * p.stride_h + dh, wq = wo * p.stride_w + dw;
+        ok = ok && (unsigned)hi < (unsigned)p.Hi && (unsigned)wq < (unsigned)p.Wi;
+        regJ[i] = cn_buf_ld16(xbuf, ok ? (unsigned int)((n * p.Hi + hi) * p.Wi + wq) * rowJ_pitch + colJ_b : CN_OOB);
+      }
     }
   };
   auto store_stage = [&]() {
@@ -286,6 +301,14 @@ extern "C" int cn_conv2d_wgrad(const void* x, const void* dy, float* dw_krsc, in
   p.ntaps = R * S; p.cpt = C / CH; p.ncols = pl.ncols;
   p.cpt_shift = 0;
   p.div_cpt = cn_make_fastdiv((unsigned)p.cpt);
+  const long long EBl = dtype == CN_BF16 ? 2 : 4;
+  const long long xb = (long long)N * H * W * C * EBl, dyb = (long long)N * P * Q * K * EBl;
+  if (xb >= (1ll << 31) || dyb >= (1ll << 31)) {
+    cn_set_error("conv2d_wgrad: operand exceeds the 2 GiB buffer-descriptor window");
+    return CN_ESHAPE;
+  }
+  p.x_bytes = (unsigned int)xb; p.dy_bytes = (unsigned int)dyb;
+  p.simple = (R == 1 && S == 1 && stride_h == 1 && stride_w == 1 && pad_h == 0 && pad_w == 0) ? 1 : 0;
   p.M = N * P * Q; p.m_per_split = pl.m_per_split; p.nsplit = pl.nsplit;
   p.n_itiles = pl.n_itiles; p.n_jtiles = pl.n_jtiles;
   p.div_hw = cn_make_fastdiv((unsigned)(P * Q));
