@@ -130,6 +130,20 @@ def main():
                     'frac': round(k['gbs'] / PEAK_HBM_GBS, 4), 'traffic': None}
         roof['avg_us_per_launch'] = k['avg_us_per_launch']
         roof['launches_per_step'] = k['launches_per_step']
+        # HBM traffic per launch from the committed PMC passes (profiles/*_pmc_traffic.json), if the
+        # dominant kernel was covered by them
+        try:
+            cands = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('pmc_traffic.json'))
+            pm = json.load(open(os.path.join(ROOT, 'profiles', cands[-1])))
+            for kn, kv in pm['kernels'].items():
+                if kn.replace('void ', '').startswith(dom.split(' (')[0]):
+                    roof['traffic'] = round(kv['hbm_bytes_per_launch'])
+                    roof['traffic_unit'] = 'bytes/launch (avg), ' + pm['source'] + ', ' + cands[-1]
+                    roof['algorithmic_bytes_per_launch'] = round(
+                        agg[dom]['bytes'] / max(agg[dom]['launches'], 1))
+                    break
+        except Exception:
+            pass
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -255,15 +255,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const char* dz, cons
       sh[e] = shift[col * CH + e];
     }
     const int step = gridDim.x * rpp;
-#pragma unroll 2
-    for (int row = blockIdx.x * rpp + rsub; row < M; row += step) {
-      const size_t off = ((size_t)row * C + (size_t)col * CH) * EB;
+    const size_t cb = (size_t)col * CH * EB, rb = (size_t)C * EB;
+    auto accum = [&](const u32x4& gz, const u32x4& vy, unsigned int bits) {
       float g[CH], v[CH];
-      Chunk<T>::unpack(cn_ld16(dz + off), g);
-      Chunk<T>::unpack(cn_ld16(y + off), v);
+      Chunk<T>::unpack(gz, g);
+      Chunk<T>::unpack(vy, v);
       if (relu) {
         if (zmask != nullptr) {
-          const unsigned int bits = zmask[(size_t)row * cpr + col];
 #pragma unroll
           for (int e = 0; e < CH; ++e) g[e] = ((bits >> e) & 1u) ? g[e] : 0.f;
         } else {
@@ -276,6 +274,24 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const char* dz, cons
         s1[e] += g[e];
         s2[e] = fmaf(g[e], (v[e] - mu[e]) * is[e], s2[e]);
       }
+    };
+    int row = blockIdx.x * rpp + rsub;
+    for (; row + 3 * step < M; row += 4 * step) {   // 8-12 independent loads in flight per lane
+      u32x4 gz[4], vy[4];
+      unsigned int bits[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        gz[u] = cn_ld16(dz + (size_t)(row + u * step) * rb + cb);
+        vy[u] = cn_ld16(y + (size_t)(row + u * step) * rb + cb);
+        if (relu && zmask != nullptr) bits[u] = zmask[(size_t)(row + u * step) * cpr + col];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) accum(gz[u], vy[u], bits[u]);
+    }
+    for (; row < M; row += step) {
+      unsigned int bits = 0u;
+      if (relu && zmask != nullptr) bits = zmask[(size_t)row * cpr + col];
+      accum(cn_ld16(dz + (size_t)row * rb + cb), cn_ld16(y + (size_t)row * rb + cb), bits);
     }
   }
 #pragma unroll

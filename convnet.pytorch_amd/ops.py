@@ -78,6 +78,18 @@ def _esize(t):
     return t.element_size()
 
 
+def _igemm_name(dtype, co, taps, c_red, out_f32=False):
+    """Name of the igemm_kernel instantiation the C dispatcher picks (mirrors ig_launch): used only
+    to label profiler records with the names rocprofv3 reports."""
+    ch = 4 if dtype == torch.float32 else 8
+    nkt = (taps * (c_red // ch) + 7) // 8
+    glds = nkt >= 24
+    t = 'float' if dtype == torch.float32 else 'bf16_t'
+    shape = '1, 4, 2, 1' if co <= 64 else '2, 2, 2, 2'
+    outf = 'true' if (out_f32 or dtype == torch.float32) else 'false'
+    return 'igemm_kernel<%s, %s, %d, %s, %s>' % (t, shape, 2 if glds else 1, outf, 'true' if glds else 'false')
+
+
 def conv_out_hw(H, W, R, S, stride, pad):
     return (H + 2 * pad[0] - R) // stride[0] + 1, (W + 2 * pad[1] - S) // stride[1] + 1
 
@@ -89,7 +101,7 @@ def conv2d_fwd(x, w_krsc, bias, K, R, S, stride, pad, out_f32=False, relu=False)
     N, H, W, C = x.shape
     P, Q = conv_out_hw(H, W, R, S, stride, pad)
     y = torch.empty((N, P, Q, K), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
-    PROFILER.run('igemm_fwd_%s_%s' % ('bn64' if K <= 64 else 'bn128', 'bf16' if x.dtype == torch.bfloat16 else 'f32'),
+    PROFILER.run(_igemm_name(x.dtype, K, R * S, C, out_f32),
                  1, 2.0 * N * P * Q * K * C * R * S,
                  x.numel() * _esize(x) + y.numel() * _esize(y) + K * R * S * C * _esize(x),
                  lambda: check(_L().cn_conv2d_fwd(ptr(x), ptr(w_krsc), ptr(y), ptr(bias), N, H, W, C, K, R, S,
@@ -102,7 +114,7 @@ def conv2d_fwd(x, w_krsc, bias, K, R, S, stride, pad, out_f32=False, relu=False)
 def conv2d_dgrad(dy, w_crsk, x_shape, K, R, S, stride, pad, addend=None):
     N, H, W, C = x_shape
     dx = torch.empty((N, H, W, C), dtype=dy.dtype, device=dy.device)
-    PROFILER.run('igemm_dgrad_%s_%s' % ('bn64' if C <= 64 else 'bn128', 'bf16' if dy.dtype == torch.bfloat16 else 'f32'),
+    PROFILER.run(_igemm_name(dy.dtype, C, max(1, -(-R // stride[0]) * -(-S // stride[1])), K),
                  stride[0] * stride[1], 2.0 * dy.numel() * C * R * S,
                  dy.numel() * _esize(dy) + dx.numel() * _esize(dx) * (2 if addend is not None else 1)
                  + K * R * S * C * _esize(dy),
@@ -120,7 +132,7 @@ def conv2d_wgrad(x, dy, dw_krsc, c_real, K, R, S, stride, pad, beta=1.0, scale=1
     L = _L()
     need = L.cn_conv2d_wgrad_workspace(N, H, W, C, K, R, S, stride[0], stride[1], pad[0], pad[1], code)
     ws = workspace(need, x.device)
-    PROFILER.run('wgrad_%s_%s' % ('bi64' if K <= 64 else 'bi128', 'bf16' if x.dtype == torch.bfloat16 else 'f32'),
+    PROFILER.run('wgrad_kernel<%s, %d, 128> (+wgrad_reduce)' % ('float' if x.dtype == torch.float32 else 'bf16_t', 64 if K <= 64 else 128),
                  2, 2.0 * dy.numel() * C * R * S,
                  x.numel() * _esize(x) + dy.numel() * _esize(dy) + K * R * S * C * 4,
                  lambda: check(L.cn_conv2d_wgrad(ptr(x), ptr(dy), ptr(dw_krsc), c_real, N, H, W, C, K, R, S,
@@ -247,7 +259,7 @@ class BatchNormActFunction(Function):
         momentum = mod.effective_momentum()
         track = mod.track_running_stats
         nb = y.numel() * _esize(y)
-        PROFILER.run('bn_fwd_train', 3, 0.0, nb * (4 if residual is not None else 3) + (mask.numel() if mask is not None else 0),
+        PROFILER.run('bn_stats+bn_finalize+bn_apply', 3, 0.0, nb * (4 if residual is not None else 3) + (mask.numel() if mask is not None else 0),
                      lambda: check(L.cn_bn_fwd_train(ptr(y), ptr(residual), ptr(z), ptr(mask), ptr(gamma), ptr(beta),
                                                      ptr(mod.running_mean) if track else None,
                                                      ptr(mod.running_var) if track else None,
@@ -281,7 +293,7 @@ class BatchNormActFunction(Function):
         dres = torch.empty_like(y) if want_res else None
         coef = torch.empty(3 * C, dtype=torch.float32, device=y.device)
         nb = y.numel() * _esize(y)
-        PROFILER.run('bn_bwd', 3, 0.0, nb * (5 + (1 if dres is not None else 0)) + (2 * zmask.numel() if zmask is not None else 0),
+        PROFILER.run('bn_bwd_reduce+bn_bwd_finalize+bn_bwd_apply', 3, 0.0, nb * (5 + (1 if dres is not None else 0)) + (2 * zmask.numel() if zmask is not None else 0),
                      lambda: check(L.cn_bn_bwd(ptr(dz), ptr(y), ptr(zmask), ptr(mod.weight), ptr(stats), ptr(dy),
                                                ptr(dres), ptr(mod.grad_view('weight')), ptr(mod.grad_view('bias')),
                                                1.0, 1.0, ptr(coef), M, C, int(ctx.relu), code, ptr(ws),
