@@ -120,7 +120,8 @@ def main():
                 'tflops': round(a['flops'] / sec / 1e12, 2) if a['flops'] else None,
                 'gbs': round(a['bytes'] / sec / 1e9, 1),
             }
-        dom = next(iter(kernels))
+        # the dominant single HIP kernel ('+' names are multi-kernel C-ABI calls, reported in `kernels`)
+        dom = next(k for k in kernels if '+' not in k)
         k = kernels[dom]
         if k['tflops'] and k['tflops'] / PEAK_TFLOPS[args.dtype] >= k['gbs'] / PEAK_HBM_GBS:
             roof = {'kernel': dom, 'bound': 'mfma', 'achieved': k['tflops'], 'peak': PEAK_TFLOPS[args.dtype],

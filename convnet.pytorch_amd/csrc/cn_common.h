@@ -65,9 +65,21 @@ __host__ __device__ __forceinline__ unsigned short cn_f32_to_bf16(float f) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return (unsigned short)(u >> 16);
 }
+// Two fp32 -> packed bf16 (round to nearest even).  On gfx950 this is ONE v_cvt_pk_bf16_f32 (hipcc
+// emits it from the native __bf16 conversion); the software form (~5 VALU per element) made the
+// igemm epilogue cost more VALU issue than the MFMAs of a short reduction (profiles/r01_pmc_sq*).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CN_EMULATE)
+typedef __bf16 cn_bf16x2_native __attribute__((ext_vector_type(2)));
+typedef float cn_f32x2_native __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned int cn_pack_bf16x2(float lo, float hi) {
+  cn_f32x2_native f = {lo, hi};
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(f, cn_bf16x2_native));
+}
+#else
 __host__ __device__ __forceinline__ unsigned int cn_pack_bf16x2(float lo, float hi) {
   return (unsigned int)cn_f32_to_bf16(lo) | ((unsigned int)cn_f32_to_bf16(hi) << 16);
 }
+#endif
 
 // element traits: T = float or bf16_t
 template <typename T> struct ElemTraits;
@@ -124,7 +136,11 @@ template <> __host__ __device__ __forceinline__ float cn_load_elem<bf16_t>(const
 template <typename T> __host__ __device__ __forceinline__ void cn_store_elem(T* p, float v);
 template <> __host__ __device__ __forceinline__ void cn_store_elem<float>(float* p, float v) { *p = v; }
 template <> __host__ __device__ __forceinline__ void cn_store_elem<bf16_t>(bf16_t* p, float v) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CN_EMULATE)
+  p->v = __builtin_bit_cast(unsigned short, (__bf16)v);   // v_cvt_pk_bf16_f32, RNE
+#else
   p->v = cn_f32_to_bf16(v);
+#endif
 }
 
 // ---------------------------------------------------------------- fast division (host-precomputed)
