@@ -108,13 +108,17 @@ __device__ __forceinline__ void bn_sum_partials(const float* partial, int nrb, i
   double s = 0.0, q = 0.0;
   if (c < C) {
     int r = part;
-    for (; r + 24 < nrb; r += 32) {
-      const float a0 = partial[(size_t)r * 2 * C + c], b0 = partial[(size_t)r * 2 * C + C + c];
-      const float a1 = partial[(size_t)(r + 8) * 2 * C + c], b1 = partial[(size_t)(r + 8) * 2 * C + C + c];
-      const float a2 = partial[(size_t)(r + 16) * 2 * C + c], b2 = partial[(size_t)(r + 16) * 2 * C + C + c];
-      const float a3 = partial[(size_t)(r + 24) * 2 * C + c], b3 = partial[(size_t)(r + 24) * 2 * C + C + c];
-      s += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
-      q += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+    for (; r + 56 < nrb; r += 64) {   // 16 independent loads in flight per thread
+      float a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        a[u] = partial[(size_t)(r + 8 * u) * 2 * C + c];
+        b[u] = partial[(size_t)(r + 8 * u) * 2 * C + C + c];
+      }
+      s += (((double)a[0] + (double)a[1]) + ((double)a[2] + (double)a[3])) +
+           (((double)a[4] + (double)a[5]) + ((double)a[6] + (double)a[7]));
+      q += (((double)b[0] + (double)b[1]) + ((double)b[2] + (double)b[3])) +
+           (((double)b[4] + (double)b[5]) + ((double)b[6] + (double)b[7]));
     }
     for (; r < nrb; r += 8) {
       s += (double)partial[(size_t)r * 2 * C + c];

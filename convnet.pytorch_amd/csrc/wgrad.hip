@@ -215,14 +215,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, fl
     int c = (int)(idx % Creal);
     long long rest = idx / Creal;  // co*ntaps + t
     const float* src = part + rest * Ci + c;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // 8 loads in flight; summation order is fixed
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // 16 loads in flight; summation order is fixed
     int k = 0;
-    for (; k + 7 < nsplit; k += 8) {
-      const float v0 = src[(long long)(k + 0) * stride_split], v1 = src[(long long)(k + 1) * stride_split];
-      const float v2 = src[(long long)(k + 2) * stride_split], v3 = src[(long long)(k + 3) * stride_split];
-      const float v4 = src[(long long)(k + 4) * stride_split], v5 = src[(long long)(k + 5) * stride_split];
-      const float v6 = src[(long long)(k + 6) * stride_split], v7 = src[(long long)(k + 7) * stride_split];
-      s0 += v0 + v4; s1 += v1 + v5; s2 += v2 + v6; s3 += v3 + v7;
+    for (; k + 15 < nsplit; k += 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = src[(long long)(k + u) * stride_split];
+      s0 += (v[0] + v[4]) + (v[8] + v[12]);
+      s1 += (v[1] + v[5]) + (v[9] + v[13]);
+      s2 += (v[2] + v[6]) + (v[10] + v[14]);
+      s3 += (v[3] + v[7]) + (v[11] + v[15]);
     }
     for (; k < nsplit; ++k) s0 += src[(long long)k * stride_split];
     float s = ((s0 + s1) + (s2 + s3)) * scale;
