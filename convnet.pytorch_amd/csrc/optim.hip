@@ -130,6 +130,47 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* partial,
   out[c] = (beta != 0.f ? beta * out[c] : 0.f) + s * scale;
 }
 
+// Small dense layers whose width is not a multiple of the 16-byte chunk (the 10-way MNIST head of
+// /root/reference models/mnist.py:30): one thread per output element, plain fp32 dot products.
+//   fwd  : y[b][k]  = sum_c x[b][c] w[k][c] + bias[k]            (x in T, y fp32)
+//   dgrad: dx[b][c] = sum_k dy[b][k] w[k][c]                      (dx in T)
+//   wgrad: dw[k][c] += sum_b dy[b][k] x[b][c];  db[k] += sum_b dy[b][k]
+template <typename T>
+__global__ __launch_bounds__(256) void small_linear_fwd_kernel(const T* x, const float* w, const float* bias,
+                                                              float* y, int B, int C, int K) {
+  const int id = blockIdx.x * 256 + threadIdx.x;
+  if (id >= B * K) return;
+  const int b = id / K, k = id - b * K;
+  float s = bias != nullptr ? bias[k] : 0.f;
+  for (int c = 0; c < C; ++c) s = fmaf(cn_load_elem<T>(x + (size_t)b * C + c), w[(size_t)k * C + c], s);
+  y[id] = s;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void small_linear_dgrad_kernel(const float* dy, const float* w, T* dx, int B, int C,
+                                                                int K) {
+  const int id = blockIdx.x * 256 + threadIdx.x;
+  if (id >= B * C) return;
+  const int b = id / C, c = id - b * C;
+  float s = 0.f;
+  for (int k = 0; k < K; ++k) s = fmaf(dy[(size_t)b * K + k], w[(size_t)k * C + c], s);
+  cn_store_elem<T>(dx + id, s);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void small_linear_wgrad_kernel(const T* x, const float* dy, float* dw, float* db,
+                                                                int B, int C, int K) {
+  const int id = blockIdx.x * 256 + threadIdx.x;
+  if (id >= K * (C + 1)) return;
+  const int k = id / (C + 1), c = id - k * (C + 1);
+  float s = 0.f;
+  if (c < C) {
+    for (int b = 0; b < B; ++b) s = fmaf(dy[(size_t)b * K + k], cn_load_elem<T>(x + (size_t)b * C + c), s);
+    dw[(size_t)k * C + c] += s;
+  } else if (db != nullptr) {
+    for (int b = 0; b < B; ++b) s += dy[(size_t)b * K + k];
+    db[k] += s;
+  }
+}
+
 // y = (T) x  (fp32 -> compute dtype), used for the fp32 logits gradient hand-off and tests
 template <typename T>
 __global__ __launch_bounds__(256) void cast_kernel(const float* x, T* y, long long n) {
@@ -222,6 +263,29 @@ extern "C" int cn_colsum(const void* x, float* out, int M, int C, int dtype, flo
   CN_LAUNCH(colsum_final_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), stream, (const float*)workspace,
             out, parts, C, beta, scale);
   return cn_check_launch("colsum");
+}
+
+extern "C" int cn_small_linear(int mode, const void* x, const float* w, const float* bias, void* out, float* dw,
+                               float* db, int B, int C, int K, int dtype, void* stream_) {
+  // mode 0: out = y (fp32) from x;  1: out = dx (T) from x := dy (fp32);  2: dw/db += from x (T), out := dy (fp32)
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B <= 0 || C <= 0 || K <= 0) { cn_set_error("small_linear: empty"); return CN_ESHAPE; }
+  if (dtype != CN_BF16 && dtype != CN_F32) { cn_set_error("small_linear: bad dtype"); return CN_EINVAL; }
+#define SL(T)                                                                                                       \
+  do {                                                                                                              \
+    if (mode == 0)                                                                                                  \
+      CN_LAUNCH(small_linear_fwd_kernel<T>, dim3((unsigned)((B * K + 255) / 256)), dim3(256), stream, (const T*)x, w, \
+                bias, (float*)out, B, C, K);                                                                        \
+    else if (mode == 1)                                                                                             \
+      CN_LAUNCH(small_linear_dgrad_kernel<T>, dim3((unsigned)((B * C + 255) / 256)), dim3(256), stream,              \
+                (const float*)x, w, (T*)out, B, C, K);                                                              \
+    else                                                                                                            \
+      CN_LAUNCH(small_linear_wgrad_kernel<T>, dim3((unsigned)((K * (C + 1) + 255) / 256)), dim3(256), stream,        \
+                (const T*)x, (const float*)out, dw, db, B, C, K);                                                   \
+  } while (0)
+  if (dtype == CN_BF16) SL(bf16_t); else SL(float);
+#undef SL
+  return cn_check_launch("small_linear");
 }
 
 extern "C" int cn_cast_from_f32(const float* x, void* y, long long n, int dtype, void* stream_) {

@@ -190,12 +190,18 @@ __global__ __launch_bounds__(256) void eltwise_kernel(char* a, const char* b, co
       Chunk<T>::unpack(cn_ld16(b + id * 16), fb);
 #pragma unroll
       for (int e = 0; e < CH; ++e) fa[e] = fb[e] > 0.f ? fb[e] : 0.f;
-    } else {  // a = b * (c > 0)
+    } else if (OP == 2) {  // a = b * (c > 0)
       float fc[CH];
       Chunk<T>::unpack(cn_ld16(b + id * 16), fb);
       Chunk<T>::unpack(cn_ld16(c + id * 16), fc);
 #pragma unroll
       for (int e = 0; e < CH; ++e) fa[e] = fc[e] > 0.f ? fb[e] : 0.f;
+    } else {  // a = b * c   (dropout: c is the pre-scaled keep mask)
+      float fc[CH];
+      Chunk<T>::unpack(cn_ld16(b + id * 16), fb);
+      Chunk<T>::unpack(cn_ld16(c + id * 16), fc);
+#pragma unroll
+      for (int e = 0; e < CH; ++e) fa[e] = fb[e] * fc[e];
     }
     cn_st16(a + id * 16, Chunk<T>::pack(fa));
   }
@@ -282,7 +288,7 @@ extern "C" int cn_nhwc_to_nchw(const void* x, float* y, int N, int C, int H, int
   return cn_check_launch("nhwc_to_nchw");
 }
 
-// op: 0  a += b;  1  a = relu(b);  2  a = b * (c > 0).   n = element count (multiple of the chunk).
+// op: 0  a += b;  1  a = relu(b);  2  a = b * (c > 0);  3  a = b * c.   n = element count (multiple of the chunk).
 extern "C" int cn_eltwise(int op, void* a, const void* b, const void* c, long long n, int dtype, void* stream) {
   if (dtype != CN_BF16 && dtype != CN_F32) { cn_set_error("eltwise: bad dtype"); return CN_EINVAL; }
   const int CH = dtype == CN_BF16 ? 8 : 4;
@@ -294,9 +300,11 @@ extern "C" int cn_eltwise(int op, void* a, const void* b, const void* c, long lo
 #define ELT(T, OP) CN_LAUNCH((eltwise_kernel<T, OP>), grid, dim3(256), s, (char*)a, (const char*)b, (const char*)c, nch)
   if (dtype == CN_BF16) {
     if (op == 0) ELT(bf16_t, 0); else if (op == 1) ELT(bf16_t, 1); else if (op == 2) ELT(bf16_t, 2);
+    else if (op == 3) ELT(bf16_t, 3);
     else { cn_set_error("eltwise: bad op"); return CN_EINVAL; }
   } else {
     if (op == 0) ELT(float, 0); else if (op == 1) ELT(float, 1); else if (op == 2) ELT(float, 2);
+    else if (op == 3) ELT(float, 3);
     else { cn_set_error("eltwise: bad op"); return CN_EINVAL; }
   }
 #undef ELT

@@ -112,6 +112,8 @@ class ParamArena(object):
             mod = s.module
             if not s.is_filter or not isinstance(mod, (cnn.Conv2d, cnn.Linear)):
                 continue
+            if mod.out_channels % (4 if dtype == torch.float32 else 8) != 0:
+                continue   # ragged dense head: computed from the fp32 master directly (cn_small_linear)
             taps = mod.kernel_size[0] * mod.kernel_size[1]
             co, creal = mod.out_channels, mod.in_channels
             ch = 4 if dtype == torch.float32 else 8

@@ -1,9 +1,8 @@
-"""MNIST 5-conv model of /root/reference models/mnist.py:10-40 on the HIP operator modules.
-
-BASELINE config 0 ("models/mnist.py ... CPU, no GPU") is the reference's own CPU run and is served
-by the oracle; this native build keeps the registry name and the module tree (state_dict keys
-``feats.N.*`` / ``classifier.*``).  Inference (eval mode) runs on the HIP path; training needs the
-p=0.5 Dropout kernel, which is listed under "next" in DESIGN.md."""
+"""MNIST 5-conv model of /root/reference models/mnist.py:10-40 on the HIP operator modules
+(BASELINE config 0 is the reference's own CPU run; this is the same network, registry name and
+module tree - state_dict keys ``feats.N.*`` / ``classifier.*`` - for the GPU).  Training and
+inference both run on the HIP path; Dropout(0.5) draws its mask from torch's CPU generator in the
+reference's element order, so seeded trajectories are comparable with the reference's."""
 import torch
 import torch.nn as tnn
 
@@ -37,8 +36,7 @@ class MnistModel(tnn.Module):
         # average is taken first (on 128 channels, a multiple of the 16-byte chunk) and the
         # classifier runs as a [B,128]x[128,10] product with fp32 output.
         out = self.avgpool(out)
-        self.classifier.out_f32 = True
-        out = self.classifier(out)
+        out = self.classifier(out)      # 10-way dense head on the pooled [B,1,1,128] map, fp32 logits
         return out.view(-1, 10)
 
 

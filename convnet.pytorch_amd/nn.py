@@ -100,6 +100,13 @@ class Conv2d(_ArenaModule):
         if x.shape[-1] != self.padded_in_channels():
             raise _lib.ConvNetHipError('Conv2d expected %d (padded) NHWC channels, got %s'
                                        % (self.padded_in_channels(), tuple(x.shape)))
+        if self.out_channels % _lib.chunk_elems(self.compute_dtype) != 0:
+            # ragged width (MNIST's 10-way 1x1 classifier): only as a dense layer on a 1x1 map
+            if self.kernel_size != (1, 1) or x.shape[1] != 1 or x.shape[2] != 1:
+                raise NotImplementedError('Conv2d with out_channels %% chunk != 0 is only supported as a 1x1 conv '
+                                          'on a 1x1 map (dense head)')
+            y = ops.SmallLinearFunction.apply(x.reshape(x.shape[0], self.in_channels), self.weight, self.bias, self)
+            return y.view(x.shape[0], 1, 1, self.out_channels)
         return ops.Conv2dFunction.apply(x, self.weight, self.bias, self)
 
     def extra_repr(self):
@@ -222,7 +229,11 @@ class AdaptiveAvgPool2d(tnn.Module):
 
 
 class Dropout(tnn.Module):
-    """nn.Dropout(p): the reference's ResNet blocks only use p = 0 (identity)."""
+    """nn.Dropout(p).  The reference's ResNet blocks only use p = 0 (identity); models/mnist.py:32
+    uses p = 0.5.  The keep mask is drawn on the host from torch's global CPU generator in the
+    reference's NCHW element order (`empty_like(x).bernoulli_(1 - p)`, what ATen's CPU dropout
+    does), so a seeded run consumes the same random stream as the reference; the multiply (forward
+    and backward) is the HIP eltwise kernel."""
 
     def __init__(self, p=0.5, inplace=False):
         super().__init__()
@@ -231,7 +242,10 @@ class Dropout(tnn.Module):
     def forward(self, x):
         if self.p == 0 or not self.training:
             return x
-        raise NotImplementedError('HIP Dropout with p > 0 is outside the ResNet hot path')
+        N, H, W, C = x.shape
+        keep = torch.empty(N, C, H, W).bernoulli_(1 - self.p).div_(1 - self.p)
+        mask = ops.nchw_to_nhwc(keep.to(x.device), x.dtype, C)
+        return ops.DropoutFunction.apply(x, mask)
 
 
 def fork(x, holder=None):

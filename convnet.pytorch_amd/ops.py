@@ -383,6 +383,61 @@ class ReLUFunction(Function):
         return dx
 
 
+class DropoutFunction(Function):
+    """z = x * mask; `mask` (compute dtype, NHWC) already holds keep/(1-p)."""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        z = torch.empty_like(x)
+        check(_L().cn_eltwise(3, ptr(z), ptr(x), ptr(mask), x.numel(), dtype_code(x.dtype), stream_of(x)), 'cn_eltwise')
+        ctx.save_for_backward(mask)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        (mask,) = ctx.saved_tensors
+        dz = dz.contiguous()
+        dx = torch.empty_like(dz)
+        check(_L().cn_eltwise(3, ptr(dx), ptr(dz), ptr(mask), dz.numel(), dtype_code(dz.dtype), stream_of(dz)),
+              'cn_eltwise')
+        return dx, None
+
+
+class SmallLinearFunction(Function):
+    """Dense layer whose output width is not a multiple of the 16-byte chunk (MNIST's 10-way head)."""
+
+    @staticmethod
+    def forward(ctx, x2d, weight, bias, mod):
+        B, C = x2d.shape
+        K = mod.out_channels
+        y = torch.empty((B, K), dtype=torch.float32, device=x2d.device)
+        check(_L().cn_small_linear(0, ptr(x2d), ptr(mod.master_view('weight')), ptr(bias), ptr(y), None, None, B, C,
+                                   K, dtype_code(x2d.dtype), stream_of(x2d)), 'cn_small_linear')
+        ctx.mod = mod
+        ctx.save_for_backward(x2d)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2d,) = ctx.saved_tensors
+        mod = ctx.mod
+        B, C = x2d.shape
+        K = mod.out_channels
+        dy = dy.contiguous().float()
+        L = _L()
+        code = dtype_code(x2d.dtype)
+        db = mod.grad_view('bias') if mod.bias is not None else None
+        check(L.cn_small_linear(2, ptr(x2d), None, None, ptr(dy), ptr(mod.grad_view('weight')), ptr(db), B, C, K, code,
+                                stream_of(x2d)), 'cn_small_linear')
+        mod._notify_grad_ready()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x2d)
+            check(L.cn_small_linear(1, ptr(dy), ptr(mod.master_view('weight')), None, ptr(dx), None, None, B, C, K,
+                                    code, stream_of(x2d)), 'cn_small_linear')
+        return dx, None, None, None
+
+
 class ForkFunction(Function):
     """Two aliases of one activation (block input -> conv branch + residual branch).  Backward sums
     the two incoming gradients with our own kernel, so autograd never launches its accumulate."""

@@ -92,7 +92,7 @@ int cn_nchw_to_nhwc(const float* x_nchw, void* y_nhwc, int N, int C, int H, int 
                     void* stream);
 int cn_nhwc_to_nchw(const void* x_nhwc, float* y_nchw, int N, int C, int H, int W, int Cpad, int dtype,
                     void* stream);
-/* op 0: a += b;  1: a = relu(b);  2: a = b * (c > 0).  n elements (multiple of the chunk). */
+/* op 0: a += b;  1: a = relu(b);  2: a = b * (c > 0);  3: a = b * c.  n elements (multiple of the chunk). */
 int cn_eltwise(int op, void* a, const void* b, const void* c, long long n, int dtype, void* stream);
 
 /* ---- criterion + accuracy + meters (main.py:231-235; trainer.py:143,153,224-229) ------------ */
@@ -120,6 +120,10 @@ int cn_weight_prep_multi(const float* master_arena, void* wbuf, const long long*
 size_t cn_colsum_workspace(int C);
 int cn_colsum(const void* x, float* out, int M, int C, int dtype, float beta, float scale, float* workspace,
               void* stream);
+/* dense layers whose width is not a multiple of the chunk (10-way head of models/mnist.py:30), fp32 master
+ * weights w[K][C]: mode 0 y=x.w^T+b (x T, out fp32); 1 dx=dy.w (x:=dy fp32, out T); 2 dw,db += (x T, out:=dy fp32) */
+int cn_small_linear(int mode, const void* x, const float* w, const float* bias, void* out, float* dw, float* db,
+                    int B, int C, int K, int dtype, void* stream);
 int cn_cast_from_f32(const float* x, void* y, long long n, int dtype, void* stream);
 int cn_fill_f32(float* x, long long n, float v, void* stream);
 

@@ -104,6 +104,34 @@ def trajectory(tag, model_kw, B, size, classes, steps, seed, loss_scale=1.0, gra
     print(tag, recs[0], recs[-1], 'val', out['validate'])
 
 
+def mnist_trajectory(steps=3, B=16, seed=31):
+    """BASELINE config 0 shape: models/mnist.py trained by the reference Trainer on CPU with the CLI
+    default regime (main.py:243-247: SGD lr 0.1, momentum 0.9, wd 0).  Dropout(0.5) is active and
+    draws from torch's global CPU generator after manual_seed(123) + model construction."""
+    torch.manual_seed(123)
+    model = ref_models.mnist()
+    opt = OptimRegime(model, [{'epoch': 0, 'optimizer': 'SGD', 'lr': 0.1, 'momentum': 0.9, 'weight_decay': 0}])
+    tr = RefTrainer(model, CrossEntropyLoss(), opt, device_ids=None, device='cpu', dtype=torch.float,
+                    distributed=False, grad_clip=1e9, print_freq=10 ** 9)
+    g = torch.Generator().manual_seed(seed)
+    data = [(torch.randn(B, 1, 28, 28, generator=g), torch.randint(0, 10, (B,), generator=g)) for _ in range(steps)]
+    recs = []
+    for x, t in data:
+        r = tr.train([(x, t)])
+        recs.append({k: float(r[k]) for k in ('loss', 'prec1', 'prec5', 'grad')})
+    val = tr.validate(data[:2])
+    sd = model.state_dict()
+    out = {'B': B, 'steps': steps, 'seed': seed, 'records': recs,
+           'validate': {k: float(val[k]) for k in ('loss', 'prec1', 'prec5')},
+           'final_sums': tensor_sums({k: v for k, v in sd.items() if v.dtype.is_floating_point})}
+    with open(os.path.join(OUT, 'traj_mnist.json'), 'w') as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    torch.save({k: sd[k].clone() for k in ('feats.0.weight', 'feats.0.bias', 'feats.3.running_var',
+                                           'classifier.weight', 'classifier.bias')},
+               os.path.join(OUT, 'traj_mnist_final.pt'))
+    print('mnist', recs[0], recs[-1], out['validate'])
+
+
 def mnist_eval():
     torch.manual_seed(123)
     m = ref_models.mnist()
@@ -125,4 +153,5 @@ if __name__ == '__main__':
     trajectory('r18_full', dict(depth=18), B=4, size=224, classes=1000, steps=2, seed=21)
     trajectory('r50_full', dict(depth=50), B=4, size=224, classes=1000, steps=2, seed=22)
     mnist_eval()
+    mnist_trajectory()
     assert not os.path.exists(os.path.join(REF, '__pycache__')), 'bytecode leaked into the reference tree'

@@ -1,0 +1,93 @@
+"""BASELINE config 0 (models/mnist.py, b<=64, SGD) on the HIP path against the golden records of the
+reference's CPU Trainer, plus Trainer.calibrate_bn (trainer.py:277-285) against the oracle."""
+import json
+import os
+
+import pytest
+import torch
+
+from conftest import HAS_GPU
+from helpers import GOLDEN, rel_l2
+
+MODES = [pytest.param('emul'), pytest.param('gpu', marks=pytest.mark.gpu)]
+
+
+def _dev(mode):
+    if mode == 'emul' and HAS_GPU:
+        pytest.skip('emulator mode is for GPU-less hosts')
+    if mode == 'gpu' and not HAS_GPU:
+        pytest.skip('no GPU')
+    return torch.device('cuda', 0) if mode == 'gpu' else torch.device('cpu')
+
+
+@pytest.mark.parametrize('mode', MODES)
+def test_mnist_training_matches_reference(mode):
+    dev = _dev(mode)
+    import convnet_amd as ca
+    with open(os.path.join(GOLDEN, 'traj_mnist.json')) as f:
+        meta = json.load(f)
+    final = torch.load(os.path.join(GOLDEN, 'traj_mnist_final.pt'))
+    torch.manual_seed(123)
+    model = ca.models.mnist()
+    regime = [{'epoch': 0, 'optimizer': 'SGD', 'lr': 0.1, 'momentum': 0.9, 'weight_decay': 0}]   # main.py:243-247
+    tr = ca.Trainer(model, ca.CrossEntropyLoss(), ca.OptimRegime(model, regime), device=str(dev),
+                    dtype=torch.float32, grad_clip=1e9, print_freq=10 ** 9)
+    g = torch.Generator().manual_seed(meta['seed'])
+    data = [(torch.randn(meta['B'], 1, 28, 28, generator=g), torch.randint(0, 10, (meta['B'],), generator=g))
+            for _ in range(meta['steps'])]
+    steps = meta['steps'] if mode == 'gpu' else 2
+    for (x, t), gr in list(zip(data, meta['records']))[:steps]:
+        r = tr.train([(x, t)])
+        assert r['loss'] == pytest.approx(gr['loss'], abs=1e-4)
+        assert r['prec1'] == gr['prec1'] and r['prec5'] == gr['prec5']
+        assert r['grad'] == pytest.approx(gr['grad'], rel=1e-3)
+    if steps == meta['steps']:
+        sd = model.state_dict()
+        for k, v in final.items():
+            assert rel_l2(sd[k].float().cpu(), v) < 1e-4, k
+        val = tr.validate(data[:2])
+        assert val['loss'] == pytest.approx(meta['validate']['loss'], rel=1e-4)
+        assert val['prec1'] == meta['validate']['prec1']
+
+
+@pytest.mark.parametrize('mode', MODES)
+def test_mnist_eval_logits_match_reference(mode):
+    dev = _dev(mode)
+    import convnet_amd as ca
+    fx = torch.load(os.path.join(GOLDEN, 'mnist_eval.pt'))
+    torch.manual_seed(123)
+    model = ca.models.mnist()
+    ca.engine.prepare(model, dev, torch.float32)
+    model.eval()
+    with torch.no_grad():
+        y = model(fx['x'].to(dev))
+    assert torch.allclose(y.cpu(), fx['logits'], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('mode', MODES)
+def test_calibrate_bn_cumulative_statistics(mode):
+    """calibrate_bn: momentum=None => running stats become the plain average over the batches."""
+    dev = _dev(mode)
+    import convnet_amd as ca
+    from oracle import convnet_oracle as O
+    kw = dict(depth=18, num_classes=16, inplanes=8, width=(8, 16, 32, 64))
+    torch.manual_seed(123)
+    model = ca.models.resnet(**kw)
+    tr = ca.Trainer(model, ca.CrossEntropyLoss(), ca.OptimRegime(model, model.regime), device=str(dev),
+                    dtype=torch.float32, print_freq=10 ** 9)
+    data = O.synthetic_batches(3, 4, size=32, classes=16, seed=9)
+    tr.calibrate_bn(data)
+    torch.manual_seed(123)
+    ref = O.OracleResNet(**kw)
+    for m in ref.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.momentum = None
+            m.reset_running_stats()
+    ref.train()
+    with torch.no_grad():
+        for x, _ in data:
+            ref(x)
+    sd, rsd = model.state_dict(), ref.state_dict()
+    for k in ('bn1.running_mean', 'bn1.running_var', 'layer3.0.downsample.1.running_var', 'layer4.1.bn2.running_mean'):
+        assert rel_l2(sd[k].float().cpu(), rsd[k]) < 1e-4, k
+    assert int(sd['bn1.num_batches_tracked']) == 3

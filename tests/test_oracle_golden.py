@@ -64,3 +64,19 @@ def test_trajectory_matches_reference_trainer(tag):
     val = O.oracle_validate(model, golden_batches(meta)[:2], meta['smooth_eps'])
     assert val['loss'] == pytest.approx(meta['validate']['loss'], rel=1e-4)
     assert val['prec1'] == meta['validate']['prec1']
+
+
+def test_mnist_trajectory_matches_reference_trainer():
+    """BASELINE config 0: models/mnist.py + reference Trainer on CPU (Dropout active, same RNG stream)."""
+    with open(os.path.join(GOLDEN, 'traj_mnist.json')) as f:
+        meta = json.load(f)
+    torch.manual_seed(123)
+    model = O.OracleMnist()
+    g = torch.Generator().manual_seed(meta['seed'])
+    data = [(torch.randn(meta['B'], 1, 28, 28, generator=g), torch.randint(0, 10, (meta['B'],), generator=g))
+            for _ in range(meta['steps'])]
+    recs = O.oracle_train(model, data, lr=0.1, momentum=0.9, weight_decay=0, wd_filter=None)
+    for r, gr in zip(recs, meta['records']):
+        assert r['loss'] == pytest.approx(gr['loss'], rel=2e-5)
+        assert r['prec1'] == gr['prec1'] and r['prec5'] == gr['prec5']
+        assert r['grad'] == pytest.approx(gr['grad'], rel=1e-4)
