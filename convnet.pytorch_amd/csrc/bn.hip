@@ -392,7 +392,7 @@ extern "C" size_t cn_bn_workspace(int M, int C, int dtype) {
   const int CH = dtype == CN_BF16 ? 8 : 4;
   if (C % CH != 0 || M <= 0) return 0;
   BnMap m = bn_map(C / CH);
-  int nrb = bn_row_blocks(M, m, BN_TARGET_BLOCKS);
+  int nrb = bn_row_blocks(M, m, 2048);   // upper bound over the tunable reduce-grid sizes
   return (size_t)nrb * 2 * C * sizeof(float);
 }
 
@@ -418,7 +418,7 @@ extern "C" int cn_bn_fwd_train(const void* y, const void* residual, void* z, uns
   hipStream_t stream = (hipStream_t)stream_;
   const int CH = dtype == CN_BF16 ? 8 : 4;
   BnMap m = bn_map(C / CH);
-  int nrb = bn_row_blocks(M, m, BN_TARGET_BLOCKS);
+  int nrb = bn_row_blocks(M, m, cn_get_option("bn_reduce_blocks", BN_TARGET_BLOCKS));
   if (workspace == nullptr || ws_bytes < (size_t)nrb * 2 * C * sizeof(float)) {
     cn_set_error("bn_fwd_train: workspace too small");
     return CN_EWORKSPACE;
@@ -432,7 +432,7 @@ extern "C" int cn_bn_fwd_train(const void* y, const void* residual, void* z, uns
   CN_LAUNCH(bn_finalize_kernel, dim3((unsigned)((C + 31) / 32)), dim3(256), stream, (const float*)partial, nrb,
             M, C, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, stats_out,
             stats_out + C, stats_out + 2 * C, stats_out + 3 * C);
-  int nab = bn_row_blocks(M, m, BN_APPLY_BLOCKS);
+  int nab = bn_row_blocks(M, m, cn_get_option("bn_apply_blocks", BN_APPLY_BLOCKS));
   dim3 agrid((unsigned)nab, (unsigned)m.gy);
   if (dtype == CN_BF16)
     CN_LAUNCH(bn_apply_kernel<bf16_t>, agrid, dim3(256), stream, (const char*)y, (const char*)residual,
@@ -456,7 +456,7 @@ extern "C" int cn_bn_fwd_infer(const void* y, const void* residual, void* z, con
   BnMap m = bn_map(C / CH);
   CN_LAUNCH(bn_infer_coeffs_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), stream, C, gamma, beta,
             running_mean, running_var, eps, coeffs, coeffs + C);
-  int nab = bn_row_blocks(M, m, BN_APPLY_BLOCKS);
+  int nab = bn_row_blocks(M, m, cn_get_option("bn_apply_blocks", BN_APPLY_BLOCKS));
   dim3 agrid((unsigned)nab, (unsigned)m.gy);
   if (dtype == CN_BF16)
     CN_LAUNCH(bn_apply_kernel<bf16_t>, agrid, dim3(256), stream, (const char*)y, (const char*)residual,
@@ -480,7 +480,7 @@ extern "C" int cn_bn_bwd(const void* dz, const void* y, const unsigned char* rel
   hipStream_t stream = (hipStream_t)stream_;
   const int CH = dtype == CN_BF16 ? 8 : 4;
   BnMap m = bn_map(C / CH);
-  int nrb = bn_row_blocks(M, m, BN_TARGET_BLOCKS);
+  int nrb = bn_row_blocks(M, m, cn_get_option("bn_reduce_blocks", BN_TARGET_BLOCKS));
   if (workspace == nullptr || ws_bytes < (size_t)nrb * 2 * C * sizeof(float)) {
     cn_set_error("bn_bwd: workspace too small");
     return CN_EWORKSPACE;
@@ -499,7 +499,7 @@ extern "C" int cn_bn_bwd(const void* dz, const void* y, const unsigned char* rel
               relu_mask, mean, invstd, scale, shift, partial, M, C, relu, m.tpr_log2);
   CN_LAUNCH(bn_bwd_finalize_kernel, dim3((unsigned)((C + 31) / 32)), dim3(256), stream, (const float*)partial,
             nrb, M, C, gamma, mean, invstd, dgamma, dbeta, beta_acc, gscale, coef_scratch);
-  int nab = bn_row_blocks(M, m, BN_APPLY_BLOCKS);
+  int nab = bn_row_blocks(M, m, cn_get_option("bn_apply_blocks", BN_APPLY_BLOCKS));
   dim3 agrid((unsigned)nab, (unsigned)m.gy);
   if (dtype == CN_BF16)
     CN_LAUNCH(bn_bwd_apply_kernel<bf16_t>, agrid, dim3(256), stream, (const char*)dz, (const char*)y,

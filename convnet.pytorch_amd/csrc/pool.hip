@@ -47,8 +47,17 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const char* x, char* y
     }
     const size_t o = ((size_t)(n * P + pp) * Q + q) * C + (size_t)col * CH;
     cn_st16(y + o * EB, Chunk<T>::pack(best));
+    if (CH == 8) {   // one 8-byte store of the chunk's winning taps
+      unsigned long long pk = 0;
 #pragma unroll
-    for (int e = 0; e < CH; ++e) idx[o + e] = (unsigned char)bi[e];
+      for (int e = 0; e < CH; ++e) pk |= (unsigned long long)(unsigned char)bi[e] << (8 * e);
+      *(unsigned long long*)(idx + o) = pk;
+    } else {
+      unsigned int pk = 0;
+#pragma unroll
+      for (int e = 0; e < CH; ++e) pk |= (unsigned int)(unsigned char)bi[e] << (8 * e);
+      *(unsigned int*)(idx + o) = pk;
+    }
   }
 }
 
@@ -85,9 +94,12 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const char* dy, const 
         const size_t o = ((size_t)(n * P + pp) * Q + q) * C + (size_t)col * CH;
         float g[CH];
         Chunk<T>::unpack(cn_ld16(dy + o * EB), g);
+        unsigned long long pk;
+        if (CH == 8) pk = *(const unsigned long long*)(idx + o);
+        else pk = *(const unsigned int*)(idx + o);
 #pragma unroll
         for (int e = 0; e < CH; ++e)
-          if ((int)idx[o + e] == t) acc[e] += g[e];
+          if ((int)((pk >> (8 * e)) & 0xffull) == t) acc[e] += g[e];
       }
     cn_st16(dx + (((size_t)(n * H + h) * W + w) * C + (size_t)col * CH) * EB, Chunk<T>::pack(acc));
   }

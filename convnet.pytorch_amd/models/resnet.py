@@ -74,12 +74,14 @@ class ResidualBlock(tnn.Module):
             self.dropout = cnn.Dropout(0)
         self.stride = stride
         self.expansion = expansion
-        self._holder = None
-        if downsample is None:   # identity block: fold the residual gradient into conv1's dgrad epilogue
-            from ..ops import ResGradHolder
-            self._holder = ResGradHolder()
-            self.conv1._res_holder = self._holder
-            self.last_bn()._res_holder = self._holder
+        # the two gradients meeting at the block input are summed inside a dgrad epilogue
+        from ..ops import ResGradHolder
+        self._holder = ResGradHolder()
+        self.conv1._res_holder = self._holder
+        if downsample is None:
+            self.last_bn()._res_holder = self._holder     # identity: last BN's dres + conv1 dgrad
+        else:
+            downsample[0]._res_holder = self._holder      # downsample conv dgrad + conv1 dgrad
 
     def last_bn(self):
         return getattr(self, 'bn%d' % self.n_convs)

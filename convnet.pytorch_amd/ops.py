@@ -233,11 +233,15 @@ class Conv2dFunction(Function):
         if ctx.needs_input_grad[0]:
             addend = None
             holder = getattr(mod, '_res_holder', None)
-            if holder is not None and holder.dres is not None and holder.dres.shape == x.shape:
-                addend = holder.dres          # residual-branch gradient folded into the dgrad epilogue
+            if holder is not None and holder.dres is not None and holder.dres.shape == x.shape \
+                    and holder.dres.dtype == dy.dtype:
+                addend = holder.dres          # the other branch's gradient, folded into this dgrad epilogue
                 holder.fused = True
             dx = conv2d_dgrad(dy, mod.w_crsk, x.shape, mod.out_channels, R, S, mod.stride, mod.padding,
                               addend=addend)
+            if holder is not None and addend is None:
+                holder.dres = dx              # first producer of the fork gradient: park it for the other
+                holder.fused = False
         return dx, None, None, None
 
 
@@ -451,19 +455,24 @@ class ForkFunction(Function):
     def backward(ctx, ga, gb):
         holder = ctx.holder
         fused = holder is not None and holder.fused
+        first = holder.dres if holder is not None else None
         if holder is not None:
             holder.dres, holder.fused = None, False
         if ga is None:
             return gb, None
-        if gb is None or fused:      # the conv-branch dgrad already added the residual-branch gradient
+        if gb is None:
             return ga, None
+        if fused:   # the later of the two branch gradients already contains the earlier one
+            return (gb if (first is not None and first.data_ptr() == ga.data_ptr()) else ga), None
         ga = ga.contiguous()
         return add_(ga, gb.contiguous()), None
 
 
 class ResGradHolder(object):
-    """Per-block mailbox: the last BN's backward leaves the residual-branch gradient here so that the
-    first conv's dgrad can add it in its epilogue (one pass instead of a separate add kernel)."""
+    """Per-block mailbox for the two gradients that meet at a residual block's input: whichever branch
+    finishes first (the last BN's `dres` in identity blocks, one of the two convs in downsample
+    blocks) parks its gradient here; the other branch's conv dgrad adds it in its epilogue (one pass
+    instead of a separate add kernel), independent of autograd's execution order."""
     __slots__ = ('dres', 'fused')
 
     def __init__(self):
