@@ -46,6 +46,8 @@ def main():
     ap.add_argument('--depth', type=int, default=50)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--pool', type=int, default=4, help='distinct pre-staged device batches')
+    ap.add_argument('--host-inputs', action='store_true',
+                    help='feed pinned HOST batches (PCIe-inclusive rate, for DESIGN.md; never the contract value)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
     args = ap.parse_args()
@@ -56,6 +58,9 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    if args.gpus != world and rank == 0:
+        print('bench.py: --gpus %d but WORLD_SIZE=%d (launch through torch.distributed.run for N > 1)'
+              % (args.gpus, world), file=sys.stderr)
     distributed = world > 1 or os.environ.get('BENCH_FORCE_DIST') == '1'   # world-1 RCCL smoke test
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
@@ -75,8 +80,12 @@ def main():
 
     B = args.batch
     g = torch.Generator().manual_seed(123 + rank)
-    pool = [(torch.randn(B, 3, 224, 224, generator=g).to(device),
-             torch.randint(0, 1000, (B,), generator=g).to(device)) for _ in range(args.pool)]
+    pool = [(torch.randn(B, 3, 224, 224, generator=g), torch.randint(0, 1000, (B,), generator=g))
+            for _ in range(args.pool)]
+    if args.host_inputs:
+        pool = [(x.pin_memory(), t.pin_memory()) for x, t in pool]
+    else:
+        pool = [(x.to(device), t.to(device)) for x, t in pool]
 
     def loader(n):
         return [pool[i % len(pool)] for i in range(n)]
@@ -163,7 +172,7 @@ def main():
             'value': round(img_s, 1), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
-            'data': 'synthetic',
+            'data': 'synthetic' + (' (host batches, H2D inside the timed loop)' if args.host_inputs else ''),
             'config': {'workload': 'ResNet-%d (depth:%d) synthetic 3x224x224 b=%d/GPU %s, SGD+momentum, '
                                    '%s' % (args.depth, args.depth, B, args.dtype,
                                            'dp%d RCCL all-reduce' % world if world > 1 else '1 MI355X'),

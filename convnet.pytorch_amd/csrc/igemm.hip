@@ -32,7 +32,7 @@ struct IgemmParams {
   int Hg, Wg, a_h, a_w;
   int Ho, Wo, Co;
   int oh_mul, oh_off, ow_mul, ow_off;
-  int ntaps, cpt, cpt_shift, nchunks;
+  int ntaps, cpt, nchunks;
   long long w_row;
   int out_f32, relu;
   int M, n_ntiles;
@@ -378,12 +378,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-static int ig_log2_exact(int v) {
-  int s = 0;
-  while ((1 << s) < v) ++s;
-  return ((1 << s) == v) ? s : -1;
-}
-
 template <typename T, bool OUTF32>
 static int ig_launch(IgemmParams& p, hipStream_t stream) {
   const int nkt = (p.nchunks + 7) / 8;
@@ -426,7 +420,6 @@ static int ig_common(IgemmParams& p, int dtype, int Ci, int ntaps) {
     return CN_ESHAPE;
   }
   p.cpt = Ci / CH;
-  p.cpt_shift = ig_log2_exact(p.cpt);
   p.div_cpt = cn_make_fastdiv((unsigned)p.cpt);
   p.ntaps = ntaps;
   p.nchunks = ntaps * p.cpt;

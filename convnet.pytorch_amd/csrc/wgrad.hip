@@ -24,7 +24,7 @@ struct WgradParams {
   float* part;
   int N, Hi, Wi, Ci, Ho, Wo, Co;
   int stride_h, stride_w;
-  int ntaps, cpt, cpt_shift, ncols;
+  int ntaps, cpt, ncols;
   int M, m_per_split, nsplit;
   int n_itiles, n_jtiles;
   unsigned int x_bytes, dy_bytes;
@@ -301,7 +301,6 @@ extern "C" int cn_conv2d_wgrad(const void* x, const void* dy, float* dw_krsc, in
   p.N = N; p.Hi = H; p.Wi = W; p.Ci = C; p.Ho = P; p.Wo = Q; p.Co = K;
   p.stride_h = stride_h; p.stride_w = stride_w;
   p.ntaps = R * S; p.cpt = C / CH; p.ncols = pl.ncols;
-  p.cpt_shift = 0;
   p.div_cpt = cn_make_fastdiv((unsigned)p.cpt);
   const long long EBl = dtype == CN_BF16 ? 2 : 4;
   const long long xb = (long long)N * H * W * C * EBl, dyb = (long long)N * P * Q * K * EBl;

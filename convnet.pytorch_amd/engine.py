@@ -86,7 +86,6 @@ class ParamArena(object):
             cur_len += seglen
         if members:
             self.buckets.append((cur_start, cur_len, members))
-        self._owner_buckets = {}
         for bi, (_, _, members) in enumerate(self.buckets):
             for s in members:
                 s.bucket = bi
@@ -216,8 +215,6 @@ def prepare(model, device, dtype=torch.float32, bucket_mb=25.0):
     if arena is not None and arena.device == torch.device(device) and getattr(model, '_cn_dtype', None) == dtype:
         return arena
     device = torch.device(device)
-    for name, buf in list(model.named_buffers()):
-        pass
     # buffers (BN running stats) move with a plain .to(); parameters are re-homed into the arena
     for mod in model.modules():
         for bname, buf in list(mod._buffers.items()):

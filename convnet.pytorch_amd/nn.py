@@ -80,9 +80,8 @@ class Conv2d(_ArenaModule):
             init.uniform_(self.bias, -bound, bound)
         else:
             self.register_parameter('bias', None)
-        self.w_krsc = None
+        self.w_krsc = None      # compute-dtype filter copies: views into ParamArena.wbuf
         self.w_crsk = None
-        self._prep_version = -1
         self.needs_dgrad = True
 
     def padded_in_channels(self):
@@ -135,7 +134,6 @@ class Linear(_ArenaModule):
             self.register_parameter('bias', None)
         self.w_krsc = None
         self.w_crsk = None
-        self._prep_version = -1
 
     def padded_in_channels(self):
         return self.in_features

@@ -29,11 +29,6 @@ def workspace(nbytes, device, tag='main'):
     return buf
 
 
-def reserve_workspace(nbytes, device, tag='main'):
-    """Pre-size a workspace (needed before HIP-graph capture: no allocation inside a capture)."""
-    workspace(nbytes, device, tag)
-
-
 def _L():
     return _lib.load()
 

@@ -27,6 +27,52 @@ from .cross_entropy import CrossEntropyLoss
 from .meters import AverageMeter, accuracy
 
 
+class DevicePrefetcher(object):
+    """Overlaps the host->device copy of batch i+1 with the compute of batch i (the reference moves
+    each batch synchronously inside the step, trainer.py:116-117).  Batches already on the device
+    pass through untouched.  Copies run on a side stream; the compute stream waits on an event and
+    `record_stream` keeps the caching allocator from recycling a batch still in use."""
+
+    def __init__(self, loader, device):
+        self.loader, self.device = loader, device
+        self.stream = torch.cuda.Stream(device) if device.type == 'cuda' else None
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _stage(self, batch):
+        inputs, target = batch
+        if self.stream is None or (inputs.is_cuda and target.is_cuda):
+            return inputs, target, None
+        with torch.cuda.stream(self.stream):
+            if not inputs.is_pinned():
+                inputs = inputs.pin_memory()
+            x = inputs.to(self.device, dtype=torch.float32, non_blocking=True)
+            t = target.to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        return x, t, ev
+
+    def __iter__(self):
+        it = iter(self.loader)
+        try:
+            nxt = self._stage(next(it))
+        except StopIteration:
+            return
+        while nxt is not None:
+            x, t, ev = nxt
+            try:
+                nxt = self._stage(next(it))
+            except StopIteration:
+                nxt = None
+            if ev is not None:
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(ev)
+                x.record_stream(cur)
+                t.record_stream(cur)
+            yield x, t
+
+
 class Trainer(object):
 
     def __init__(self, model, criterion, optimizer=None,
@@ -185,7 +231,7 @@ class Trainer(object):
         end = time.time()
         n_batches = len(data_loader)
         try:
-            for i, (inputs, target) in enumerate(data_loader):
+            for i, (inputs, target) in enumerate(DevicePrefetcher(data_loader, self.device)):
                 if inputs.dim() > 4:
                     raise NotImplementedError('duplicates (B x D x C x H x W inputs) are outside the hot path')
                 meters['data'].update(time.time() - end)

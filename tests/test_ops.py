@@ -161,8 +161,6 @@ def test_batchnorm_train_fwd_bwd(mode, dtype, relu, use_res):
         y, gamma, beta, r, z, rm, rv = _bn_ref(y0, gamma0, beta0, res0, relu)
         z.backward(dz)
 
-        class Holder:   # minimal stand-in for nn.BatchNorm2d's attributes used by the Function
-            pass
         bn = ca.nn.BatchNorm2d(C)
         model = torch.nn.Sequential(bn)
         ca.engine.prepare(model, dev, dtype)
