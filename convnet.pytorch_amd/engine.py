@@ -191,12 +191,14 @@ class BucketReducer(object):
         b = slot.bucket
         self._pending[b] -= 1
         if self._pending[b] == 0:
+            ops.SIDE.join(self.arena.device)   # wgrad kernels of this bucket may sit on the side stream
             start, length, _ = self.arena.buckets[b]
             view = self.arena.grads[start:start + length]
             self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def finish(self):
         """Flush buckets that never filled (unused parameters) and wait for all reductions."""
+        ops.SIDE.join(self.arena.device)
         if self.enabled:
             for b, left in enumerate(self._pending):
                 if left > 0:

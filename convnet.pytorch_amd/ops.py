@@ -69,6 +69,39 @@ class KernelProfiler(object):
 PROFILER = KernelProfiler()
 
 
+class SideStream(object):
+    """Optional second HIP stream for the weight-gradient kernels: wgrad(x, dy) and dgrad(dy, w) of a
+    layer are independent, and the late layers' launches are too small to fill 256 CUs on their
+    own, so running wgrad beside the main backward stream packs the machine better.
+    Enabled with CONVNET_AMD_WGRAD_STREAM=1 (or ops.SIDE.enabled = True); Trainer joins the stream
+    before the gradient all-reduce / optimizer step."""
+
+    def __init__(self):
+        import os
+        self.enabled = os.environ.get('CONVNET_AMD_WGRAD_STREAM', '0') == '1'
+        self._streams = {}
+        self.used = False
+
+    def get(self, device):
+        s = self._streams.get(device)
+        if s is None:
+            s = torch.cuda.Stream(device)
+            self._streams[device] = s
+        return s
+
+    def active(self, t):
+        return self.enabled and t.is_cuda and not PROFILER.enabled
+
+    def join(self, device):
+        """Make the current stream wait for everything queued on the side stream."""
+        if self.used and device.type == 'cuda':
+            torch.cuda.current_stream(device).wait_stream(self.get(device))
+            self.used = False
+
+
+SIDE = SideStream()
+
+
 def _esize(t):
     return t.element_size()
 
@@ -120,13 +153,13 @@ def conv2d_dgrad(dy, w_crsk, x_shape, K, R, S, stride, pad, addend=None):
     return dx
 
 
-def conv2d_wgrad(x, dy, dw_krsc, c_real, K, R, S, stride, pad, beta=1.0, scale=1.0):
+def conv2d_wgrad(x, dy, dw_krsc, c_real, K, R, S, stride, pad, beta=1.0, scale=1.0, tag='main'):
     """dw_krsc (fp32, [K][R][S][c_real] memory order) = beta*dw + scale*wgrad."""
     N, H, W, C = x.shape
     code = dtype_code(x.dtype)
     L = _L()
     need = L.cn_conv2d_wgrad_workspace(N, H, W, C, K, R, S, stride[0], stride[1], pad[0], pad[1], code)
-    ws = workspace(need, x.device)
+    ws = workspace(need, x.device, tag)
     PROFILER.run('wgrad_kernel<%s, %d, 128> (+wgrad_reduce)' % ('float' if x.dtype == torch.float32 else 'bf16_t', 64 if K <= 64 else 128),
                  2, 2.0 * dy.numel() * C * R * S,
                  x.numel() * _esize(x) + dy.numel() * _esize(dy) + K * R * S * C * 4,
@@ -219,8 +252,19 @@ class Conv2dFunction(Function):
         if dy.dtype != x.dtype:  # fp32 logits gradient -> compute dtype
             dy = cast_from_f32(dy, x.dtype)
         R, S = mod.kernel_size
-        conv2d_wgrad(x, dy, mod.grad_view('weight'), mod.in_channels, mod.out_channels, R, S, mod.stride,
-                     mod.padding)
+        if SIDE.active(x):
+            cur = torch.cuda.current_stream(x.device)
+            side = SIDE.get(x.device)
+            side.wait_stream(cur)                       # dy (and everything before it) is ready
+            with torch.cuda.stream(side):
+                conv2d_wgrad(x, dy, mod.grad_view('weight'), mod.in_channels, mod.out_channels, R, S, mod.stride,
+                             mod.padding, tag='side')
+            x.record_stream(side)
+            dy.record_stream(side)
+            SIDE.used = True
+        else:
+            conv2d_wgrad(x, dy, mod.grad_view('weight'), mod.in_channels, mod.out_channels, R, S, mod.stride,
+                         mod.padding)
         if ctx.has_bias:
             colsum(dy.view(-1, mod.out_channels), mod.grad_view('bias'))
         mod._notify_grad_ready()

@@ -175,6 +175,7 @@ class Trainer(object):
                 loss.backward()
 
         if training:
+            ops.SIDE.join(self.device)      # weight-gradient kernels queued on the side stream
             if self.reducer is not None:
                 self.reducer.finish()
             gscale = 1.0 / float(self.world_size)
