@@ -302,6 +302,17 @@ static inline void cn_buf_ld16_lds(cn_buf_t b, unsigned int off, void* lds_wave_
 }
 #endif
 
+// Counted wait on outstanding vector-memory operations (LDS-DMA included) and a raw workgroup barrier
+// without the fence of __syncthreads(): lets DMA tiles stay in flight across barriers (multi-stage
+// ring).  N must be a literal.  The emulator's DMA is synchronous, so the wait is a no-op there.
+#ifndef CN_EMULATE
+#define CN_WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+__device__ __forceinline__ void cn_raw_barrier() { __builtin_amdgcn_s_barrier(); }
+#else
+#define CN_WAIT_VMCNT(N) do { } while (0)
+static inline void cn_raw_barrier() { cn_emul::sync_threads(); }
+#endif
+
 // 16-byte global / LDS accessors
 __host__ __device__ __forceinline__ u32x4 cn_ld16(const void* p) { return *(const u32x4*)p; }
 __host__ __device__ __forceinline__ void cn_st16(void* p, const u32x4& v) { *(u32x4*)p = v; }

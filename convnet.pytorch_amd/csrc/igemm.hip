@@ -76,9 +76,11 @@ __device__ __forceinline__ int ig_slot(int row, int chunk) {
 // GLDS: operands are DMA'd straight into the (source-permuted, hence still XOR-swizzled) LDS tiles
 //       with `buffer_load ... lds`: no prefetch registers, no ds_write pass (the register-staged
 //       variant spends ~416 LDS cycles per K tile on ds_write_b128 against 512 MFMA cycles).
+//       STAGES = 4 with GLDS: a 4-deep DMA ring (3 K tiles in flight across raw barriers, counted
+//       vmcnt waits) for long reductions, one workgroup per CU.
 template <typename T, int WC, int WP, int TI, int TJ, int STAGES, bool OUTF32, bool GLDS>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
-  static_assert(!GLDS || STAGES == 2, "LDS-DMA needs the double-buffered tile");
+  static_assert(!GLDS || STAGES == 2 || STAGES == 4, "LDS-DMA needs the double-buffered tile or the 4-deep ring");
   constexpr int BN = WC * TI * 32;  // output channels per block
   constexpr int BM = WP * TJ * 32;  // pixels per block
   static_assert(WC * WP == 4, "4 waves");
@@ -249,7 +251,28 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   if (nkt > 0) {
     load_tile(0, 0);
     if (!GLDS) store_tile(0);
-    __syncthreads();
+    if (!(GLDS && STAGES == 4)) __syncthreads();
+    if (GLDS && STAGES == 4) {
+      // ring: tiles kt+1, kt+2 (and, once issued, kt+3) stay in flight while tile kt is consumed.
+      // Every thread issues exactly NWR+NPR DMA instructions per tile, so "tile kt has landed" is a
+      // counted wait: at most (tiles issued after kt) * (NWR+NPR) operations may remain outstanding.
+      constexpr int L = NWR + NPR;
+      static_assert(L == 8 || L == 6, "wait immediates below assume 6 or 8 DMA instructions per tile");
+      if (nkt > 1) load_tile(1, 1);
+      if (nkt > 2) load_tile(2, 2);
+      for (int kt = 0; kt < nkt; ++kt) {
+        const int ahead = nkt - 1 - kt < 2 ? nkt - 1 - kt : 2;   // tiles issued after kt at this point
+        if (L == 8) {
+          if (ahead == 2) CN_WAIT_VMCNT(16); else if (ahead == 1) CN_WAIT_VMCNT(8); else CN_WAIT_VMCNT(0);
+        } else {
+          if (ahead == 2) CN_WAIT_VMCNT(12); else if (ahead == 1) CN_WAIT_VMCNT(6); else CN_WAIT_VMCNT(0);
+        }
+        cn_raw_barrier();   // tile kt visible to every wave; buffer (kt+3)%4 == (kt-1)%4 is free again
+        if (kt + 3 < nkt) load_tile(kt + 3, (kt + 3) & 3);
+        compute(kt & 3);
+      }
+      __syncthreads();
+    } else
     for (int kt = 0; kt < nkt; ++kt) {
       if (GLDS) {
         const int buf = kt & 1;
@@ -382,9 +405,9 @@ template <typename T, bool OUTF32>
 static int ig_launch(IgemmParams& p, hipStream_t stream) {
   const int nkt = (p.nchunks + 7) / 8;
   // variant: 1 = register-staged single buffer, 2 = register-staged double buffer, 3 = LDS-DMA double
-  // buffer; 0 / unset = heuristic (tuning knob "igemm_variant", profiles/r01_conv_layers*)
+  // buffer, 4 = LDS-DMA 4-deep ring; 0 / unset = heuristic (tuning knob "igemm_variant", profiles/r01_conv_layers*)
   int variant = cn_get_option("igemm_variant", 0);
-  if (variant < 1 || variant > 3) variant = cn_get_option("igemm_default_variant", nkt < 24 ? 1 : 3);
+  if (variant < 1 || variant > 4) variant = cn_get_option("igemm_default_variant", nkt < 24 ? 1 : 3);
   const int BM = 128, BN = p.Co <= 64 ? 64 : 128;
   p.n_ntiles = (p.Co + BN - 1) / BN;
   const int n_mtiles = (p.M + BM - 1) / BM;
@@ -393,7 +416,8 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
   do {                                                                                                         \
     if (variant == 1) CN_LAUNCH((igemm_kernel<T, WC, WP, TI, TJ, 1, OUTF32, false>), grid, dim3(256), stream, p); \
     else if (variant == 2) CN_LAUNCH((igemm_kernel<T, WC, WP, TI, TJ, 2, OUTF32, false>), grid, dim3(256), stream, p); \
-    else CN_LAUNCH((igemm_kernel<T, WC, WP, TI, TJ, 2, OUTF32, true>), grid, dim3(256), stream, p);             \
+    else if (variant == 3) CN_LAUNCH((igemm_kernel<T, WC, WP, TI, TJ, 2, OUTF32, true>), grid, dim3(256), stream, p); \
+    else CN_LAUNCH((igemm_kernel<T, WC, WP, TI, TJ, 4, OUTF32, true>), grid, dim3(256), stream, p);             \
   } while (0)
   if (p.Co <= 64) IG_GO(1, 4, 2, 1);
   else IG_GO(2, 2, 2, 2);
