@@ -79,14 +79,16 @@ __device__ __forceinline__ int ig_slot(int row, int chunk) {
 //       STAGES = 4 with GLDS: a 4-deep DMA ring (3 K tiles in flight across raw barriers, counted
 //       vmcnt waits) for long reductions, one workgroup per CU.
 template <typename T, int WC, int WP, int TI, int TJ, int STAGES, bool OUTF32, bool GLDS>
-__global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
+__global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
   static_assert(!GLDS || STAGES == 2 || STAGES == 4, "LDS-DMA needs the double-buffered tile or the 4-deep ring");
   constexpr int BN = WC * TI * 32;  // output channels per block
   constexpr int BM = WP * TJ * 32;  // pixels per block
-  static_assert(WC * WP == 4, "4 waves");
+  constexpr int NT = WC * WP * 64;  // threads (4 or 8 waves)
+  static_assert(NT == 256 || NT == 512, "4 or 8 waves");
+  constexpr int RS = NT / 8;        // tile rows covered by one staging pass (8 chunks per row)
   constexpr int EB = ElemTraits<T>::kBytes;
-  constexpr int NPR = BM / 32;  // pixel rows staged per thread
-  constexpr int NWR = BN / 32;  // filter rows staged per thread
+  constexpr int NPR = BM / RS;  // pixel rows staged per thread
+  constexpr int NWR = BN / RS;  // filter rows staged per thread
   constexpr int STAGE = (BM + BN) * 128;
   constexpr int OUT_MAX = BM * (BN * (OUTF32 ? 4 : EB) + 16);
   constexpr int MAIN = (STAGES * STAGE > OUT_MAX) ? STAGES * STAGE : OUT_MAX;
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   unsigned int prow[NPR], wrow[NWR];   // byte offsets of the row starts (CN_OOB = row not valid)
 #pragma unroll
   for (int i = 0; i < NPR; ++i) {
-    int m = m0 + r0 + 32 * i;
+    int m = m0 + r0 + RS * i;
     const bool valid = m < p.M;
     int mm = valid ? m : 0;
     int n = (int)cn_fastdiv((unsigned)mm, p.div_hw);
@@ -156,11 +158,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   }
 #pragma unroll
   for (int i = 0; i < NWR; ++i) {
-    const int co = n0 + r0 + 32 * i;
+    const int co = n0 + r0 + RS * i;
     wrow[i] = co < p.Co ? (unsigned int)(co * (int)p.w_row * EB) : CN_OOB;
   }
   // loop-invariant LDS addresses: staging stores and fragment reads
-  const int st0 = ig_slot(r0, cc);   // rows r0 + 32*i share the swizzle: slot(i) = st0 + i*32*128
+  const int st0 = ig_slot(r0, cc);   // rows r0 + RS*i share the swizzle: slot(i) = st0 + i*RS*128
   const int wc = wave % WC;
   const int wp = wave / WC;
   const int lrow = lane & 31;
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 #pragma unroll
       for (int i = 0; i < NPR; ++i) {
         const unsigned int o = (prow[i] | kb) >= CN_OOB ? CN_OOB : prow[i] + xofs;
-        if (GLDS) cn_buf_ld16_lds(xbuf, o, dp_ + i * 32 * 128);
+        if (GLDS) cn_buf_ld16_lds(xbuf, o, dp_ + i * RS * 128);
         else preg[i] = cn_buf_ld16(xbuf, o);
       }
     } else {
@@ -213,23 +215,23 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
         const bool ok = (unsigned)(phin[i] + dh) < (unsigned)p.Hi && (unsigned)(pwin[i] + dw) < (unsigned)p.Wi &&
                         kb < CN_OOB;
         const unsigned int o = ok ? prow[i] + xofs : CN_OOB;
-        if (GLDS) cn_buf_ld16_lds(xbuf, o, dp_ + i * 32 * 128);
+        if (GLDS) cn_buf_ld16_lds(xbuf, o, dp_ + i * RS * 128);
         else preg[i] = cn_buf_ld16(xbuf, o);
       }
     }
 #pragma unroll
     for (int i = 0; i < NWR; ++i) {
       const unsigned int o = (wrow[i] | kb) >= CN_OOB ? CN_OOB : wrow[i] + wofs;
-      if (GLDS) cn_buf_ld16_lds(wbuf, o, dw_ + i * 32 * 128);
+      if (GLDS) cn_buf_ld16_lds(wbuf, o, dw_ + i * RS * 128);
       else wreg[i] = cn_buf_ld16(wbuf, o);
     }
   };
   auto store_tile = [&](int buf) {
     char* base = lds + buf * STAGE;
 #pragma unroll
-    for (int i = 0; i < NWR; ++i) cn_st16(base + st0 + i * 32 * 128, wreg[i]);
+    for (int i = 0; i < NWR; ++i) cn_st16(base + st0 + i * RS * 128, wreg[i]);
 #pragma unroll
-    for (int i = 0; i < NPR; ++i) cn_st16(base + st0 + BN * 128 + i * 32 * 128, preg[i]);
+    for (int i = 0; i < NPR; ++i) cn_st16(base + st0 + BN * 128 + i * RS * 128, preg[i]);
   };
   auto compute = [&](int buf) {
     const char* wt = lds + buf * STAGE + rd_w;
@@ -257,15 +259,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
       // Every thread issues exactly NWR+NPR DMA instructions per tile, so "tile kt has landed" is a
       // counted wait: at most (tiles issued after kt) * (NWR+NPR) operations may remain outstanding.
       constexpr int L = NWR + NPR;
-      static_assert(L == 8 || L == 6, "wait immediates below assume 6 or 8 DMA instructions per tile");
+      static_assert(L == 8 || L == 6 || L == 4, "wait immediates below assume 4, 6 or 8 DMA instructions per tile");
       if (nkt > 1) load_tile(1, 1);
       if (nkt > 2) load_tile(2, 2);
       for (int kt = 0; kt < nkt; ++kt) {
         const int ahead = nkt - 1 - kt < 2 ? nkt - 1 - kt : 2;   // tiles issued after kt at this point
         if (L == 8) {
           if (ahead == 2) CN_WAIT_VMCNT(16); else if (ahead == 1) CN_WAIT_VMCNT(8); else CN_WAIT_VMCNT(0);
-        } else {
+        } else if (L == 6) {
           if (ahead == 2) CN_WAIT_VMCNT(12); else if (ahead == 1) CN_WAIT_VMCNT(6); else CN_WAIT_VMCNT(0);
+        } else {
+          if (ahead == 2) CN_WAIT_VMCNT(8); else if (ahead == 1) CN_WAIT_VMCNT(4); else CN_WAIT_VMCNT(0);
         }
         cn_raw_barrier();   // tile kt visible to every wave; buffer (kt+3)%4 == (kt-1)%4 is free again
         if (kt + 3 < nkt) load_tile(kt + 3, (kt + 3) & 3);
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   const int epc = 16 / OEB;            // elements per 16-byte chunk of the output
   const int cpr = BN / epc;            // chunks per tile row
   const bool vec_ok = ((p.Co * OEB) & 15) == 0;
-  for (int id = tid; id < BM * cpr; id += 256) {
+  for (int id = tid; id < BM * cpr; id += NT) {
     const int row = id / cpr, col = id - row * cpr;
     const int pix = s_outpix[row];
     if (pix < 0) continue;
@@ -405,9 +409,9 @@ template <typename T, bool OUTF32>
 static int ig_launch(IgemmParams& p, hipStream_t stream) {
   const int nkt = (p.nchunks + 7) / 8;
   // variant: 1 = register-staged single buffer, 2 = register-staged double buffer, 3 = LDS-DMA double
-  // buffer, 4 = LDS-DMA 4-deep ring; 0 / unset = heuristic (tuning knob "igemm_variant", profiles/r01_conv_layers*)
+  // buffer, 4 = LDS-DMA 4-deep ring (4 waves), 5 = LDS-DMA 4-deep ring with 8 waves; 0 / unset = heuristic (tuning knob "igemm_variant", profiles/r01_conv_layers*)
   int variant = cn_get_option("igemm_variant", 0);
-  if (variant < 1 || variant > 4) variant = cn_get_option("igemm_default_variant", nkt < 24 ? 1 : 3);
+  if (variant < 1 || variant > 5) variant = cn_get_option("igemm_default_variant", nkt < 24 ? 1 : 3);
   const int BM = 128, BN = p.Co <= 64 ? 64 : 128;
   p.n_ntiles = (p.Co + BN - 1) / BN;
   const int n_mtiles = (p.M + BM - 1) / BM;
@@ -419,6 +423,11 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
     else if (variant == 3) CN_LAUNCH((igemm_kernel<T, WC, WP, TI, TJ, 2, OUTF32, true>), grid, dim3(256), stream, p); \
     else CN_LAUNCH((igemm_kernel<T, WC, WP, TI, TJ, 4, OUTF32, true>), grid, dim3(256), stream, p);             \
   } while (0)
+  if (variant == 5 && p.Co > 64) {   // 8 waves, 4-deep DMA ring: 2 waves per SIMD with 3 tiles in flight
+    CN_LAUNCH((igemm_kernel<T, 2, 4, 2, 1, 4, OUTF32, true>), grid, dim3(512), stream, p);
+    return cn_check_launch("igemm");
+  }
+  if (variant == 5) variant = 3;
   if (p.Co <= 64) IG_GO(1, 4, 2, 1);
   else IG_GO(2, 2, 2, 2);
 #undef IG_GO

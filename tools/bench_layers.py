@@ -37,7 +37,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--iters', type=int, default=5)
-    ap.add_argument('--variants', default='0,1,3,4', help='igemm_variant values to A/B (0 = heuristic, 1 = reg-staged 1 buf, 2 = reg-staged 2 buf, 3 = LDS-DMA)')
+    ap.add_argument('--variants', default='0,1,3,5', help='igemm_variant values to A/B (0 = heuristic, 1 = reg-staged 1 buf, 2 = reg-staged 2 buf, 3 = LDS-DMA)')
     ap.add_argument('--only', default='', help='comma-separated layer indices (default: all)')
     args = ap.parse_args()
     dev = torch.device('cuda', 0)
