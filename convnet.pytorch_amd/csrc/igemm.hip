@@ -35,7 +35,9 @@ struct IgemmParams {
   int ntaps, cpt, nchunks;
   long long w_row;
   int out_f32, relu;
-  int M, n_ntiles;
+  int M, n_ntiles, n_mtiles;
+  int mt_fastest;   // tile order inside an XCD chunk: 0 = channel tiles fastest (share the activation tile),
+                    // 1 = pixel tiles fastest (share one filter slab in the XCD's L2; weight-heavy layers)
   unsigned int x_bytes, w_bytes;   // extents of the gather source / filter tensors (buffer descriptors)
   int simple;                      // 1: no tap of a valid row ever leaves the image (skip bounds tests)
   FastDiv div_hw, div_w, div_cpt;
@@ -101,8 +103,8 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const unsigned int tile = cn_xcd_remap(blockIdx.x, gridDim.x);
-  const int nt = tile % p.n_ntiles;
-  const int mt = tile / p.n_ntiles;
+  const int nt = p.mt_fastest ? (int)(tile / p.n_mtiles) : (int)(tile % p.n_ntiles);
+  const int mt = p.mt_fastest ? (int)(tile % p.n_mtiles) : (int)(tile / p.n_ntiles);
   const int m0 = mt * BM;
   const int n0 = nt * BN;
   const int HgWg = p.Hg * p.Wg;
@@ -415,6 +417,12 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
   const int BM = 128, BN = p.Co <= 64 ? 64 : 128;
   p.n_ntiles = (p.Co + BN - 1) / BN;
   const int n_mtiles = (p.M + BM - 1) / BM;
+  p.n_mtiles = n_mtiles;
+  {
+    const long long wbytes = (long long)p.Co * p.nchunks * 16;   // filter bytes of this launch
+    int order = cn_get_option("igemm_order", -1);
+    p.mt_fastest = order >= 0 ? order : (wbytes > (1ll << 20) && p.n_ntiles > 1 ? 1 : 0);
+  }
   dim3 grid((unsigned)(p.n_ntiles * n_mtiles));
 #define IG_GO(WC, WP, TI, TJ)                                                                                  \
   do {                                                                                                         \
