@@ -313,6 +313,14 @@ __device__ __forceinline__ void cn_raw_barrier() { __builtin_amdgcn_s_barrier();
 static inline void cn_raw_barrier() { cn_emul::sync_threads(); }
 #endif
 
+// Scheduling fence: nothing is moved across it by hipcc's machine scheduler (used to keep the
+// fragment reads of the NEXT k-step ahead of the MFMAs of the current one).
+#ifndef CN_EMULATE
+__device__ __forceinline__ void cn_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+#else
+static inline void cn_sched_fence() {}
+#endif
+
 // 16-byte global / LDS accessors
 __host__ __device__ __forceinline__ u32x4 cn_ld16(const void* p) { return *(const u32x4*)p; }
 __host__ __device__ __forceinline__ void cn_st16(void* p, const u32x4& v) { *(u32x4*)p = v; }

@@ -238,17 +238,28 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
   auto compute = [&](int buf) {
     const char* wt = lds + buf * STAGE + rd_w;
     const char* pt = lds + buf * STAGE + rd_p;
+    // fragments are double-buffered in registers: the ds_read_b128 of k-step kk+1 are in flight while
+    // the MFMAs of k-step kk issue (hipcc otherwise reuses one register set and serialises
+    // read -> wait -> MFMA four times per K tile; PMC showed waves waiting 45 % of their cycles)
+    u32x4 af[2][TI], bfr[2][TJ];
+#pragma unroll
+    for (int a = 0; a < TI; ++a) af[0][a] = cn_ld16(wt + koff[0] + a * 32 * 128);
+#pragma unroll
+    for (int b = 0; b < TJ; ++b) bfr[0][b] = cn_ld16(pt + koff[0] + b * 32 * 128);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      u32x4 af[TI], bfr[TJ];
+      const int cur = kk & 1, nxt = cur ^ 1;
+      if (kk < 3) {
 #pragma unroll
-      for (int a = 0; a < TI; ++a) af[a] = cn_ld16(wt + koff[kk] + a * 32 * 128);
+        for (int a = 0; a < TI; ++a) af[nxt][a] = cn_ld16(wt + koff[kk + 1] + a * 32 * 128);
 #pragma unroll
-      for (int b = 0; b < TJ; ++b) bfr[b] = cn_ld16(pt + koff[kk] + b * 32 * 128);
+        for (int b = 0; b < TJ; ++b) bfr[nxt][b] = cn_ld16(pt + koff[kk + 1] + b * 32 * 128);
+      }
+      cn_sched_fence();   // reads of k-step kk+1 stay ahead of the MFMAs of k-step kk
 #pragma unroll
       for (int a = 0; a < TI; ++a)
 #pragma unroll
-        for (int b = 0; b < TJ; ++b) ig_mma<T>(af[a], bfr[b], acc[a][b]);
+        for (int b = 0; b < TJ; ++b) ig_mma<T>(af[cur][a], bfr[cur][b], acc[a][b]);
     }
   };
 
