@@ -80,7 +80,7 @@ __device__ __forceinline__ int ig_slot(int row, int chunk) {
 //       variant spends ~416 LDS cycles per K tile on ds_write_b128 against 512 MFMA cycles).
 //       STAGES = 4 with GLDS: a 4-deep DMA ring (3 K tiles in flight across raw barriers, counted
 //       vmcnt waits) for long reductions, one workgroup per CU.
-template <typename T, int WC, int WP, int TI, int TJ, int STAGES, bool OUTF32, bool GLDS>
+template <typename T, int WC, int WP, int TI, int TJ, int STAGES, bool OUTF32, bool GLDS, bool FRAGDB>
 __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
   static_assert(!GLDS || STAGES == 2 || STAGES == 4, "LDS-DMA needs the double-buffered tile or the 4-deep ring");
   constexpr int BN = WC * TI * 32;  // output channels per block
@@ -238,28 +238,42 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
   auto compute = [&](int buf) {
     const char* wt = lds + buf * STAGE + rd_w;
     const char* pt = lds + buf * STAGE + rd_p;
-    // fragments are double-buffered in registers: the ds_read_b128 of k-step kk+1 are in flight while
-    // the MFMAs of k-step kk issue (hipcc otherwise reuses one register set and serialises
-    // read -> wait -> MFMA four times per K tile; PMC showed waves waiting 45 % of their cycles)
-    u32x4 af[2][TI], bfr[2][TJ];
+    if (FRAGDB) {
+      // fragments double-buffered in registers: the ds_read_b128 of k-step kk+1 are issued (and kept
+      // there by a scheduling fence) ahead of the MFMAs of k-step kk
+      u32x4 af[2][TI], bfr[2][TJ];
 #pragma unroll
-    for (int a = 0; a < TI; ++a) af[0][a] = cn_ld16(wt + koff[0] + a * 32 * 128);
+      for (int a = 0; a < TI; ++a) af[0][a] = cn_ld16(wt + koff[0] + a * 32 * 128);
 #pragma unroll
-    for (int b = 0; b < TJ; ++b) bfr[0][b] = cn_ld16(pt + koff[0] + b * 32 * 128);
+      for (int b = 0; b < TJ; ++b) bfr[0][b] = cn_ld16(pt + koff[0] + b * 32 * 128);
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int cur = kk & 1, nxt = cur ^ 1;
-      if (kk < 3) {
+      for (int kk = 0; kk < 4; ++kk) {
+        const int cur = kk & 1, nxt = cur ^ 1;
+        if (kk < 3) {
 #pragma unroll
-        for (int a = 0; a < TI; ++a) af[nxt][a] = cn_ld16(wt + koff[kk + 1] + a * 32 * 128);
+          for (int a = 0; a < TI; ++a) af[nxt][a] = cn_ld16(wt + koff[kk + 1] + a * 32 * 128);
 #pragma unroll
-        for (int b = 0; b < TJ; ++b) bfr[nxt][b] = cn_ld16(pt + koff[kk + 1] + b * 32 * 128);
+          for (int b = 0; b < TJ; ++b) bfr[nxt][b] = cn_ld16(pt + koff[kk + 1] + b * 32 * 128);
+        }
+        cn_sched_fence();
+#pragma unroll
+        for (int a = 0; a < TI; ++a)
+#pragma unroll
+          for (int b = 0; b < TJ; ++b) ig_mma<T>(af[cur][a], bfr[cur][b], acc[a][b]);
       }
-      cn_sched_fence();   // reads of k-step kk+1 stay ahead of the MFMAs of k-step kk
+    } else {
 #pragma unroll
-      for (int a = 0; a < TI; ++a)
+      for (int kk = 0; kk < 4; ++kk) {
+        u32x4 af[TI], bfr[TJ];
 #pragma unroll
-        for (int b = 0; b < TJ; ++b) ig_mma<T>(af[cur][a], bfr[cur][b], acc[a][b]);
+        for (int a = 0; a < TI; ++a) af[a] = cn_ld16(wt + koff[kk] + a * 32 * 128);
+#pragma unroll
+        for (int b = 0; b < TJ; ++b) bfr[b] = cn_ld16(pt + koff[kk] + b * 32 * 128);
+#pragma unroll
+        for (int a = 0; a < TI; ++a)
+#pragma unroll
+          for (int b = 0; b < TJ; ++b) ig_mma<T>(af[a], bfr[b], acc[a][b]);
+      }
     }
   };
 
@@ -435,21 +449,25 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
     p.mt_fastest = order >= 0 ? order : (wbytes > (1ll << 20) && p.n_ntiles > 1 ? 1 : 0);
   }
   dim3 grid((unsigned)(p.n_ntiles * n_mtiles));
-#define IG_GO(WC, WP, TI, TJ)                                                                                  \
+  const bool fragdb = cn_get_option("igemm_fragdb", 0) != 0;
+#define IG_GO2(WC, WP, TI, TJ, DB)                                                                              \
   do {                                                                                                         \
-    if (variant == 1) CN_LAUNCH((igemm_kernel<T, WC, WP, TI, TJ, 1, OUTF32, false>), grid, dim3(256), stream, p); \
-    else if (variant == 2) CN_LAUNCH((igemm_kernel<T, WC, WP, TI, TJ, 2, OUTF32, false>), grid, dim3(256), stream, p); \
-    else if (variant == 3) CN_LAUNCH((igemm_kernel<T, WC, WP, TI, TJ, 2, OUTF32, true>), grid, dim3(256), stream, p); \
-    else CN_LAUNCH((igemm_kernel<T, WC, WP, TI, TJ, 4, OUTF32, true>), grid, dim3(256), stream, p);             \
+    if (variant == 1) CN_LAUNCH((igemm_kernel<T, WC, WP, TI, TJ, 1, OUTF32, false, DB>), grid, dim3(256), stream, p); \
+    else if (variant == 2) CN_LAUNCH((igemm_kernel<T, WC, WP, TI, TJ, 2, OUTF32, false, DB>), grid, dim3(256), stream, p); \
+    else CN_LAUNCH((igemm_kernel<T, WC, WP, TI, TJ, 2, OUTF32, true, DB>), grid, dim3(256), stream, p);        \
   } while (0)
-  if (variant == 5 && p.Co > 64) {   // 8 waves, 4-deep DMA ring: 2 waves per SIMD with 3 tiles in flight
-    CN_LAUNCH((igemm_kernel<T, 2, 4, 2, 1, 4, OUTF32, true>), grid, dim3(512), stream, p);
+#define IG_GO(WC, WP, TI, TJ) do { if (fragdb) IG_GO2(WC, WP, TI, TJ, true); else IG_GO2(WC, WP, TI, TJ, false); } while (0)
+  if (variant >= 4 && p.Co > 64) {
+    // experimental 4-deep DMA rings (4 = 4 waves, 5 = 8 waves): measured slower than variant 3, kept for A/B
+    if (variant == 4) CN_LAUNCH((igemm_kernel<T, 2, 2, 2, 2, 4, OUTF32, true, false>), grid, dim3(256), stream, p);
+    else CN_LAUNCH((igemm_kernel<T, 2, 4, 2, 1, 4, OUTF32, true, false>), grid, dim3(512), stream, p);
     return cn_check_launch("igemm");
   }
-  if (variant == 5) variant = 3;
+  if (variant >= 4) variant = 3;
   if (p.Co <= 64) IG_GO(1, 4, 2, 1);
   else IG_GO(2, 2, 2, 2);
 #undef IG_GO
+#undef IG_GO2
   return cn_check_launch("igemm");
 }
 
