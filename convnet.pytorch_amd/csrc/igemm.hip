@@ -438,8 +438,8 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
   // variant: 1 = register-staged single buffer, 2 = register-staged double buffer, 3 = LDS-DMA double
   // buffer, 4 = LDS-DMA 4-deep ring (4 waves), 5 = LDS-DMA 4-deep ring with 8 waves; 0 / unset = heuristic (tuning knob "igemm_variant", profiles/r01_conv_layers*)
   int variant = cn_get_option("igemm_variant", 0);
-  if (variant < 1 || variant > 5) variant = cn_get_option("igemm_default_variant", nkt < 24 ? 1 : 3);
-  const int BM = 128, BN = p.Co <= 64 ? 64 : 128;
+  if (variant < 1 || variant > 6) variant = cn_get_option("igemm_default_variant", nkt < 24 ? 1 : 3);
+  const int BM = (variant == 6 && p.Co > 64) ? 256 : 128, BN = p.Co <= 64 ? 64 : 128;
   p.n_ntiles = (p.Co + BN - 1) / BN;
   const int n_mtiles = (p.M + BM - 1) / BM;
   p.n_mtiles = n_mtiles;
@@ -458,9 +458,11 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
   } while (0)
 #define IG_GO(WC, WP, TI, TJ) do { if (fragdb) IG_GO2(WC, WP, TI, TJ, true); else IG_GO2(WC, WP, TI, TJ, false); } while (0)
   if (variant >= 4 && p.Co > 64) {
-    // experimental 4-deep DMA rings (4 = 4 waves, 5 = 8 waves): measured slower than variant 3, kept for A/B
+    // 4 / 5: experimental 4-deep DMA rings (4 or 8 waves), measured slower than variant 3, kept for A/B;
+    // 6: 256-pixel x 128-channel tile, 8 waves, LDS-DMA double buffer (fewer operand bytes per flop)
     if (variant == 4) CN_LAUNCH((igemm_kernel<T, 2, 2, 2, 2, 4, OUTF32, true, false>), grid, dim3(256), stream, p);
-    else CN_LAUNCH((igemm_kernel<T, 2, 4, 2, 1, 4, OUTF32, true, false>), grid, dim3(512), stream, p);
+    else if (variant == 5) CN_LAUNCH((igemm_kernel<T, 2, 4, 2, 1, 4, OUTF32, true, false>), grid, dim3(512), stream, p);
+    else CN_LAUNCH((igemm_kernel<T, 2, 4, 2, 2, 2, OUTF32, true, true>), grid, dim3(512), stream, p);
     return cn_check_launch("igemm");
   }
   if (variant >= 4) variant = 3;
