@@ -137,6 +137,26 @@ __device__ __forceinline__ void bn_sum_partials(const float* partial, int nrb, i
   q_out = q;
 }
 
+// out[r2][col] = sum of the G consecutive partial rows r2*G .. r2*G+G-1 (fixed order).  Brings the
+// per-pixel-tile partials a convolution epilogue emitted (thousands of rows for the 56x56 layers) down
+// to the few hundred rows bn_finalize_kernel walks.
+__global__ __launch_bounds__(256) void bn_partials_compress_kernel(const float* in, float* out, int nrb, int G,
+                                                                  int W) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= W) return;
+  int r = blockIdx.y * G;
+  const int re = r + G < nrb ? r + G : nrb;
+  float acc = 0.f;
+  for (; r + 7 < re; r += 8) {
+    float a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = in[(size_t)(r + u) * W + col];
+    acc += ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  }
+  for (; r < re; ++r) acc += in[(size_t)r * W + col];
+  out[(size_t)blockIdx.y * W + col] = acc;
+}
+
 // 32 channels per workgroup: statistics, running-stat update and the fused scale/shift the apply
 // kernel consumes.
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* partial, int nrb, int M, int C,
@@ -406,6 +426,27 @@ static int bn_check(const char* who, int M, int C, int dtype) {
   return CN_OK;
 }
 
+// finalize + apply shared by both training-forward entry points
+static int bn_fwd_tail(const float* partial, int nrb, const void* y, const void* residual, void* z,
+                       unsigned char* relu_mask, const float* gamma, const float* beta, float* running_mean,
+                       float* running_var, long long* num_batches_tracked, float momentum, float eps,
+                       float* stats_out, int M, int C, int relu, int dtype, const BnMap& m, hipStream_t stream) {
+  CN_LAUNCH(bn_finalize_kernel, dim3((unsigned)((C + 31) / 32)), dim3(256), stream, partial, nrb,
+            M, C, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, stats_out,
+            stats_out + C, stats_out + 2 * C, stats_out + 3 * C);
+  int nab = bn_row_blocks(M, m, cn_get_option("bn_apply_blocks", BN_APPLY_BLOCKS));
+  dim3 agrid((unsigned)nab, (unsigned)m.gy);
+  if (dtype == CN_BF16)
+    CN_LAUNCH(bn_apply_kernel<bf16_t>, agrid, dim3(256), stream, (const char*)y, (const char*)residual,
+              (char*)z, relu_mask, (const float*)(stats_out + 2 * C), (const float*)(stats_out + 3 * C), M, C,
+              relu, m.tpr_log2);
+  else
+    CN_LAUNCH(bn_apply_kernel<float>, agrid, dim3(256), stream, (const char*)y, (const char*)residual, (char*)z,
+              relu_mask, (const float*)(stats_out + 2 * C), (const float*)(stats_out + 3 * C), M, C, relu,
+              m.tpr_log2);
+  return cn_check_launch("bn_fwd_train");
+}
+
 // Training forward.  stats_out = [save_mean | save_invstd | scale | shift] (4*C floats).
 extern "C" int cn_bn_fwd_train(const void* y, const void* residual, void* z, unsigned char* relu_mask,
                                const float* gamma,
@@ -429,20 +470,38 @@ extern "C" int cn_bn_fwd_train(const void* y, const void* residual, void* z, uns
     CN_LAUNCH(bn_stats_kernel<bf16_t>, grid, dim3(256), stream, (const char*)y, partial, M, C, m.tpr_log2);
   else
     CN_LAUNCH(bn_stats_kernel<float>, grid, dim3(256), stream, (const char*)y, partial, M, C, m.tpr_log2);
-  CN_LAUNCH(bn_finalize_kernel, dim3((unsigned)((C + 31) / 32)), dim3(256), stream, (const float*)partial, nrb,
-            M, C, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, stats_out,
-            stats_out + C, stats_out + 2 * C, stats_out + 3 * C);
-  int nab = bn_row_blocks(M, m, cn_get_option("bn_apply_blocks", BN_APPLY_BLOCKS));
-  dim3 agrid((unsigned)nab, (unsigned)m.gy);
-  if (dtype == CN_BF16)
-    CN_LAUNCH(bn_apply_kernel<bf16_t>, agrid, dim3(256), stream, (const char*)y, (const char*)residual,
-              (char*)z, relu_mask, (const float*)(stats_out + 2 * C), (const float*)(stats_out + 3 * C), M, C,
-              relu, m.tpr_log2);
-  else
-    CN_LAUNCH(bn_apply_kernel<float>, agrid, dim3(256), stream, (const char*)y, (const char*)residual, (char*)z,
-              relu_mask, (const float*)(stats_out + 2 * C), (const float*)(stats_out + 3 * C), M, C, relu,
-              m.tpr_log2);
-  return cn_check_launch("bn_fwd_train");
+  return bn_fwd_tail(partial, nrb, y, residual, z, relu_mask, gamma, beta, running_mean, running_var,
+                     num_batches_tracked, momentum, eps, stats_out, M, C, relu, dtype, m, stream);
+}
+
+// Training forward from statistics partials a producer already reduced (cn_conv2d_fwd_bnstats):
+// partial = [nrb][2*C] floats (sum | sum of squares per row).  Skips the statistics read of y.
+extern "C" int cn_bn_fwd_train_partials(const void* y, const void* residual, void* z, unsigned char* relu_mask,
+                                        const float* gamma, const float* beta, float* running_mean,
+                                        float* running_var, long long* num_batches_tracked, float momentum,
+                                        float eps, float* stats_out, int M, int C, int relu, int dtype,
+                                        const float* partial, int nrb, void* workspace, size_t ws_bytes,
+                                        void* stream_) {
+  int rc = bn_check("bn_fwd_train_partials", M, C, dtype);
+  if (rc) return rc;
+  if (partial == nullptr || nrb <= 0) { cn_set_error("bn_fwd_train_partials: no partials"); return CN_EINVAL; }
+  hipStream_t stream = (hipStream_t)stream_;
+  const int CH = dtype == CN_BF16 ? 8 : 4;
+  BnMap m = bn_map(C / CH);
+  if (nrb > BN_TARGET_BLOCKS) {
+    const int G = (nrb + BN_TARGET_BLOCKS - 1) / BN_TARGET_BLOCKS;
+    const int nr2 = (nrb + G - 1) / G;
+    if (workspace == nullptr || ws_bytes < (size_t)nr2 * 2 * C * sizeof(float)) {
+      cn_set_error("bn_fwd_train_partials: workspace too small");
+      return CN_EWORKSPACE;
+    }
+    CN_LAUNCH(bn_partials_compress_kernel, dim3((unsigned)((2 * C + 255) / 256), (unsigned)nr2), dim3(256), stream,
+              partial, (float*)workspace, nrb, G, 2 * C);
+    partial = (const float*)workspace;
+    nrb = nr2;
+  }
+  return bn_fwd_tail(partial, nrb, y, residual, z, relu_mask, gamma, beta, running_mean, running_var,
+                     num_batches_tracked, momentum, eps, stats_out, M, C, relu, dtype, m, stream);
 }
 
 // Inference forward from running statistics.  coeffs = scratch of 2*C floats.

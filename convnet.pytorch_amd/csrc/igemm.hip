@@ -28,6 +28,7 @@ struct IgemmParams {
   char* y;
   const char* addend;   // optional tensor added to the output (same layout / dtype as y)
   const float* bias;
+  float* stats;         // optional [n_mtiles][2*Co]: per pixel-tile sum / sum of squares of the stored outputs
   int N, Hi, Wi, Ci;
   int Hg, Wg, a_h, a_w;
   int Ho, Wo, Co;
@@ -382,6 +383,40 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
       }
     }
   __syncthreads();
+  // ---- optional BatchNorm statistics of this tile (what bn_stats_kernel would re-read from HBM):
+  // per-channel sum and sum of squares of the *stored* (rounded) outputs, one partial row per pixel tile
+  constexpr int OEBc = OUTF32 ? 4 : EB;
+  constexpr int NCOL = BN * OEBc / 4;   // dword columns of the out tile (2 channels each for bf16)
+  constexpr int NG = NT / NCOL;         // row groups
+  constexpr int RPG = BM / NG;
+  float st[4] = {0.f, 0.f, 0.f, 0.f};
+  if (p.stats != nullptr) {
+    const int col = tid % NCOL, g = tid / NCOL;
+    int nrows = p.M - m0;
+    if (nrows > BM) nrows = BM;
+    const char* src = lds + col * 4 + g * RPG * pitch;
+    auto acc_row = [&](int r) {
+      const unsigned int v = *(const unsigned int*)(src + r * pitch);
+      if (OEBc == 4) {
+        const float f = __builtin_bit_cast(float, v);
+        st[0] += f;
+        st[2] = fmaf(f, f, st[2]);
+      } else {
+        const float lo = __builtin_bit_cast(float, v << 16), hi = __builtin_bit_cast(float, v & 0xffff0000u);
+        st[0] += lo;
+        st[1] += hi;
+        st[2] = fmaf(lo, lo, st[2]);
+        st[3] = fmaf(hi, hi, st[3]);
+      }
+    };
+    if (nrows == BM) {
+#pragma unroll 8
+      for (int r = 0; r < RPG; ++r) acc_row(r);
+    } else {
+      const int cnt = nrows - g * RPG;
+      for (int r = 0; r < RPG && r < cnt; ++r) acc_row(r);
+    }
+  }
   const int epc = 16 / OEB;            // elements per 16-byte chunk of the output
   const int cpr = BN / epc;            // chunks per tile row
   const bool vec_ok = ((p.Co * OEB) & 15) == 0;
@@ -429,6 +464,31 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
       }
     }
   }
+  if (p.stats != nullptr) {
+    __syncthreads();   // the out tile has been consumed: reuse its first bytes for the row-group partials
+    f32x4* red = (f32x4*)lds;
+    f32x4 mine;
+    mine[0] = st[0]; mine[1] = st[1]; mine[2] = st[2]; mine[3] = st[3];
+    red[tid] = mine;
+    __syncthreads();
+    if (tid < NCOL) {
+      f32x4 a = red[tid];
+#pragma unroll
+      for (int g = 1; g < NG; ++g) {   // fixed order: deterministic
+        const f32x4 b = red[g * NCOL + tid];
+        a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+      }
+      float* dst = p.stats + (size_t)mt * 2 * (size_t)p.Co;
+      if (OEBc == 4) {
+        const int c = n0 + tid;
+        if (c < p.Co) { dst[c] = a[0]; dst[p.Co + c] = a[2]; }
+      } else {
+        const int c = n0 + 2 * tid;
+        if (c < p.Co) { dst[c] = a[0]; dst[p.Co + c] = a[2]; }
+        if (c + 1 < p.Co) { dst[c + 1] = a[1]; dst[p.Co + c + 1] = a[3]; }
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -439,6 +499,7 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
   // buffer, 4 = LDS-DMA 4-deep ring (4 waves), 5 = LDS-DMA 4-deep ring with 8 waves; 0 / unset = heuristic (tuning knob "igemm_variant", profiles/r01_conv_layers*)
   int variant = cn_get_option("igemm_variant", 0);
   if (variant < 1 || variant > 6) variant = cn_get_option("igemm_default_variant", nkt < 24 ? 1 : 3);
+  if (p.stats != nullptr && variant == 6) variant = 3;   // statistics rows are defined per 128-pixel tile
   const int BM = (variant == 6 && p.Co > 64) ? 256 : 128, BN = p.Co <= 64 ? 64 : 128;
   p.n_ntiles = (p.Co + BN - 1) / BN;
   const int n_mtiles = (p.M + BM - 1) / BM;
@@ -446,7 +507,8 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
   {
     const long long wbytes = (long long)p.Co * p.nchunks * 16;   // filter bytes of this launch
     int order = cn_get_option("igemm_order", -1);
-    p.mt_fastest = order >= 0 ? order : (wbytes > (1ll << 20) && p.n_ntiles > 1 ? 1 : 0);
+    (void)wbytes;   // pixel-tiles-fastest for weight-heavy layers measured 1-2 % slower (profiles/README.md)
+    p.mt_fastest = order > 0 ? 1 : 0;
   }
   dim3 grid((unsigned)(p.n_ntiles * n_mtiles));
   const bool fragdb = cn_get_option("igemm_fragdb", 0) != 0;
@@ -520,15 +582,15 @@ static int ig_is_simple(const IgemmParams& p, const int* dhdw, int ntaps) {
   return 1;
 }
 
-extern "C" int cn_conv2d_fwd(const void* x, const void* w_krsc, void* y, const float* bias, int N, int H,
-                             int W, int C, int K, int R, int S, int stride_h, int stride_w, int pad_h,
-                             int pad_w, int dtype, int out_f32, int relu, void* stream) {
+static int ig_conv_fwd(const void* x, const void* w_krsc, void* y, const float* bias, float* stats, int N, int H,
+                       int W, int C, int K, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w,
+                       int dtype, int out_f32, int relu, void* stream) {
   const int P = (H + 2 * pad_h - R) / stride_h + 1;
   const int Q = (W + 2 * pad_w - S) / stride_w + 1;
   if (P <= 0 || Q <= 0 || N <= 0) { cn_set_error("conv2d_fwd: empty output"); return CN_ESHAPE; }
   IgemmParams p;
   memset(&p, 0, sizeof(p));
-  p.x = (const char*)x; p.w = (const char*)w_krsc; p.y = (char*)y; p.bias = bias;
+  p.x = (const char*)x; p.w = (const char*)w_krsc; p.y = (char*)y; p.bias = bias; p.stats = stats;
   p.N = N; p.Hi = H; p.Wi = W; p.Ci = C;
   p.Hg = P; p.Wg = Q; p.a_h = stride_h; p.a_w = stride_w;
   p.Ho = P; p.Wo = Q; p.Co = K;
@@ -545,6 +607,33 @@ extern "C" int cn_conv2d_fwd(const void* x, const void* w_krsc, void* y, const f
     }
   p.simple = ig_is_simple(p, p.tap_dhdw, R * S);
   return ig_dispatch(p, dtype, (hipStream_t)stream);
+}
+
+extern "C" int cn_conv2d_fwd(const void* x, const void* w_krsc, void* y, const float* bias, int N, int H,
+                             int W, int C, int K, int R, int S, int stride_h, int stride_w, int pad_h,
+                             int pad_w, int dtype, int out_f32, int relu, void* stream) {
+  return ig_conv_fwd(x, w_krsc, y, bias, nullptr, N, H, W, C, K, R, S, stride_h, stride_w, pad_h, pad_w, dtype,
+                     out_f32, relu, stream);
+}
+
+// Rows of the statistics partial buffer cn_conv2d_fwd_bnstats writes for M = N*P*Q output pixels.
+extern "C" int cn_conv2d_bnstats_rows(long long M) { return (int)((M + 127) / 128); }
+
+// Convolution forward that also emits, per 128-pixel tile, the per-channel sum and sum of squares of
+// the outputs it stores: partial[row][0:K] = sum, partial[row][K:2K] = sum of squares, with
+// cn_conv2d_bnstats_rows(N*P*Q) rows.  cn_bn_fwd_train_partials consumes them, which removes the
+// statistics pass over y (one full HBM read of the conv output per BatchNorm).
+extern "C" int cn_conv2d_fwd_bnstats(const void* x, const void* w_krsc, void* y, const float* bias, int N, int H,
+                                     int W, int C, int K, int R, int S, int stride_h, int stride_w, int pad_h,
+                                     int pad_w, int dtype, int relu, float* partial, int partial_rows,
+                                     void* stream) {
+  const long long P = (H + 2 * pad_h - R) / stride_h + 1, Q = (W + 2 * pad_w - S) / stride_w + 1;
+  if (partial == nullptr || partial_rows < cn_conv2d_bnstats_rows((long long)N * P * Q)) {
+    cn_set_error("conv2d_fwd_bnstats: partial buffer of %d rows is too small", partial_rows);
+    return CN_EWORKSPACE;
+  }
+  return ig_conv_fwd(x, w_krsc, y, bias, partial, N, H, W, C, K, R, S, stride_h, stride_w, pad_h, pad_w, dtype,
+                     0, relu, stream);
 }
 
 extern "C" int cn_conv2d_dgrad(const void* dy, const void* w_crsk, void* dx, const void* addend, int N, int H,

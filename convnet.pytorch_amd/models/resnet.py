@@ -63,6 +63,7 @@ class ResidualBlock(tnn.Module):
             setattr(self, 'conv%d' % i, cnn.Conv2d(cin, cout, kernel_size=k, stride=stride if strided else 1,
                                                    padding=k // 2, bias=False))
             setattr(self, 'bn%d' % i, cnn.BatchNorm2d(cout))
+            getattr(self, 'conv%d' % i).feeds_batchnorm = True   # BN statistics come out of the conv epilogue
             if i == 1 and kind == 'basic':
                 self.relu = cnn.ReLU(inplace=True)  # registration order of the reference BasicBlock
             cin = cout
@@ -82,6 +83,7 @@ class ResidualBlock(tnn.Module):
             self.last_bn()._res_holder = self._holder     # identity: last BN's dres + conv1 dgrad
         else:
             downsample[0]._res_holder = self._holder      # downsample conv dgrad + conv1 dgrad
+            downsample[0].feeds_batchnorm = True
 
     def last_bn(self):
         return getattr(self, 'bn%d' % self.n_convs)
@@ -126,6 +128,7 @@ class ResNetImagenet(tnn.Module):
         self.inplanes = inplanes
         self.conv1 = cnn.Conv2d(3, inplanes, kernel_size=7, stride=2, padding=3, bias=False)
         self.conv1.needs_dgrad = False  # network input needs no gradient
+        self.conv1.feeds_batchnorm = True
         self.bn1 = cnn.BatchNorm2d(inplanes)
         self.relu = cnn.ReLU(inplace=True)
         self.maxpool = cnn.MaxPool2d(kernel_size=3, stride=2, padding=1)

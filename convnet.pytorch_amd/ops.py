@@ -7,6 +7,9 @@ NCHW / OIHW shapes at their boundary): activations are contiguous NHWC tensors i
 PyTorch is used here for allocation, stream handles and the autograd tape only; every arithmetic
 pass over tensor data is one of the `cn_*` kernels.
 """
+import os
+import weakref
+
 import torch
 from torch.autograd import Function
 
@@ -126,10 +129,53 @@ def conv_out_hw(H, W, R, S, stride, pad):
 # ---------------------------------------------------------------------------------------------
 # raw (non-autograd) kernel calls
 
-def conv2d_fwd(x, w_krsc, bias, K, R, S, stride, pad, out_f32=False, relu=False):
+# A/B switch: 0 = every BatchNorm re-reads its input for the statistics (bn_stats_kernel)
+FUSE_BN_STATS = os.environ.get('CONVNET_AMD_FUSE_BN_STATS', '1') != '0'
+
+
+class _PendingStats(object):
+    """BatchNorm statistics partials a convolution emitted for its output tensor, waiting for the
+    BatchNorm that consumes that very tensor object (checked by identity through a weak reference)."""
+    __slots__ = ('ref', 'partial', 'rows')
+
+
+_PENDING = {}   # id(y) -> _PendingStats; a handful of entries at most
+
+
+def _park_stats(y, partial, rows):
+    ps = _PendingStats()
+    ps.ref, ps.partial, ps.rows = weakref.ref(y), partial, rows
+    if len(_PENDING) >= 4:     # never consumed (e.g. the BatchNorm ran in eval mode): drop
+        _PENDING.clear()
+    _PENDING[id(y)] = ps
+
+
+def take_pending_stats(y):
+    """The partials emitted for exactly this tensor object, else None."""
+    ps = _PENDING.pop(id(y), None)
+    if ps is not None and ps.ref() is y:
+        return ps
+    return None
+
+
+def conv2d_fwd(x, w_krsc, bias, K, R, S, stride, pad, out_f32=False, relu=False, bn_stats=False):
     N, H, W, C = x.shape
     P, Q = conv_out_hw(H, W, R, S, stride, pad)
     y = torch.empty((N, P, Q, K), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+    if bn_stats and not out_f32:
+        L = _L()
+        rows = L.cn_conv2d_bnstats_rows(N * P * Q)
+        partial = torch.empty((rows, 2 * K), dtype=torch.float32, device=x.device)
+        PROFILER.run(_igemm_name(x.dtype, K, R * S, C, out_f32),
+                     1, 2.0 * N * P * Q * K * C * R * S,
+                     x.numel() * _esize(x) + y.numel() * _esize(y) + K * R * S * C * _esize(x) + partial.numel() * 4,
+                     lambda: check(L.cn_conv2d_fwd_bnstats(ptr(x), ptr(w_krsc), ptr(y), ptr(bias), N, H, W, C, K, R, S,
+                                                           stride[0], stride[1], pad[0], pad[1], dtype_code(x.dtype),
+                                                           int(relu), ptr(partial), rows, stream_of(x)),
+                                   'cn_conv2d_fwd_bnstats'),
+                     x.device)
+        _park_stats(y, partial, rows)
+        return y
     PROFILER.run(_igemm_name(x.dtype, K, R * S, C, out_f32),
                  1, 2.0 * N * P * Q * K * C * R * S,
                  x.numel() * _esize(x) + y.numel() * _esize(y) + K * R * S * C * _esize(x),
@@ -239,7 +285,8 @@ class Conv2dFunction(Function):
     def forward(ctx, x, weight, bias, mod):
         mod.ensure_prepared()
         y = conv2d_fwd(x, mod.w_krsc, bias, mod.out_channels, mod.kernel_size[0], mod.kernel_size[1],
-                       mod.stride, mod.padding, out_f32=mod.out_f32)
+                       mod.stride, mod.padding, out_f32=mod.out_f32,
+                       bn_stats=FUSE_BN_STATS and mod.training and getattr(mod, 'feeds_batchnorm', False))
         ctx.mod = mod
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x)
@@ -303,14 +350,27 @@ class BatchNormActFunction(Function):
         momentum = mod.effective_momentum()
         track = mod.track_running_stats
         nb = y.numel() * _esize(y)
-        PROFILER.run('bn_stats+bn_finalize+bn_apply', 3, 0.0, nb * (4 if residual is not None else 3) + (mask.numel() if mask is not None else 0),
-                     lambda: check(L.cn_bn_fwd_train(ptr(y), ptr(residual), ptr(z), ptr(mask), ptr(gamma), ptr(beta),
-                                                     ptr(mod.running_mean) if track else None,
-                                                     ptr(mod.running_var) if track else None,
-                                                     ptr(mod.num_batches_tracked) if track else None,
-                                                     momentum, mod.eps, ptr(stats), M, C, int(relu), code, ptr(ws),
-                                                     ws.numel() * 4, stream_of(y)), 'cn_bn_fwd_train'),
-                     y.device)
+        ps = take_pending_stats(y)
+        if ps is not None:   # statistics came out of the producing convolution's epilogue: no pass over y
+            PROFILER.run('bn_finalize+bn_apply (stats from conv epilogue)', 2 if ps.rows <= 512 else 3, 0.0,
+                         nb * (3 if residual is not None else 2) + (mask.numel() if mask is not None else 0)
+                         + ps.partial.numel() * 4,
+                         lambda: check(L.cn_bn_fwd_train_partials(
+                             ptr(y), ptr(residual), ptr(z), ptr(mask), ptr(gamma), ptr(beta),
+                             ptr(mod.running_mean) if track else None, ptr(mod.running_var) if track else None,
+                             ptr(mod.num_batches_tracked) if track else None, momentum, mod.eps, ptr(stats), M, C,
+                             int(relu), code, ptr(ps.partial), ps.rows, ptr(ws), ws.numel() * 4, stream_of(y)),
+                             'cn_bn_fwd_train_partials'),
+                         y.device)
+        else:
+            PROFILER.run('bn_stats+bn_finalize+bn_apply', 3, 0.0,
+                         nb * (4 if residual is not None else 3) + (mask.numel() if mask is not None else 0),
+                         lambda: check(L.cn_bn_fwd_train(
+                             ptr(y), ptr(residual), ptr(z), ptr(mask), ptr(gamma), ptr(beta),
+                             ptr(mod.running_mean) if track else None, ptr(mod.running_var) if track else None,
+                             ptr(mod.num_batches_tracked) if track else None, momentum, mod.eps, ptr(stats), M, C,
+                             int(relu), code, ptr(ws), ws.numel() * 4, stream_of(y)), 'cn_bn_fwd_train'),
+                         y.device)
         ctx.mod = mod
         ctx.relu = relu
         ctx.has_res = residual is not None
@@ -352,6 +412,7 @@ class BatchNormActFunction(Function):
 
 
 def batch_norm_infer(y, residual, mod, relu):
+    _PENDING.pop(id(y), None)
     N, H, W, C = y.shape
     z = torch.empty_like(y)
     coeffs = torch.empty(2 * C, dtype=torch.float32, device=y.device)

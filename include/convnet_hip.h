@@ -45,6 +45,14 @@ int cn_set_option(const char* name, int value);
 int cn_conv2d_fwd(const void* x, const void* w_krsc, void* y, const float* bias, int N, int H, int W, int C,
                   int K, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w, int dtype,
                   int out_f32, int relu, void* stream);
+/* Same convolution, additionally emitting the BatchNorm statistics partials of its own output from the
+ * epilogue: partial[row][0:K] = per-channel sum, partial[row][K:2K] = sum of squares of the stored
+ * outputs of pixel tile `row` (cn_conv2d_bnstats_rows(N*P*Q) rows of 2*K floats).  Fuses the
+ * nn.Conv2d -> nn.BatchNorm2d pairs of models/resnet.py:141-165 so the statistics pass never re-reads y. */
+int cn_conv2d_bnstats_rows(long long M);
+int cn_conv2d_fwd_bnstats(const void* x, const void* w_krsc, void* y, const float* bias, int N, int H, int W,
+                          int C, int K, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w,
+                          int dtype, int relu, float* partial, int partial_rows, void* stream);
 /* dx[N,H,W,C] from dy[N,P,Q,K] and the transposed filter w_crsk[C][R][S][K]
  * (written by cn_weight_prep).  Strided convs run one launch per output-parity class. */
 int cn_conv2d_dgrad(const void* dy, const void* w_crsk, void* dx, const void* addend /*optional: dx += addend,
@@ -69,6 +77,13 @@ int cn_bn_fwd_train(const void* y, const void* residual, void* z, unsigned char*
                     float* running_mean, float* running_var, long long* num_batches_tracked, float momentum,
                     float eps, float* stats_out, int M, int C, int relu, int dtype, void* workspace,
                     size_t ws_bytes, void* stream);
+/* cn_bn_fwd_train with the statistics partials supplied by the producer of y (cn_conv2d_fwd_bnstats):
+ * partial = [nrb][2*C] floats. */
+int cn_bn_fwd_train_partials(const void* y, const void* residual, void* z, unsigned char* relu_mask,
+                             const float* gamma, const float* beta, float* running_mean, float* running_var,
+                             long long* num_batches_tracked, float momentum, float eps, float* stats_out,
+                             int M, int C, int relu, int dtype, const float* partial, int nrb, void* workspace,
+                             size_t ws_bytes, void* stream);
 int cn_bn_fwd_infer(const void* y, const void* residual, void* z, const float* gamma, const float* beta,
                     const float* running_mean, const float* running_var, float eps, float* coeffs /*2C*/,
                     int M, int C, int relu, int dtype, void* stream);

@@ -96,6 +96,58 @@ def test_conv2d_fwd_dgrad_wgrad(mode, dtype):
     assert not bad, 'conv mismatches (cfg, fwd, dgrad, wgrad rel-L2): %s' % bad
 
 
+# (N, H, W, C, K, R, stride, pad): ragged pixel tiles (M % 128 != 0), K below / above one channel tile,
+# > 512 partial rows (the compress pass) on the GPU
+STATS_EMUL = [(2, 9, 9, 16, 64, 3, 1, 1), (3, 7, 5, 16, 72, 1, 1, 0), (1, 20, 20, 8, 136, 3, 2, 1)]
+STATS_GPU = [(8, 56, 56, 64, 64, 1, 1, 0), (32, 56, 56, 64, 256, 1, 1, 0), (4, 28, 28, 128, 128, 3, 1, 1),
+             (5, 14, 14, 1024, 256, 1, 1, 0), (3, 17, 13, 64, 72, 3, 2, 1), (2, 224, 224, 8, 64, 7, 2, 3)]
+
+
+@pytest.mark.parametrize('mode', MODES)
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_conv_epilogue_bn_statistics(mode, dtype):
+    """cn_conv2d_fwd_bnstats: same y as cn_conv2d_fwd (bit for bit), partial rows that sum to the
+    per-channel sum / sum of squares of the stored y, and a BatchNorm fed from those partials that
+    matches the BatchNorm that re-reads y (models/resnet.py:141-165 conv -> bn pairs)."""
+    dev = _dev(mode)
+    import convnet_amd as ca
+    ops, L = ca.ops, ca._lib.load()
+    for (N, H, W, C, K, R, st, pad) in (STATS_EMUL if mode == 'emul' else STATS_GPU):
+        if dtype == torch.bfloat16 and C % 8:
+            continue
+        g = torch.Generator().manual_seed(K + H)
+        xh = _nhwc(torch.randn(N, C, H, W, generator=g), dtype, dev)
+        wk = (torch.randn(K, R, R, C, generator=g) * (2.0 / (C * R * R)) ** 0.5).to(dtype).to(dev)
+        y_plain = ops.conv2d_fwd(xh, wk, None, K, R, R, (st, st), (pad, pad))
+        y = ops.conv2d_fwd(xh, wk, None, K, R, R, (st, st), (pad, pad), bn_stats=True)
+        assert torch.equal(y.cpu(), y_plain.cpu())
+        ps = ops.take_pending_stats(y)
+        assert ps is not None and ps.rows == (y.numel() // K + 127) // 128 and ops.take_pending_stats(y) is None
+        y2 = y.float().cpu().double().reshape(-1, K)
+        part = ps.partial.cpu().double()
+        tol = 1e-5 if dtype == torch.float32 else 1e-5   # fp32 sums of the *stored* values in both cases
+        assert rel_l2(part[:, :K].sum(0), y2.sum(0)) < tol
+        assert rel_l2(part[:, K:].sum(0), (y2 * y2).sum(0)) < tol
+        # per-tile rows, not just their total
+        r0 = y2[:128]
+        assert rel_l2(part[0, :K], r0.sum(0)) < tol and rel_l2(part[0, K:], (r0 * r0).sum(0)) < tol
+
+        # BatchNorm from the partials == BatchNorm that re-reads y
+        outs = []
+        for fused in (True, False):
+            bn = ca.nn.BatchNorm2d(K)
+            ca.engine.prepare(torch.nn.Sequential(bn), dev, dtype)
+            bn.train()
+            with torch.no_grad():
+                yy = ops.conv2d_fwd(xh, wk, None, K, R, R, (st, st), (pad, pad), bn_stats=fused)
+                z = bn(yy, relu=True)
+            assert (yy is not None) and len(ops._PENDING) == 0
+            outs.append((z.float().cpu(), bn.running_mean.cpu().clone(), bn.running_var.cpu().clone()))
+        (zf, mf, vf), (zp, mp, vp) = outs
+        assert rel_l2(mf, mp) < 1e-5 and rel_l2(vf, vp) < 1e-5
+        assert rel_l2(zf, zp) < (1e-5 if dtype == torch.float32 else 4e-3)
+
+
 @pytest.mark.parametrize('mode', MODES)
 def test_wgrad_accumulates_and_scales(mode):
     dev = _dev(mode)
