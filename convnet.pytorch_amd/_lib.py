@@ -36,6 +36,8 @@ _SIGNATURES = {
     'cn_conv2d_bnstats_rows': (c_i, [c_ll]),
     'cn_conv2d_fwd_bnstats': (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 11 + [c_i, c_i, c_p, c_i, c_p]),
     'cn_conv2d_dgrad': (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 11 + [c_i, c_i, c_p]),
+    'cn_conv2d_dgrad_bnbwd_rows': (c_i, [c_i] * 5),
+    'cn_conv2d_dgrad_bnbwd': (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 11 + [c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_p]),
     'cn_conv2d_wgrad_workspace': (c_sz, [c_i] * 12),
     'cn_conv2d_wgrad': (c_i, [c_p, c_p, c_p, c_i] + [c_i] * 11 + [c_i, c_f, c_f, c_p, c_sz, c_p]),
     'cn_bn_workspace': (c_sz, [c_i, c_i, c_i]),
@@ -43,6 +45,7 @@ _SIGNATURES = {
     'cn_bn_fwd_train_partials': (c_i, [c_p] * 9 + [c_f, c_f, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_sz, c_p]),
     'cn_bn_fwd_infer': (c_i, [c_p] * 7 + [c_f, c_p, c_i, c_i, c_i, c_i, c_p]),
     'cn_bn_bwd': (c_i, [c_p] * 9 + [c_f, c_f, c_p, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
+    'cn_bn_bwd_partials': (c_i, [c_p] * 7 + [c_f, c_f, c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_sz, c_p]),
     'cn_maxpool_fwd': (c_i, [c_p, c_p, c_p] + [c_i] * 8 + [c_p]),
     'cn_maxpool_bwd': (c_i, [c_p, c_p, c_p] + [c_i] * 8 + [c_p]),
     'cn_avgpool_fwd': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
@@ -109,7 +112,17 @@ def load():
             'g.build()"` (hipcc --offload-arch=gfx950).  There is no CPU / PyTorch fallback.' % HIP_LIB)
     _lib = _bind(HIP_LIB)
     _emulated = False
+    _apply_env_options(_lib)
     return _lib
+
+
+def _apply_env_options(lib):
+    """CONVNET_AMD_OPTIONS="name=value,..." -> cn_set_option: kernel-variant tuning knobs for A/B
+    measurement (results never change)."""
+    for item in os.environ.get('CONVNET_AMD_OPTIONS', '').split(','):
+        if '=' in item:
+            k, v = item.split('=', 1)
+            lib.cn_set_option(k.strip().encode(), int(v))
 
 
 def is_emulated():

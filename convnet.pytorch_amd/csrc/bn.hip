@@ -211,7 +211,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const char* y, const char* res, char* z,
                                                       unsigned char* mask, const float* scale,
                                                       const float* shift, int M, int C, int relu,
-                                                      int tpr_log2) {
+                                                      int tpr_log2, int rev) {
   constexpr int CH = ElemTraits<T>::kChunk;
   constexpr int EB = ElemTraits<T>::kBytes;
   const int tid = threadIdx.x;
@@ -224,7 +224,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const char* y, const char
   for (int e = 0; e < CH; ++e) { sc[e] = scale[col * CH + e]; sh[e] = shift[col * CH + e]; }
   const int step = gridDim.x * rpp;
 #pragma unroll 4
-  for (int row = blockIdx.x * rpp + rsub; row < M; row += step) {
+  for (int it = blockIdx.x * rpp + rsub; it < M; it += step) {
+    const int row = rev ? M - 1 - it : it;   // rev: sweep back to front (the producer's freshest rows first)
     const size_t off = ((size_t)row * C + (size_t)col * CH) * EB;
     float f[CH];
     Chunk<T>::unpack(cn_ld16(y + off), f);
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const char* dz, cons
                                                            const float* mean, const float* invstd,
                                                            const float* scale, const float* shift,
                                                            float* partial, int M, int C, int relu,
-                                                           int tpr_log2) {
+                                                           int tpr_log2, int rev) {
   constexpr int CH = ElemTraits<T>::kChunk;
   constexpr int EB = ElemTraits<T>::kBytes;
   __shared__ float red[256 * 2 * CH];
@@ -299,20 +300,22 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const char* dz, cons
         s2[e] = fmaf(g[e], (v[e] - mu[e]) * is[e], s2[e]);
       }
     };
-    int row = blockIdx.x * rpp + rsub;
-    for (; row + 3 * step < M; row += 4 * step) {   // 8-12 independent loads in flight per lane
+    int it = blockIdx.x * rpp + rsub;
+    for (; it + 3 * step < M; it += 4 * step) {   // 8-12 independent loads in flight per lane
       u32x4 gz[4], vy[4];
       unsigned int bits[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        gz[u] = cn_ld16(dz + (size_t)(row + u * step) * rb + cb);
-        vy[u] = cn_ld16(y + (size_t)(row + u * step) * rb + cb);
-        if (relu && zmask != nullptr) bits[u] = zmask[(size_t)(row + u * step) * cpr + col];
+        const int row = rev ? M - 1 - (it + u * step) : it + u * step;
+        gz[u] = cn_ld16(dz + (size_t)row * rb + cb);
+        vy[u] = cn_ld16(y + (size_t)row * rb + cb);
+        if (relu && zmask != nullptr) bits[u] = zmask[(size_t)row * cpr + col];
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) accum(gz[u], vy[u], bits[u]);
     }
-    for (; row < M; row += step) {
+    for (; it < M; it += step) {
+      const int row = rev ? M - 1 - it : it;
       unsigned int bits = 0u;
       if (relu && zmask != nullptr) bits = zmask[(size_t)row * cpr + col];
       accum(cn_ld16(dz + (size_t)row * rb + cb), cn_ld16(y + (size_t)row * rb + cb), bits);
@@ -360,7 +363,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char* dz, const char* y, const unsigned char* zmask,
                                                           const float* scale, const float* shift,
                                                           const float* coef, char* dy, char* dres, int M,
-                                                          int C, int relu, int tpr_log2) {
+                                                          int C, int relu, int tpr_log2, int rev) {
   constexpr int CH = ElemTraits<T>::kChunk;
   constexpr int EB = ElemTraits<T>::kBytes;
   const int tid = threadIdx.x;
@@ -379,7 +382,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char* dz, const
   }
   const int step = gridDim.x * rpp;
 #pragma unroll 2
-  for (int row = blockIdx.x * rpp + rsub; row < M; row += step) {
+  for (int it = blockIdx.x * rpp + rsub; it < M; it += step) {
+    const int row = rev ? M - 1 - it : it;
     const size_t off = ((size_t)row * C + (size_t)col * CH) * EB;
     float g[CH], v[CH];
     Chunk<T>::unpack(cn_ld16(dz + off), g);
@@ -407,6 +411,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char* dz, const
 // ------------------------------------------------------------------------------------------------
 #define BN_TARGET_BLOCKS 512   /* reduction kernels: partial rows per channel (kept small) */
 #define BN_APPLY_BLOCKS 2048   /* pure streaming kernels */
+/* Sweep direction of the streaming kernels, bit 0: forward apply, bit 1: backward reduce, bit 2: backward
+ * apply.  A kernel that sweeps in the opposite direction to the one that last touched its input finds
+ * the freshest part of that tensor still in the 256 MB Infinity Cache (tuning knob "bn_reverse"). */
+#define BN_REVERSE_DEFAULT 0
 
 extern "C" size_t cn_bn_workspace(int M, int C, int dtype) {
   const int CH = dtype == CN_BF16 ? 8 : 4;
@@ -436,14 +444,15 @@ static int bn_fwd_tail(const float* partial, int nrb, const void* y, const void*
             stats_out + C, stats_out + 2 * C, stats_out + 3 * C);
   int nab = bn_row_blocks(M, m, cn_get_option("bn_apply_blocks", BN_APPLY_BLOCKS));
   dim3 agrid((unsigned)nab, (unsigned)m.gy);
+  const int rev = cn_get_option("bn_reverse", BN_REVERSE_DEFAULT) & 1;
   if (dtype == CN_BF16)
     CN_LAUNCH(bn_apply_kernel<bf16_t>, agrid, dim3(256), stream, (const char*)y, (const char*)residual,
               (char*)z, relu_mask, (const float*)(stats_out + 2 * C), (const float*)(stats_out + 3 * C), M, C,
-              relu, m.tpr_log2);
+              relu, m.tpr_log2, rev);
   else
     CN_LAUNCH(bn_apply_kernel<float>, agrid, dim3(256), stream, (const char*)y, (const char*)residual, (char*)z,
               relu_mask, (const float*)(stats_out + 2 * C), (const float*)(stats_out + 3 * C), M, C, relu,
-              m.tpr_log2);
+              m.tpr_log2, rev);
   return cn_check_launch("bn_fwd_train");
 }
 
@@ -517,13 +526,15 @@ extern "C" int cn_bn_fwd_infer(const void* y, const void* residual, void* z, con
             running_mean, running_var, eps, coeffs, coeffs + C);
   int nab = bn_row_blocks(M, m, cn_get_option("bn_apply_blocks", BN_APPLY_BLOCKS));
   dim3 agrid((unsigned)nab, (unsigned)m.gy);
+  const int rev = cn_get_option("bn_reverse", BN_REVERSE_DEFAULT) & 1;
   if (dtype == CN_BF16)
     CN_LAUNCH(bn_apply_kernel<bf16_t>, agrid, dim3(256), stream, (const char*)y, (const char*)residual,
               (char*)z, (unsigned char*)nullptr, (const float*)coeffs, (const float*)(coeffs + C), M, C, relu,
-              m.tpr_log2);
+              m.tpr_log2, rev);
   else
     CN_LAUNCH(bn_apply_kernel<float>, agrid, dim3(256), stream, (const char*)y, (const char*)residual, (char*)z,
-              (unsigned char*)nullptr, (const float*)coeffs, (const float*)(coeffs + C), M, C, relu, m.tpr_log2);
+              (unsigned char*)nullptr, (const float*)coeffs, (const float*)(coeffs + C), M, C, relu, m.tpr_log2,
+              rev);
   return cn_check_launch("bn_fwd_infer");
 }
 
@@ -550,12 +561,14 @@ extern "C" int cn_bn_bwd(const void* dz, const void* y, const unsigned char* rel
   const float* scale = stats + 2 * C;
   const float* shift = stats + 3 * C;
   dim3 grid((unsigned)nrb, (unsigned)m.gy);
+  const int revopt = cn_get_option("bn_reverse", BN_REVERSE_DEFAULT);
+  const int rev_r = (revopt >> 1) & 1, rev_a = (revopt >> 2) & 1;
   if (dtype == CN_BF16)
     CN_LAUNCH(bn_bwd_reduce_kernel<bf16_t>, grid, dim3(256), stream, (const char*)dz, (const char*)y,
-              relu_mask, mean, invstd, scale, shift, partial, M, C, relu, m.tpr_log2);
+              relu_mask, mean, invstd, scale, shift, partial, M, C, relu, m.tpr_log2, rev_r);
   else
     CN_LAUNCH(bn_bwd_reduce_kernel<float>, grid, dim3(256), stream, (const char*)dz, (const char*)y,
-              relu_mask, mean, invstd, scale, shift, partial, M, C, relu, m.tpr_log2);
+              relu_mask, mean, invstd, scale, shift, partial, M, C, relu, m.tpr_log2, rev_r);
   CN_LAUNCH(bn_bwd_finalize_kernel, dim3((unsigned)((C + 31) / 32)), dim3(256), stream, (const float*)partial,
             nrb, M, C, gamma, mean, invstd, dgamma, dbeta, beta_acc, gscale, coef_scratch);
   int nab = bn_row_blocks(M, m, cn_get_option("bn_apply_blocks", BN_APPLY_BLOCKS));
@@ -563,10 +576,55 @@ extern "C" int cn_bn_bwd(const void* dz, const void* y, const unsigned char* rel
   if (dtype == CN_BF16)
     CN_LAUNCH(bn_bwd_apply_kernel<bf16_t>, agrid, dim3(256), stream, (const char*)dz, (const char*)y,
               relu_mask, scale, shift, (const float*)coef_scratch, (char*)dy, (char*)dres, M, C, relu,
-              m.tpr_log2);
+              m.tpr_log2, rev_a);
   else
     CN_LAUNCH(bn_bwd_apply_kernel<float>, agrid, dim3(256), stream, (const char*)dz, (const char*)y,
               relu_mask, scale, shift, (const float*)coef_scratch, (char*)dy, (char*)dres, M, C, relu,
-              m.tpr_log2);
+              m.tpr_log2, rev_a);
   return cn_check_launch("bn_bwd");
+}
+
+// Training backward when the producer of the upstream gradient already masked it and reduced it
+// (cn_conv2d_dgrad_bnbwd): g = dz * relu_mask, partial = [nrb][2*C] floats of sum g | sum g*xhat.
+// Runs finalize + apply only (no second pass over g and y for the sums, no dres: it is g itself).
+extern "C" int cn_bn_bwd_partials(const void* g, const void* y, const float* gamma, const float* stats, void* dy,
+                                  float* dgamma, float* dbeta, float beta_acc, float gscale,
+                                  float* coef_scratch, int M, int C, int dtype, const float* partial, int nrb,
+                                  void* workspace, size_t ws_bytes, void* stream_) {
+  int rc = bn_check("bn_bwd_partials", M, C, dtype);
+  if (rc) return rc;
+  if (partial == nullptr || nrb <= 0) { cn_set_error("bn_bwd_partials: no partials"); return CN_EINVAL; }
+  hipStream_t stream = (hipStream_t)stream_;
+  const int CH = dtype == CN_BF16 ? 8 : 4;
+  BnMap m = bn_map(C / CH);
+  if (nrb > BN_TARGET_BLOCKS) {
+    const int G = (nrb + BN_TARGET_BLOCKS - 1) / BN_TARGET_BLOCKS;
+    const int nr2 = (nrb + G - 1) / G;
+    if (workspace == nullptr || ws_bytes < (size_t)nr2 * 2 * C * sizeof(float)) {
+      cn_set_error("bn_bwd_partials: workspace too small");
+      return CN_EWORKSPACE;
+    }
+    CN_LAUNCH(bn_partials_compress_kernel, dim3((unsigned)((2 * C + 255) / 256), (unsigned)nr2), dim3(256), stream,
+              partial, (float*)workspace, nrb, G, 2 * C);
+    partial = (const float*)workspace;
+    nrb = nr2;
+  }
+  const float* mean = stats;
+  const float* invstd = stats + C;
+  const float* scale = stats + 2 * C;
+  const float* shift = stats + 3 * C;
+  CN_LAUNCH(bn_bwd_finalize_kernel, dim3((unsigned)((C + 31) / 32)), dim3(256), stream, partial, nrb, M, C, gamma,
+            mean, invstd, dgamma, dbeta, beta_acc, gscale, coef_scratch);
+  int nab = bn_row_blocks(M, m, cn_get_option("bn_apply_blocks", BN_APPLY_BLOCKS));
+  dim3 agrid((unsigned)nab, (unsigned)m.gy);
+  const int rev_a = (cn_get_option("bn_reverse", BN_REVERSE_DEFAULT) >> 2) & 1;
+  if (dtype == CN_BF16)
+    CN_LAUNCH(bn_bwd_apply_kernel<bf16_t>, agrid, dim3(256), stream, (const char*)g, (const char*)y,
+              (const unsigned char*)nullptr, scale, shift, (const float*)coef_scratch, (char*)dy, (char*)nullptr, M,
+              C, 0, m.tpr_log2, rev_a);
+  else
+    CN_LAUNCH(bn_bwd_apply_kernel<float>, agrid, dim3(256), stream, (const char*)g, (const char*)y,
+              (const unsigned char*)nullptr, scale, shift, (const float*)coef_scratch, (char*)dy, (char*)nullptr, M,
+              C, 0, m.tpr_log2, rev_a);
+  return cn_check_launch("bn_bwd_partials");
 }

@@ -19,6 +19,7 @@
 // ds_read_b128 fragment reads are bank-conflict free.
 #include "cn_common.h"
 #include "cn_api_internal.h"
+#include <type_traits>
 
 #define IG_MAX_TAPS 64
 
@@ -29,6 +30,13 @@ struct IgemmParams {
   const char* addend;   // optional tensor added to the output (same layout / dtype as y)
   const float* bias;
   float* stats;         // optional [n_mtiles][2*Co]: per pixel-tile sum / sum of squares of the stored outputs
+  // optional fused BatchNorm-backward reduction (dgrad): the output is the gradient w.r.t. z = act(BN(bn_y));
+  // the epilogue applies the ReLU mask, stores g = dz*mask and emits per-tile sum(g), sum(g*xhat)
+  const char* bn_y;              // BN input, same layout / dtype as the output
+  const unsigned char* bn_mask;  // optional bit mask (one byte per 16-byte chunk) written by bn_apply
+  const float* bn_coef;          // [mean | invstd | scale | shift], 4*Co floats
+  float* bn_partial;             // [rows][2*Co]
+  int bn_row0, bn_relu;
   int N, Hi, Wi, Ci;
   int Hg, Wg, a_h, a_w;
   int Ho, Wo, Co;
@@ -419,6 +427,25 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
   }
   const int epc = 16 / OEB;            // elements per 16-byte chunk of the output
   const int cpr = BN / epc;            // chunks per tile row
+  typedef typename std::conditional<OUTF32, float, T>::type TO;   // element type of the stored output
+  constexpr int EPC = 16 / OEBc;
+  constexpr int CPR = BN / EPC;
+  static_assert(NT % CPR == 0, "a thread keeps one chunk column for the whole store loop");
+  const bool bnb = p.bn_y != nullptr;
+  float bs1[EPC], bs2[EPC], bmu[EPC], bis[EPC], bsc[EPC], bsh[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) { bs1[e] = 0.f; bs2[e] = 0.f; bmu[e] = 0.f; bis[e] = 0.f; bsc[e] = 0.f; bsh[e] = 0.f; }
+  if (bnb) {
+    const int c0 = n0 + (tid % CPR) * EPC;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e)
+      if (c0 + e < p.Co) {
+        bmu[e] = p.bn_coef[c0 + e];
+        bis[e] = p.bn_coef[p.Co + c0 + e];
+        bsc[e] = p.bn_coef[2 * p.Co + c0 + e];
+        bsh[e] = p.bn_coef[3 * p.Co + c0 + e];
+      }
+  }
   const bool vec_ok = ((p.Co * OEB) & 15) == 0;
   for (int id = tid; id < BM * cpr; id += NT) {
     const int row = id / cpr, col = id - row * cpr;
@@ -431,22 +458,35 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
     const size_t goff = ((size_t)pix * (size_t)p.Co + (size_t)c_first) * OEB;
     if (vec_ok && c_first + epc <= p.Co) {
       u32x4 v = cn_ld16(src);
-      if (p.addend != nullptr) {   // e.g. the residual-branch gradient folded into dgrad
-        const u32x4 a = cn_ld16(p.addend + goff);
-        if (OEB == 4) {
-          float fv[4], fa[4];
-          Chunk<float>::unpack(v, fv);
-          Chunk<float>::unpack(a, fa);
+      if (p.addend != nullptr || bnb) {
+        float fv[EPC];
+        Chunk<TO>::unpack(v, fv);
+        if (p.addend != nullptr) {   // e.g. the residual-branch gradient folded into dgrad
+          float fa[EPC];
+          Chunk<TO>::unpack(cn_ld16(p.addend + goff), fa);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) fv[e] += fa[e];
-          v = Chunk<float>::pack(fv);
+          for (int e = 0; e < EPC; ++e) fv[e] += fa[e];
+        }
+        if (bnb) {
+          float yv[EPC];
+          Chunk<TO>::unpack(cn_ld16(p.bn_y + goff), yv);
+          if (p.bn_mask != nullptr) {
+            const unsigned int bits = p.bn_mask[goff >> 4];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) fv[e] = ((bits >> e) & 1u) ? fv[e] : 0.f;
+          } else if (p.bn_relu) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) fv[e] = fmaf(yv[e], bsc[e], bsh[e]) > 0.f ? fv[e] : 0.f;
+          }
+          v = Chunk<TO>::pack(fv);
+          Chunk<TO>::unpack(v, fv);   // statistics of the values as stored (rounded)
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) {
+            bs1[e] += fv[e];
+            bs2[e] = fmaf(fv[e], (yv[e] - bmu[e]) * bis[e], bs2[e]);
+          }
         } else {
-          float fv[8], fa[8];
-          Chunk<bf16_t>::unpack(v, fv);
-          Chunk<bf16_t>::unpack(a, fa);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) fv[e] += fa[e];
-          v = Chunk<bf16_t>::pack(fv);
+          v = Chunk<TO>::pack(fv);
         }
       }
       cn_st16(dst, v);
@@ -461,6 +501,28 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
           if (p.addend != nullptr) f += cn_bf16_to_f32(((const unsigned short*)(p.addend + goff))[e]);
           ((unsigned short*)dst)[e] = cn_f32_to_bf16(f);
         }
+      }
+    }
+  }
+  if (bnb) {
+    __syncthreads();   // the out tile has been consumed: its first 16 KiB take the per-thread partials
+    float* red = (float*)lds;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { red[tid * 2 * EPC + e] = bs1[e]; red[tid * 2 * EPC + EPC + e] = bs2[e]; }
+    __syncthreads();
+    if (tid < BN) {
+      const int cchunk = tid / EPC, e = tid % EPC;
+      float a1 = 0.f, a2 = 0.f;
+      for (int j = 0; j < NT / CPR; ++j) {   // fixed order: deterministic
+        const float* o = red + (j * CPR + cchunk) * 2 * EPC;
+        a1 += o[e];
+        a2 += o[EPC + e];
+      }
+      const int c = n0 + tid;
+      if (c < p.Co) {
+        float* dst = p.bn_partial + (size_t)(p.bn_row0 + mt) * 2 * (size_t)p.Co;
+        dst[c] = a1;
+        dst[p.Co + c] = a2;
       }
     }
   }
@@ -499,7 +561,7 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
   // buffer, 4 = LDS-DMA 4-deep ring (4 waves), 5 = LDS-DMA 4-deep ring with 8 waves; 0 / unset = heuristic (tuning knob "igemm_variant", profiles/r01_conv_layers*)
   int variant = cn_get_option("igemm_variant", 0);
   if (variant < 1 || variant > 6) variant = cn_get_option("igemm_default_variant", nkt < 24 ? 1 : 3);
-  if (p.stats != nullptr && variant == 6) variant = 3;   // statistics rows are defined per 128-pixel tile
+  if ((p.stats != nullptr || p.bn_y != nullptr) && variant == 6) variant = 3;   // statistics rows are defined per 128-pixel tile
   const int BM = (variant == 6 && p.Co > 64) ? 256 : 128, BN = p.Co <= 64 ? 64 : 128;
   p.n_ntiles = (p.Co + BN - 1) / BN;
   const int n_mtiles = (p.M + BM - 1) / BM;
@@ -636,9 +698,18 @@ extern "C" int cn_conv2d_fwd_bnstats(const void* x, const void* w_krsc, void* y,
                      0, relu, stream);
 }
 
-extern "C" int cn_conv2d_dgrad(const void* dy, const void* w_crsk, void* dx, const void* addend, int N, int H,
-                               int W, int C, int K, int R, int S, int stride_h, int stride_w, int pad_h,
-                               int pad_w, int dtype, int out_f32, void* stream) {
+struct IgBnBwd {
+  const void* y;
+  const unsigned char* mask;
+  const float* coef;
+  float* partial;
+  int relu, rows_cap;
+};
+
+static int ig_conv_dgrad(const void* dy, const void* w_crsk, void* dx, const void* addend, int N, int H,
+                         int W, int C, int K, int R, int S, int stride_h, int stride_w, int pad_h,
+                         int pad_w, int dtype, int out_f32, const IgBnBwd* bn, void* stream) {
+  int bn_row = 0;
   const int P = (H + 2 * pad_h - R) / stride_h + 1;
   const int Q = (W + 2 * pad_w - S) / stride_w + 1;
   if (P <= 0 || Q <= 0 || N <= 0) { cn_set_error("conv2d_dgrad: empty output"); return CN_ESHAPE; }
@@ -678,8 +749,60 @@ extern "C" int cn_conv2d_dgrad(const void* dy, const void* w_crsk, void* dx, con
       if (rc) return rc;
       for (int t = 0; t < nt; ++t) { p.tap_dhdw[t] = dhdw[t]; p.tap_woff[t] = woff[t]; }
       p.simple = ig_is_simple(p, dhdw, nt);
+      if (bn != nullptr) {
+        const int rows = (p.M + 127) / 128;
+        if (bn_row + rows > bn->rows_cap) {
+          cn_set_error("conv2d_dgrad_bnbwd: partial buffer of %d rows is too small", bn->rows_cap);
+          return CN_EWORKSPACE;
+        }
+        p.bn_y = (const char*)bn->y; p.bn_mask = bn->mask; p.bn_coef = bn->coef; p.bn_partial = bn->partial;
+        p.bn_relu = bn->relu; p.bn_row0 = bn_row;
+        bn_row += rows;
+      }
       rc = ig_dispatch(p, dtype, (hipStream_t)stream);
       if (rc) return rc;
     }
   return CN_OK;
+}
+
+extern "C" int cn_conv2d_dgrad(const void* dy, const void* w_crsk, void* dx, const void* addend, int N, int H,
+                               int W, int C, int K, int R, int S, int stride_h, int stride_w, int pad_h,
+                               int pad_w, int dtype, int out_f32, void* stream) {
+  return ig_conv_dgrad(dy, w_crsk, dx, addend, N, H, W, C, K, R, S, stride_h, stride_w, pad_h, pad_w, dtype,
+                       out_f32, nullptr, stream);
+}
+
+// Partial rows cn_conv2d_dgrad_bnbwd writes: one per 128-pixel tile of every output-parity class.
+extern "C" int cn_conv2d_dgrad_bnbwd_rows(int N, int H, int W, int stride_h, int stride_w) {
+  int rows = 0;
+  for (int ph = 0; ph < stride_h; ++ph)
+    for (int pw = 0; pw < stride_w; ++pw) {
+      const long long hg = (H - ph + stride_h - 1) / stride_h, wg = (W - pw + stride_w - 1) / stride_w;
+      if (hg <= 0 || wg <= 0) continue;
+      rows += (int)(((long long)N * hg * wg + 127) / 128);
+    }
+  return rows;
+}
+
+// Data gradient fused with the reduction half of the BatchNorm backward of the layer that produced
+// this convolution's input: x = act(BN(bn_y) [+ residual]).  Stores g = dx * relu_mask instead of dx
+// (mask from `bn_mask` bits, or recomputed from bn_y*scale+shift > 0 when bn_relu and no mask) and
+// writes partial[row] = [sum g | sum g*(bn_y-mean)*invstd] per 128-pixel tile
+// (cn_conv2d_dgrad_bnbwd_rows rows of 2*C floats) for cn_bn_bwd_partials.  bn_coef = the 4*C floats
+// [mean | invstd | scale | shift] cn_bn_fwd_train wrote.
+extern "C" int cn_conv2d_dgrad_bnbwd(const void* dy, const void* w_crsk, void* g, const void* addend, int N, int H,
+                                     int W, int C, int K, int R, int S, int stride_h, int stride_w, int pad_h,
+                                     int pad_w, int dtype, const void* bn_y, const unsigned char* bn_mask,
+                                     const float* bn_coef, int bn_relu, float* partial, int partial_rows,
+                                     void* stream) {
+  const int CH = dtype == CN_BF16 ? 8 : 4;
+  if (bn_y == nullptr || bn_coef == nullptr || partial == nullptr || C % CH != 0) {
+    cn_set_error("conv2d_dgrad_bnbwd: needs bn_y, bn_coef, partial and C (%d) a multiple of %d", C, CH);
+    return CN_EINVAL;
+  }
+  IgBnBwd bn;
+  bn.y = bn_y; bn.mask = bn_mask; bn.coef = bn_coef; bn.partial = partial; bn.relu = bn_relu;
+  bn.rows_cap = partial_rows;
+  return ig_conv_dgrad(dy, w_crsk, g, addend, N, H, W, C, K, R, S, stride_h, stride_w, pad_h, pad_w, dtype, 0, &bn,
+                       stream);
 }

@@ -64,6 +64,9 @@ class ResidualBlock(tnn.Module):
                                                    padding=k // 2, bias=False))
             setattr(self, 'bn%d' % i, cnn.BatchNorm2d(cout))
             getattr(self, 'conv%d' % i).feeds_batchnorm = True   # BN statistics come out of the conv epilogue
+            if i > 1:   # this conv reads relu(bn_{i-1}(.)): its dgrad epilogue does that BN's backward reduction
+                # (instance dict, not setattr: the BN must not become a registered sub-module of the conv)
+                getattr(self, 'conv%d' % i).__dict__['input_bn'] = getattr(self, 'bn%d' % (i - 1))
             if i == 1 and kind == 'basic':
                 self.relu = cnn.ReLU(inplace=True)  # registration order of the reference BasicBlock
             cin = cout
@@ -87,6 +90,13 @@ class ResidualBlock(tnn.Module):
 
     def last_bn(self):
         return getattr(self, 'bn%d' % self.n_convs)
+
+    def set_input_bn(self, bn):
+        """The block input is the output of `bn` (the previous block's last BN, ReLU and residual fused):
+        whichever of conv1 / downsample conv completes the input gradient reduces it for that BN."""
+        self.conv1.__dict__['input_bn'] = bn
+        if self.downsample is not None:
+            self.downsample[0].__dict__['input_bn'] = bn
 
     def forward(self, x):
         xa, xb = cnn.fork(x, self._holder)
@@ -135,6 +145,12 @@ class ResNetImagenet(tnn.Module):
         for i, nblocks in enumerate(layers):
             setattr(self, 'layer%d' % (i + 1),
                     self._make_layer(block, width[i], nblocks, expansion, stride=1 if i == 0 else 2))
+        prev = None
+        for m in self.modules():   # registration order = execution order of the residual blocks
+            if isinstance(m, ResidualBlock):
+                if prev is not None:
+                    m.set_input_bn(prev.last_bn())
+                prev = m
         self.avgpool = cnn.AdaptiveAvgPool2d(1)
         self.fc = cnn.Linear(width[-1] * expansion, num_classes)
         init_model(self)

@@ -131,6 +131,12 @@ def conv_out_hw(H, W, R, S, stride, pad):
 
 # A/B switch: 0 = every BatchNorm re-reads its input for the statistics (bn_stats_kernel)
 FUSE_BN_STATS = os.environ.get('CONVNET_AMD_FUSE_BN_STATS', '1') != '0'
+# A/B switch: 0 = BatchNorm backward always runs its own reduction pass over (dz, y)
+FUSE_BN_BWD = os.environ.get('CONVNET_AMD_FUSE_BN_BWD', '1') != '0'
+
+
+# how often each BatchNorm path ran (tests assert that the fused paths really are the ones in use)
+COUNTERS = {'bn_fwd_fused': 0, 'bn_fwd_plain': 0, 'bn_bwd_fused': 0, 'bn_bwd_plain': 0}
 
 
 class _PendingStats(object):
@@ -186,18 +192,33 @@ def conv2d_fwd(x, w_krsc, bias, K, R, S, stride, pad, out_f32=False, relu=False,
     return y
 
 
-def conv2d_dgrad(dy, w_crsk, x_shape, K, R, S, stride, pad, addend=None):
+def conv2d_dgrad(dy, w_crsk, x_shape, K, R, S, stride, pad, addend=None, bn=None):
+    """dx (NHWC).  With bn = (bn_y, bn_mask_or_None, bn_stats[4C], relu) the epilogue also does the
+    reduction half of that BatchNorm's backward: returns (g = dx*relu_mask, partial, rows)."""
     N, H, W, C = x_shape
     dx = torch.empty((N, H, W, C), dtype=dy.dtype, device=dy.device)
-    PROFILER.run(_igemm_name(dy.dtype, C, max(1, -(-R // stride[0]) * -(-S // stride[1])), K),
-                 stride[0] * stride[1], 2.0 * dy.numel() * C * R * S,
-                 dy.numel() * _esize(dy) + dx.numel() * _esize(dx) * (2 if addend is not None else 1)
-                 + K * R * S * C * _esize(dy),
-                 lambda: check(_L().cn_conv2d_dgrad(ptr(dy), ptr(w_crsk), ptr(dx), ptr(addend), N, H, W, C, K, R, S, stride[0],
-                                                    stride[1], pad[0], pad[1], dtype_code(dy.dtype), 0,
-                                                    stream_of(dy)), 'cn_conv2d_dgrad'),
+    name = _igemm_name(dy.dtype, C, max(1, -(-R // stride[0]) * -(-S // stride[1])), K)
+    flops = 2.0 * dy.numel() * C * R * S
+    nbytes = dy.numel() * _esize(dy) + dx.numel() * _esize(dx) * (2 if addend is not None else 1) \
+        + K * R * S * C * _esize(dy)
+    if bn is None:
+        PROFILER.run(name, stride[0] * stride[1], flops, nbytes,
+                     lambda: check(_L().cn_conv2d_dgrad(ptr(dy), ptr(w_crsk), ptr(dx), ptr(addend), N, H, W, C, K, R, S,
+                                                        stride[0], stride[1], pad[0], pad[1], dtype_code(dy.dtype), 0,
+                                                        stream_of(dy)), 'cn_conv2d_dgrad'),
+                     dy.device)
+        return dx
+    bn_y, bn_mask, bn_stats, bn_relu = bn
+    L = _L()
+    rows = L.cn_conv2d_dgrad_bnbwd_rows(N, H, W, stride[0], stride[1])
+    partial = torch.empty((rows, 2 * C), dtype=torch.float32, device=dy.device)
+    PROFILER.run(name, stride[0] * stride[1], flops, nbytes + dx.numel() * _esize(dx) + partial.numel() * 4,
+                 lambda: check(L.cn_conv2d_dgrad_bnbwd(ptr(dy), ptr(w_crsk), ptr(dx), ptr(addend), N, H, W, C, K, R, S,
+                                                       stride[0], stride[1], pad[0], pad[1], dtype_code(dy.dtype),
+                                                       ptr(bn_y), ptr(bn_mask), ptr(bn_stats), int(bn_relu),
+                                                       ptr(partial), rows, stream_of(dy)), 'cn_conv2d_dgrad_bnbwd'),
                  dy.device)
-    return dx
+    return dx, partial, rows
 
 
 def conv2d_wgrad(x, dy, dw_krsc, c_real, K, R, S, stride, pad, beta=1.0, scale=1.0, tag='main'):
@@ -280,6 +301,32 @@ def fill_f32_(x, v=0.0):
 # never runs an accumulation kernel of its own; `mod._notify_grad_ready()` lets the data-parallel
 # bucket manager start the all-reduce of a finished bucket while backward continues.
 
+def _input_bn_state(conv_mod, x):
+    """(bn module, y, mask, stats, relu) of the BatchNorm whose output *is* the convolution input `x`
+    (wired by the model as conv.input_bn), when that BatchNorm's forward state is still alive and
+    belongs to this very tensor; else None."""
+    bn_mod = getattr(conv_mod, 'input_bn', None)
+    if bn_mod is None:
+        return None
+    ref = getattr(bn_mod, '_fwd_ctx', None)
+    bctx = ref() if ref is not None else None
+    if bctx is None or getattr(bctx, 'out_ptr', None) != x.data_ptr():
+        return None
+    try:
+        saved = bctx.saved_tensors
+    except RuntimeError:      # already released
+        return None
+    y, stats = saved[0], saved[1]
+    mask = saved[2] if len(saved) > 2 else None
+    if tuple(y.shape) != tuple(x.shape) or y.dtype != x.dtype:
+        return None
+    if bctx.has_res and bctx.relu and mask is None:
+        return None
+    if y.shape[-1] % _lib.chunk_elems(y.dtype) != 0:
+        return None
+    return bn_mod, y, mask, stats, bctx.relu
+
+
 class Conv2dFunction(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, mod):
@@ -324,8 +371,18 @@ class Conv2dFunction(Function):
                     and holder.dres.dtype == dy.dtype:
                 addend = holder.dres          # the other branch's gradient, folded into this dgrad epilogue
                 holder.fused = True
-            dx = conv2d_dgrad(dy, mod.w_crsk, x.shape, mod.out_channels, R, S, mod.stride, mod.padding,
-                              addend=addend)
+            # this dgrad is the last contribution to the gradient of x when x has no other consumer
+            # (inner convs) or when the other branch's gradient is being added right here
+            final = holder is None or addend is not None
+            bn_args = _input_bn_state(mod, x) if (final and FUSE_BN_BWD) else None
+            if bn_args is not None:
+                bn_mod, bn_y, bn_mask, bn_stats, bn_relu = bn_args
+                dx, partial, rows = conv2d_dgrad(dy, mod.w_crsk, x.shape, mod.out_channels, R, S, mod.stride,
+                                                 mod.padding, addend=addend, bn=(bn_y, bn_mask, bn_stats, bn_relu))
+                bn_mod._bwd_partials = (dx.data_ptr(), tuple(dx.shape), partial, rows)
+            else:
+                dx = conv2d_dgrad(dy, mod.w_crsk, x.shape, mod.out_channels, R, S, mod.stride, mod.padding,
+                                  addend=addend)
             if holder is not None and addend is None:
                 holder.dres = dx              # first producer of the fork gradient: park it for the other
                 holder.fused = False
@@ -351,6 +408,7 @@ class BatchNormActFunction(Function):
         track = mod.track_running_stats
         nb = y.numel() * _esize(y)
         ps = take_pending_stats(y)
+        COUNTERS['bn_fwd_fused' if ps is not None else 'bn_fwd_plain'] += 1
         if ps is not None:   # statistics came out of the producing convolution's epilogue: no pass over y
             PROFILER.run('bn_finalize+bn_apply (stats from conv epilogue)', 2 if ps.rows <= 512 else 3, 0.0,
                          nb * (3 if residual is not None else 2) + (mask.numel() if mask is not None else 0)
@@ -374,6 +432,8 @@ class BatchNormActFunction(Function):
         ctx.mod = mod
         ctx.relu = relu
         ctx.has_res = residual is not None
+        ctx.out_ptr = z.data_ptr()
+        mod._fwd_ctx = weakref.ref(ctx)      # lets the consumer conv's dgrad fuse this BN's backward reduction
         if mask is not None:
             ctx.save_for_backward(y, stats, mask)
         else:
@@ -394,15 +454,33 @@ class BatchNormActFunction(Function):
         ws = workspace(L.cn_bn_workspace(M, C, code), y.device)
         dy = torch.empty_like(y)
         want_res = ctx.has_res and ctx.needs_input_grad[3]
-        dres = torch.empty_like(y) if want_res else None
         coef = torch.empty(3 * C, dtype=torch.float32, device=y.device)
         nb = y.numel() * _esize(y)
-        PROFILER.run('bn_bwd_reduce+bn_bwd_finalize+bn_bwd_apply', 3, 0.0, nb * (5 + (1 if dres is not None else 0)) + (2 * zmask.numel() if zmask is not None else 0),
-                     lambda: check(L.cn_bn_bwd(ptr(dz), ptr(y), ptr(zmask), ptr(mod.weight), ptr(stats), ptr(dy),
-                                               ptr(dres), ptr(mod.grad_view('weight')), ptr(mod.grad_view('bias')),
-                                               1.0, 1.0, ptr(coef), M, C, int(ctx.relu), code, ptr(ws),
-                                               ws.numel() * 4, stream_of(y)), 'cn_bn_bwd'),
-                     y.device)
+        pp = getattr(mod, '_bwd_partials', None)
+        mod._bwd_partials = None
+        if pp is not None and pp[0] == dz.data_ptr() and pp[1] == tuple(dz.shape) and dz.dtype == y.dtype:
+            # dz arrived masked (g) with its reduction partials from the producing dgrad's epilogue
+            _, _, partial, rows = pp
+            COUNTERS['bn_bwd_fused'] += 1
+            dres = dz if want_res else None       # the residual branch's gradient is g itself
+            PROFILER.run('bn_bwd_finalize+bn_bwd_apply (reduce in dgrad epilogue)', 2 if rows <= 512 else 3, 0.0,
+                         nb * 3 + partial.numel() * 4,
+                         lambda: check(L.cn_bn_bwd_partials(ptr(dz), ptr(y), ptr(mod.weight), ptr(stats), ptr(dy),
+                                                            ptr(mod.grad_view('weight')), ptr(mod.grad_view('bias')),
+                                                            1.0, 1.0, ptr(coef), M, C, code, ptr(partial), rows,
+                                                            ptr(ws), ws.numel() * 4, stream_of(y)),
+                                       'cn_bn_bwd_partials'),
+                         y.device)
+        else:
+            COUNTERS['bn_bwd_plain'] += 1
+            dres = torch.empty_like(y) if want_res else None
+            PROFILER.run('bn_bwd_reduce+bn_bwd_finalize+bn_bwd_apply', 3, 0.0,
+                         nb * (5 + (1 if dres is not None else 0)) + (2 * zmask.numel() if zmask is not None else 0),
+                         lambda: check(L.cn_bn_bwd(ptr(dz), ptr(y), ptr(zmask), ptr(mod.weight), ptr(stats), ptr(dy),
+                                                   ptr(dres), ptr(mod.grad_view('weight')), ptr(mod.grad_view('bias')),
+                                                   1.0, 1.0, ptr(coef), M, C, int(ctx.relu), code, ptr(ws),
+                                                   ws.numel() * 4, stream_of(y)), 'cn_bn_bwd'),
+                         y.device)
         mod._notify_grad_ready()
         holder = getattr(mod, '_res_holder', None)
         if holder is not None:

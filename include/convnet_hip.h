@@ -59,6 +59,16 @@ int cn_conv2d_dgrad(const void* dy, const void* w_crsk, void* dx, const void* ad
                     the residual-branch gradient of models/resnet.py:162 folded into the epilogue*/, int N, int H,
                     int W, int C, int K, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w,
                     int dtype, int out_f32, void* stream);
+/* Data gradient fused with the reduction half of the BatchNorm backward of the layer that produced the
+ * convolution's input x = act(BN(bn_y) [+ residual]) (models/resnet.py:141-165): stores g = dx * relu_mask
+ * (mask bits from bn_mask, or recomputed from bn_y*scale+shift > 0 when bn_relu and bn_mask == NULL) and one
+ * partial row [sum g | sum g*xhat] (2*C floats) per 128-pixel tile for cn_bn_bwd_partials.
+ * bn_coef = the 4*C floats cn_bn_fwd_train wrote. */
+int cn_conv2d_dgrad_bnbwd_rows(int N, int H, int W, int stride_h, int stride_w);
+int cn_conv2d_dgrad_bnbwd(const void* dy, const void* w_crsk, void* g, const void* addend, int N, int H, int W,
+                          int C, int K, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w, int dtype,
+                          const void* bn_y, const unsigned char* bn_mask, const float* bn_coef, int bn_relu,
+                          float* partial, int partial_rows, void* stream);
 /* dw[K,R,S,C_real] (fp32) = beta*dw + scale * sum_pixels dy (x) x ; split reduction through
  * `workspace` (cn_conv2d_wgrad_workspace bytes), fixed summation order. */
 size_t cn_conv2d_wgrad_workspace(int N, int H, int W, int C, int K, int R, int S, int stride_h, int stride_w,
@@ -93,6 +103,13 @@ int cn_bn_bwd(const void* dz, const void* y, const unsigned char* relu_mask, con
               void* dy, void* dres, float* dgamma, float* dbeta, float beta_acc, float gscale,
               float* coef_scratch /*3C*/, int M, int C, int relu, int dtype, void* workspace,
               size_t ws_bytes, void* stream);
+
+/* cn_bn_bwd when the upstream gradient arrives already masked (g = dz * relu_mask) together with its
+ * reduction partials ([nrb][2*C]: sum g | sum g*xhat) from cn_conv2d_dgrad_bnbwd: finalize + apply only. */
+int cn_bn_bwd_partials(const void* g, const void* y, const float* gamma, const float* stats, void* dy,
+                       float* dgamma, float* dbeta, float beta_acc, float gscale, float* coef_scratch /*3C*/,
+                       int M, int C, int dtype, const float* partial, int nrb, void* workspace, size_t ws_bytes,
+                       void* stream);
 
 /* ---- nn.MaxPool2d / nn.AdaptiveAvgPool2d(1) (models/resnet.py:230,241) ---------------------- */
 int cn_maxpool_fwd(const void* x, void* y, unsigned char* argmax_tap, int N, int H, int W, int C, int k,

@@ -148,6 +148,84 @@ def test_conv_epilogue_bn_statistics(mode, dtype):
         assert rel_l2(zf, zp) < (1e-5 if dtype == torch.float32 else 4e-3)
 
 
+# (N, H, W, C, K, R, stride, pad, use_bits, use_addend)
+BNBWD_EMUL = [(2, 9, 9, 16, 64, 3, 1, 1, False, False), (3, 7, 5, 72, 16, 1, 1, 0, True, True),
+              (1, 12, 12, 16, 24, 3, 2, 1, False, True), (2, 8, 8, 64, 32, 1, 2, 0, True, False)]
+BNBWD_GPU = [(8, 56, 56, 64, 64, 3, 1, 1, False, False), (16, 56, 56, 256, 64, 1, 1, 0, True, True),
+             (4, 56, 56, 128, 128, 3, 2, 1, False, False), (4, 56, 56, 256, 512, 1, 2, 0, True, True),
+             (5, 14, 14, 1024, 256, 1, 1, 0, True, True), (3, 17, 13, 72, 64, 3, 2, 1, False, True)]
+
+
+@pytest.mark.parametrize('mode', MODES)
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_dgrad_epilogue_bn_backward_reduction(mode, dtype):
+    """cn_conv2d_dgrad_bnbwd + cn_bn_bwd_partials == cn_conv2d_dgrad followed by cn_bn_bwd: the masked
+    gradient g, the per-tile partial sums, and the BatchNorm input/parameter gradients."""
+    dev = _dev(mode)
+    import convnet_amd as ca
+    ops, L = ca.ops, ca._lib.load()
+    ch = ca._lib.chunk_elems(dtype)
+    for (N, H, W, C, K, R, st, pad, use_bits, use_addend) in (BNBWD_EMUL if mode == 'emul' else BNBWD_GPU):
+        if C % ch:
+            continue
+        g_ = torch.Generator().manual_seed(C + K + H)
+        P, Q = ops.conv_out_hw(H, W, R, R, (st, st), (pad, pad))
+        dyh = _nhwc(torch.randn(N, K, P, Q, generator=g_), dtype, dev)
+        wc = (torch.randn(C, R, R, K, generator=g_) * (2.0 / (K * R * R)) ** 0.5).to(dtype).to(dev)
+        bn_y = _nhwc(torch.randn(N, C, H, W, generator=g_) * 1.5 + 0.3, dtype, dev)
+        addend = _nhwc(torch.randn(N, C, H, W, generator=g_), dtype, dev) if use_addend else None
+        M = N * H * W
+        # forward state of the BN that produced the conv input: stats = [mean | invstd | scale | shift]
+        yf = bn_y.float().reshape(M, C)
+        mean, var = yf.mean(0), yf.var(0, unbiased=False)
+        invstd = 1.0 / torch.sqrt(var + 1e-5)
+        gamma = (torch.rand(C, generator=g_) + 0.5).to(dev)
+        beta = (torch.randn(C, generator=g_) * 0.2).to(dev)
+        stats = torch.cat([mean, invstd, gamma * invstd, beta - mean * gamma * invstd]).contiguous()
+        pre = yf * stats[2 * C:3 * C] + stats[3 * C:]
+        if use_bits:   # ReLU after a residual add: positive-output bits are an input, not recomputable
+            on = torch.rand(M, C, generator=g_).to(dev) > 0.4
+            w8 = (2 ** torch.arange(ch, device=dev)).view(1, 1, ch)
+            bits = (on.view(M, C // ch, ch).long() * w8).sum(-1).to(torch.uint8).contiguous()
+        else:
+            on, bits = pre > 0, None
+        dx_plain = ops.conv2d_dgrad(dyh, wc, (N, H, W, C), K, R, R, (st, st), (pad, pad), addend=addend)
+        g, partial, rows = ops.conv2d_dgrad(dyh, wc, (N, H, W, C), K, R, R, (st, st), (pad, pad), addend=addend,
+                                            bn=(bn_y, bits, stats, True))
+        g_ref = torch.where(on.view(N, H, W, C), dx_plain, torch.zeros_like(dx_plain))
+        assert torch.equal(g.cpu(), g_ref.cpu()), (N, H, W, C, K, R, st)
+        assert rows == L.cn_conv2d_dgrad_bnbwd_rows(N, H, W, st, st) and tuple(partial.shape) == (rows, 2 * C)
+        gd = g.float().reshape(M, C).double()
+        xhat = ((yf - mean) * invstd).double()
+        s1, s2 = partial[:, :C].double().sum(0), partial[:, C:].double().sum(0)
+        assert rel_l2(s1.cpu(), gd.sum(0).cpu()) < 1e-5
+        assert rel_l2(s2.cpu(), (gd * xhat).sum(0).cpu()) < 2e-5
+
+        # BatchNorm backward from the partials == the plain three-kernel backward on (dx_plain, mask)
+        code = ca._lib.dtype_code(dtype)
+        ws = ops.workspace(L.cn_bn_workspace(M, C, code), dev)
+        outs = []
+        for fused in (True, False):
+            dy = torch.empty_like(bn_y)
+            dgam, dbet = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+            coef = torch.empty(3 * C, device=dev)
+            if fused:
+                ca._lib.check(L.cn_bn_bwd_partials(ca._lib.ptr(g), ca._lib.ptr(bn_y), ca._lib.ptr(gamma),
+                                                   ca._lib.ptr(stats), ca._lib.ptr(dy), ca._lib.ptr(dgam),
+                                                   ca._lib.ptr(dbet), 0.0, 1.0, ca._lib.ptr(coef), M, C, code,
+                                                   ca._lib.ptr(partial), rows, ca._lib.ptr(ws), ws.numel() * 4,
+                                                   ca._lib.stream_of(g)), 'cn_bn_bwd_partials')
+            else:
+                ca._lib.check(L.cn_bn_bwd(ca._lib.ptr(dx_plain), ca._lib.ptr(bn_y), ca._lib.ptr(bits),
+                                          ca._lib.ptr(gamma), ca._lib.ptr(stats), ca._lib.ptr(dy), None,
+                                          ca._lib.ptr(dgam), ca._lib.ptr(dbet), 0.0, 1.0, ca._lib.ptr(coef), M, C, 1,
+                                          code, ca._lib.ptr(ws), ws.numel() * 4, ca._lib.stream_of(g)), 'cn_bn_bwd')
+            outs.append((dy.float().cpu(), dgam.cpu(), dbet.cpu()))
+        (dyf, gf, bf), (dyp, gp, bp) = outs
+        assert rel_l2(gf, gp) < 1e-4 and rel_l2(bf, bp) < 1e-4
+        assert rel_l2(dyf, dyp) < (1e-5 if dtype == torch.float32 else 4e-3)
+
+
 @pytest.mark.parametrize('mode', MODES)
 def test_wgrad_accumulates_and_scales(mode):
     dev = _dev(mode)
