@@ -89,7 +89,7 @@ __device__ __forceinline__ int ig_slot(int row, int chunk) {
 //       variant spends ~416 LDS cycles per K tile on ds_write_b128 against 512 MFMA cycles).
 //       STAGES = 4 with GLDS: a 4-deep DMA ring (3 K tiles in flight across raw barriers, counted
 //       vmcnt waits) for long reductions, one workgroup per CU.
-template <typename T, int WC, int WP, int TI, int TJ, int STAGES, bool OUTF32, bool GLDS, bool FRAGDB>
+template <typename T, int WC, int WP, int TI, int TJ, int STAGES, bool OUTF32, bool GLDS, bool FRAGDB, bool EPI>
 __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
   static_assert(!GLDS || STAGES == 2 || STAGES == 4, "LDS-DMA needs the double-buffered tile or the 4-deep ring");
   constexpr int BN = WC * TI * 32;  // output channels per block
@@ -366,8 +366,51 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][b][r] = acc[a][b][r] > 0.f ? acc[a][b][r] : 0.f;
   }
-  const int OEB = OUTF32 ? 4 : EB;
+  constexpr int OEBc = OUTF32 ? 4 : EB;
+  const int OEB = OEBc;
   const int pitch = BN * OEB + 16;
+  typedef typename std::conditional<OUTF32, float, T>::type TO;   // element type of the stored output
+  constexpr int EPC = 16 / OEBc;       // elements per 16-byte chunk of the output
+  constexpr int CPR = BN / EPC;        // chunks per tile row
+  constexpr int NPASS = BM * CPR / NT; // store passes: pass k handles tile row tid / CPR + k * (NT / CPR)
+  constexpr int PB = !EPI ? 1 : (NPASS < 8 ? NPASS : 8);
+  static_assert(NT % CPR == 0 && NPASS % PB == 0, "a thread keeps one chunk column for the whole store loop");
+  const int epc = EPC, cpr = CPR;
+  const int ecol = tid % CPR, erow0 = tid / CPR;
+  const int c_first = n0 + ecol * EPC;
+  const bool vec_ok = ((p.Co * OEB) & 15) == 0 && c_first + EPC <= p.Co;
+  const bool bnb = EPI && p.bn_y != nullptr;
+  // EPI instantiations only (dgrad with a residual-branch addend and / or the fused BN-backward
+  // reduction; the plain kernel keeps its register budget).  Global-side epilogue operands (residual-branch gradient, BN input, ReLU bits) are fetched a batch of
+  // passes at a time, the first batch *before* the accumulators are staged through LDS, so their
+  // latency is overlapped instead of being exposed once per store pass.
+  const bool pre = EPI && vec_ok && (p.addend != nullptr || bnb);
+  u32x4 adv[PB], yvv[PB];
+  unsigned int bitv[PB];
+  auto preload = [&](int k0) {
+#pragma unroll
+    for (int kk = 0; kk < PB; ++kk) {
+      const int pix = s_outpix[erow0 + (k0 + kk) * (NT / CPR)];
+      const size_t goff = ((size_t)(pix < 0 ? 0 : pix) * (size_t)p.Co + (size_t)c_first) * OEBc;
+      const u32x4 zero = {0u, 0u, 0u, 0u};
+      adv[kk] = (pix >= 0 && p.addend != nullptr) ? cn_ld16(p.addend + goff) : zero;
+      yvv[kk] = (pix >= 0 && bnb) ? cn_ld16(p.bn_y + goff) : zero;
+      bitv[kk] = (pix >= 0 && bnb && p.bn_mask != nullptr) ? (unsigned int)p.bn_mask[goff >> 4] : 0u;
+    }
+  };
+  float bs1[EPC], bs2[EPC], bmu[EPC], bis[EPC], bsc[EPC], bsh[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) { bs1[e] = 0.f; bs2[e] = 0.f; bmu[e] = 0.f; bis[e] = 0.f; bsc[e] = 0.f; bsh[e] = 0.f; }
+  if (bnb && vec_ok) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      bmu[e] = p.bn_coef[c_first + e];
+      bis[e] = p.bn_coef[p.Co + c_first + e];
+      bsc[e] = p.bn_coef[2 * p.Co + c_first + e];
+      bsh[e] = p.bn_coef[3 * p.Co + c_first + e];
+    }
+  }
+  if (pre) preload(0);
 #pragma unroll
   for (int a = 0; a < TI; ++a)
 #pragma unroll
@@ -393,7 +436,6 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
   __syncthreads();
   // ---- optional BatchNorm statistics of this tile (what bn_stats_kernel would re-read from HBM):
   // per-channel sum and sum of squares of the *stored* (rounded) outputs, one partial row per pixel tile
-  constexpr int OEBc = OUTF32 ? 4 : EB;
   constexpr int NCOL = BN * OEBc / 4;   // dword columns of the out tile (2 channels each for bf16)
   constexpr int NG = NT / NCOL;         // row groups
   constexpr int RPG = BM / NG;
@@ -425,85 +467,68 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
       for (int r = 0; r < RPG && r < cnt; ++r) acc_row(r);
     }
   }
-  const int epc = 16 / OEB;            // elements per 16-byte chunk of the output
-  const int cpr = BN / epc;            // chunks per tile row
-  typedef typename std::conditional<OUTF32, float, T>::type TO;   // element type of the stored output
-  constexpr int EPC = 16 / OEBc;
-  constexpr int CPR = BN / EPC;
-  static_assert(NT % CPR == 0, "a thread keeps one chunk column for the whole store loop");
-  const bool bnb = p.bn_y != nullptr;
-  float bs1[EPC], bs2[EPC], bmu[EPC], bis[EPC], bsc[EPC], bsh[EPC];
+  if (c_first < p.Co) {
+    for (int k0 = 0; k0 < NPASS; k0 += PB) {
+      if (pre && k0 > 0) preload(k0);
 #pragma unroll
-  for (int e = 0; e < EPC; ++e) { bs1[e] = 0.f; bs2[e] = 0.f; bmu[e] = 0.f; bis[e] = 0.f; bsc[e] = 0.f; bsh[e] = 0.f; }
-  if (bnb) {
-    const int c0 = n0 + (tid % CPR) * EPC;
+      for (int kk = 0; kk < PB; ++kk) {
+        const int row = erow0 + (k0 + kk) * (NT / CPR);
+        const int pix = s_outpix[row];
+        if (pix < 0) continue;
+        const char* src = lds + row * pitch + ecol * 16;
+        const size_t goff = ((size_t)pix * (size_t)p.Co + (size_t)c_first) * OEB;
+        char* dst = p.y + goff;
+        if (vec_ok) {
+          u32x4 v = cn_ld16(src);
+          if (pre) {
+            float fv[EPC];
+            Chunk<TO>::unpack(v, fv);
+            if (p.addend != nullptr) {   // e.g. the residual-branch gradient folded into dgrad
+              float fa[EPC];
+              Chunk<TO>::unpack(adv[kk], fa);
 #pragma unroll
-    for (int e = 0; e < EPC; ++e)
-      if (c0 + e < p.Co) {
-        bmu[e] = p.bn_coef[c0 + e];
-        bis[e] = p.bn_coef[p.Co + c0 + e];
-        bsc[e] = p.bn_coef[2 * p.Co + c0 + e];
-        bsh[e] = p.bn_coef[3 * p.Co + c0 + e];
-      }
-  }
-  const bool vec_ok = ((p.Co * OEB) & 15) == 0;
-  for (int id = tid; id < BM * cpr; id += NT) {
-    const int row = id / cpr, col = id - row * cpr;
-    const int pix = s_outpix[row];
-    if (pix < 0) continue;
-    const int c_first = n0 + col * epc;
-    if (c_first >= p.Co) continue;
-    const char* src = lds + row * pitch + col * 16;
-    char* dst = p.y + ((size_t)pix * (size_t)p.Co + (size_t)c_first) * OEB;
-    const size_t goff = ((size_t)pix * (size_t)p.Co + (size_t)c_first) * OEB;
-    if (vec_ok && c_first + epc <= p.Co) {
-      u32x4 v = cn_ld16(src);
-      if (p.addend != nullptr || bnb) {
-        float fv[EPC];
-        Chunk<TO>::unpack(v, fv);
-        if (p.addend != nullptr) {   // e.g. the residual-branch gradient folded into dgrad
-          float fa[EPC];
-          Chunk<TO>::unpack(cn_ld16(p.addend + goff), fa);
+              for (int e = 0; e < EPC; ++e) fv[e] += fa[e];
+            }
+            if (bnb) {
+              float yv[EPC];
+              Chunk<TO>::unpack(yvv[kk], yv);
+              if (p.bn_mask != nullptr) {
+                const unsigned int bits = bitv[kk];
 #pragma unroll
-          for (int e = 0; e < EPC; ++e) fv[e] += fa[e];
-        }
-        if (bnb) {
-          float yv[EPC];
-          Chunk<TO>::unpack(cn_ld16(p.bn_y + goff), yv);
-          if (p.bn_mask != nullptr) {
-            const unsigned int bits = p.bn_mask[goff >> 4];
+                for (int e = 0; e < EPC; ++e) fv[e] = ((bits >> e) & 1u) ? fv[e] : 0.f;
+              } else if (p.bn_relu) {
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) fv[e] = ((bits >> e) & 1u) ? fv[e] : 0.f;
-          } else if (p.bn_relu) {
+                for (int e = 0; e < EPC; ++e) fv[e] = fmaf(yv[e], bsc[e], bsh[e]) > 0.f ? fv[e] : 0.f;
+              }
+              v = Chunk<TO>::pack(fv);
+              Chunk<TO>::unpack(v, fv);   // statistics of the values as stored (rounded)
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) fv[e] = fmaf(yv[e], bsc[e], bsh[e]) > 0.f ? fv[e] : 0.f;
+              for (int e = 0; e < EPC; ++e) {
+                bs1[e] += fv[e];
+                bs2[e] = fmaf(fv[e], (yv[e] - bmu[e]) * bis[e], bs2[e]);
+              }
+            } else {
+              v = Chunk<TO>::pack(fv);
+            }
           }
-          v = Chunk<TO>::pack(fv);
-          Chunk<TO>::unpack(v, fv);   // statistics of the values as stored (rounded)
-#pragma unroll
-          for (int e = 0; e < EPC; ++e) {
-            bs1[e] += fv[e];
-            bs2[e] = fmaf(fv[e], (yv[e] - bmu[e]) * bis[e], bs2[e]);
+          cn_st16(dst, v);
+        } else {   // ragged channel count: element-wise tail (never combined with the BN reduction)
+          for (int e = 0; e < epc && c_first + e < p.Co; ++e) {
+            if (OEB == 4) {
+              float f = ((const float*)src)[e];
+              if (p.addend != nullptr) f += ((const float*)(p.addend + goff))[e];
+              ((float*)dst)[e] = f;
+            } else {
+              float f = cn_bf16_to_f32(((const unsigned short*)src)[e]);
+              if (p.addend != nullptr) f += cn_bf16_to_f32(((const unsigned short*)(p.addend + goff))[e]);
+              ((unsigned short*)dst)[e] = cn_f32_to_bf16(f);
+            }
           }
-        } else {
-          v = Chunk<TO>::pack(fv);
-        }
-      }
-      cn_st16(dst, v);
-    } else {
-      for (int e = 0; e < epc && c_first + e < p.Co; ++e) {
-        if (OEB == 4) {
-          float f = ((const float*)src)[e];
-          if (p.addend != nullptr) f += ((const float*)(p.addend + goff))[e];
-          ((float*)dst)[e] = f;
-        } else {
-          float f = cn_bf16_to_f32(((const unsigned short*)src)[e]);
-          if (p.addend != nullptr) f += cn_bf16_to_f32(((const unsigned short*)(p.addend + goff))[e]);
-          ((unsigned short*)dst)[e] = cn_f32_to_bf16(f);
         }
       }
     }
   }
+  (void)cpr;
   if (bnb) {
     __syncthreads();   // the out tile has been consumed: its first 16 KiB take the per-thread partials
     float* red = (float*)lds;
@@ -561,7 +586,7 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
   // buffer, 4 = LDS-DMA 4-deep ring (4 waves), 5 = LDS-DMA 4-deep ring with 8 waves; 0 / unset = heuristic (tuning knob "igemm_variant", profiles/r01_conv_layers*)
   int variant = cn_get_option("igemm_variant", 0);
   if (variant < 1 || variant > 6) variant = cn_get_option("igemm_default_variant", nkt < 24 ? 1 : 3);
-  if ((p.stats != nullptr || p.bn_y != nullptr) && variant == 6) variant = 3;   // statistics rows are defined per 128-pixel tile
+  if ((p.stats != nullptr || p.bn_y != nullptr || p.addend != nullptr) && variant == 6) variant = 3;   // 128-pixel tiles   // statistics rows are defined per 128-pixel tile
   const int BM = (variant == 6 && p.Co > 64) ? 256 : 128, BN = p.Co <= 64 ? 64 : 128;
   p.n_ntiles = (p.Co + BN - 1) / BN;
   const int n_mtiles = (p.M + BM - 1) / BM;
@@ -573,20 +598,22 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
     p.mt_fastest = order > 0 ? 1 : 0;
   }
   dim3 grid((unsigned)(p.n_ntiles * n_mtiles));
-  const bool fragdb = cn_get_option("igemm_fragdb", 0) != 0;
-#define IG_GO2(WC, WP, TI, TJ, DB)                                                                              \
+  // EPI: epilogue with global-side operands (residual-branch addend, fused BN-backward reduction)
+  const bool epi = p.addend != nullptr || p.bn_y != nullptr;
+#define IG_GO2(WC, WP, TI, TJ, EP)                                                                              \
   do {                                                                                                         \
-    if (variant == 1) CN_LAUNCH((igemm_kernel<T, WC, WP, TI, TJ, 1, OUTF32, false, DB>), grid, dim3(256), stream, p); \
-    else if (variant == 2) CN_LAUNCH((igemm_kernel<T, WC, WP, TI, TJ, 2, OUTF32, false, DB>), grid, dim3(256), stream, p); \
-    else CN_LAUNCH((igemm_kernel<T, WC, WP, TI, TJ, 2, OUTF32, true, DB>), grid, dim3(256), stream, p);        \
+    if (variant == 1) CN_LAUNCH((igemm_kernel<T, WC, WP, TI, TJ, 1, OUTF32, false, false, EP>), grid, dim3(256), stream, p); \
+    else if (variant == 2) CN_LAUNCH((igemm_kernel<T, WC, WP, TI, TJ, 2, OUTF32, false, false, EP>), grid, dim3(256), stream, p); \
+    else CN_LAUNCH((igemm_kernel<T, WC, WP, TI, TJ, 2, OUTF32, true, false, EP>), grid, dim3(256), stream, p);        \
   } while (0)
-#define IG_GO(WC, WP, TI, TJ) do { if (fragdb) IG_GO2(WC, WP, TI, TJ, true); else IG_GO2(WC, WP, TI, TJ, false); } while (0)
-  if (variant >= 4 && p.Co > 64) {
+#define IG_GO(WC, WP, TI, TJ) do { if (epi) IG_GO2(WC, WP, TI, TJ, true); else IG_GO2(WC, WP, TI, TJ, false); } while (0)
+  if (variant >= 4 && p.Co > 64 && !epi) {
     // 4 / 5: experimental 4-deep DMA rings (4 or 8 waves), measured slower than variant 3, kept for A/B;
-    // 6: 256-pixel x 128-channel tile, 8 waves, LDS-DMA double buffer (fewer operand bytes per flop)
-    if (variant == 4) CN_LAUNCH((igemm_kernel<T, 2, 2, 2, 2, 4, OUTF32, true, false>), grid, dim3(256), stream, p);
-    else if (variant == 5) CN_LAUNCH((igemm_kernel<T, 2, 4, 2, 1, 4, OUTF32, true, false>), grid, dim3(512), stream, p);
-    else CN_LAUNCH((igemm_kernel<T, 2, 4, 2, 2, 2, OUTF32, true, true>), grid, dim3(512), stream, p);
+    // 6: 256-pixel x 128-channel tile, 8 waves, LDS-DMA double buffer with register-double-buffered
+    //    fragments (fewer operand bytes per flop; not faster either, profiles/README.md)
+    if (variant == 4) CN_LAUNCH((igemm_kernel<T, 2, 2, 2, 2, 4, OUTF32, true, false, false>), grid, dim3(256), stream, p);
+    else if (variant == 5) CN_LAUNCH((igemm_kernel<T, 2, 4, 2, 1, 4, OUTF32, true, false, false>), grid, dim3(512), stream, p);
+    else CN_LAUNCH((igemm_kernel<T, 2, 4, 2, 2, 2, OUTF32, true, true, false>), grid, dim3(512), stream, p);
     return cn_check_launch("igemm");
   }
   if (variant >= 4) variant = 3;

@@ -47,7 +47,6 @@ def main():
     L = ca._lib.load()
     variants = [int(v) for v in args.variants.split(',')]
     L.cn_set_option(b'igemm_order', args.order)
-    L.cn_set_option(b'igemm_fragdb', args.fragdb)
     tot = {('fwd', v): 0.0 for v in variants}
     tot.update({('dgrad', v): 0.0 for v in variants})
     tot['wgrad'] = 0.0
