@@ -59,6 +59,7 @@ _SIGNATURES = {
     'cn_grad_norm_clip': (c_i, [c_p, c_ll, c_f, c_f, c_p, c_p, c_f, c_p, c_p]),
     'cn_weight_prep': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     'cn_weight_prep_multi': (c_i, [c_p, c_p, c_p, c_i, c_ll, c_i, c_p]),
+    'cn_weight_prep_tiled': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
     'cn_colsum_workspace': (c_sz, [c_i]),
     'cn_colsum': (c_i, [c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_p, c_p]),
     'cn_small_linear': (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),

@@ -111,6 +111,48 @@ __global__ __launch_bounds__(256) void weight_prep_multi_kernel(const float* mas
   }
 }
 
+// Tiled variant for the regular filters (Cpad == Creal): one workgroup per 64 (co) x 64 (j = tap*C + c)
+// tile of the fp32 master, staged through LDS so that both the KRSC copy (same order) and the CRSK
+// copy (transposed: rows (c*taps + t), co contiguous) are written with coalesced stores.  The
+// per-element kernel above spends a descriptor binary search and a scattered 2-byte store per
+// weight (0.33 ms per ResNet-50 step, profiles/r01_*kernel_stats*); this one streams.
+//   tiles: int[ntiles][4] = {descriptor index, co0, j0, 0}
+template <typename T>
+__global__ __launch_bounds__(256) void weight_prep_tiled_kernel(const float* master, T* wbuf, const long long* desc,
+                                                               const int* tiles) {
+  __shared__ float tile[64][65];
+  const int* tl = tiles + (size_t)blockIdx.x * 4;
+  const long long* d = desc + (size_t)tl[0] * 8;
+  const int co0 = tl[1], j0 = tl[2];
+  const int Co = (int)d[4], taps = (int)d[5], C = (int)d[6];
+  const int J = taps * C;
+  const float* src = master + d[0];
+  const int lane64 = threadIdx.x & 63, grp = threadIdx.x >> 6;
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int r = grp + 4 * i, co = co0 + r, j = j0 + lane64;
+    tile[r][lane64] = (co < Co && j < J) ? src[(size_t)co * J + j] : 0.f;
+  }
+  __syncthreads();
+  T* krsc = wbuf + d[2];
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int r = grp + 4 * i, co = co0 + r, j = j0 + lane64;
+    if (co < Co && j < J) cn_store_elem<T>(krsc + (size_t)co * J + j, tile[r][lane64]);
+  }
+  if (d[3] >= 0) {
+    T* crsk = wbuf + d[3];
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+      const int jj = grp + 4 * i, j = j0 + jj, co = co0 + lane64;
+      if (j < J && co < Co) {
+        const int t = j / C, c = j - t * C;
+        cn_store_elem<T>(crsk + ((size_t)c * taps + t) * Co + co, tile[lane64][jj]);
+      }
+    }
+  }
+}
+
 // out[c] (+)= sum_m x[m][c], x fp32 or bf16 row-major [M][C]; one thread per column, rows strided
 // over gridDim.y with a fixed-order second stage.
 template <typename T>
@@ -244,6 +286,20 @@ extern "C" int cn_weight_prep_multi(const float* master, void* wbuf, const long 
     CN_LAUNCH(weight_prep_multi_kernel<float>, grid, dim3(256), stream, master, (float*)wbuf, desc, nd, total);
   else { cn_set_error("weight_prep_multi: bad dtype"); return CN_EINVAL; }
   return cn_check_launch("weight_prep_multi");
+}
+
+extern "C" int cn_weight_prep_tiled(const float* master, void* wbuf, const long long* desc, const int* tiles,
+                                    int ntiles, int dtype, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (ntiles <= 0) return CN_OK;
+  if (dtype == CN_BF16)
+    CN_LAUNCH(weight_prep_tiled_kernel<bf16_t>, dim3((unsigned)ntiles), dim3(256), stream, master, (bf16_t*)wbuf,
+              desc, tiles);
+  else if (dtype == CN_F32)
+    CN_LAUNCH(weight_prep_tiled_kernel<float>, dim3((unsigned)ntiles), dim3(256), stream, master, (float*)wbuf, desc,
+              tiles);
+  else { cn_set_error("weight_prep_tiled: bad dtype"); return CN_EINVAL; }
+  return cn_check_launch("weight_prep_tiled");
 }
 
 #define CN_COLSUM_PARTS 64

@@ -97,6 +97,9 @@ class ParamArena(object):
         self.reducer = None
         self.wbuf = None          # compute-dtype filter copies of every conv / linear (one buffer)
         self._wdesc = None
+        self._wdesc_reg = None
+        self._wtiles = None
+        self._wbytes = 0
         self._wtotal = 0
         self._wversion = -1
 
@@ -129,24 +132,48 @@ class ParamArena(object):
             start += n
             mods.append((mod, krsc_off, crsk_off, n))
         self.wbuf = torch.zeros(max(off, _ALIGN), dtype=dtype, device=self.device)
-        self._wdesc = torch.tensor(rows, dtype=torch.int64, device=self.device) if rows else None
+        # regular filters (no channel padding) go through the tiled, coalescing kernel; the few padded
+        # ones (the 3 -> 8 channel stem) through the per-element kernel
+        regular = [r for r in rows if r[6] == r[7]]
+        ragged = [list(r) for r in rows if r[6] != r[7]]
+        start = 0
+        for r in ragged:
+            r[1] = start
+            start += r[4] * r[5] * r[7]
         self._wtotal = start
+        self._wdesc = torch.tensor(ragged, dtype=torch.int64, device=self.device) if ragged else None
+        self._wdesc_reg = torch.tensor(regular, dtype=torch.int64, device=self.device) if regular else None
+        tiles = []
+        for di, r in enumerate(regular):
+            co, J = r[4], r[5] * r[6]
+            for co0 in range(0, co, 64):
+                for j0 in range(0, J, 64):
+                    tiles.append((di, co0, j0, 0))
+        self._wtiles = torch.tensor(tiles, dtype=torch.int32, device=self.device) if tiles else None
+        self._wbytes = sum(r[4] * r[5] * (r[6] * 4 + r[7] * self.wbuf.element_size() * (2 if r[3] >= 0 else 1))
+                           for r in rows)
         self._wversion = -1
         for mod, krsc_off, crsk_off, n in mods:
             mod.w_krsc = self.wbuf[krsc_off:krsc_off + n]
             mod.w_crsk = self.wbuf[crsk_off:crsk_off + n] if crsk_off >= 0 else None
 
     def prepare_weights(self):
-        if self._wversion == self.version or self._wdesc is None:
+        if self._wversion == self.version or (self._wdesc is None and self._wdesc_reg is None):
             return
         from . import _lib
         L = _lib.load()
-        ops.PROFILER.run('weight_prep', 1, 0.0, 8.0 * self._wtotal,
-                         lambda: _lib.check(L.cn_weight_prep_multi(self.params.data_ptr(), self.wbuf.data_ptr(),
-                                                                   self._wdesc.data_ptr(), self._wdesc.shape[0],
-                                                                   self._wtotal, _lib.dtype_code(self.wbuf.dtype),
-                                                                   _lib.stream_of(self.params)),
-                                            'cn_weight_prep_multi'), self.device)
+        code, st = _lib.dtype_code(self.wbuf.dtype), _lib.stream_of(self.params)
+
+        def run():
+            if self._wdesc_reg is not None:
+                _lib.check(L.cn_weight_prep_tiled(self.params.data_ptr(), self.wbuf.data_ptr(),
+                                                  self._wdesc_reg.data_ptr(), self._wtiles.data_ptr(),
+                                                  self._wtiles.shape[0], code, st), 'cn_weight_prep_tiled')
+            if self._wdesc is not None:
+                _lib.check(L.cn_weight_prep_multi(self.params.data_ptr(), self.wbuf.data_ptr(),
+                                                  self._wdesc.data_ptr(), self._wdesc.shape[0], self._wtotal, code,
+                                                  st), 'cn_weight_prep_multi')
+        ops.PROFILER.run('weight_prep', 2, 0.0, float(self._wbytes), run, self.device)
         self._wversion = self.version
 
     # -- gradient lifecycle ---------------------------------------------------------------

@@ -149,6 +149,11 @@ int cn_weight_prep(const float* w_master_krsc, void* w_krsc, void* w_crsk /*opti
  * {src_off, start, krsc_off, crsk_off (<0: none), Co, taps, Creal, Cpad} */
 int cn_weight_prep_multi(const float* master_arena, void* wbuf, const long long* desc, int nd, long long total,
                          int dtype, void* stream);
+/* Same conversion for the descriptors with Cpad == Creal, one workgroup per 64x64 tile of a filter
+ * matrix (coalesced KRSC and CRSK stores).  tiles: int[ntiles][4] = {descriptor row, co0, j0, 0},
+ * j = tap*C + c. */
+int cn_weight_prep_tiled(const float* master, void* wbuf, const long long* desc, const int* tiles, int ntiles,
+                         int dtype, void* stream);
 size_t cn_colsum_workspace(int C);
 int cn_colsum(const void* x, float* out, int M, int C, int dtype, float beta, float scale, float* workspace,
               void* stream);
