@@ -110,16 +110,18 @@ def _esize(t):
     return t.element_size()
 
 
-def _igemm_name(dtype, co, taps, c_red, out_f32=False):
+def _igemm_name(dtype, co, taps, c_red, out_f32=False, epi=False):
     """Name of the igemm_kernel instantiation the C dispatcher picks (mirrors ig_launch): used only
-    to label profiler records with the names rocprofv3 reports."""
+    to label profiler records with the names rocprofv3 reports.  Template arguments:
+    <T, WC, WP, TI, TJ, STAGES, OUTF32, GLDS, FRAGDB, EPI>."""
     ch = 4 if dtype == torch.float32 else 8
     nkt = (taps * (c_red // ch) + 7) // 8
     glds = nkt >= 24
     t = 'float' if dtype == torch.float32 else 'bf16_t'
     shape = '1, 4, 2, 1' if co <= 64 else '2, 2, 2, 2'
     outf = 'true' if (out_f32 or dtype == torch.float32) else 'false'
-    return 'igemm_kernel<%s, %s, %d, %s, %s>' % (t, shape, 2 if glds else 1, outf, 'true' if glds else 'false')
+    return 'igemm_kernel<%s, %s, %d, %s, %s, false, %s>' % (t, shape, 2 if glds else 1, outf,
+                                                            'true' if glds else 'false', 'true' if epi else 'false')
 
 
 def conv_out_hw(H, W, R, S, stride, pad):
@@ -197,7 +199,8 @@ def conv2d_dgrad(dy, w_crsk, x_shape, K, R, S, stride, pad, addend=None, bn=None
     reduction half of that BatchNorm's backward: returns (g = dx*relu_mask, partial, rows)."""
     N, H, W, C = x_shape
     dx = torch.empty((N, H, W, C), dtype=dy.dtype, device=dy.device)
-    name = _igemm_name(dy.dtype, C, max(1, -(-R // stride[0]) * -(-S // stride[1])), K)
+    name = _igemm_name(dy.dtype, C, max(1, -(-R // stride[0]) * -(-S // stride[1])), K,
+                       epi=addend is not None or bn is not None)
     flops = 2.0 * dy.numel() * C * R * S
     nbytes = dy.numel() * _esize(dy) + dx.numel() * _esize(dx) * (2 if addend is not None else 1) \
         + K * R * S * C * _esize(dy)
