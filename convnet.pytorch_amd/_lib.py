@@ -46,6 +46,10 @@ _SIGNATURES = {
     'cn_bn_fwd_infer': (c_i, [c_p] * 7 + [c_f, c_p, c_i, c_i, c_i, c_i, c_p]),
     'cn_bn_bwd': (c_i, [c_p] * 9 + [c_f, c_f, c_p, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
     'cn_bn_bwd_partials': (c_i, [c_p] * 7 + [c_f, c_f, c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_sz, c_p]),
+    'cn_bn_local_sums': (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_sz, c_p]),
+    'cn_bn_fwd_train_sums': (c_i, [c_p] * 9 + [c_f, c_f, c_p, c_i, c_i, c_i, c_i, c_p, c_ll, c_p]),
+    'cn_bn_bwd_local_sums': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_sz, c_p]),
+    'cn_bn_bwd_sums': (c_i, [c_p] * 9 + [c_f, c_f, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_ll, c_p]),
     'cn_maxpool_fwd': (c_i, [c_p, c_p, c_p] + [c_i] * 8 + [c_p]),
     'cn_maxpool_bwd': (c_i, [c_p, c_p, c_p] + [c_i] * 8 + [c_p]),
     'cn_avgpool_fwd': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),

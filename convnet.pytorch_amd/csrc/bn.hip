@@ -628,3 +628,201 @@ extern "C" int cn_bn_bwd_partials(const void* g, const void* y, const float* gam
               C, 0, m.tpr_log2, rev_a);
   return cn_check_launch("bn_bwd_partials");
 }
+
+// ------------------------------------------------------------------------------------------------
+// Cross-rank (SyncBatchNorm) building blocks, /root/reference main.py:190-191
+// (nn.SyncBatchNorm.convert_sync_batchnorm).  The library holds no communicator: each rank reduces
+// its own partials to 2*C double-precision sums, the caller all-reduces that small buffer
+// (torch.distributed over RCCL) and hands the global sums + global row count back.
+
+// out[col] = sum_r partial[r][col]  (double accumulation, fixed order, 8 threads per column)
+__global__ __launch_bounds__(256) void bn_partials_total_kernel(const float* partial, int nrb, int W, double* out) {
+  __shared__ double red[256];
+  const int lc = threadIdx.x & 31, part = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + lc;
+  double s = 0.0;
+  if (col < W) {
+    int r = part;
+    for (; r + 56 < nrb; r += 64) {
+      float a[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] = partial[(size_t)(r + 8 * u) * W + col];
+      s += (((double)a[0] + (double)a[1]) + ((double)a[2] + (double)a[3])) +
+           (((double)a[4] + (double)a[5]) + ((double)a[6] + (double)a[7]));
+    }
+    for (; r < nrb; r += 8) s += (double)partial[(size_t)r * W + col];
+  }
+  red[part * 32 + lc] = s;
+  __syncthreads();
+  if (part == 0 && col < W) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k * 32 + lc];
+    out[col] = t;
+  }
+}
+
+// statistics from global sums: sums = [sum x | sum x^2] over m_total rows of all ranks
+__global__ __launch_bounds__(256) void bn_finalize_sums_kernel(const double* sums, long long m_total, int C,
+                                                              const float* gamma, const float* beta,
+                                                              float* running_mean, float* running_var,
+                                                              long long* num_batches_tracked, float momentum,
+                                                              float eps, float* save_mean, float* save_invstd,
+                                                              float* scale, float* shift) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked != nullptr) *num_batches_tracked += 1;
+  if (c >= C) return;
+  const double mean = sums[c] / (double)m_total;
+  double var = sums[C + c] / (double)m_total - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  save_mean[c] = (float)mean;
+  save_invstd[c] = invstd;
+  if (running_mean != nullptr) {
+    const double unbiased = m_total > 1 ? var * (double)m_total / (double)(m_total - 1) : var;
+    running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
+    running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+  }
+  const float g = gamma != nullptr ? gamma[c] : 1.f;
+  const float b = beta != nullptr ? beta[c] : 0.f;
+  const float sc = g * invstd;
+  scale[c] = sc;
+  shift[c] = b - (float)mean * sc;
+}
+
+// dgamma / dbeta from this rank's sums (the data-parallel gradient all-reduce averages them like every
+// other parameter gradient), input-gradient coefficients from the global sums over m_total rows
+__global__ __launch_bounds__(256) void bn_bwd_finalize_sums_kernel(const double* local, const double* global,
+                                                                  long long m_total, int C, const float* gamma,
+                                                                  const float* mean, const float* invstd,
+                                                                  float* dgamma, float* dbeta, float beta_acc,
+                                                                  float gscale, float* coef) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float g = gamma != nullptr ? gamma[c] : 1.f;
+  if (dgamma != nullptr) dgamma[c] = (beta_acc != 0.f ? beta_acc * dgamma[c] : 0.f) + (float)local[C + c] * gscale;
+  if (dbeta != nullptr) dbeta[c] = (beta_acc != 0.f ? beta_acc * dbeta[c] : 0.f) + (float)local[c] * gscale;
+  const double k = (double)g * (double)invstd[c];
+  const double a2 = k * (double)invstd[c] * global[C + c] / (double)m_total;
+  coef[c] = (float)k;
+  coef[C + c] = (float)(-a2);
+  coef[2 * C + c] = (float)(a2 * (double)mean[c] - k * global[c] / (double)m_total);
+}
+
+// This rank's [sum y | sum y^2] (2*C doubles).  partial/nrb: rows a conv epilogue already produced
+// (cn_conv2d_fwd_bnstats), or NULL/0 to run the statistics pass over y here.
+extern "C" int cn_bn_local_sums(const void* y, int M, int C, int dtype, const float* partial, int nrb, double* sums,
+                                void* workspace, size_t ws_bytes, void* stream_) {
+  int rc = bn_check("bn_local_sums", M, C, dtype);
+  if (rc) return rc;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (partial == nullptr) {
+    const int CH = dtype == CN_BF16 ? 8 : 4;
+    BnMap m = bn_map(C / CH);
+    nrb = bn_row_blocks(M, m, cn_get_option("bn_reduce_blocks", BN_TARGET_BLOCKS));
+    if (workspace == nullptr || ws_bytes < (size_t)nrb * 2 * C * sizeof(float)) {
+      cn_set_error("bn_local_sums: workspace too small");
+      return CN_EWORKSPACE;
+    }
+    dim3 grid((unsigned)nrb, (unsigned)m.gy);
+    if (dtype == CN_BF16)
+      CN_LAUNCH(bn_stats_kernel<bf16_t>, grid, dim3(256), stream, (const char*)y, (float*)workspace, M, C, m.tpr_log2);
+    else
+      CN_LAUNCH(bn_stats_kernel<float>, grid, dim3(256), stream, (const char*)y, (float*)workspace, M, C, m.tpr_log2);
+    partial = (const float*)workspace;
+  }
+  CN_LAUNCH(bn_partials_total_kernel, dim3((unsigned)((2 * C + 31) / 32)), dim3(256), stream, partial, nrb, 2 * C, sums);
+  return cn_check_launch("bn_local_sums");
+}
+
+// Training forward from (all-reduced) sums over m_total rows; M = this rank's rows.
+extern "C" int cn_bn_fwd_train_sums(const void* y, const void* residual, void* z, unsigned char* relu_mask,
+                                    const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                    long long* num_batches_tracked, float momentum, float eps, float* stats_out,
+                                    int M, int C, int relu, int dtype, const double* sums, long long m_total,
+                                    void* stream_) {
+  int rc = bn_check("bn_fwd_train_sums", M, C, dtype);
+  if (rc) return rc;
+  if (sums == nullptr || m_total < M) { cn_set_error("bn_fwd_train_sums: bad sums / m_total"); return CN_EINVAL; }
+  hipStream_t stream = (hipStream_t)stream_;
+  const int CH = dtype == CN_BF16 ? 8 : 4;
+  BnMap m = bn_map(C / CH);
+  CN_LAUNCH(bn_finalize_sums_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), stream, sums, m_total, C, gamma,
+            beta, running_mean, running_var, num_batches_tracked, momentum, eps, stats_out, stats_out + C,
+            stats_out + 2 * C, stats_out + 3 * C);
+  int nab = bn_row_blocks(M, m, cn_get_option("bn_apply_blocks", BN_APPLY_BLOCKS));
+  dim3 agrid((unsigned)nab, (unsigned)m.gy);
+  if (dtype == CN_BF16)
+    CN_LAUNCH(bn_apply_kernel<bf16_t>, agrid, dim3(256), stream, (const char*)y, (const char*)residual,
+              (char*)z, relu_mask, (const float*)(stats_out + 2 * C), (const float*)(stats_out + 3 * C), M, C,
+              relu, m.tpr_log2, 0);
+  else
+    CN_LAUNCH(bn_apply_kernel<float>, agrid, dim3(256), stream, (const char*)y, (const char*)residual, (char*)z,
+              relu_mask, (const float*)(stats_out + 2 * C), (const float*)(stats_out + 3 * C), M, C, relu,
+              m.tpr_log2, 0);
+  return cn_check_launch("bn_fwd_train_sums");
+}
+
+// This rank's [sum g | sum g*xhat] (2*C doubles), g = dz * relu_mask.  partial/nrb: rows a dgrad
+// epilogue already produced (then dz is g), or NULL/0 to run the reduction pass here.
+extern "C" int cn_bn_bwd_local_sums(const void* dz, const void* y, const unsigned char* relu_mask,
+                                    const float* stats, int M, int C, int relu, int dtype, const float* partial,
+                                    int nrb, double* sums, void* workspace, size_t ws_bytes, void* stream_) {
+  int rc = bn_check("bn_bwd_local_sums", M, C, dtype);
+  if (rc) return rc;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (partial == nullptr) {
+    const int CH = dtype == CN_BF16 ? 8 : 4;
+    BnMap m = bn_map(C / CH);
+    nrb = bn_row_blocks(M, m, cn_get_option("bn_reduce_blocks", BN_TARGET_BLOCKS));
+    if (workspace == nullptr || ws_bytes < (size_t)nrb * 2 * C * sizeof(float)) {
+      cn_set_error("bn_bwd_local_sums: workspace too small");
+      return CN_EWORKSPACE;
+    }
+    dim3 grid((unsigned)nrb, (unsigned)m.gy);
+    if (dtype == CN_BF16)
+      CN_LAUNCH(bn_bwd_reduce_kernel<bf16_t>, grid, dim3(256), stream, (const char*)dz, (const char*)y, relu_mask,
+                stats, stats + C, stats + 2 * C, stats + 3 * C, (float*)workspace, M, C, relu, m.tpr_log2, 0);
+    else
+      CN_LAUNCH(bn_bwd_reduce_kernel<float>, grid, dim3(256), stream, (const char*)dz, (const char*)y, relu_mask,
+                stats, stats + C, stats + 2 * C, stats + 3 * C, (float*)workspace, M, C, relu, m.tpr_log2, 0);
+    partial = (const float*)workspace;
+  }
+  CN_LAUNCH(bn_partials_total_kernel, dim3((unsigned)((2 * C + 31) / 32)), dim3(256), stream, partial, nrb, 2 * C, sums);
+  return cn_check_launch("bn_bwd_local_sums");
+}
+
+// Training backward from sums: dgamma/dbeta from `local_sums`, dy from `global_sums` / m_total.
+// pre_masked != 0: dz is already g (masked by the dgrad epilogue).
+extern "C" int cn_bn_bwd_sums(const void* dz, const void* y, const unsigned char* relu_mask, const float* gamma,
+                              const float* stats, void* dy, void* dres, float* dgamma, float* dbeta, float beta_acc,
+                              float gscale, float* coef_scratch, int M, int C, int relu, int pre_masked, int dtype,
+                              const double* local_sums, const double* global_sums, long long m_total,
+                              void* stream_) {
+  int rc = bn_check("bn_bwd_sums", M, C, dtype);
+  if (rc) return rc;
+  if (local_sums == nullptr || global_sums == nullptr || m_total < M) {
+    cn_set_error("bn_bwd_sums: bad sums / m_total");
+    return CN_EINVAL;
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  const int CH = dtype == CN_BF16 ? 8 : 4;
+  BnMap m = bn_map(C / CH);
+  const float* mean = stats;
+  const float* invstd = stats + C;
+  const float* scale = stats + 2 * C;
+  const float* shift = stats + 3 * C;
+  CN_LAUNCH(bn_bwd_finalize_sums_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), stream, local_sums,
+            global_sums, m_total, C, gamma, mean, invstd, dgamma, dbeta, beta_acc, gscale, coef_scratch);
+  int nab = bn_row_blocks(M, m, cn_get_option("bn_apply_blocks", BN_APPLY_BLOCKS));
+  dim3 agrid((unsigned)nab, (unsigned)m.gy);
+  const int arelu = pre_masked ? 0 : relu;
+  const unsigned char* amask = pre_masked ? nullptr : relu_mask;
+  if (dtype == CN_BF16)
+    CN_LAUNCH(bn_bwd_apply_kernel<bf16_t>, agrid, dim3(256), stream, (const char*)dz, (const char*)y, amask, scale,
+              shift, (const float*)coef_scratch, (char*)dy, (char*)dres, M, C, arelu, m.tpr_log2, 0);
+  else
+    CN_LAUNCH(bn_bwd_apply_kernel<float>, agrid, dim3(256), stream, (const char*)dz, (const char*)y, amask, scale,
+              shift, (const float*)coef_scratch, (char*)dy, (char*)dres, M, C, arelu, m.tpr_log2, 0);
+  return cn_check_launch("bn_bwd_sums");
+}

@@ -205,8 +205,9 @@ def main_worker(args):
     if args.model_config != '':
         model_config = dict(model_config, **literal_eval(args.model_config))
     model = models.__dict__[args.model](**model_config)
-    if args.sync_bn:
-        raise NotImplementedError('--sync-bn is listed under "next" in DESIGN.md')
+    if args.sync_bn:   # main.py:190-191
+        from . import nn as cnn
+        model = cnn.convert_sync_batchnorm(model)
     logging.info('created model with configuration: %s', model_config)
     logging.info('number of parameters: %d', sum(p.nelement() for p in model.parameters()))
 

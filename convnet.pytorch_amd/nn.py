@@ -169,6 +169,7 @@ class BatchNorm2d(_ArenaModule):
         self.register_buffer('running_var', torch.ones(num_features))
         self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
         self._host_batches = 0  # host mirror of num_batches_tracked (momentum=None averaging)
+        self.sync_group = None  # set by convert_sync_batchnorm: batch statistics over all ranks
 
     def reset_running_stats(self):
         self.running_mean.zero_()
@@ -244,6 +245,16 @@ class Dropout(tnn.Module):
         keep = torch.empty(N, C, H, W).bernoulli_(1 - self.p).div_(1 - self.p)
         mask = ops.nchw_to_nhwc(keep.to(x.device), x.dtype, C)
         return ops.DropoutFunction.apply(x, mask)
+
+
+def convert_sync_batchnorm(model, process_group=None):
+    """nn.SyncBatchNorm.convert_sync_batchnorm(model) of the reference's --sync-bn (main.py:190-191):
+    every BatchNorm2d of `model` takes its training-mode batch statistics (and the matching backward
+    sums) over the batches of all ranks of `process_group` (default group when None)."""
+    for m in model.modules():
+        if isinstance(m, BatchNorm2d):
+            m.sync_group = process_group if process_group is not None else True
+    return model
 
 
 def fork(x, holder=None):

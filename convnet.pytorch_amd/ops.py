@@ -11,6 +11,7 @@ import os
 import weakref
 
 import torch
+import torch.distributed as dist
 from torch.autograd import Function
 
 from . import _lib
@@ -392,6 +393,17 @@ class Conv2dFunction(Function):
         return dx, None, None, None
 
 
+def _sync_group(mod):
+    """(process group, world size) when this BatchNorm synchronises its batch statistics across ranks
+    (nn.convert_sync_batchnorm + an initialised process group of more than one rank), else None."""
+    sg = getattr(mod, 'sync_group', None)
+    if sg is None or not dist.is_available() or not dist.is_initialized():
+        return None
+    group = None if sg is True else sg
+    world = dist.get_world_size(group)
+    return (group, world) if world > 1 else None
+
+
 class BatchNormActFunction(Function):
     """z = act(BN(y) + residual), training mode (batch statistics)."""
 
@@ -412,7 +424,25 @@ class BatchNormActFunction(Function):
         nb = y.numel() * _esize(y)
         ps = take_pending_stats(y)
         COUNTERS['bn_fwd_fused' if ps is not None else 'bn_fwd_plain'] += 1
-        if ps is not None:   # statistics came out of the producing convolution's epilogue: no pass over y
+        sync = _sync_group(mod)
+        ctx.sync = sync
+        if sync is not None:
+            # nn.SyncBatchNorm semantics (main.py:190-191): statistics over the batch of every rank.  Each
+            # rank reduces its rows to 2*C doubles, one small all-reduce, then normalise with global stats.
+            # Equal per-rank batch sizes (DistributedSampler pads to that) give the global row count.
+            group, world = sync
+            sums = torch.empty(2 * C, dtype=torch.float64, device=y.device)
+            check(L.cn_bn_local_sums(ptr(y), M, C, code, ptr(ps.partial) if ps is not None else None,
+                                     ps.rows if ps is not None else 0, ptr(sums), ptr(ws), ws.numel() * 4,
+                                     stream_of(y)), 'cn_bn_local_sums')
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+            check(L.cn_bn_fwd_train_sums(ptr(y), ptr(residual), ptr(z), ptr(mask), ptr(gamma), ptr(beta),
+                                         ptr(mod.running_mean) if track else None,
+                                         ptr(mod.running_var) if track else None,
+                                         ptr(mod.num_batches_tracked) if track else None, momentum, mod.eps,
+                                         ptr(stats), M, C, int(relu), code, ptr(sums), M * world, stream_of(y)),
+                  'cn_bn_fwd_train_sums')
+        elif ps is not None:   # statistics came out of the producing convolution's epilogue: no pass over y
             PROFILER.run('bn_finalize+bn_apply (stats from conv epilogue)', 2 if ps.rows <= 512 else 3, 0.0,
                          nb * (3 if residual is not None else 2) + (mask.numel() if mask is not None else 0)
                          + ps.partial.numel() * 4,
@@ -461,7 +491,26 @@ class BatchNormActFunction(Function):
         nb = y.numel() * _esize(y)
         pp = getattr(mod, '_bwd_partials', None)
         mod._bwd_partials = None
-        if pp is not None and pp[0] == dz.data_ptr() and pp[1] == tuple(dz.shape) and dz.dtype == y.dtype:
+        fused_in = pp is not None and pp[0] == dz.data_ptr() and pp[1] == tuple(dz.shape) and dz.dtype == y.dtype
+        if ctx.sync is not None:
+            group, world = ctx.sync
+            COUNTERS['bn_bwd_fused' if fused_in else 'bn_bwd_plain'] += 1
+            local = torch.empty(2 * C, dtype=torch.float64, device=y.device)
+            check(L.cn_bn_bwd_local_sums(ptr(dz), ptr(y), ptr(zmask), ptr(stats), M, C, int(ctx.relu), code,
+                                         ptr(pp[2]) if fused_in else None, pp[3] if fused_in else 0, ptr(local),
+                                         ptr(ws), ws.numel() * 4, stream_of(y)), 'cn_bn_bwd_local_sums')
+            glob = local.clone()
+            dist.all_reduce(glob, op=dist.ReduceOp.SUM, group=group)
+            if fused_in:
+                dres = dz if want_res else None
+            else:
+                dres = torch.empty_like(y) if want_res else None
+            check(L.cn_bn_bwd_sums(ptr(dz), ptr(y), ptr(zmask), ptr(mod.weight), ptr(stats), ptr(dy),
+                                   None if fused_in else ptr(dres), ptr(mod.grad_view('weight')),
+                                   ptr(mod.grad_view('bias')), 1.0, 1.0, ptr(coef), M, C, int(ctx.relu),
+                                   int(fused_in), code, ptr(local), ptr(glob), M * world, stream_of(y)),
+                  'cn_bn_bwd_sums')
+        elif fused_in:
             # dz arrived masked (g) with its reduction partials from the producing dgrad's epilogue
             _, _, partial, rows = pp
             COUNTERS['bn_bwd_fused'] += 1

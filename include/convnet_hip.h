@@ -111,6 +111,24 @@ int cn_bn_bwd_partials(const void* g, const void* y, const float* gamma, const f
                        int M, int C, int dtype, const float* partial, int nrb, void* workspace, size_t ws_bytes,
                        void* stream);
 
+/* ---- nn.SyncBatchNorm (main.py:190-191, --sync-bn) ----------------------------------------------
+ * The library holds no communicator.  Each rank reduces its own statistics to 2*C doubles, the caller
+ * all-reduces that buffer (torch.distributed over RCCL) and passes the global sums and the global row
+ * count back; dgamma/dbeta stay per-rank sums (averaged by the data-parallel gradient all-reduce). */
+int cn_bn_local_sums(const void* y, int M, int C, int dtype, const float* partial /*optional conv-epilogue rows*/,
+                     int nrb, double* sums /*[sum y | sum y^2]*/, void* workspace, size_t ws_bytes, void* stream);
+int cn_bn_fwd_train_sums(const void* y, const void* residual, void* z, unsigned char* relu_mask, const float* gamma,
+                         const float* beta, float* running_mean, float* running_var,
+                         long long* num_batches_tracked, float momentum, float eps, float* stats_out, int M, int C,
+                         int relu, int dtype, const double* sums, long long m_total, void* stream);
+int cn_bn_bwd_local_sums(const void* dz, const void* y, const unsigned char* relu_mask, const float* stats, int M,
+                         int C, int relu, int dtype, const float* partial /*optional dgrad-epilogue rows*/, int nrb,
+                         double* sums /*[sum g | sum g*xhat]*/, void* workspace, size_t ws_bytes, void* stream);
+int cn_bn_bwd_sums(const void* dz, const void* y, const unsigned char* relu_mask, const float* gamma,
+                   const float* stats, void* dy, void* dres, float* dgamma, float* dbeta, float beta_acc,
+                   float gscale, float* coef_scratch /*3C*/, int M, int C, int relu, int pre_masked, int dtype,
+                   const double* local_sums, const double* global_sums, long long m_total, void* stream);
+
 /* ---- nn.MaxPool2d / nn.AdaptiveAvgPool2d(1) (models/resnet.py:230,241) ---------------------- */
 int cn_maxpool_fwd(const void* x, void* y, unsigned char* argmax_tap, int N, int H, int W, int C, int k,
                    int stride, int pad, int dtype, void* stream);

@@ -119,3 +119,46 @@ def test_data_parallel_two_ranks_gloo(tmp_path):
     ref_sd = replicas[0].state_dict()
     for k in ('conv1.weight', 'layer2.0.downsample.0.weight', 'fc.weight', 'layer4.1.bn2.bias'):
         assert rel_l2(outs[0]['sd'][k], ref_sd[k]) < 1e-4, k
+
+
+def test_sync_batchnorm_two_ranks_equals_global_batch(tmp_path):
+    """--sync-bn (main.py:190-191, nn.SyncBatchNorm): 2 ranks x 4 samples with synchronised batch
+    statistics train exactly like one process on the 8-sample batch (statistics, input gradients and,
+    after the data-parallel averaging, parameter gradients).  Oracle = the plain-PyTorch model on the
+    full batch."""
+    script = tmp_path / 'sync_worker.py'
+    out_pat = str(tmp_path / 'sync_rank%d.pt')
+    worker = DP_WORKER.replace("tr = ca.Trainer(", "ca.nn.convert_sync_batchnorm(model)\ntr = ca.Trainer(", 1)
+    assert worker != DP_WORKER
+    script.write_text(worker % {'root': ROOT, 'out': out_pat})
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', WORLD_SIZE='2',
+               CONVNET_AMD_EMULATE='1', OMP_NUM_THREADS='2')
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)))
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=900) == 0
+    outs = [torch.load(out_pat % r) for r in range(2)]
+    for k in outs[0]['sd']:   # with synchronised statistics even the running stats agree across ranks
+        if 'num_batches' in k:
+            continue
+        assert torch.equal(outs[0]['sd'][k], outs[1]['sd'][k]), k
+    from oracle import convnet_oracle as O
+    torch.manual_seed(123)
+    model = O.OracleResNet(18, 16, 8, (8, 16, 32, 64))
+    opt = O.OracleSGD(model)
+    g = torch.Generator().manual_seed(77)
+    data = [(torch.randn(8, 3, 32, 32, generator=g), torch.randint(0, 16, (8,), generator=g)) for _ in range(2)]
+    for step, (x, t) in enumerate(data):
+        model.train()
+        opt.zero_grad()
+        loss = O.oracle_cross_entropy(model(x), t)
+        loss.backward()
+        gnorm = torch.norm(torch.stack([p.grad.norm(2) for p in model.parameters()]), 2).item()
+        opt.step()
+        rank_mean = 0.5 * (outs[0]['recs'][step]['loss'] + outs[1]['recs'][step]['loss'])
+        assert rank_mean == pytest.approx(float(loss), abs=1e-4)
+        assert outs[0]['recs'][step]['grad'] == pytest.approx(gnorm, rel=1e-3)
+    ref_sd = model.state_dict()
+    for k in ('conv1.weight', 'layer2.0.downsample.0.weight', 'fc.weight', 'layer4.1.bn2.bias',
+              'bn1.running_mean', 'layer3.0.bn1.running_var', 'layer1.1.bn2.weight'):
+        assert rel_l2(outs[0]['sd'][k], ref_sd[k]) < 1e-4, k

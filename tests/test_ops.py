@@ -227,6 +227,90 @@ def test_dgrad_epilogue_bn_backward_reduction(mode, dtype):
 
 
 @pytest.mark.parametrize('mode', MODES)
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_sync_batchnorm_building_blocks(mode, dtype):
+    """The --sync-bn kernels (local double-precision sums -> caller's all-reduce -> forward / backward
+    from global sums) reproduce the single-rank BatchNorm when the 'global' sums are the local ones, and
+    a two-shard split (sums added on the host, as the all-reduce would) reproduces BatchNorm over the
+    concatenated batch."""
+    dev = _dev(mode)
+    import convnet_amd as ca
+    lib, L, ops = ca._lib, ca._lib.load(), ca.ops
+    code = lib.dtype_code(dtype)
+    for (N, C, H, W) in ([(4, 16, 5, 5), (2, 72, 3, 7)] if mode == 'emul' else [(8, 64, 56, 56), (6, 136, 9, 5)]):
+        g = torch.Generator().manual_seed(C)
+        y = _nhwc(torch.randn(N, C, H, W, generator=g) * 2 + 0.5, dtype, dev)
+        dz = _nhwc(torch.randn(N, C, H, W, generator=g), dtype, dev)
+        gamma = (torch.rand(C, generator=g) + 0.5).to(dev)
+        beta = (torch.randn(C, generator=g) * 0.1).to(dev)
+        M = N * H * W
+        ws = ops.workspace(L.cn_bn_workspace(M, C, code), dev)
+
+        def plain(yy, dzz, m):
+            z, dy = torch.empty_like(yy), torch.empty_like(yy)
+            st, coef = torch.empty(4 * C, device=dev), torch.empty(3 * C, device=dev)
+            rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+            dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+            lib.check(L.cn_bn_fwd_train(lib.ptr(yy), None, lib.ptr(z), None, lib.ptr(gamma), lib.ptr(beta), lib.ptr(rm),
+                                        lib.ptr(rv), None, 0.1, 1e-5, lib.ptr(st), m, C, 1, code, lib.ptr(ws),
+                                        ws.numel() * 4, lib.stream_of(yy)))
+            lib.check(L.cn_bn_bwd(lib.ptr(dzz), lib.ptr(yy), None, lib.ptr(gamma), lib.ptr(st), lib.ptr(dy), None,
+                                  lib.ptr(dg), lib.ptr(db), 0.0, 1.0, lib.ptr(coef), m, C, 1, code, lib.ptr(ws),
+                                  ws.numel() * 4, lib.stream_of(yy)))
+            return z.float().cpu(), dy.float().cpu(), dg.cpu(), db.cpu(), rm.cpu(), rv.cpu()
+
+        def synced(shards):
+            """shards: list of (y, dz) per 'rank'; returns per-rank outputs with host-summed sums."""
+            m_tot = sum(yy.numel() // C for yy, _ in shards)
+            fs = []
+            for yy, _ in shards:
+                sm = torch.empty(2 * C, dtype=torch.float64, device=dev)
+                lib.check(L.cn_bn_local_sums(lib.ptr(yy), yy.numel() // C, C, code, None, 0, lib.ptr(sm), lib.ptr(ws),
+                                             ws.numel() * 4, lib.stream_of(yy)))
+                fs.append(sm)
+            gsum = torch.stack(fs).sum(0).contiguous()
+            outs, states = [], []
+            for yy, _ in shards:
+                m = yy.numel() // C
+                z = torch.empty_like(yy)
+                st = torch.empty(4 * C, device=dev)
+                rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+                lib.check(L.cn_bn_fwd_train_sums(lib.ptr(yy), None, lib.ptr(z), None, lib.ptr(gamma), lib.ptr(beta),
+                                                 lib.ptr(rm), lib.ptr(rv), None, 0.1, 1e-5, lib.ptr(st), m, C, 1, code,
+                                                 lib.ptr(gsum), m_tot, lib.stream_of(yy)))
+                states.append((z, st, rm, rv))
+            ls = []
+            for (yy, dzz), (z, st, rm, rv) in zip(shards, states):
+                sm = torch.empty(2 * C, dtype=torch.float64, device=dev)
+                lib.check(L.cn_bn_bwd_local_sums(lib.ptr(dzz), lib.ptr(yy), None, lib.ptr(st), yy.numel() // C, C, 1,
+                                                 code, None, 0, lib.ptr(sm), lib.ptr(ws), ws.numel() * 4,
+                                                 lib.stream_of(yy)))
+                ls.append(sm)
+            gl = torch.stack(ls).sum(0).contiguous()
+            for (yy, dzz), (z, st, rm, rv), loc in zip(shards, states, ls):
+                m = yy.numel() // C
+                dy, coef = torch.empty_like(yy), torch.empty(3 * C, device=dev)
+                dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+                lib.check(L.cn_bn_bwd_sums(lib.ptr(dzz), lib.ptr(yy), None, lib.ptr(gamma), lib.ptr(st), lib.ptr(dy), None,
+                                           lib.ptr(dg), lib.ptr(db), 0.0, 1.0, lib.ptr(coef), m, C, 1, 0, code,
+                                           lib.ptr(loc), lib.ptr(gl), m_tot, lib.stream_of(yy)))
+                outs.append((z.float().cpu(), dy.float().cpu(), dg.cpu(), db.cpu(), rm.cpu(), rv.cpu()))
+            return outs
+
+        ref = plain(y, dz, M)
+        one = synced([(y, dz)])[0]
+        tol = 1e-5 if dtype == torch.float32 else 4e-3
+        for a, b in zip(one, ref):
+            assert rel_l2(a, b) < max(tol, 2e-5)
+        h = N // 2
+        two = synced([(y[:h].contiguous(), dz[:h].contiguous()), (y[h:].contiguous(), dz[h:].contiguous())])
+        assert rel_l2(torch.cat([two[0][0], two[1][0]]), ref[0]) < tol
+        assert rel_l2(torch.cat([two[0][1], two[1][1]]), ref[1]) < tol
+        assert rel_l2(two[0][2] + two[1][2], ref[2]) < 1e-4 and rel_l2(two[0][3] + two[1][3], ref[3]) < 1e-4
+        assert rel_l2(two[0][4], ref[4]) < 1e-5 and rel_l2(two[1][5], ref[5]) < 1e-5
+
+
+@pytest.mark.parametrize('mode', MODES)
 def test_wgrad_accumulates_and_scales(mode):
     dev = _dev(mode)
     import convnet_amd as ca
