@@ -185,6 +185,51 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
   const int rd_p = BN * 128 + wp * TJ * 32 * 128;
   __syncthreads();
 
+  constexpr int OEBc = OUTF32 ? 4 : EB;
+  const int OEB = OEBc;
+  const int pitch = BN * OEB + 16;
+  typedef typename std::conditional<OUTF32, float, T>::type TO;   // element type of the stored output
+  constexpr int EPC = 16 / OEBc;       // elements per 16-byte chunk of the output
+  constexpr int CPR = BN / EPC;        // chunks per tile row
+  constexpr int NPASS = BM * CPR / NT; // store passes: pass k handles tile row tid / CPR + k * (NT / CPR)
+  constexpr int PB = !EPI ? 1 : (NPASS < 8 ? NPASS : 8);
+  static_assert(NT % CPR == 0 && NPASS % PB == 0, "a thread keeps one chunk column for the whole store loop");
+  const int epc = EPC, cpr = CPR;
+  const int ecol = tid % CPR, erow0 = tid / CPR;
+  const int c_first = n0 + ecol * EPC;
+  const bool vec_ok = ((p.Co * OEB) & 15) == 0 && c_first + EPC <= p.Co;
+  const bool bnb = EPI && p.bn_y != nullptr;
+  // EPI instantiations only (dgrad with a residual-branch addend and / or the fused BN-backward
+  // reduction; the plain kernel keeps its register budget).  Global-side epilogue operands (residual-branch gradient, BN input, ReLU bits) are fetched a batch of
+  // passes at a time, the first batch *before* the accumulators are staged through LDS, so their
+  // latency is overlapped instead of being exposed once per store pass.
+  const bool pre = EPI && vec_ok && (p.addend != nullptr || bnb);
+  u32x4 adv[PB], yvv[PB];
+  unsigned int bitv[PB];
+  auto preload_y = [&](int k0) {    // BN input tiles
+#pragma unroll
+    for (int kk = 0; kk < PB; ++kk) {
+      const int pix = s_outpix[erow0 + (k0 + kk) * (NT / CPR)];
+      const size_t goff = ((size_t)(pix < 0 ? 0 : pix) * (size_t)p.Co + (size_t)c_first) * OEBc;
+      const u32x4 zero = {0u, 0u, 0u, 0u};
+      yvv[kk] = (pix >= 0 && bnb) ? cn_ld16(p.bn_y + goff) : zero;
+    }
+  };
+  auto preload_ab = [&](int k0) {   // residual-branch gradient and ReLU bits
+#pragma unroll
+    for (int kk = 0; kk < PB; ++kk) {
+      const int pix = s_outpix[erow0 + (k0 + kk) * (NT / CPR)];
+      const size_t goff = ((size_t)(pix < 0 ? 0 : pix) * (size_t)p.Co + (size_t)c_first) * OEBc;
+      const u32x4 zero = {0u, 0u, 0u, 0u};
+      adv[kk] = (pix >= 0 && p.addend != nullptr) ? cn_ld16(p.addend + goff) : zero;
+      bitv[kk] = (pix >= 0 && bnb && p.bn_mask != nullptr) ? (unsigned int)p.bn_mask[goff >> 4] : 0u;
+    }
+  };
+  // the BN-input tile is requested before the reduction loop (for the short reductions of the 1x1 layers it
+  // is then in flight together with the GEMM operands); the addend / mask bits follow once the K loop's
+  // staging registers are free (two waves per SIMD fit in the register file that way)
+  if (pre && bnb) preload_y(0);
+
   f32x16 acc[TI][TJ];
 #pragma unroll
   for (int a = 0; a < TI; ++a)
@@ -337,6 +382,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
     }
   }
 
+  if (pre) preload_ab(0);
   // ---- epilogue: (bias, ReLU) -> LDS out tile [BM pixels][BN channels] -> coalesced global store
   if (p.bias != nullptr) {   // uniform branch; a lane's 4 consecutive channels = one 16-byte bias load
 #pragma unroll
@@ -366,51 +412,6 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][b][r] = acc[a][b][r] > 0.f ? acc[a][b][r] : 0.f;
   }
-  constexpr int OEBc = OUTF32 ? 4 : EB;
-  const int OEB = OEBc;
-  const int pitch = BN * OEB + 16;
-  typedef typename std::conditional<OUTF32, float, T>::type TO;   // element type of the stored output
-  constexpr int EPC = 16 / OEBc;       // elements per 16-byte chunk of the output
-  constexpr int CPR = BN / EPC;        // chunks per tile row
-  constexpr int NPASS = BM * CPR / NT; // store passes: pass k handles tile row tid / CPR + k * (NT / CPR)
-  constexpr int PB = !EPI ? 1 : (NPASS < 8 ? NPASS : 8);
-  static_assert(NT % CPR == 0 && NPASS % PB == 0, "a thread keeps one chunk column for the whole store loop");
-  const int epc = EPC, cpr = CPR;
-  const int ecol = tid % CPR, erow0 = tid / CPR;
-  const int c_first = n0 + ecol * EPC;
-  const bool vec_ok = ((p.Co * OEB) & 15) == 0 && c_first + EPC <= p.Co;
-  const bool bnb = EPI && p.bn_y != nullptr;
-  // EPI instantiations only (dgrad with a residual-branch addend and / or the fused BN-backward
-  // reduction; the plain kernel keeps its register budget).  Global-side epilogue operands (residual-branch gradient, BN input, ReLU bits) are fetched a batch of
-  // passes at a time, the first batch *before* the accumulators are staged through LDS, so their
-  // latency is overlapped instead of being exposed once per store pass.
-  const bool pre = EPI && vec_ok && (p.addend != nullptr || bnb);
-  u32x4 adv[PB], yvv[PB];
-  unsigned int bitv[PB];
-  auto preload = [&](int k0) {
-#pragma unroll
-    for (int kk = 0; kk < PB; ++kk) {
-      const int pix = s_outpix[erow0 + (k0 + kk) * (NT / CPR)];
-      const size_t goff = ((size_t)(pix < 0 ? 0 : pix) * (size_t)p.Co + (size_t)c_first) * OEBc;
-      const u32x4 zero = {0u, 0u, 0u, 0u};
-      adv[kk] = (pix >= 0 && p.addend != nullptr) ? cn_ld16(p.addend + goff) : zero;
-      yvv[kk] = (pix >= 0 && bnb) ? cn_ld16(p.bn_y + goff) : zero;
-      bitv[kk] = (pix >= 0 && bnb && p.bn_mask != nullptr) ? (unsigned int)p.bn_mask[goff >> 4] : 0u;
-    }
-  };
-  float bs1[EPC], bs2[EPC], bmu[EPC], bis[EPC], bsc[EPC], bsh[EPC];
-#pragma unroll
-  for (int e = 0; e < EPC; ++e) { bs1[e] = 0.f; bs2[e] = 0.f; bmu[e] = 0.f; bis[e] = 0.f; bsc[e] = 0.f; bsh[e] = 0.f; }
-  if (bnb && vec_ok) {
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) {
-      bmu[e] = p.bn_coef[c_first + e];
-      bis[e] = p.bn_coef[p.Co + c_first + e];
-      bsc[e] = p.bn_coef[2 * p.Co + c_first + e];
-      bsh[e] = p.bn_coef[3 * p.Co + c_first + e];
-    }
-  }
-  if (pre) preload(0);
 #pragma unroll
   for (int a = 0; a < TI; ++a)
 #pragma unroll
@@ -467,9 +468,22 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
       for (int r = 0; r < RPG && r < cnt; ++r) acc_row(r);
     }
   }
+  // per-channel BN coefficients of this thread's chunk column (loaded after the staging pass: kept out of its register peak)
+  float bs1[EPC], bs2[EPC], bmu[EPC], bis[EPC], bsc[EPC], bsh[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) { bs1[e] = 0.f; bs2[e] = 0.f; bmu[e] = 0.f; bis[e] = 0.f; bsc[e] = 0.f; bsh[e] = 0.f; }
+  if (bnb && vec_ok) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      bmu[e] = p.bn_coef[c_first + e];
+      bis[e] = p.bn_coef[p.Co + c_first + e];
+      bsc[e] = p.bn_coef[2 * p.Co + c_first + e];
+      bsh[e] = p.bn_coef[3 * p.Co + c_first + e];
+    }
+  }
   if (c_first < p.Co) {
     for (int k0 = 0; k0 < NPASS; k0 += PB) {
-      if (pre && k0 > 0) preload(k0);
+      if (pre && k0 > 0) { preload_y(k0); preload_ab(k0); }
 #pragma unroll
       for (int kk = 0; kk < PB; ++kk) {
         const int row = erow0 + (k0 + kk) * (NT / CPR);
