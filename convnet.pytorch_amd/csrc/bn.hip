@@ -99,40 +99,43 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const char* y, float* par
   }
 }
 
-// Fixed-order, latency-tolerant reduction of the per-workgroup partials: 32 channels per workgroup,
-// 8 threads per channel each summing every 8th partial with 4 independent loads in flight, then a
-// fixed-order LDS combine.  (A single thread walking all partials is a chain of dependent L2
-// round trips: measured 0.5 ms per launch at 2048 partials.)
+// Fixed-order, latency-tolerant reduction of the per-workgroup partials: BN_FC channels per workgroup,
+// BN_FP threads per channel each summing every BN_FP-th partial row with 16 independent loads in
+// flight, then a fixed-order LDS combine.  (A single thread walking all partials is a chain of
+// dependent L2 round trips: measured 0.5 ms per launch at 2048 partials; with 8 threads per channel
+// 512 rows still took 4 dependent rounds, with 32 it is one or two.)
+#define BN_FC 8     /* channels per workgroup */
+#define BN_FP 32    /* row slices (threads per channel) */
 __device__ __forceinline__ void bn_sum_partials(const float* partial, int nrb, int C, int c, int part,
-                                                double* red /*[2][8][32]*/, double& s_out, double& q_out) {
+                                                double* red /*[2][BN_FP][BN_FC]*/, double& s_out, double& q_out) {
   double s = 0.0, q = 0.0;
   if (c < C) {
     int r = part;
-    for (; r + 56 < nrb; r += 64) {   // 16 independent loads in flight per thread
+    for (; r + 7 * BN_FP < nrb; r += 8 * BN_FP) {   // 16 independent loads in flight per thread
       float a[8], b[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        a[u] = partial[(size_t)(r + 8 * u) * 2 * C + c];
-        b[u] = partial[(size_t)(r + 8 * u) * 2 * C + C + c];
+        a[u] = partial[(size_t)(r + BN_FP * u) * 2 * C + c];
+        b[u] = partial[(size_t)(r + BN_FP * u) * 2 * C + C + c];
       }
       s += (((double)a[0] + (double)a[1]) + ((double)a[2] + (double)a[3])) +
            (((double)a[4] + (double)a[5]) + ((double)a[6] + (double)a[7]));
       q += (((double)b[0] + (double)b[1]) + ((double)b[2] + (double)b[3])) +
            (((double)b[4] + (double)b[5]) + ((double)b[6] + (double)b[7]));
     }
-    for (; r < nrb; r += 8) {
+    for (; r < nrb; r += BN_FP) {
       s += (double)partial[(size_t)r * 2 * C + c];
       q += (double)partial[(size_t)r * 2 * C + C + c];
     }
   }
-  const int lc = threadIdx.x & 31;
-  red[part * 32 + lc] = s;
-  red[256 + part * 32 + lc] = q;
+  const int lc = threadIdx.x % BN_FC;
+  red[part * BN_FC + lc] = s;
+  red[BN_FP * BN_FC + part * BN_FC + lc] = q;
   __syncthreads();
   s = 0.0;
   q = 0.0;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) { s += red[k * 32 + lc]; q += red[256 + k * 32 + lc]; }
+  for (int k = 0; k < BN_FP; ++k) { s += red[k * BN_FC + lc]; q += red[BN_FP * BN_FC + k * BN_FC + lc]; }
   s_out = s;
   q_out = q;
 }
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(256) void bn_partials_compress_kernel(const float* 
   out[(size_t)blockIdx.y * W + col] = acc;
 }
 
-// 32 channels per workgroup: statistics, running-stat update and the fused scale/shift the apply
+// BN_FC channels per workgroup: statistics, running-stat update and the fused scale/shift the apply
 // kernel consumes.
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* partial, int nrb, int M, int C,
                                                          const float* gamma, const float* beta,
@@ -166,8 +169,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* partial, 
                                                          float eps, float* save_mean, float* save_invstd,
                                                          float* scale, float* shift) {
   __shared__ double red[512];
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
-  const int part = threadIdx.x >> 5;
+  const int c = blockIdx.x * BN_FC + (threadIdx.x % BN_FC);
+  const int part = threadIdx.x / BN_FC;
   if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked != nullptr) *num_batches_tracked += 1;
   double s, q;
   bn_sum_partials(partial, nrb, C, c, part, red, s, q);
@@ -344,8 +347,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* parti
                                                              float* dbeta, float beta_acc, float gscale,
                                                              float* coef) {
   __shared__ double red[512];
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
-  const int part = threadIdx.x >> 5;
+  const int c = blockIdx.x * BN_FC + (threadIdx.x % BN_FC);
+  const int part = threadIdx.x / BN_FC;
   double s1, s2;
   bn_sum_partials(partial, nrb, C, c, part, red, s1, s2);
   if (c >= C || part != 0) return;
@@ -439,7 +442,7 @@ static int bn_fwd_tail(const float* partial, int nrb, const void* y, const void*
                        unsigned char* relu_mask, const float* gamma, const float* beta, float* running_mean,
                        float* running_var, long long* num_batches_tracked, float momentum, float eps,
                        float* stats_out, int M, int C, int relu, int dtype, const BnMap& m, hipStream_t stream) {
-  CN_LAUNCH(bn_finalize_kernel, dim3((unsigned)((C + 31) / 32)), dim3(256), stream, partial, nrb,
+  CN_LAUNCH(bn_finalize_kernel, dim3((unsigned)((C + BN_FC - 1) / BN_FC)), dim3(256), stream, partial, nrb,
             M, C, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, stats_out,
             stats_out + C, stats_out + 2 * C, stats_out + 3 * C);
   int nab = bn_row_blocks(M, m, cn_get_option("bn_apply_blocks", BN_APPLY_BLOCKS));
@@ -569,7 +572,7 @@ extern "C" int cn_bn_bwd(const void* dz, const void* y, const unsigned char* rel
   else
     CN_LAUNCH(bn_bwd_reduce_kernel<float>, grid, dim3(256), stream, (const char*)dz, (const char*)y,
               relu_mask, mean, invstd, scale, shift, partial, M, C, relu, m.tpr_log2, rev_r);
-  CN_LAUNCH(bn_bwd_finalize_kernel, dim3((unsigned)((C + 31) / 32)), dim3(256), stream, (const float*)partial,
+  CN_LAUNCH(bn_bwd_finalize_kernel, dim3((unsigned)((C + BN_FC - 1) / BN_FC)), dim3(256), stream, (const float*)partial,
             nrb, M, C, gamma, mean, invstd, dgamma, dbeta, beta_acc, gscale, coef_scratch);
   int nab = bn_row_blocks(M, m, cn_get_option("bn_apply_blocks", BN_APPLY_BLOCKS));
   dim3 agrid((unsigned)nab, (unsigned)m.gy);
@@ -613,7 +616,7 @@ extern "C" int cn_bn_bwd_partials(const void* g, const void* y, const float* gam
   const float* invstd = stats + C;
   const float* scale = stats + 2 * C;
   const float* shift = stats + 3 * C;
-  CN_LAUNCH(bn_bwd_finalize_kernel, dim3((unsigned)((C + 31) / 32)), dim3(256), stream, partial, nrb, M, C, gamma,
+  CN_LAUNCH(bn_bwd_finalize_kernel, dim3((unsigned)((C + BN_FC - 1) / BN_FC)), dim3(256), stream, partial, nrb, M, C, gamma,
             mean, invstd, dgamma, dbeta, beta_acc, gscale, coef_scratch);
   int nab = bn_row_blocks(M, m, cn_get_option("bn_apply_blocks", BN_APPLY_BLOCKS));
   dim3 agrid((unsigned)nab, (unsigned)m.gy);

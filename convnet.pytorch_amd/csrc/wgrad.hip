@@ -203,6 +203,178 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16 variant with LDS-DMA staging (`buffer_load ... lds`), double-buffered, one barrier per stage.
+// The register-staged kernel above moves every operand byte through ds_write_b128 (13 LDS-path
+// cycles per wave instruction): 8 of them per thread and stage = 416 cycles per workgroup-stage on
+// top of 256 cycles of transpose reads, against 512 MFMA cycles - the LDS path, not the matrix
+// core, was the limiter.  Here the tiles land in LDS without passing through VGPRs.
+//
+// LDS image of a tile: [64 pixel rows][row bytes], unpadded (a DMA wave instruction fills one
+// contiguous KiB).  The transpose read touches 4 consecutive rows x 64 bytes per half-wave, so the
+// 64-byte granule index is XOR-swizzled with the row (256-byte rows: ^ (row & 3); 128-byte rows:
+// ^ ((row >> 1) & 1)) to keep it bank-conflict free; the swizzle is applied on the *source* side of
+// the DMA (the lane that owns LDS slot s fetches global chunk s ^ swizzle).
+template <int BI>
+__global__ __launch_bounds__(256) void wgrad_dma_kernel(WgradParams p) {
+  typedef bf16_t T;
+  constexpr int BJ = 128, BKP = 64;
+  constexpr int TI = BI / 64, TJ = BJ / 64;
+  constexpr int RBI = BI * 2, RBJ = BJ * 2;         // row bytes
+  constexpr int SZI = BKP * RBI, SZJ = BKP * RBJ;   // tile bytes per stage
+  constexpr int STAGE = SZI + SZJ;
+  constexpr int NI = SZI / 1024 / 4, NJ = SZJ / 1024 / 4;   // DMA instructions per thread and stage
+  constexpr int CPRI = RBI / 16, CPRJ = RBJ / 16;           // 16-byte chunks per row
+  __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wi = wave & 1, wj = wave >> 1;
+
+  unsigned int tile = cn_xcd_remap(blockIdx.x, gridDim.x);
+  const int jt = tile % p.n_jtiles;
+  tile /= p.n_jtiles;
+  const int it = tile % p.n_itiles;
+  const int split = tile / p.n_itiles;
+  const int i0 = it * BI, j0 = jt * BJ;
+  const int m_begin = split * p.m_per_split;
+  int m_end = m_begin + p.m_per_split;
+  if (m_end > p.M) m_end = p.M;
+  const int HoWo = p.Ho * p.Wo;
+
+  const cn_buf_t xbuf = cn_make_buf(p.x, p.x_bytes);
+  const cn_buf_t dybuf = cn_make_buf(p.dy, p.dy_bytes);
+  const unsigned int rowI_pitch = (unsigned int)(p.Co * 2), rowJ_pitch = (unsigned int)(p.Ci * 2);
+
+  // per-thread DMA coordinates: instruction i of wave w fills KiB (i * 4 + w) of the tile
+  const int rI = lane / CPRI, sI = lane % CPRI;   // row inside the KiB, slot inside the row
+  const int rJ = lane / CPRJ, sJ = lane % CPRJ;
+  auto swzI = [](int row) { return BI == 128 ? ((row & 3) << 2) : (((row >> 1) & 1) << 2); };
+  // rows of one thread differ by multiples of 4 (BI = 128: 1024 / 256) or 8 (BI = 64) between KiB
+  // blocks, so the swizzle and hence the fetched chunk column are fixed per thread
+  const int cI = sI ^ swzI(rI);
+  const int cJ = sJ ^ ((rJ & 3) << 2);
+  const bool validI = i0 + cI * 8 < p.Co;
+  const unsigned int colI_b = validI ? (unsigned int)((i0 + cI * 8) * 2) : CN_OOB;
+  const int jc = j0 / 8 + cJ;
+  const bool validJ = jc < p.ntaps * p.cpt;
+  int tap = 0, cchunk = jc;
+  if (p.ntaps > 1) {
+    tap = validJ ? (int)cn_fastdiv((unsigned)jc, p.div_cpt) : 0;
+    cchunk = validJ ? jc - tap * p.cpt : 0;
+  }
+  const int dhdw = p.tap_dhdw[tap];
+  const int dh = (int)(short)(dhdw & 0xffff), dw = dhdw >> 16;
+  const unsigned int colJ_b = validJ ? (unsigned int)(cchunk * 16) : CN_OOB;
+
+  auto load_stage = [&](int mb, int buf) {
+    char* baseI = lds + buf * STAGE;
+    char* baseJ = baseI + SZI;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int blk = i * 4 + wave;
+      const int m = mb + blk * (1024 / RBI) + rI;
+      const bool ok = m < m_end && colI_b < CN_OOB;
+      cn_buf_ld16_lds(dybuf, ok ? (unsigned int)m * rowI_pitch + colI_b : CN_OOB, baseI + blk * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+      const int blk = i * 4 + wave;
+      const int m = mb + blk * (1024 / RBJ) + rJ;
+      bool ok = m < m_end && colJ_b < CN_OOB;
+      unsigned int off;
+      if (p.simple) {
+        off = (unsigned int)m * rowJ_pitch + colJ_b;
+      } else {
+        const int mm = ok ? m : 0;
+        const int n = (int)cn_fastdiv((unsigned)mm, p.div_hw);
+        const int rem = mm - n * HoWo;
+        const int ho = (int)cn_fastdiv((unsigned)rem, p.div_w);
+        const int wo = rem - ho * p.Wo;
+        const int hi = ho * p.stride_h + dh, wq = wo * p.stride_w + dw;
+        ok = ok && (unsigned)hi < (unsigned)p.Hi && (unsigned)wq < (unsigned)p.Wi;
+        off = (unsigned int)((n * p.Hi + hi) * p.Wi + wq) * rowJ_pitch + colJ_b;
+      }
+      cn_buf_ld16_lds(xbuf, ok ? off : CN_OOB, baseJ + blk * 1024);
+    }
+  };
+
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int a = 0; a < TI; ++a)
+#pragma unroll
+    for (int b = 0; b < TJ; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // fragment addressing (see cn_lds_read_tr16_b64): loop-invariant byte offsets inside a stage
+  const int L = lane & 15, g1 = (lane >> 4) & 1, h = lane >> 5;
+  const int rlo = h * 8 + (L >> 2);                       // + kk * 16 (+ 4 for the upper half)
+  const int inner = g1 * 32 + (L & 3) * 8;                // byte offset inside the 64-byte granule
+  int offI[TI], offJ[TJ];
+#pragma unroll
+  for (int a = 0; a < TI; ++a) {
+    const int g = wi * TI + a;
+    const int gs = BI == 128 ? (g ^ (rlo & 3)) : (g ^ ((rlo >> 1) & 1));
+    offI[a] = rlo * RBI + (gs << 6) + inner;
+  }
+#pragma unroll
+  for (int b = 0; b < TJ; ++b) offJ[b] = rlo * RBJ + (((wj * TJ + b) ^ (rlo & 3)) << 6) + inner;
+  // (rows rlo + 4 and rlo + 16*kk keep the same row & 3; for 128-byte rows (row >> 1) & 1 flips with +4
+  //  only through bit 2, which the swizzle does not use, so one offset per tile serves all reads)
+
+  auto compute = [&](int buf) {
+    const char* tI = lds + buf * STAGE;
+    const char* tJ = tI + SZI;
+#pragma unroll
+    for (int kk = 0; kk < BKP / 16; ++kk) {
+      s16x8 af[TI], bfr[TJ];
+#pragma unroll
+      for (int a = 0; a < TI; ++a) {
+        const char* q = tI + kk * 16 * RBI + offI[a];
+        s16x4 lo = cn_lds_read_tr16_b64(q);
+        s16x4 hi = cn_lds_read_tr16_b64(q + 4 * RBI);
+        af[a] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int b = 0; b < TJ; ++b) {
+        const char* q = tJ + kk * 16 * RBJ + offJ[b];
+        s16x4 lo = cn_lds_read_tr16_b64(q);
+        s16x4 hi = cn_lds_read_tr16_b64(q + 4 * RBJ);
+        bfr[b] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int a = 0; a < TI; ++a)
+#pragma unroll
+        for (int b = 0; b < TJ; ++b) acc[a][b] = cn_mfma_32x32x16_bf16(af[a], bfr[b], acc[a][b]);
+    }
+  };
+
+  if (m_begin < m_end) {
+    load_stage(m_begin, 0);
+    int buf = 0;
+    for (int mb = m_begin; mb < m_end; mb += BKP, buf ^= 1) {
+      __syncthreads();   // stage `buf` has landed (hipcc drains vmcnt first); the other buffer is free
+      if (mb + BKP < m_end) load_stage(mb + BKP, buf ^ 1);
+      compute(buf);
+    }
+  }
+
+  float* out = p.part + (size_t)split * (size_t)p.Co * (size_t)p.ncols;
+#pragma unroll
+  for (int a = 0; a < TI; ++a)
+#pragma unroll
+    for (int b = 0; b < TJ; ++b) {
+      const int col = j0 + (wj * TJ + b) * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = i0 + (wi * TI + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (co < p.Co && col < p.ncols) out[(size_t)co * p.ncols + col] = acc[a][b][r];
+      }
+    }
+}
+
 // Fixed-order reduction of the split partials into the KRSC fp32 gradient (C_real <= Ci channels
 // kept per tap: the stem's input is channel-padded).  beta = 1 accumulates (chunked batches).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, float* dw, int nsplit, int Co,
@@ -271,6 +443,12 @@ extern "C" size_t cn_conv2d_wgrad_workspace(int N, int H, int W, int C, int K, i
 template <typename T>
 static void wg_launch(const WgradParams& p, const WgradPlan& pl, hipStream_t stream) {
   dim3 grid((unsigned)(pl.n_itiles * pl.n_jtiles * pl.nsplit));
+  // bf16: LDS-DMA staging by default (tuning knob "wgrad_variant": 1 = register-staged, 2 = LDS-DMA)
+  if (sizeof(T) == 2 && cn_get_option("wgrad_variant", 2) == 2) {
+    if (pl.BI == 64) CN_LAUNCH((wgrad_dma_kernel<64>), grid, dim3(256), stream, p);
+    else CN_LAUNCH((wgrad_dma_kernel<128>), grid, dim3(256), stream, p);
+    return;
+  }
   if (pl.BI == 64) CN_LAUNCH((wgrad_kernel<T, 64, 128>), grid, dim3(256), stream, p);
   else CN_LAUNCH((wgrad_kernel<T, 128, 128>), grid, dim3(256), stream, p);
 }
