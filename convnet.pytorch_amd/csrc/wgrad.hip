@@ -443,8 +443,12 @@ extern "C" size_t cn_conv2d_wgrad_workspace(int N, int H, int W, int C, int K, i
 template <typename T>
 static void wg_launch(const WgradParams& p, const WgradPlan& pl, hipStream_t stream) {
   dim3 grid((unsigned)(pl.n_itiles * pl.n_jtiles * pl.nsplit));
-  // bf16: LDS-DMA staging by default (tuning knob "wgrad_variant": 1 = register-staged, 2 = LDS-DMA)
-  if (sizeof(T) == 2 && cn_get_option("wgrad_variant", 2) == 2) {
+  // bf16, identity gather (1x1 stride 1): LDS-DMA staging (+5-10 % on those layers); with a real gather
+  // (3x3, strided) the register-staged kernel at 3 workgroups/CU measured 20-30 % faster than the DMA one
+  // at 2 (profiles/README.md).  Tuning knob "wgrad_variant": 0 = this heuristic, 1 = register-staged,
+  // 2 = LDS-DMA everywhere.
+  const int wv = cn_get_option("wgrad_variant", 0);
+  if (sizeof(T) == 2 && (wv == 2 || (wv == 0 && p.simple))) {
     if (pl.BI == 64) CN_LAUNCH((wgrad_dma_kernel<64>), grid, dim3(256), stream, p);
     else CN_LAUNCH((wgrad_dma_kernel<128>), grid, dim3(256), stream, p);
     return;
