@@ -55,6 +55,9 @@ _SIGNATURES = {
     'cn_avgpool_fwd': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     'cn_avgpool_bwd': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     'cn_nchw_to_nhwc': (c_i, [c_p, c_p] + [c_i] * 6 + [c_p]),
+    'cn_nchw_to_pairs': (c_i, [c_p, c_p] + [c_i] * 6 + [c_p]),
+    'cn_weight_prep_pairs': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    'cn_wgrad_unpack_pairs': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
     'cn_nhwc_to_nchw': (c_i, [c_p, c_p] + [c_i] * 6 + [c_p]),
     'cn_eltwise': (c_i, [c_i, c_p, c_p, c_p, c_ll, c_i, c_p]),
     'cn_softmax_ce': (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_f, c_p, c_f, c_p]),

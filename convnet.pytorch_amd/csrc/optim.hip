@@ -153,6 +153,35 @@ __global__ __launch_bounds__(256) void weight_prep_tiled_kernel(const float* mas
   }
 }
 
+// Pixel-pair packing of a stem filter (see nchw_to_pairs_kernel): master [K][R][S][C] fp32 (C <= 4) ->
+// out [K][R][S2][8] bf16, S2 = ceil(S/2), out[k][r][s2][j*4 + c] = master[k][r][2*s2 + j][c] (zero for
+// 2*s2 + j >= S or c >= C); and the inverse scatter of the weight gradient computed in the packed layout.
+__global__ __launch_bounds__(256) void weight_prep_pairs_kernel(const float* master, bf16_t* out, int K, int R, int S,
+                                                               int C, int S2) {
+  const int total = K * R * S2 * 8;
+  for (int id = blockIdx.x * 256 + threadIdx.x; id < total; id += gridDim.x * 256) {
+    const int e = id & 7, j = e >> 2, c = e & 3;
+    int rest = id >> 3;
+    const int s2 = rest % S2;
+    rest /= S2;   // k * R + r
+    const int s = 2 * s2 + j;
+    const float v = (s < S && c < C) ? master[((size_t)rest * S + s) * C + c] : 0.f;
+    cn_store_elem<bf16_t>(out + id, v);
+  }
+}
+__global__ __launch_bounds__(256) void wgrad_unpack_pairs_kernel(const float* packed, float* dw, int K, int R, int S,
+                                                                int C, int S2, float beta) {
+  const int total = K * R * S * C;
+  for (int id = blockIdx.x * 256 + threadIdx.x; id < total; id += gridDim.x * 256) {
+    const int c = id % C;
+    int rest = id / C;
+    const int s = rest % S;
+    rest /= S;   // k * R + r
+    const float g = packed[((size_t)rest * S2 + (s >> 1)) * 8 + (s & 1) * 4 + c];
+    dw[id] = beta != 0.f ? beta * dw[id] + g : g;
+  }
+}
+
 // out[c] (+)= sum_m x[m][c], x fp32 or bf16 row-major [M][C]; one thread per column, rows strided
 // over gridDim.y with a fixed-order second stage.
 template <typename T>
@@ -300,6 +329,23 @@ extern "C" int cn_weight_prep_tiled(const float* master, void* wbuf, const long 
               tiles);
   else { cn_set_error("weight_prep_tiled: bad dtype"); return CN_EINVAL; }
   return cn_check_launch("weight_prep_tiled");
+}
+
+extern "C" int cn_weight_prep_pairs(const float* master_krsc, void* out, int K, int R, int S, int C, void* stream) {
+  if (K <= 0 || R <= 0 || S <= 0 || C < 1 || C > 4) { cn_set_error("weight_prep_pairs: need 1 <= C <= 4"); return CN_ESHAPE; }
+  const int S2 = (S + 1) / 2;
+  CN_LAUNCH(weight_prep_pairs_kernel, dim3(opt_grid((long long)K * R * S2 * 8, 256)), dim3(256), (hipStream_t)stream,
+            master_krsc, (bf16_t*)out, K, R, S, C, S2);
+  return cn_check_launch("weight_prep_pairs");
+}
+
+extern "C" int cn_wgrad_unpack_pairs(const float* packed, float* dw_krsc, int K, int R, int S, int C, float beta,
+                                     void* stream) {
+  if (K <= 0 || R <= 0 || S <= 0 || C < 1 || C > 4) { cn_set_error("wgrad_unpack_pairs: need 1 <= C <= 4"); return CN_ESHAPE; }
+  const int S2 = (S + 1) / 2;
+  CN_LAUNCH(wgrad_unpack_pairs_kernel, dim3(opt_grid((long long)K * R * S * C, 256)), dim3(256), (hipStream_t)stream,
+            packed, dw_krsc, K, R, S, C, S2, beta);
+  return cn_check_launch("wgrad_unpack_pairs");
 }
 
 #define CN_COLSUM_PARTS 64

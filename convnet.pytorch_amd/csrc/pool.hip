@@ -173,6 +173,33 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* x, char*
   }
 }
 
+// fp32 NCHW with C <= 4 channels -> zero-padded "pixel pair" image for a stride-2 stem convolution
+// (models/resnet.py:226: 7x7/2, pad 3, C = 3): y[n][hp][jp][8] (bf16) holds the two horizontally adjacent
+// padded pixels wp = 2*jp, 2*jp + 1 with 4 channels each (source pixel (hp - pad_h, wp - pad_w), zero outside
+// the image and for channels >= C).  One 16-byte chunk per pixel pair: the implicit GEMM then needs
+// ceil(S/2) chunks per filter row instead of S, and no bounds tests (the padding is in the data).
+__global__ __launch_bounds__(256) void nchw_to_pairs_kernel(const float* x, char* y, int N, int C, int H, int W,
+                                                           int pad_h, int pad_w, int Hp, int Jp) {
+  const long long total = (long long)N * Hp * Jp;
+  for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
+    const int jp = (int)(id % Jp);
+    const long long rest = id / Jp;
+    const int hp = (int)(rest % Hp);
+    const int n = (int)(rest / Hp);
+    const int h = hp - pad_h;
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int w = 2 * jp + j - pad_w;
+      const bool in = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        f[j * 4 + c] = (in && c < C) ? x[(((size_t)n * C + c) * H + h) * W + w] : 0.f;
+    }
+    cn_st16(y + (size_t)id * 16, Chunk<bf16_t>::pack(f));
+  }
+}
+
 // NHWC T -> NCHW fp32 (only used to hand feature maps back in the reference layout)
 template <typename T>
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const char* x, float* y, int N, int C, int HW,
@@ -290,6 +317,18 @@ extern "C" int cn_nchw_to_nhwc(const float* x, void* y, int N, int C, int H, int
   dim3 grid(pool_grid((long long)N * H * W * (Cpad / CH)));
   POOL_DISPATCH(nchw_to_nhwc_kernel, grid, (hipStream_t)stream, x, (char*)y, N, C, H * W, Cpad);
   return cn_check_launch("nchw_to_nhwc");
+}
+
+extern "C" int cn_nchw_to_pairs(const float* x, void* y, int N, int C, int H, int W, int pad_h, int pad_w,
+                                void* stream) {
+  if (C < 1 || C > 4 || N <= 0 || H <= 0 || W <= 0 || pad_h < 0 || pad_w < 0 || ((W + 2 * pad_w) & 1)) {
+    cn_set_error("nchw_to_pairs: need 1 <= C <= 4 and an even padded width (C=%d, W=%d, pad_w=%d)", C, W, pad_w);
+    return CN_ESHAPE;
+  }
+  const int Hp = H + 2 * pad_h, Jp = (W + 2 * pad_w) / 2;
+  dim3 grid(pool_grid((long long)N * Hp * Jp));
+  CN_LAUNCH(nchw_to_pairs_kernel, grid, dim3(256), (hipStream_t)stream, x, (char*)y, N, C, H, W, pad_h, pad_w, Hp, Jp);
+  return cn_check_launch("nchw_to_pairs");
 }
 
 extern "C" int cn_nhwc_to_nchw(const void* x, float* y, int N, int C, int H, int W, int Cpad, int dtype,

@@ -419,7 +419,11 @@ static WgradPlan wg_plan(int M, int Co, int ntaps, int Ci, int dtype) {
   pl.n_jtiles = (pl.ncols + pl.BJ - 1) / pl.BJ;
   int tiles = pl.n_itiles * pl.n_jtiles;
   int stages = (M + pl.BKP - 1) / pl.BKP;
-  const int target = cn_get_option("wgrad_target_wgs", 512);   // ~2 workgroups per CU (tuning knob; 384..1024 measured within 1 %)
+  // workgroups per launch: ~2 per CU for the 128-wide tile (fewer, longer splits = less partial traffic),
+  // ~4 per CU for the 64-wide one (small LDS / register footprint; measured per layer, profiles/README.md).
+  // Tuning knob "wgrad_target_wgs" overrides both.
+  int target = cn_get_option("wgrad_target_wgs", 0);
+  if (target <= 0) target = pl.BI == 64 ? 1024 : 512;
   int want = (target + tiles - 1) / tiles;
   int max_split = (stages + 7) / 8;               // at least 8 stages per split
   if (max_split < 1) max_split = 1;

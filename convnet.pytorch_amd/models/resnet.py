@@ -199,10 +199,10 @@ class ResNetImagenet(tnn.Module):
 
     def features(self, x):
         """x: fp32 NCHW (the loader layout) or an already-converted NHWC compute tensor."""
-        dtype = self.conv1.compute_dtype
         if x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3 and x.shape[-1] != self.conv1.padded_in_channels():
-            x = cnn.to_nhwc(x, dtype, self.conv1.padded_in_channels())
-        x = self.conv1(x)
+            x = self.conv1.forward_from_nchw(x)
+        else:
+            x = self.conv1(x)
         x = self.bn1(x, relu=True)
         x = self.maxpool(x)
         x = self.layer1(x)

@@ -108,6 +108,23 @@ class Conv2d(_ArenaModule):
             return y.view(x.shape[0], 1, 1, self.out_channels)
         return ops.Conv2dFunction.apply(x, self.weight, self.bias, self)
 
+    def pair_eligible(self, x_nchw):
+        """The pixel-pair stem form (ops.StemPairConvFunction) applies: bf16, <= 4 input channels, stride 2,
+        no bias, no input gradient needed, even padded width."""
+        return (ops.STEM_PAIRS and self.compute_dtype == torch.bfloat16 and self.in_channels <= 4
+                and self.bias is None and self.stride == (2, 2) and not getattr(self, 'needs_dgrad', True)
+                and x_nchw.dim() == 4 and (x_nchw.shape[3] + 2 * self.padding[1]) % 2 == 0
+                and x_nchw.shape[2] + 2 * self.padding[0] >= self.kernel_size[0])
+
+    def forward_from_nchw(self, x_nchw):
+        """The host->device boundary of trainer.py:116-117 fused with the first convolution: fp32 NCHW
+        batch -> layout conversion in the form this conv consumes -> conv."""
+        self._require_prepared()
+        if self.pair_eligible(x_nchw):
+            xp = ops.nchw_to_pairs(x_nchw, self.padding)
+            return ops.StemPairConvFunction.apply(xp, self.weight, self)
+        return self.forward(ops.nchw_to_nhwc(x_nchw, self.compute_dtype, self.padded_in_channels()))
+
     def extra_repr(self):
         return '{}, {}, kernel_size={}, stride={}, padding={}, bias={}'.format(
             self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding,

@@ -134,6 +134,8 @@ def conv_out_hw(H, W, R, S, stride, pad):
 
 # A/B switch: 0 = every BatchNorm re-reads its input for the statistics (bn_stats_kernel)
 FUSE_BN_STATS = os.environ.get('CONVNET_AMD_FUSE_BN_STATS', '1') != '0'
+# A/B switch: 0 = the stem runs as a 49-tap conv on a 3->8 channel padded image instead of the pixel-pair form
+STEM_PAIRS = os.environ.get('CONVNET_AMD_STEM_PAIRS', '1') != '0'
 # A/B switch: 0 = BatchNorm backward always runs its own reduction pass over (dz, y)
 FUSE_BN_BWD = os.environ.get('CONVNET_AMD_FUSE_BN_BWD', '1') != '0'
 
@@ -272,6 +274,19 @@ def nchw_to_nhwc(x_nchw, dtype, c_pad=None):
     return y
 
 
+def nchw_to_pairs(x_nchw, pad):
+    """fp32 NCHW (C <= 4) -> zero-padded bf16 pixel-pair image [N, H+2ph, (W+2pw)/2, 8] (cn_nchw_to_pairs)."""
+    N, C, H, W = x_nchw.shape
+    x_nchw = x_nchw.contiguous()
+    if x_nchw.dtype != torch.float32:
+        raise _lib.ConvNetHipError('nchw_to_pairs expects float32 input, got %s' % x_nchw.dtype)
+    y = torch.empty((N, H + 2 * pad[0], (W + 2 * pad[1]) // 2, 8), dtype=torch.bfloat16, device=x_nchw.device)
+    PROFILER.run('nchw_to_pairs', 1, 0.0, x_nchw.numel() * 4 + y.numel() * 2,
+                 lambda: check(_L().cn_nchw_to_pairs(ptr(x_nchw), ptr(y), N, C, H, W, pad[0], pad[1],
+                                                     stream_of(x_nchw)), 'cn_nchw_to_pairs'), x_nchw.device)
+    return y
+
+
 def nhwc_to_nchw(x_nhwc, C=None):
     N, H, W, Cp = x_nhwc.shape
     C = C or Cp
@@ -402,6 +417,56 @@ def _sync_group(mod):
     group = None if sg is True else sg
     world = dist.get_world_size(group)
     return (group, world) if world > 1 else None
+
+
+class StemPairConvFunction(Function):
+    """The stride-2 stem convolution on the pixel-pair image (ops.nchw_to_pairs): same result as
+    Conv2dFunction on the channel-padded NHWC image, with ceil(S/2) instead of S reduction chunks per
+    filter row and no bounds tests.  The network input needs no gradient, so backward is wgrad only."""
+
+    @staticmethod
+    def forward(ctx, x_pairs, weight, mod):
+        K, (R, S) = mod.out_channels, mod.kernel_size
+        S2 = (S + 1) // 2
+        L = _L()
+        wp = torch.empty(K * R * S2 * 8, dtype=torch.bfloat16, device=x_pairs.device)
+        check(L.cn_weight_prep_pairs(ptr(mod.master_view('weight')), ptr(wp), K, R, S, mod.in_channels,
+                                     stream_of(x_pairs)), 'cn_weight_prep_pairs')
+        y = conv2d_fwd(x_pairs, wp, None, K, R, S2, (mod.stride[0], 1), (0, 0),
+                       bn_stats=FUSE_BN_STATS and mod.training and getattr(mod, 'feeds_batchnorm', False))
+        ctx.mod = mod
+        ctx.save_for_backward(x_pairs)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        mod = ctx.mod
+        dy = dy.contiguous()
+        K, (R, S) = mod.out_channels, mod.kernel_size
+        S2 = (S + 1) // 2
+        L = _L()
+
+        def run(tag):
+            tmp = torch.empty(K * R * S2 * 8, dtype=torch.float32, device=x.device)
+            conv2d_wgrad(x, dy, tmp, 8, K, R, S2, (mod.stride[0], 1), (0, 0), beta=0.0, tag=tag)
+            check(L.cn_wgrad_unpack_pairs(ptr(tmp), ptr(mod.grad_view('weight')), K, R, S, mod.in_channels, 1.0,
+                                          stream_of(x)), 'cn_wgrad_unpack_pairs')
+            return tmp
+
+        if SIDE.active(x):
+            cur = torch.cuda.current_stream(x.device)
+            side = SIDE.get(x.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                tmp = run('side')
+            for t in (x, dy, tmp):
+                t.record_stream(side)
+            SIDE.used = True
+        else:
+            run('main')
+        mod._notify_grad_ready()
+        return None, None, None
 
 
 class BatchNormActFunction(Function):

@@ -140,6 +140,15 @@ int cn_avgpool_bwd(const void* dy, void* dx, int N, int HW, int C, int dtype, vo
 /* ---- host->device boundary and autograd fan-in (trainer.py:116-117; models/resnet.py:115,162) */
 int cn_nchw_to_nhwc(const float* x_nchw, void* y_nhwc, int N, int C, int H, int W, int Cpad, int dtype,
                     void* stream);
+/* Stride-2 stem (models/resnet.py:226, 7x7/2 pad 3 on 3 channels) in "pixel pair" form: the fp32 NCHW batch
+ * becomes a zero-padded bf16 image [N][H+2*pad_h][(W+2*pad_w)/2][8] whose 16-byte chunks hold two adjacent
+ * pixels x 4 channels; with the filter packed the same way (cn_weight_prep_pairs: [K][R][ceil(S/2)][8]) the
+ * stem is cn_conv2d_fwd(C=8, R, S=ceil(S/2), stride (2,1), pad 0) - 28 instead of 49 reduction chunks for
+ * 7x7 and no bounds tests; cn_conv2d_wgrad on the same view + cn_wgrad_unpack_pairs gives the KRSC gradient. */
+int cn_nchw_to_pairs(const float* x_nchw, void* y_pairs, int N, int C, int H, int W, int pad_h, int pad_w,
+                     void* stream);
+int cn_weight_prep_pairs(const float* master_krsc, void* out_pairs, int K, int R, int S, int C, void* stream);
+int cn_wgrad_unpack_pairs(const float* packed, float* dw_krsc, int K, int R, int S, int C, float beta, void* stream);
 int cn_nhwc_to_nchw(const void* x_nhwc, float* y_nchw, int N, int C, int H, int W, int Cpad, int dtype,
                     void* stream);
 /* op 0: a += b;  1: a = relu(b);  2: a = b * (c > 0);  3: a = b * c.  n elements (multiple of the chunk). */

@@ -311,6 +311,44 @@ def test_sync_batchnorm_building_blocks(mode, dtype):
 
 
 @pytest.mark.parametrize('mode', MODES)
+def test_stem_pixel_pair_convolution(mode):
+    """The stride-2 stem in pixel-pair form (cn_nchw_to_pairs + cn_weight_prep_pairs + igemm with
+    ceil(S/2) taps per row + cn_wgrad_unpack_pairs) against F.conv2d (models/resnet.py:226: 7x7/2 pad 3,
+    3 input channels), plus an even kernel and a 1-channel input."""
+    dev = _dev(mode)
+    import convnet_amd as ca
+    cases = [(2, 3, 20, 20, 64, 7, 3), (1, 1, 12, 18, 16, 4, 1), (2, 4, 9, 14, 72, 3, 1)]
+    if mode == 'gpu':
+        cases += [(4, 3, 224, 224, 64, 7, 3)]
+    for (N, C, H, W, K, R, pad) in cases:
+        g = torch.Generator().manual_seed(H + K)
+        x = _q(torch.randn(N, C, H, W, generator=g), torch.bfloat16)
+        conv = ca.nn.Conv2d(C, K, kernel_size=R, stride=2, padding=pad, bias=False)
+        conv.needs_dgrad = False
+        model = torch.nn.Sequential(conv)
+        ca.engine.prepare(model, dev, torch.bfloat16)
+        w0 = _q(torch.randn(K, C, R, R, generator=g) * (2.0 / (C * R * R)) ** 0.5, torch.bfloat16)
+        conv.weight.data.copy_(w0.to(dev))
+        model._cn_arena.bump_version()
+        assert conv.pair_eligible(x)
+        xr, wr = x.clone().requires_grad_(False), w0.clone().requires_grad_(True)
+        y_ref = F.conv2d(xr, wr, stride=2, padding=pad)
+        dy = _q(torch.randn(y_ref.shape, generator=g), torch.bfloat16)
+        y_ref.backward(dy)
+        model._cn_arena.zero_grad()
+        y = conv.forward_from_nchw(x.to(dev))
+        assert tuple(y.shape) == (N, y_ref.shape[2], y_ref.shape[3], K)
+        assert rel_l2(y.float().cpu().permute(0, 3, 1, 2), y_ref.detach()) < 1e-2
+        y.backward(_nhwc(dy, torch.bfloat16, dev))
+        ca.ops.SIDE.join(dev) if dev.type == 'cuda' else None
+        assert rel_l2(conv.weight.grad.float().cpu(), wr.grad) < 1e-2
+        # and it agrees with the channel-padded 49-tap form of the same conv
+        model._cn_arena.zero_grad()
+        y2 = conv(ca.nn.to_nhwc(x.to(dev), torch.bfloat16, conv.padded_in_channels()))
+        assert rel_l2(y.float().cpu(), y2.float().cpu()) < 4e-3
+
+
+@pytest.mark.parametrize('mode', MODES)
 def test_wgrad_accumulates_and_scales(mode):
     dev = _dev(mode)
     import convnet_amd as ca
