@@ -218,10 +218,20 @@ class BucketReducer(object):
         b = slot.bucket
         self._pending[b] -= 1
         if self._pending[b] == 0:
-            ops.SIDE.join(self.arena.device)   # wgrad kernels of this bucket may sit on the side stream
             start, length, _ = self.arena.buckets[b]
             view = self.arena.grads[start:start + length]
-            self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            dev = self.arena.device
+            if dev.type == 'cuda' and ops.SIDE.enabled and ops.SIDE.used:
+                # The bucket's weight gradients are queued on the wgrad side stream, its BN / bias gradients
+                # on the main stream.  Issue the collective from the side stream after making IT wait for
+                # the main stream: the communication stream then depends on both, while the main stream
+                # (dgrad / BN chain) is never stalled at a bucket boundary.  finish() joins everything.
+                side = ops.SIDE.get(dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            else:
+                self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def finish(self):
         """Flush buckets that never filled (unused parameters) and wait for all reductions."""
