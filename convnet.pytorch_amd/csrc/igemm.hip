@@ -515,11 +515,12 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
                 for (int e = 0; e < EPC; ++e) fv[e] = fmaf(yv[e], bsc[e], bsh[e]) > 0.f ? fv[e] : 0.f;
               }
               v = Chunk<TO>::pack(fv);
-              Chunk<TO>::unpack(v, fv);   // statistics of the values as stored (rounded)
+              // statistics of the values as stored: exact already unless an addend made fv wider than T
+              if (p.addend != nullptr) Chunk<TO>::unpack(v, fv);
 #pragma unroll
-              for (int e = 0; e < EPC; ++e) {
+              for (int e = 0; e < EPC; ++e) {   // sum g and sum g*y; the mean / invstd fix-up is per thread, below
                 bs1[e] += fv[e];
-                bs2[e] = fmaf(fv[e], (yv[e] - bmu[e]) * bis[e], bs2[e]);
+                bs2[e] = fmaf(fv[e], yv[e], bs2[e]);
               }
             } else {
               v = Chunk<TO>::pack(fv);
@@ -547,7 +548,12 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
     __syncthreads();   // the out tile has been consumed: its first 16 KiB take the per-thread partials
     float* red = (float*)lds;
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) { red[tid * 2 * EPC + e] = bs1[e]; red[tid * 2 * EPC + EPC + e] = bs2[e]; }
+    for (int e = 0; e < EPC; ++e) {
+      // sum g*xhat = invstd * (sum g*y - mean * sum g) over this thread's <= 16 rows (fp32: the cancellation
+      // costs ~1e-7 * |mean|/sigma relative, far inside the stated tolerances)
+      red[tid * 2 * EPC + e] = bs1[e];
+      red[tid * 2 * EPC + EPC + e] = bis[e] * (bs2[e] - bmu[e] * bs1[e]);
+    }
     __syncthreads();
     if (tid < BN) {
       const int cchunk = tid / EPC, e = tid % EPC;
