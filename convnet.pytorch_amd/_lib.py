@@ -36,7 +36,7 @@ _SIGNATURES = {
     'cn_conv2d_bnstats_rows': (c_i, [c_ll]),
     'cn_conv2d_fwd_bnstats': (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 11 + [c_i, c_i, c_p, c_i, c_p]),
     'cn_conv2d_dgrad': (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 11 + [c_i, c_i, c_p]),
-    'cn_conv2d_dgrad_bnbwd_rows': (c_i, [c_i] * 5),
+    'cn_conv2d_dgrad_bnbwd_rows': (c_i, [c_i] * 6),
     'cn_conv2d_dgrad_bnbwd': (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 11 + [c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_p]),
     'cn_conv2d_wgrad_workspace': (c_sz, [c_i] * 12),
     'cn_conv2d_wgrad': (c_i, [c_p, c_p, c_p, c_i] + [c_i] * 11 + [c_i, c_f, c_f, c_p, c_sz, c_p]),
@@ -113,6 +113,7 @@ def load():
             raise ConvNetHipError('emulator library missing: run csrc/build.sh emul')
         _lib = _bind(EMUL_LIB)
         _emulated = True
+        _apply_env_options(_lib)
         return _lib
     if not os.path.exists(HIP_LIB):
         raise ConvNetHipError(

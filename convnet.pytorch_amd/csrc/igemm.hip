@@ -599,6 +599,10 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+static bool ig_epi_bm64() { return cn_get_option("igemm_epi_bm64", 0) != 0; }
+// pixels per partial row of the fused BN-backward reduction for an output of Co channels
+static int ig_epi_rows_bm(int Co) { return (Co > 64 && ig_epi_bm64()) ? 64 : 128; }
+
 template <typename T, bool OUTF32>
 static int ig_launch(IgemmParams& p, hipStream_t stream) {
   const int nkt = (p.nchunks + 7) / 8;
@@ -607,7 +611,11 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
   int variant = cn_get_option("igemm_variant", 0);
   if (variant < 1 || variant > 6) variant = cn_get_option("igemm_default_variant", nkt < 24 ? 1 : 3);
   if ((p.stats != nullptr || p.bn_y != nullptr || p.addend != nullptr) && variant == 6) variant = 3;   // 128-pixel tiles   // statistics rows are defined per 128-pixel tile
-  const int BM = (variant == 6 && p.Co > 64) ? 256 : 128, BN = p.Co <= 64 ? 64 : 128;
+  const bool epi = p.addend != nullptr || p.bn_y != nullptr;
+  // EPI launches on wide outputs can run on 64-pixel tiles (32 accumulator registers, half the prefetch
+  // registers: 3 workgroups per CU instead of 2); knob "igemm_epi_bm64"
+  const bool bm64 = epi && p.Co > 64 && ig_epi_bm64();
+  const int BM = bm64 ? 64 : ((variant == 6 && p.Co > 64) ? 256 : 128), BN = p.Co <= 64 ? 64 : 128;
   p.n_ntiles = (p.Co + BN - 1) / BN;
   const int n_mtiles = (p.M + BM - 1) / BM;
   p.n_mtiles = n_mtiles;
@@ -619,7 +627,6 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
   }
   dim3 grid((unsigned)(p.n_ntiles * n_mtiles));
   // EPI: epilogue with global-side operands (residual-branch addend, fused BN-backward reduction)
-  const bool epi = p.addend != nullptr || p.bn_y != nullptr;
 #define IG_GO2(WC, WP, TI, TJ, EP)                                                                              \
   do {                                                                                                         \
     if (variant == 1) CN_LAUNCH((igemm_kernel<T, WC, WP, TI, TJ, 1, OUTF32, false, false, EP>), grid, dim3(256), stream, p); \
@@ -638,6 +645,7 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
   }
   if (variant >= 4) variant = 3;
   if (p.Co <= 64) IG_GO(1, 4, 2, 1);
+  else if (bm64) IG_GO2(2, 2, 2, 1, true);
   else IG_GO(2, 2, 2, 2);
 #undef IG_GO
 #undef IG_GO2
@@ -797,7 +805,8 @@ static int ig_conv_dgrad(const void* dy, const void* w_crsk, void* dx, const voi
       for (int t = 0; t < nt; ++t) { p.tap_dhdw[t] = dhdw[t]; p.tap_woff[t] = woff[t]; }
       p.simple = ig_is_simple(p, dhdw, nt);
       if (bn != nullptr) {
-        const int rows = (p.M + 127) / 128;
+        const int rbm = ig_epi_rows_bm(p.Co);
+        const int rows = (p.M + rbm - 1) / rbm;
         if (bn_row + rows > bn->rows_cap) {
           cn_set_error("conv2d_dgrad_bnbwd: partial buffer of %d rows is too small", bn->rows_cap);
           return CN_EWORKSPACE;
@@ -819,14 +828,16 @@ extern "C" int cn_conv2d_dgrad(const void* dy, const void* w_crsk, void* dx, con
                        out_f32, nullptr, stream);
 }
 
-// Partial rows cn_conv2d_dgrad_bnbwd writes: one per 128-pixel tile of every output-parity class.
-extern "C" int cn_conv2d_dgrad_bnbwd_rows(int N, int H, int W, int stride_h, int stride_w) {
+// Partial rows cn_conv2d_dgrad_bnbwd writes: one per pixel tile (128, or 64 with "igemm_epi_bm64") of every
+// output-parity class.
+extern "C" int cn_conv2d_dgrad_bnbwd_rows(int N, int H, int W, int C, int stride_h, int stride_w) {
   int rows = 0;
+  const int rbm = ig_epi_rows_bm(C);
   for (int ph = 0; ph < stride_h; ++ph)
     for (int pw = 0; pw < stride_w; ++pw) {
       const long long hg = (H - ph + stride_h - 1) / stride_h, wg = (W - pw + stride_w - 1) / stride_w;
       if (hg <= 0 || wg <= 0) continue;
-      rows += (int)(((long long)N * hg * wg + 127) / 128);
+      rows += (int)(((long long)N * hg * wg + rbm - 1) / rbm);
     }
   return rows;
 }

@@ -216,7 +216,7 @@ def conv2d_dgrad(dy, w_crsk, x_shape, K, R, S, stride, pad, addend=None, bn=None
         return dx
     bn_y, bn_mask, bn_stats, bn_relu = bn
     L = _L()
-    rows = L.cn_conv2d_dgrad_bnbwd_rows(N, H, W, stride[0], stride[1])
+    rows = L.cn_conv2d_dgrad_bnbwd_rows(N, H, W, C, stride[0], stride[1])
     partial = torch.empty((rows, 2 * C), dtype=torch.float32, device=dy.device)
     PROFILER.run(name, stride[0] * stride[1], flops, nbytes + dx.numel() * _esize(dx) + partial.numel() * 4,
                  lambda: check(L.cn_conv2d_dgrad_bnbwd(ptr(dy), ptr(w_crsk), ptr(dx), ptr(addend), N, H, W, C, K, R, S,

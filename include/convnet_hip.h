@@ -64,7 +64,7 @@ int cn_conv2d_dgrad(const void* dy, const void* w_crsk, void* dx, const void* ad
  * (mask bits from bn_mask, or recomputed from bn_y*scale+shift > 0 when bn_relu and bn_mask == NULL) and one
  * partial row [sum g | sum g*xhat] (2*C floats) per 128-pixel tile for cn_bn_bwd_partials.
  * bn_coef = the 4*C floats cn_bn_fwd_train wrote. */
-int cn_conv2d_dgrad_bnbwd_rows(int N, int H, int W, int stride_h, int stride_w);
+int cn_conv2d_dgrad_bnbwd_rows(int N, int H, int W, int C, int stride_h, int stride_w);
 int cn_conv2d_dgrad_bnbwd(const void* dy, const void* w_crsk, void* g, const void* addend, int N, int H, int W,
                           int C, int K, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w, int dtype,
                           const void* bn_y, const unsigned char* bn_mask, const float* bn_coef, int bn_relu,

@@ -194,7 +194,7 @@ def test_dgrad_epilogue_bn_backward_reduction(mode, dtype):
                                             bn=(bn_y, bits, stats, True))
         g_ref = torch.where(on.view(N, H, W, C), dx_plain, torch.zeros_like(dx_plain))
         assert torch.equal(g.cpu(), g_ref.cpu()), (N, H, W, C, K, R, st)
-        assert rows == L.cn_conv2d_dgrad_bnbwd_rows(N, H, W, st, st) and tuple(partial.shape) == (rows, 2 * C)
+        assert rows == L.cn_conv2d_dgrad_bnbwd_rows(N, H, W, C, st, st) and tuple(partial.shape) == (rows, 2 * C)
         gd = g.float().reshape(M, C).double()
         xhat = ((yf - mean) * invstd).double()
         s1, s2 = partial[:, :C].double().sum(0), partial[:, C:].double().sum(0)
