@@ -409,6 +409,140 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char* dz, const
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Stem variant: the upstream gradient is the gradient of the max-pooled map (models/resnet.py:228-230:
+// bn1 -> relu -> maxpool).  dz[n,h,w,c] is gathered on the fly from the pooled gradient and the winning
+// taps the fused forward stored (cn_maxpool_fwd_bnrelu), so the dense 112x112 dz is never written or
+// re-read: both passes read y plus (L2-resident) pooled data.
+struct BnPoolGeom {
+  const char* dpool;            // [N,P,Q,C] gradient of the pooled map
+  const unsigned char* idx;     // [N,P,Q,C] winning tap (kh*k + kw) per pooled element
+  int H, W, P, Q, k, st, pad;
+  FastDiv div_hw, div_w;
+};
+
+template <typename T>
+__device__ __forceinline__ void bn_pool_gather(const BnPoolGeom& g, int row, int col, int C, float* out) {
+  constexpr int CH = ElemTraits<T>::kChunk;
+  constexpr int EB = ElemTraits<T>::kBytes;
+  const int n = (int)cn_fastdiv((unsigned)row, g.div_hw);
+  const int rem = row - n * g.H * g.W;
+  const int h = (int)cn_fastdiv((unsigned)rem, g.div_w);
+  const int w = rem - h * g.W;
+#pragma unroll
+  for (int e = 0; e < CH; ++e) out[e] = 0.f;
+  int p_lo = h + g.pad - g.k + 1;
+  p_lo = p_lo > 0 ? (p_lo + g.st - 1) / g.st : 0;
+  int p_hi = (h + g.pad) / g.st;
+  if (p_hi > g.P - 1) p_hi = g.P - 1;
+  int q_lo = w + g.pad - g.k + 1;
+  q_lo = q_lo > 0 ? (q_lo + g.st - 1) / g.st : 0;
+  int q_hi = (w + g.pad) / g.st;
+  if (q_hi > g.Q - 1) q_hi = g.Q - 1;
+  for (int pp = p_lo; pp <= p_hi; ++pp)
+    for (int q = q_lo; q <= q_hi; ++q) {
+      const int t = (h - (pp * g.st - g.pad)) * g.k + (w - (q * g.st - g.pad));
+      const size_t o = ((size_t)(n * g.P + pp) * g.Q + q) * C + (size_t)col * CH;
+      float v[CH];
+      Chunk<T>::unpack(cn_ld16(g.dpool + o * EB), v);
+      unsigned long long pk;
+      if (CH == 8) pk = *(const unsigned long long*)(g.idx + o);
+      else pk = *(const unsigned int*)(g.idx + o);
+#pragma unroll
+      for (int e = 0; e < CH; ++e)
+        if ((int)((pk >> (8 * e)) & 0xffull) == t) out[e] += v[e];
+    }
+  Chunk<T>::unpack(Chunk<T>::pack(out), out);   // what the unfused chain's max-pool backward would have stored
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(BnPoolGeom geo, const char* y, const float* mean,
+                                                                const float* invstd, const float* scale,
+                                                                const float* shift, float* partial, int M, int C,
+                                                                int tpr_log2) {
+  constexpr int CH = ElemTraits<T>::kChunk;
+  constexpr int EB = ElemTraits<T>::kBytes;
+  __shared__ float red[256 * 2 * CH];
+  const int tid = threadIdx.x;
+  const int tpr = 1 << tpr_log2, rpp = 256 >> tpr_log2;
+  const int cpr = C / CH;
+  const int tcol = tid & (tpr - 1), rsub = tid >> tpr_log2;
+  const int col = blockIdx.y * tpr + tcol;
+  float s1[CH], s2[CH];
+#pragma unroll
+  for (int e = 0; e < CH; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  if (col < cpr) {
+    float mu[CH], is[CH], sc[CH], sh[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+      mu[e] = mean[col * CH + e];
+      is[e] = invstd[col * CH + e];
+      sc[e] = scale[col * CH + e];
+      sh[e] = shift[col * CH + e];
+    }
+    const int step = gridDim.x * rpp;
+    for (int row = blockIdx.x * rpp + rsub; row < M; row += step) {
+      float g[CH], v[CH];
+      Chunk<T>::unpack(cn_ld16(y + ((size_t)row * C + (size_t)col * CH) * EB), v);
+      bn_pool_gather<T>(geo, row, col, C, g);
+#pragma unroll
+      for (int e = 0; e < CH; ++e) {
+        const float gm = fmaf(v[e], sc[e], sh[e]) > 0.f ? g[e] : 0.f;
+        s1[e] += gm;
+        s2[e] = fmaf(gm, (v[e] - mu[e]) * is[e], s2[e]);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < CH; ++e) { red[tid * 2 * CH + e] = s1[e]; red[tid * 2 * CH + CH + e] = s2[e]; }
+  __syncthreads();
+  if (rsub == 0 && col < cpr) {
+    for (int r = 1; r < rpp; ++r) {
+      const float* o = red + (r * tpr + tcol) * 2 * CH;
+#pragma unroll
+      for (int e = 0; e < CH; ++e) { s1[e] += o[e]; s2[e] += o[CH + e]; }
+    }
+    float* dst = partial + (size_t)blockIdx.x * 2 * C + col * CH;
+#pragma unroll
+    for (int e = 0; e < CH; ++e) { dst[e] = s1[e]; dst[C + e] = s2[e]; }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(BnPoolGeom geo, const char* y, const float* scale,
+                                                               const float* shift, const float* coef, char* dy,
+                                                               int M, int C, int tpr_log2) {
+  constexpr int CH = ElemTraits<T>::kChunk;
+  constexpr int EB = ElemTraits<T>::kBytes;
+  const int tid = threadIdx.x;
+  const int tpr = 1 << tpr_log2, rpp = 256 >> tpr_log2;
+  const int cpr = C / CH;
+  const int col = blockIdx.y * tpr + (tid & (tpr - 1)), rsub = tid >> tpr_log2;
+  if (col >= cpr) return;
+  float c1[CH], c2[CH], c3[CH], sc[CH], sh[CH];
+#pragma unroll
+  for (int e = 0; e < CH; ++e) {
+    c1[e] = coef[col * CH + e];
+    c2[e] = coef[C + col * CH + e];
+    c3[e] = coef[2 * C + col * CH + e];
+    sc[e] = scale[col * CH + e];
+    sh[e] = shift[col * CH + e];
+  }
+  const int step = gridDim.x * rpp;
+  for (int row = blockIdx.x * rpp + rsub; row < M; row += step) {
+    const size_t off = ((size_t)row * C + (size_t)col * CH) * EB;
+    float g[CH], v[CH], o[CH];
+    Chunk<T>::unpack(cn_ld16(y + off), v);
+    bn_pool_gather<T>(geo, row, col, C, g);
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+      const float gm = fmaf(v[e], sc[e], sh[e]) > 0.f ? g[e] : 0.f;
+      o[e] = fmaf(c1[e], gm, fmaf(c2[e], v[e], c3[e]));
+    }
+    cn_st16(dy + off, Chunk<T>::pack(o));
+  }
+}
+
 // Inference-mode backward is not part of the reference hot path (validate() runs under no_grad).
 
 // ------------------------------------------------------------------------------------------------
@@ -445,6 +579,7 @@ static int bn_fwd_tail(const float* partial, int nrb, const void* y, const void*
   CN_LAUNCH(bn_finalize_kernel, dim3((unsigned)((C + BN_FC - 1) / BN_FC)), dim3(256), stream, partial, nrb,
             M, C, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, stats_out,
             stats_out + C, stats_out + 2 * C, stats_out + 3 * C);
+  if (z == nullptr) return cn_check_launch("bn_fwd_train");   // statistics only (the consumer applies them itself)
   int nab = bn_row_blocks(M, m, cn_get_option("bn_apply_blocks", BN_APPLY_BLOCKS));
   dim3 agrid((unsigned)nab, (unsigned)m.gy);
   const int rev = cn_get_option("bn_reverse", BN_REVERSE_DEFAULT) & 1;
@@ -828,4 +963,57 @@ extern "C" int cn_bn_bwd_sums(const void* dz, const void* y, const unsigned char
     CN_LAUNCH(bn_bwd_apply_kernel<float>, agrid, dim3(256), stream, (const char*)dz, (const char*)y, amask, scale,
               shift, (const float*)coef_scratch, (char*)dy, (char*)dres, M, C, arelu, m.tpr_log2, 0);
   return cn_check_launch("bn_bwd_sums");
+}
+
+// Backward of bn -> relu -> maxpool(k, stride, pad) given the gradient of the pooled map: the pool's
+// gather backward is folded into both BatchNorm-backward passes (no dense dz tensor).
+// y = BN input [N,H,W,C]; dpool / idx = [N,P,Q,C]; stats = the 4*C floats of the forward.
+extern "C" int cn_bn_bwd_maxpool(const void* dpool, const unsigned char* idx, const void* y, const float* gamma,
+                                 const float* stats, void* dy, float* dgamma, float* dbeta, float beta_acc,
+                                 float gscale, float* coef_scratch, int N, int H, int W, int C, int k, int stride,
+                                 int pad, int dtype, void* workspace, size_t ws_bytes, void* stream_) {
+  const long long Ml = (long long)N * H * W;
+  if (Ml >= (1ll << 31)) { cn_set_error("bn_bwd_maxpool: too many rows"); return CN_ESHAPE; }
+  const int M = (int)Ml;
+  int rc = bn_check("bn_bwd_maxpool", M, C, dtype);
+  if (rc) return rc;
+  if (k * k > 255 || pad * 2 > k || stride <= 0) { cn_set_error("bn_bwd_maxpool: unsupported window"); return CN_ESHAPE; }
+  hipStream_t stream = (hipStream_t)stream_;
+  const int CH = dtype == CN_BF16 ? 8 : 4;
+  BnMap m = bn_map(C / CH);
+  int nrb = bn_row_blocks(M, m, cn_get_option("bn_reduce_blocks", BN_TARGET_BLOCKS));
+  if (workspace == nullptr || ws_bytes < (size_t)nrb * 2 * C * sizeof(float)) {
+    cn_set_error("bn_bwd_maxpool: workspace too small");
+    return CN_EWORKSPACE;
+  }
+  BnPoolGeom geo;
+  geo.dpool = (const char*)dpool; geo.idx = idx;
+  geo.H = H; geo.W = W; geo.k = k; geo.st = stride; geo.pad = pad;
+  geo.P = (H + 2 * pad - k) / stride + 1;
+  geo.Q = (W + 2 * pad - k) / stride + 1;
+  geo.div_hw = cn_make_fastdiv((unsigned)(H * W));
+  geo.div_w = cn_make_fastdiv((unsigned)W);
+  float* partial = (float*)workspace;
+  const float* mean = stats;
+  const float* invstd = stats + C;
+  const float* scale = stats + 2 * C;
+  const float* shift = stats + 3 * C;
+  dim3 grid((unsigned)nrb, (unsigned)m.gy);
+  if (dtype == CN_BF16)
+    CN_LAUNCH(bn_bwd_reduce_pool_kernel<bf16_t>, grid, dim3(256), stream, geo, (const char*)y, mean, invstd, scale,
+              shift, partial, M, C, m.tpr_log2);
+  else
+    CN_LAUNCH(bn_bwd_reduce_pool_kernel<float>, grid, dim3(256), stream, geo, (const char*)y, mean, invstd, scale,
+              shift, partial, M, C, m.tpr_log2);
+  CN_LAUNCH(bn_bwd_finalize_kernel, dim3((unsigned)((C + BN_FC - 1) / BN_FC)), dim3(256), stream, (const float*)partial,
+            nrb, M, C, gamma, mean, invstd, dgamma, dbeta, beta_acc, gscale, coef_scratch);
+  int nab = bn_row_blocks(M, m, cn_get_option("bn_apply_blocks", BN_APPLY_BLOCKS));
+  dim3 agrid((unsigned)nab, (unsigned)m.gy);
+  if (dtype == CN_BF16)
+    CN_LAUNCH(bn_bwd_apply_pool_kernel<bf16_t>, agrid, dim3(256), stream, geo, (const char*)y, scale, shift,
+              (const float*)coef_scratch, (char*)dy, M, C, m.tpr_log2);
+  else
+    CN_LAUNCH(bn_bwd_apply_pool_kernel<float>, agrid, dim3(256), stream, geo, (const char*)y, scale, shift,
+              (const float*)coef_scratch, (char*)dy, M, C, m.tpr_log2);
+  return cn_check_launch("bn_bwd_maxpool");
 }

@@ -10,21 +10,30 @@
 #include "cn_common.h"
 #include "cn_api_internal.h"
 
-template <typename T>
+// Both max-pool kernels: blockIdx.y walks image rows (n, output row), blockIdx.x * 256 + tid walks the
+// (pixel, 16-byte channel chunk) pairs of one row - all index math is 32-bit with one host-precomputed
+// fast division (the first version spent three 64-bit divisions per thread and ran at 2.3 TB/s).
+// AFF: the input is a pre-BatchNorm tensor and every tap is first mapped through relu(x*scale[c] + shift[c])
+// - the stem's BatchNorm apply + ReLU + max-pool (models/resnet.py:228-230) in one pass, so the
+// normalised 112x112 map is never written to or re-read from HBM.
+template <typename T, bool AFF>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const char* x, char* y, unsigned char* idx, int N,
                                                          int H, int W, int C, int P, int Q, int k, int st,
-                                                         int pad) {
+                                                         int pad, FastDiv div_cpr, const float* scale,
+                                                         const float* shift) {
   constexpr int CH = ElemTraits<T>::kChunk;
   constexpr int EB = ElemTraits<T>::kBytes;
   const int cpr = C / CH;
-  const long long total = (long long)N * P * Q * cpr;
-  for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
-    const int col = (int)(id % cpr);
-    long long pix = id / cpr;
-    const int q = (int)(pix % Q);
-    pix /= Q;
-    const int pp = (int)(pix % P);
-    const int n = (int)(pix / P);
+  const int idr = blockIdx.x * 256 + threadIdx.x;
+  if (idr >= Q * cpr) return;
+  const int q = (int)cn_fastdiv((unsigned)idr, div_cpr);
+  const int col = idr - q * cpr;
+  const int w0 = q * st - pad;
+  float sc[CH], sh[CH];
+#pragma unroll
+  for (int e = 0; e < CH; ++e) { sc[e] = AFF ? scale[col * CH + e] : 1.f; sh[e] = AFF ? shift[col * CH + e] : 0.f; }
+  for (int row = blockIdx.y; row < N * P; row += gridDim.y) {
+    const int n = row / P, pp = row - n * P;
     float best[CH];
     int bi[CH];
 #pragma unroll
@@ -33,11 +42,20 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const char* x, char* y
     for (int r = 0; r < k; ++r) {
       const int h = pp * st - pad + r;
       if ((unsigned)h >= (unsigned)H) continue;
+      const char* xr = x + ((size_t)(n * H + h) * W * C + (size_t)col * CH) * EB;
       for (int s = 0; s < k; ++s) {
-        const int w = q * st - pad + s;
+        const int w = w0 + s;
         if ((unsigned)w >= (unsigned)W) continue;
         float f[CH];
-        Chunk<T>::unpack(cn_ld16(x + (((size_t)(n * H + h) * W + w) * C + (size_t)col * CH) * EB), f);
+        Chunk<T>::unpack(cn_ld16(xr + (size_t)w * C * EB), f);
+        if (AFF) {
+#pragma unroll
+          for (int e = 0; e < CH; ++e) {
+            const float v = fmaf(f[e], sc[e], sh[e]);
+            f[e] = v > 0.f ? v : 0.f;
+          }
+          Chunk<T>::unpack(Chunk<T>::pack(f), f);   // compare what the unfused chain would have stored (rounded z)
+        }
         const int t = r * k + s;
 #pragma unroll
         for (int e = 0; e < CH; ++e)
@@ -45,7 +63,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const char* x, char* y
         first = false;
       }
     }
-    const size_t o = ((size_t)(n * P + pp) * Q + q) * C + (size_t)col * CH;
+    const size_t o = ((size_t)row * Q + q) * C + (size_t)col * CH;
     cn_st16(y + o * EB, Chunk<T>::pack(best));
     if (CH == 8) {   // one 8-byte store of the chunk's winning taps
       unsigned long long pk = 0;
@@ -64,30 +82,28 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const char* x, char* y
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const char* dy, const unsigned char* idx, char* dx,
                                                          int N, int H, int W, int C, int P, int Q, int k,
-                                                         int st, int pad) {
+                                                         int st, int pad, FastDiv div_cpr) {
   constexpr int CH = ElemTraits<T>::kChunk;
   constexpr int EB = ElemTraits<T>::kBytes;
   const int cpr = C / CH;
-  const long long total = (long long)N * H * W * cpr;
-  for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
-    const int col = (int)(id % cpr);
-    long long pix = id / cpr;
-    const int w = (int)(pix % W);
-    pix /= W;
-    const int h = (int)(pix % H);
-    const int n = (int)(pix / H);
+  const int idr = blockIdx.x * 256 + threadIdx.x;
+  if (idr >= W * cpr) return;
+  const int w = (int)cn_fastdiv((unsigned)idr, div_cpr);
+  const int col = idr - w * cpr;
+  // windows q with q*st - pad <= w <= q*st - pad + k - 1
+  int q_lo = w + pad - k + 1;
+  q_lo = q_lo > 0 ? (q_lo + st - 1) / st : 0;
+  int q_hi = (w + pad) / st;
+  if (q_hi > Q - 1) q_hi = Q - 1;
+  for (int row = blockIdx.y; row < N * H; row += gridDim.y) {
+    const int n = row / H, h = row - n * H;
     float acc[CH];
 #pragma unroll
     for (int e = 0; e < CH; ++e) acc[e] = 0.f;
-    // windows p with p*st - pad <= h <= p*st - pad + k - 1
     int p_lo = h + pad - k + 1;
     p_lo = p_lo > 0 ? (p_lo + st - 1) / st : 0;
     int p_hi = (h + pad) / st;
     if (p_hi > P - 1) p_hi = P - 1;
-    int q_lo = w + pad - k + 1;
-    q_lo = q_lo > 0 ? (q_lo + st - 1) / st : 0;
-    int q_hi = (w + pad) / st;
-    if (q_hi > Q - 1) q_hi = Q - 1;
     for (int pp = p_lo; pp <= p_hi; ++pp)
       for (int q = q_lo; q <= q_hi; ++q) {
         const int t = (h - (pp * st - pad)) * k + (w - (q * st - pad));
@@ -101,7 +117,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const char* dy, const 
         for (int e = 0; e < CH; ++e)
           if ((int)((pk >> (8 * e)) & 0xffull) == t) acc[e] += g[e];
       }
-    cn_st16(dx + (((size_t)(n * H + h) * W + w) * C + (size_t)col * CH) * EB, Chunk<T>::pack(acc));
+    cn_st16(dx + (((size_t)row * W + w) * C + (size_t)col * CH) * EB, Chunk<T>::pack(acc));
   }
 }
 
@@ -272,10 +288,42 @@ extern "C" int cn_maxpool_fwd(const void* x, void* y, unsigned char* idx, int N,
   if (k * k > 255 || pad * 2 > k) { cn_set_error("maxpool_fwd: unsupported window"); return CN_ESHAPE; }
   const int P = (H + 2 * pad - k) / stride + 1, Q = (W + 2 * pad - k) / stride + 1;
   const int CH = dtype == CN_BF16 ? 8 : 4;
-  dim3 grid(pool_grid((long long)N * P * Q * (C / CH)));
-  POOL_DISPATCH(maxpool_fwd_kernel, grid, (hipStream_t)stream, (const char*)x, (char*)y, idx, N, H, W, C, P, Q, k,
-                stride, pad);
+  const long long rows_f = (long long)N * P;
+  dim3 grid((unsigned)((Q * (C / CH) + 255) / 256), (unsigned)(rows_f < 65535 ? rows_f : 65535));
+  const FastDiv div_cpr = cn_make_fastdiv((unsigned)(C / CH));
+  if (dtype == CN_BF16)
+    CN_LAUNCH((maxpool_fwd_kernel<bf16_t, false>), grid, dim3(256), (hipStream_t)stream, (const char*)x, (char*)y, idx,
+              N, H, W, C, P, Q, k, stride, pad, div_cpr, (const float*)nullptr, (const float*)nullptr);
+  else
+    CN_LAUNCH((maxpool_fwd_kernel<float, false>), grid, dim3(256), (hipStream_t)stream, (const char*)x, (char*)y, idx,
+              N, H, W, C, P, Q, k, stride, pad, div_cpr, (const float*)nullptr, (const float*)nullptr);
   return cn_check_launch("maxpool_fwd");
+}
+
+// y = maxpool(relu(x*scale + shift)): x is the pre-BatchNorm tensor, scale/shift the per-channel
+// coefficients cn_bn_fwd_train* wrote (stats_out + 2C / + 3C).  The pooled values are rounded to the
+// compute dtype exactly like the unfused chain rounds z before pooling it.
+extern "C" int cn_maxpool_fwd_bnrelu(const void* x, const float* scale, const float* shift, void* y,
+                                     unsigned char* idx, int N, int H, int W, int C, int k, int stride, int pad,
+                                     int dtype, void* stream) {
+  int rc = pool_check("maxpool_fwd_bnrelu", C, dtype);
+  if (rc) return rc;
+  if (k * k > 255 || pad * 2 > k || scale == nullptr || shift == nullptr) {
+    cn_set_error("maxpool_fwd_bnrelu: unsupported window or missing coefficients");
+    return CN_ESHAPE;
+  }
+  const int P = (H + 2 * pad - k) / stride + 1, Q = (W + 2 * pad - k) / stride + 1;
+  const int CH = dtype == CN_BF16 ? 8 : 4;
+  const long long rows_f = (long long)N * P;
+  dim3 grid((unsigned)((Q * (C / CH) + 255) / 256), (unsigned)(rows_f < 65535 ? rows_f : 65535));
+  const FastDiv div_cpr = cn_make_fastdiv((unsigned)(C / CH));
+  if (dtype == CN_BF16)
+    CN_LAUNCH((maxpool_fwd_kernel<bf16_t, true>), grid, dim3(256), (hipStream_t)stream, (const char*)x, (char*)y, idx,
+              N, H, W, C, P, Q, k, stride, pad, div_cpr, scale, shift);
+  else
+    CN_LAUNCH((maxpool_fwd_kernel<float, true>), grid, dim3(256), (hipStream_t)stream, (const char*)x, (char*)y, idx, N,
+              H, W, C, P, Q, k, stride, pad, div_cpr, scale, shift);
+  return cn_check_launch("maxpool_fwd_bnrelu");
 }
 
 extern "C" int cn_maxpool_bwd(const void* dy, const unsigned char* idx, void* dx, int N, int H, int W, int C,
@@ -284,9 +332,11 @@ extern "C" int cn_maxpool_bwd(const void* dy, const unsigned char* idx, void* dx
   if (rc) return rc;
   const int P = (H + 2 * pad - k) / stride + 1, Q = (W + 2 * pad - k) / stride + 1;
   const int CH = dtype == CN_BF16 ? 8 : 4;
-  dim3 grid(pool_grid((long long)N * H * W * (C / CH)));
+  const long long rows_b = (long long)N * H;
+  dim3 grid((unsigned)((W * (C / CH) + 255) / 256), (unsigned)(rows_b < 65535 ? rows_b : 65535));
+  const FastDiv div_cpr = cn_make_fastdiv((unsigned)(C / CH));
   POOL_DISPATCH(maxpool_bwd_kernel, grid, (hipStream_t)stream, (const char*)dy, idx, (char*)dx, N, H, W, C, P, Q, k,
-                stride, pad);
+                stride, pad, div_cpr);
   return cn_check_launch("maxpool_bwd");
 }
 

@@ -203,8 +203,7 @@ class ResNetImagenet(tnn.Module):
             x = self.conv1.forward_from_nchw(x)
         else:
             x = self.conv1(x)
-        x = self.bn1(x, relu=True)
-        x = self.maxpool(x)
+        x = cnn.bn_relu_maxpool(self.bn1, self.maxpool, x)
         x = self.layer1(x)
         x = self.layer2(x)
         x = self.layer3(x)

@@ -264,6 +264,20 @@ class Dropout(tnn.Module):
         return ops.DropoutFunction.apply(x, mask)
 
 
+def bn_relu_maxpool(bn, pool, y):
+    """pool(relu(bn(y))): one fused op in training mode (ops.BnReluMaxPoolFunction), the separate modules
+    otherwise (eval mode, synchronised BatchNorm, non-square pooling arguments)."""
+    simple = all(isinstance(v, int) for v in (pool.kernel_size, pool.stride, pool.padding))
+    if (ops.FUSE_STEM_POOL and simple and bn._arena is not None and (bn.training or not bn.track_running_stats)
+            and ops._sync_group(bn) is None):
+        fn = ops.BnReluMaxPoolFunction.apply
+        if torch.is_grad_enabled():
+            return fn(y, bn.weight, bn.bias, bn, pool.kernel_size, pool.stride, pool.padding)
+        with torch.no_grad():
+            return fn(y, bn.weight, bn.bias, bn, pool.kernel_size, pool.stride, pool.padding)
+    return pool(bn(y, relu=True))
+
+
 def convert_sync_batchnorm(model, process_group=None):
     """nn.SyncBatchNorm.convert_sync_batchnorm(model) of the reference's --sync-bn (main.py:190-191):
     every BatchNorm2d of `model` takes its training-mode batch statistics (and the matching backward

@@ -136,6 +136,8 @@ def conv_out_hw(H, W, R, S, stride, pad):
 FUSE_BN_STATS = os.environ.get('CONVNET_AMD_FUSE_BN_STATS', '1') != '0'
 # A/B switch: 0 = the stem runs as a 49-tap conv on a 3->8 channel padded image instead of the pixel-pair form
 STEM_PAIRS = os.environ.get('CONVNET_AMD_STEM_PAIRS', '1') != '0'
+# A/B switch: 0 = the stem's bn1 -> relu -> maxpool runs as separate BatchNorm and max-pool passes
+FUSE_STEM_POOL = os.environ.get('CONVNET_AMD_FUSE_STEM_POOL', '1') != '0'
 # A/B switch: 0 = BatchNorm backward always runs its own reduction pass over (dz, y)
 FUSE_BN_BWD = os.environ.get('CONVNET_AMD_FUSE_BN_BWD', '1') != '0'
 
@@ -643,6 +645,71 @@ class MaxPool2dFunction(Function):
                                                        dtype_code(dy.dtype), stream_of(dy)), 'cn_maxpool_bwd'),
                      dy.device)
         return dx, None, None, None
+
+
+class BnReluMaxPoolFunction(Function):
+    """maxpool(relu(BN(y))) of the stem (models/resnet.py:228-230) without the normalised 112x112 map:
+    forward = BatchNorm statistics / coefficients (from the conv epilogue partials when present) +
+    one pooling pass over the pre-BN tensor; backward = cn_bn_bwd_maxpool (the pool's gather backward
+    folded into both BatchNorm-backward passes).  Bit-identical to the unfused chain."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, mod, k, stride, pad):
+        N, H, W, C = y.shape
+        M = N * H * W
+        L = _L()
+        code = dtype_code(y.dtype)
+        ws = workspace(L.cn_bn_workspace(M, C, code), y.device)
+        stats = torch.empty(4 * C, dtype=torch.float32, device=y.device)
+        momentum = mod.effective_momentum()
+        track = mod.track_running_stats
+        rm = ptr(mod.running_mean) if track else None
+        rv = ptr(mod.running_var) if track else None
+        nbt = ptr(mod.num_batches_tracked) if track else None
+        ps = take_pending_stats(y)
+        COUNTERS['bn_fwd_fused' if ps is not None else 'bn_fwd_plain'] += 1
+        P, Q = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        out = torch.empty((N, P, Q, C), dtype=y.dtype, device=y.device)
+        idx = torch.empty((N, P, Q, C), dtype=torch.uint8, device=y.device)
+
+        def run():
+            if ps is not None:
+                check(L.cn_bn_fwd_train_partials(ptr(y), None, None, None, ptr(gamma), ptr(beta), rm, rv, nbt, momentum,
+                                                 mod.eps, ptr(stats), M, C, 1, code, ptr(ps.partial), ps.rows, ptr(ws),
+                                                 ws.numel() * 4, stream_of(y)), 'cn_bn_fwd_train_partials')
+            else:
+                check(L.cn_bn_fwd_train(ptr(y), None, None, None, ptr(gamma), ptr(beta), rm, rv, nbt, momentum, mod.eps,
+                                        ptr(stats), M, C, 1, code, ptr(ws), ws.numel() * 4, stream_of(y)),
+                      'cn_bn_fwd_train')
+            check(L.cn_maxpool_fwd_bnrelu(ptr(y), ptr(stats[2 * C:3 * C]), ptr(stats[3 * C:]), ptr(out), ptr(idx), N, H, W,
+                                          C, k, stride, pad, code, stream_of(y)), 'cn_maxpool_fwd_bnrelu')
+        PROFILER.run('bn_finalize+maxpool_fwd_bnrelu (stem)', 3, 0.0,
+                     y.numel() * _esize(y) * (1 if ps is not None else 2) + out.numel() * (_esize(out) + 1), run, y.device)
+        ctx.mod = mod
+        ctx.cfg = (N, H, W, C, k, stride, pad)
+        ctx.save_for_backward(y, stats, idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, dpool):
+        y, stats, idx = ctx.saved_tensors
+        mod = ctx.mod
+        N, H, W, C, k, stride, pad = ctx.cfg
+        L = _L()
+        code = dtype_code(y.dtype)
+        dpool = dpool.contiguous()
+        ws = workspace(L.cn_bn_workspace(N * H * W, C, code), y.device)
+        dy = torch.empty_like(y)
+        coef = torch.empty(3 * C, dtype=torch.float32, device=y.device)
+        COUNTERS['bn_bwd_plain'] += 1
+        PROFILER.run('bn_bwd_maxpool (stem)', 3, 0.0, y.numel() * _esize(y) * 3 + dpool.numel() * (_esize(dpool) + 1) * 2,
+                     lambda: check(L.cn_bn_bwd_maxpool(ptr(dpool), ptr(idx), ptr(y), ptr(mod.weight), ptr(stats), ptr(dy),
+                                                       ptr(mod.grad_view('weight')), ptr(mod.grad_view('bias')), 1.0, 1.0,
+                                                       ptr(coef), N, H, W, C, k, stride, pad, code, ptr(ws),
+                                                       ws.numel() * 4, stream_of(y)), 'cn_bn_bwd_maxpool'),
+                     y.device)
+        mod._notify_grad_ready()
+        return dy, None, None, None, None, None, None
 
 
 class GlobalAvgPoolFunction(Function):

@@ -79,7 +79,8 @@ int cn_conv2d_wgrad(const void* x, const void* dy, float* dw_krsc, int C_real, i
 
 /* ---- nn.BatchNorm2d (+ fused residual add + ReLU) (models/resnet.py:128-134,141-165) -------- */
 size_t cn_bn_workspace(int M, int C, int dtype);
-/* stats_out: 4*C floats = [batch mean | 1/sqrt(var+eps) | scale | shift]; M = N*H*W rows. */
+/* stats_out: 4*C floats = [batch mean | 1/sqrt(var+eps) | scale | shift]; M = N*H*W rows.
+ * z == NULL: statistics / coefficients / running-stat update only (a fused consumer applies them). */
 /* relu_mask (optional, M*C/chunk bytes): one bit per output recording z > 0, written when a residual is
  * added before the ReLU so that backward need not re-read z. */
 int cn_bn_fwd_train(const void* y, const void* residual, void* z, unsigned char* relu_mask, const float* gamma,
@@ -134,6 +135,16 @@ int cn_maxpool_fwd(const void* x, void* y, unsigned char* argmax_tap, int N, int
                    int stride, int pad, int dtype, void* stream);
 int cn_maxpool_bwd(const void* dy, const unsigned char* argmax_tap, void* dx, int N, int H, int W, int C,
                    int k, int stride, int pad, int dtype, void* stream);
+/* The stem's bn1 -> relu -> maxpool (models/resnet.py:228-230) without materialising the normalised map:
+ * forward = cn_bn_fwd_train(_partials) with z = NULL (statistics + coefficients only) followed by
+ * cn_maxpool_fwd_bnrelu on the pre-BN tensor; backward = cn_bn_bwd_maxpool, which folds the pool's gather
+ * backward into both BatchNorm-backward passes. */
+int cn_maxpool_fwd_bnrelu(const void* x_prebn, const float* scale, const float* shift, void* y, unsigned char* idx,
+                          int N, int H, int W, int C, int k, int stride, int pad, int dtype, void* stream);
+int cn_bn_bwd_maxpool(const void* dpool, const unsigned char* idx, const void* y_prebn, const float* gamma,
+                      const float* stats, void* dy, float* dgamma, float* dbeta, float beta_acc, float gscale,
+                      float* coef_scratch /*3C*/, int N, int H, int W, int C, int k, int stride, int pad, int dtype,
+                      void* workspace, size_t ws_bytes, void* stream);
 int cn_avgpool_fwd(const void* x, void* y, int N, int HW, int C, int dtype, void* stream);
 int cn_avgpool_bwd(const void* dy, void* dx, int N, int HW, int C, int dtype, void* stream);
 

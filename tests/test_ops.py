@@ -349,6 +349,47 @@ def test_stem_pixel_pair_convolution(mode):
 
 
 @pytest.mark.parametrize('mode', MODES)
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_stem_bn_relu_maxpool_fused_equals_chain(mode, dtype):
+    """ops.BnReluMaxPoolFunction (bn1 -> relu -> maxpool of models/resnet.py:228-230 in one pooling pass,
+    backward with the pool's gather folded into the BatchNorm backward) against the separate BatchNorm2d
+    and MaxPool2d modules: same pooled map bit for bit, same gradients / statistics."""
+    dev = _dev(mode)
+    import convnet_amd as ca
+    shapes = [(2, 16, 9, 11), (3, 8, 12, 12)] if mode == 'emul' else [(4, 64, 112, 112), (3, 72, 17, 13)]
+    for (N, C, H, W) in shapes:
+        g = torch.Generator().manual_seed(C + H)
+        y0 = _nhwc(torch.randn(N, C, H, W, generator=g) * 1.5 + 0.2, dtype, dev)
+        outs = []
+        for fused in (True, False):
+            bn, pool = ca.nn.BatchNorm2d(C), ca.nn.MaxPool2d(3, 2, 1)
+            model = torch.nn.Sequential(bn)
+            ca.engine.prepare(model, dev, dtype)
+            gw = torch.Generator().manual_seed(5)
+            bn.weight.data.copy_((torch.rand(C, generator=gw) + 0.5).to(dev))
+            bn.bias.data.copy_((torch.randn(C, generator=gw) * 0.3).to(dev))
+            bn.train()
+            y = y0.clone().requires_grad_(True)
+            ca.ops.FUSE_STEM_POOL = fused
+            try:
+                out = ca.nn.bn_relu_maxpool(bn, pool, y)
+            finally:
+                ca.ops.FUSE_STEM_POOL = True
+            model._cn_arena.zero_grad()
+            gd = torch.Generator().manual_seed(9)
+            dout = _q(torch.randn(out.shape, generator=gd), dtype).to(dtype).to(dev)
+            out.backward(dout)
+            outs.append((out.detach().float().cpu(), y.grad.float().cpu(), bn.weight.grad.cpu().clone(),
+                         bn.bias.grad.cpu().clone(), bn.running_mean.cpu().clone(), bn.running_var.cpu().clone()))
+        f, u = outs
+        assert torch.equal(f[0], u[0])
+        tol = 1e-5 if dtype == torch.float32 else 4e-3
+        assert rel_l2(f[1], u[1]) < tol
+        assert rel_l2(f[2], u[2]) < 1e-4 and rel_l2(f[3], u[3]) < 1e-4
+        assert torch.equal(f[4], u[4]) and torch.equal(f[5], u[5])
+
+
+@pytest.mark.parametrize('mode', MODES)
 def test_wgrad_accumulates_and_scales(mode):
     dev = _dev(mode)
     import convnet_amd as ca
