@@ -421,6 +421,8 @@ struct BnPoolGeom {
   FastDiv div_hw, div_w;
 };
 
+// At most 2 x 2 windows cover an input pixel when k <= 2*stride (checked by the host): fixed-trip loops
+// with predicated loads, so the 4 (gradient, tap) pairs of a pixel are requested back to back.
 template <typename T>
 __device__ __forceinline__ void bn_pool_gather(const BnPoolGeom& g, int row, int col, int C, float* out) {
   constexpr int CH = ElemTraits<T>::kChunk;
@@ -429,8 +431,6 @@ __device__ __forceinline__ void bn_pool_gather(const BnPoolGeom& g, int row, int
   const int rem = row - n * g.H * g.W;
   const int h = (int)cn_fastdiv((unsigned)rem, g.div_w);
   const int w = rem - h * g.W;
-#pragma unroll
-  for (int e = 0; e < CH; ++e) out[e] = 0.f;
   int p_lo = h + g.pad - g.k + 1;
   p_lo = p_lo > 0 ? (p_lo + g.st - 1) / g.st : 0;
   int p_hi = (h + g.pad) / g.st;
@@ -439,19 +439,29 @@ __device__ __forceinline__ void bn_pool_gather(const BnPoolGeom& g, int row, int
   q_lo = q_lo > 0 ? (q_lo + g.st - 1) / g.st : 0;
   int q_hi = (w + g.pad) / g.st;
   if (q_hi > g.Q - 1) q_hi = g.Q - 1;
-  for (int pp = p_lo; pp <= p_hi; ++pp)
-    for (int q = q_lo; q <= q_hi; ++q) {
-      const int t = (h - (pp * g.st - g.pad)) * g.k + (w - (q * g.st - g.pad));
-      const size_t o = ((size_t)(n * g.P + pp) * g.Q + q) * C + (size_t)col * CH;
-      float v[CH];
-      Chunk<T>::unpack(cn_ld16(g.dpool + o * EB), v);
-      unsigned long long pk;
-      if (CH == 8) pk = *(const unsigned long long*)(g.idx + o);
-      else pk = *(const unsigned int*)(g.idx + o);
+  u32x4 gv[4];
+  unsigned long long pk[4];
+  int tap[4];
 #pragma unroll
-      for (int e = 0; e < CH; ++e)
-        if ((int)((pk >> (8 * e)) & 0xffull) == t) out[e] += v[e];
-    }
+  for (int i = 0; i < 4; ++i) {
+    const int pp = p_hi - (i >> 1), q = q_hi - (i & 1);
+    const bool ok = pp >= p_lo && q >= q_lo;
+    const size_t o = ok ? ((size_t)(n * g.P + pp) * g.Q + q) * C + (size_t)col * CH : 0;
+    gv[i] = cn_ld16(g.dpool + o * EB);
+    if (CH == 8) pk[i] = *(const unsigned long long*)(g.idx + o);
+    else pk[i] = *(const unsigned int*)(g.idx + o);
+    tap[i] = ok ? (h - (pp * g.st - g.pad)) * g.k + (w - (q * g.st - g.pad)) : -1;   // -1 never matches a stored tap
+  }
+#pragma unroll
+  for (int e = 0; e < CH; ++e) out[e] = 0.f;
+#pragma unroll
+  for (int i = 3; i >= 0; --i) {   // ascending (p, q): the summation order of the unfused max-pool backward
+    float v[CH];
+    Chunk<T>::unpack(gv[i], v);
+#pragma unroll
+    for (int e = 0; e < CH; ++e)
+      if ((int)((pk[i] >> (8 * e)) & 0xffull) == tap[i]) out[e] += v[e];
+  }
   Chunk<T>::unpack(Chunk<T>::pack(out), out);   // what the unfused chain's max-pool backward would have stored
 }
 
@@ -481,16 +491,31 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(BnPoolGeom geo,
       sh[e] = shift[col * CH + e];
     }
     const int step = gridDim.x * rpp;
-    for (int row = blockIdx.x * rpp + rsub; row < M; row += step) {
-      float g[CH], v[CH];
-      Chunk<T>::unpack(cn_ld16(y + ((size_t)row * C + (size_t)col * CH) * EB), v);
-      bn_pool_gather<T>(geo, row, col, C, g);
+    auto accum = [&](const float* g, const float* v) {
 #pragma unroll
       for (int e = 0; e < CH; ++e) {
         const float gm = fmaf(v[e], sc[e], sh[e]) > 0.f ? g[e] : 0.f;
         s1[e] += gm;
         s2[e] = fmaf(gm, (v[e] - mu[e]) * is[e], s2[e]);
       }
+    };
+    int row = blockIdx.x * rpp + rsub;
+    for (; row + step < M; row += 2 * step) {   // two pixels (their y chunk + 4 gathered pairs each) in flight
+      float g0[CH], g1[CH], v0[CH], v1[CH];
+      const u32x4 y0 = cn_ld16(y + ((size_t)row * C + (size_t)col * CH) * EB);
+      const u32x4 y1 = cn_ld16(y + ((size_t)(row + step) * C + (size_t)col * CH) * EB);
+      bn_pool_gather<T>(geo, row, col, C, g0);
+      bn_pool_gather<T>(geo, row + step, col, C, g1);
+      Chunk<T>::unpack(y0, v0);
+      Chunk<T>::unpack(y1, v1);
+      accum(g0, v0);
+      accum(g1, v1);
+    }
+    for (; row < M; row += step) {
+      float g[CH], v[CH];
+      Chunk<T>::unpack(cn_ld16(y + ((size_t)row * C + (size_t)col * CH) * EB), v);
+      bn_pool_gather<T>(geo, row, col, C, g);
+      accum(g, v);
     }
   }
 #pragma unroll
@@ -529,17 +554,35 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(BnPoolGeom geo, 
     sh[e] = shift[col * CH + e];
   }
   const int step = gridDim.x * rpp;
-  for (int row = blockIdx.x * rpp + rsub; row < M; row += step) {
-    const size_t off = ((size_t)row * C + (size_t)col * CH) * EB;
-    float g[CH], v[CH], o[CH];
-    Chunk<T>::unpack(cn_ld16(y + off), v);
-    bn_pool_gather<T>(geo, row, col, C, g);
+  auto emit = [&](size_t off, const float* g, const float* v) {
+    float o[CH];
 #pragma unroll
     for (int e = 0; e < CH; ++e) {
       const float gm = fmaf(v[e], sc[e], sh[e]) > 0.f ? g[e] : 0.f;
       o[e] = fmaf(c1[e], gm, fmaf(c2[e], v[e], c3[e]));
     }
     cn_st16(dy + off, Chunk<T>::pack(o));
+  };
+  int row = blockIdx.x * rpp + rsub;
+  for (; row + step < M; row += 2 * step) {
+    const size_t off0 = ((size_t)row * C + (size_t)col * CH) * EB;
+    const size_t off1 = ((size_t)(row + step) * C + (size_t)col * CH) * EB;
+    float g0[CH], g1[CH], v0[CH], v1[CH];
+    const u32x4 y0 = cn_ld16(y + off0);
+    const u32x4 y1 = cn_ld16(y + off1);
+    bn_pool_gather<T>(geo, row, col, C, g0);
+    bn_pool_gather<T>(geo, row + step, col, C, g1);
+    Chunk<T>::unpack(y0, v0);
+    Chunk<T>::unpack(y1, v1);
+    emit(off0, g0, v0);
+    emit(off1, g1, v1);
+  }
+  for (; row < M; row += step) {
+    const size_t off = ((size_t)row * C + (size_t)col * CH) * EB;
+    float g[CH], v[CH];
+    Chunk<T>::unpack(cn_ld16(y + off), v);
+    bn_pool_gather<T>(geo, row, col, C, g);
+    emit(off, g, v);
   }
 }
 
@@ -977,7 +1020,10 @@ extern "C" int cn_bn_bwd_maxpool(const void* dpool, const unsigned char* idx, co
   const int M = (int)Ml;
   int rc = bn_check("bn_bwd_maxpool", M, C, dtype);
   if (rc) return rc;
-  if (k * k > 255 || pad * 2 > k || stride <= 0) { cn_set_error("bn_bwd_maxpool: unsupported window"); return CN_ESHAPE; }
+  if (k * k > 255 || pad * 2 > k || stride <= 0 || k > 2 * stride) {
+    cn_set_error("bn_bwd_maxpool: unsupported window (needs k <= 2*stride, k*k <= 255, 2*pad <= k)");
+    return CN_ESHAPE;
+  }
   hipStream_t stream = (hipStream_t)stream_;
   const int CH = dtype == CN_BF16 ? 8 : 4;
   BnMap m = bn_map(C / CH);

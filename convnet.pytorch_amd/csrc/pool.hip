@@ -16,7 +16,7 @@
 // AFF: the input is a pre-BatchNorm tensor and every tap is first mapped through relu(x*scale[c] + shift[c])
 // - the stem's BatchNorm apply + ReLU + max-pool (models/resnet.py:228-230) in one pass, so the
 // normalised 112x112 map is never written to or re-read from HBM.
-template <typename T, bool AFF>
+template <typename T, bool AFF, int KS>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const char* x, char* y, unsigned char* idx, int N,
                                                          int H, int W, int C, int P, int Q, int k, int st,
                                                          int pad, FastDiv div_cpr, const float* scale,
@@ -39,28 +39,48 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const char* x, char* y
 #pragma unroll
     for (int e = 0; e < CH; ++e) { best[e] = -INFINITY; bi[e] = 0; }
     bool first = true;
-    for (int r = 0; r < k; ++r) {
-      const int h = pp * st - pad + r;
-      if ((unsigned)h >= (unsigned)H) continue;
-      const char* xr = x + ((size_t)(n * H + h) * W * C + (size_t)col * CH) * EB;
-      for (int s = 0; s < k; ++s) {
-        const int w = w0 + s;
-        if ((unsigned)w >= (unsigned)W) continue;
-        float f[CH];
-        Chunk<T>::unpack(cn_ld16(xr + (size_t)w * C * EB), f);
-        if (AFF) {
+    auto take = [&](const u32x4& raw, int t) {
+      float f[CH];
+      Chunk<T>::unpack(raw, f);
+      if (AFF) {
 #pragma unroll
-          for (int e = 0; e < CH; ++e) {
-            const float v = fmaf(f[e], sc[e], sh[e]);
-            f[e] = v > 0.f ? v : 0.f;
-          }
-          Chunk<T>::unpack(Chunk<T>::pack(f), f);   // compare what the unfused chain would have stored (rounded z)
+        for (int e = 0; e < CH; ++e) {
+          const float v = fmaf(f[e], sc[e], sh[e]);
+          f[e] = v > 0.f ? v : 0.f;
         }
-        const int t = r * k + s;
+        Chunk<T>::unpack(Chunk<T>::pack(f), f);   // compare what the unfused chain would have stored (rounded z)
+      }
 #pragma unroll
-        for (int e = 0; e < CH; ++e)
-          if (first || f[e] > best[e]) { best[e] = f[e]; bi[e] = t; }
-        first = false;
+      for (int e = 0; e < CH; ++e)
+        if (first || f[e] > best[e]) { best[e] = f[e]; bi[e] = t; }
+      first = false;
+    };
+    if (KS > 0) {   // compile-time window: all KS*KS taps are requested before the first comparison
+      constexpr int NT_ = KS > 0 ? KS * KS : 1;
+      u32x4 raw[NT_];
+      bool ok[NT_];
+#pragma unroll
+      for (int r = 0; r < KS; ++r)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const int h = pp * st - pad + r, w = w0 + s;
+          ok[r * KS + s] = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+          const size_t o = ok[r * KS + s] ? (((size_t)(n * H + h) * W + w) * C + (size_t)col * CH) * EB : 0;
+          raw[r * KS + s] = cn_ld16(x + o);
+        }
+#pragma unroll
+      for (int t = 0; t < KS * KS; ++t)
+        if (ok[t]) take(raw[t], t);
+    } else {
+      for (int r = 0; r < k; ++r) {
+        const int h = pp * st - pad + r;
+        if ((unsigned)h >= (unsigned)H) continue;
+        const char* xr = x + ((size_t)(n * H + h) * W * C + (size_t)col * CH) * EB;
+        for (int s = 0; s < k; ++s) {
+          const int w = w0 + s;
+          if ((unsigned)w >= (unsigned)W) continue;
+          take(cn_ld16(xr + (size_t)w * C * EB), r * k + s);
+        }
       }
     }
     const size_t o = ((size_t)row * Q + q) * C + (size_t)col * CH;
@@ -291,12 +311,12 @@ extern "C" int cn_maxpool_fwd(const void* x, void* y, unsigned char* idx, int N,
   const long long rows_f = (long long)N * P;
   dim3 grid((unsigned)((Q * (C / CH) + 255) / 256), (unsigned)(rows_f < 65535 ? rows_f : 65535));
   const FastDiv div_cpr = cn_make_fastdiv((unsigned)(C / CH));
-  if (dtype == CN_BF16)
-    CN_LAUNCH((maxpool_fwd_kernel<bf16_t, false>), grid, dim3(256), (hipStream_t)stream, (const char*)x, (char*)y, idx,
-              N, H, W, C, P, Q, k, stride, pad, div_cpr, (const float*)nullptr, (const float*)nullptr);
-  else
-    CN_LAUNCH((maxpool_fwd_kernel<float, false>), grid, dim3(256), (hipStream_t)stream, (const char*)x, (char*)y, idx,
-              N, H, W, C, P, Q, k, stride, pad, div_cpr, (const float*)nullptr, (const float*)nullptr);
+#define MP_GO(T, AFF, KS, SC, SH)                                                                               \
+  CN_LAUNCH((maxpool_fwd_kernel<T, AFF, KS>), grid, dim3(256), (hipStream_t)stream, (const char*)x, (char*)y, idx, N, H, \
+            W, C, P, Q, k, stride, pad, div_cpr, SC, SH)
+  const float* none = nullptr;
+  if (dtype == CN_BF16) { if (k == 3) MP_GO(bf16_t, false, 3, none, none); else MP_GO(bf16_t, false, 0, none, none); }
+  else { if (k == 3) MP_GO(float, false, 3, none, none); else MP_GO(float, false, 0, none, none); }
   return cn_check_launch("maxpool_fwd");
 }
 
@@ -317,12 +337,9 @@ extern "C" int cn_maxpool_fwd_bnrelu(const void* x, const float* scale, const fl
   const long long rows_f = (long long)N * P;
   dim3 grid((unsigned)((Q * (C / CH) + 255) / 256), (unsigned)(rows_f < 65535 ? rows_f : 65535));
   const FastDiv div_cpr = cn_make_fastdiv((unsigned)(C / CH));
-  if (dtype == CN_BF16)
-    CN_LAUNCH((maxpool_fwd_kernel<bf16_t, true>), grid, dim3(256), (hipStream_t)stream, (const char*)x, (char*)y, idx,
-              N, H, W, C, P, Q, k, stride, pad, div_cpr, scale, shift);
-  else
-    CN_LAUNCH((maxpool_fwd_kernel<float, true>), grid, dim3(256), (hipStream_t)stream, (const char*)x, (char*)y, idx, N,
-              H, W, C, P, Q, k, stride, pad, div_cpr, scale, shift);
+  if (dtype == CN_BF16) { if (k == 3) MP_GO(bf16_t, true, 3, scale, shift); else MP_GO(bf16_t, true, 0, scale, shift); }
+  else { if (k == 3) MP_GO(float, true, 3, scale, shift); else MP_GO(float, true, 0, scale, shift); }
+#undef MP_GO
   return cn_check_launch("maxpool_fwd_bnrelu");
 }
 
