@@ -418,7 +418,7 @@ struct BnPoolGeom {
   const char* dpool;            // [N,P,Q,C] gradient of the pooled map
   const unsigned char* idx;     // [N,P,Q,C] winning tap (kh*k + kw) per pooled element
   int H, W, P, Q, k, st, pad;
-  FastDiv div_hw, div_w;
+  FastDiv div_hw, div_w, div_st;
 };
 
 // At most 2 x 2 windows cover an input pixel when k <= 2*stride (checked by the host): fixed-trip loops
@@ -431,13 +431,14 @@ __device__ __forceinline__ void bn_pool_gather(const BnPoolGeom& g, int row, int
   const int rem = row - n * g.H * g.W;
   const int h = (int)cn_fastdiv((unsigned)rem, g.div_w);
   const int w = rem - h * g.W;
+  // window ranges with the host-precomputed fast division by the stride (runtime `/` costs ~30 VALU each)
   int p_lo = h + g.pad - g.k + 1;
-  p_lo = p_lo > 0 ? (p_lo + g.st - 1) / g.st : 0;
-  int p_hi = (h + g.pad) / g.st;
+  p_lo = p_lo > 0 ? (int)cn_fastdiv((unsigned)(p_lo + g.st - 1), g.div_st) : 0;
+  int p_hi = (int)cn_fastdiv((unsigned)(h + g.pad), g.div_st);
   if (p_hi > g.P - 1) p_hi = g.P - 1;
   int q_lo = w + g.pad - g.k + 1;
-  q_lo = q_lo > 0 ? (q_lo + g.st - 1) / g.st : 0;
-  int q_hi = (w + g.pad) / g.st;
+  q_lo = q_lo > 0 ? (int)cn_fastdiv((unsigned)(q_lo + g.st - 1), g.div_st) : 0;
+  int q_hi = (int)cn_fastdiv((unsigned)(w + g.pad), g.div_st);
   if (q_hi > g.Q - 1) q_hi = g.Q - 1;
   u32x4 gv[4];
   unsigned long long pk[4];
@@ -1039,6 +1040,7 @@ extern "C" int cn_bn_bwd_maxpool(const void* dpool, const unsigned char* idx, co
   geo.Q = (W + 2 * pad - k) / stride + 1;
   geo.div_hw = cn_make_fastdiv((unsigned)(H * W));
   geo.div_w = cn_make_fastdiv((unsigned)W);
+  geo.div_st = cn_make_fastdiv((unsigned)stride);
   float* partial = (float*)workspace;
   const float* mean = stats;
   const float* invstd = stats + C;
