@@ -140,6 +140,12 @@ STEM_PAIRS = os.environ.get('CONVNET_AMD_STEM_PAIRS', '1') != '0'
 FUSE_STEM_POOL = os.environ.get('CONVNET_AMD_FUSE_STEM_POOL', '1') != '0'
 # A/B switch: 0 = BatchNorm backward always runs its own reduction pass over (dz, y)
 FUSE_BN_BWD = os.environ.get('CONVNET_AMD_FUSE_BN_BWD', '1') != '0'
+# The fusion always pays at the residual junctions (the epilogue adds the other branch's gradient anyway and
+# no dres tensor is written).  For the BNs inside a block it only pays while the activation is small:
+# measured per layer (profiles/r01_epilogue_fusions_per_layer.txt) the epilogue costs more than the
+# standalone reduction pass it removes on the 56x56 / 28x28 maps and is a wash on the small ones; whole-step
+# A/B: junctions only 21.34 ms vs everywhere 21.71 ms.  Threshold in MB of the BN input (0 = junctions only).
+FUSE_BN_BWD_INNER_MB = float(os.environ.get('CONVNET_AMD_FUSE_BN_BWD_INNER_MB', '0'))
 
 
 # how often each BatchNorm path ran (tests assert that the fused paths really are the ones in use)
@@ -396,6 +402,8 @@ class Conv2dFunction(Function):
             # (inner convs) or when the other branch's gradient is being added right here
             final = holder is None or addend is not None
             bn_args = _input_bn_state(mod, x) if (final and FUSE_BN_BWD) else None
+            if bn_args is not None and holder is None and x.numel() * _esize(x) > FUSE_BN_BWD_INNER_MB * 2 ** 20:
+                bn_args = None
             if bn_args is not None:
                 bn_mod, bn_y, bn_mask, bn_stats, bn_relu = bn_args
                 dx, partial, rows = conv2d_dgrad(dy, mod.w_crsk, x.shape, mod.out_channels, R, S, mod.stride,
