@@ -134,6 +134,8 @@ def conv_out_hw(H, W, R, S, stride, pad):
 
 # A/B switch: 0 = every BatchNorm re-reads its input for the statistics (bn_stats_kernel)
 FUSE_BN_STATS = os.environ.get('CONVNET_AMD_FUSE_BN_STATS', '1') != '0'
+# statistics epilogue only for conv outputs of at least this many MB (A/B knob; 0 = always)
+FUSE_BN_STATS_MIN_MB = float(os.environ.get('CONVNET_AMD_FUSE_BN_STATS_MIN_MB', '0'))
 # A/B switch: 0 = the stem runs as a 49-tap conv on a 3->8 channel padded image instead of the pixel-pair form
 STEM_PAIRS = os.environ.get('CONVNET_AMD_STEM_PAIRS', '1') != '0'
 # A/B switch: 0 = the stem's bn1 -> relu -> maxpool runs as separate BatchNorm and max-pool passes
@@ -146,6 +148,8 @@ FUSE_BN_BWD = os.environ.get('CONVNET_AMD_FUSE_BN_BWD', '1') != '0'
 # standalone reduction pass it removes on the 56x56 / 28x28 maps and is a wash on the small ones; whole-step
 # A/B: junctions only 21.34 ms vs everywhere 21.71 ms.  Threshold in MB of the BN input (0 = junctions only).
 FUSE_BN_BWD_INNER_MB = float(os.environ.get('CONVNET_AMD_FUSE_BN_BWD_INNER_MB', '0'))
+# junction fusion only for BN inputs of at least this many MB (A/B knob; 0 = every junction)
+FUSE_BN_BWD_JUNC_MIN_MB = float(os.environ.get('CONVNET_AMD_FUSE_BN_BWD_JUNC_MIN_MB', '0'))
 
 
 # how often each BatchNorm path ran (tests assert that the fused paths really are the ones in use)
@@ -181,7 +185,7 @@ def conv2d_fwd(x, w_krsc, bias, K, R, S, stride, pad, out_f32=False, relu=False,
     N, H, W, C = x.shape
     P, Q = conv_out_hw(H, W, R, S, stride, pad)
     y = torch.empty((N, P, Q, K), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
-    if bn_stats and not out_f32:
+    if bn_stats and not out_f32 and y.numel() * _esize(y) >= FUSE_BN_STATS_MIN_MB * 2 ** 20:
         L = _L()
         rows = L.cn_conv2d_bnstats_rows(N * P * Q)
         partial = torch.empty((rows, 2 * K), dtype=torch.float32, device=x.device)
@@ -403,6 +407,8 @@ class Conv2dFunction(Function):
             final = holder is None or addend is not None
             bn_args = _input_bn_state(mod, x) if (final and FUSE_BN_BWD) else None
             if bn_args is not None and holder is None and x.numel() * _esize(x) > FUSE_BN_BWD_INNER_MB * 2 ** 20:
+                bn_args = None
+            if bn_args is not None and holder is not None and x.numel() * _esize(x) < FUSE_BN_BWD_JUNC_MIN_MB * 2 ** 20:
                 bn_args = None
             if bn_args is not None:
                 bn_mod, bn_y, bn_mask, bn_stats, bn_relu = bn_args
