@@ -246,7 +246,12 @@ def conv2d_wgrad(x, dy, dw_krsc, c_real, K, R, S, stride, pad, beta=1.0, scale=1
     L = _L()
     need = L.cn_conv2d_wgrad_workspace(N, H, W, C, K, R, S, stride[0], stride[1], pad[0], pad[1], code)
     ws = workspace(need, x.device, tag)
-    PROFILER.run('wgrad_kernel<%s, %d, 128> (+wgrad_reduce)' % ('float' if x.dtype == torch.float32 else 'bf16_t', 64 if K <= 64 else 128),
+    if x.dtype == torch.bfloat16 and R == 1 and S == 1 and tuple(stride) == (1, 1) and tuple(pad) == (0, 0):
+        kname = 'wgrad_dma_kernel<%d> (+wgrad_reduce)' % (64 if K <= 64 else 128)      # identity gather: LDS-DMA variant
+    else:
+        kname = 'wgrad_kernel<%s, %d, 128> (+wgrad_reduce)' % ('float' if x.dtype == torch.float32 else 'bf16_t',
+                                                               64 if K <= 64 else 128)
+    PROFILER.run(kname,
                  2, 2.0 * dy.numel() * C * R * S,
                  x.numel() * _esize(x) + dy.numel() * _esize(dy) + K * R * S * C * 4,
                  lambda: check(L.cn_conv2d_wgrad(ptr(x), ptr(dy), ptr(dw_krsc), c_real, N, H, W, C, K, R, S,
