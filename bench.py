@@ -62,12 +62,15 @@ def main():
         print('bench.py: --gpus %d but WORLD_SIZE=%d (launch through torch.distributed.run for N > 1)'
               % (args.gpus, world), file=sys.stderr)
     distributed = world > 1 or os.environ.get('BENCH_FORCE_DIST') == '1'   # world-1 RCCL smoke test
+    if os.environ.get('BENCH_SHARE_GPU') == '1':   # protocol test of the N > 1 flow on a 1-GPU box (with gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if distributed:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29517')
-        dist.init_process_group(backend='nccl', init_method='env://', world_size=world, rank=rank)
+        dist.init_process_group(backend=os.environ.get('BENCH_DIST_BACKEND', 'nccl'), init_method='env://',
+                                world_size=world, rank=rank)
     assert not ca._lib.is_emulated()
 
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
@@ -111,12 +114,16 @@ def main():
 
     # ---- live per-kernel timing (separate profiled pass, HIP events on the launch stream) ----
     kernels, roof = {}, None
-    if rank == 0 and not args.no_kernel_profile:
+    nprof = 2
+    if not args.no_kernel_profile:
+        # every rank runs the profiled steps (they contain the gradient all-reduce: a rank-0-only pass would
+        # wait for collectives the other ranks never enter); only rank 0 reports
         ca.ops.PROFILER.records = []
         ca.ops.PROFILER.enabled = True
-        nprof = 2
         tr.train(loader(nprof))
         ca.ops.PROFILER.enabled = False
+        fence()
+    if rank == 0 and not args.no_kernel_profile:
         agg = ca.ops.PROFILER.summary()
         total_ms = sum(a['ms'] for a in agg.values())
         for name, a in sorted(agg.items(), key=lambda kv: -kv[1]['ms']):
