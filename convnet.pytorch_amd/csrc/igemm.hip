@@ -654,6 +654,7 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
 
 static int ig_dispatch(IgemmParams& p, int dtype, hipStream_t stream) {
   if (p.M <= 0 || p.Co <= 0) return CN_OK;
+  if (p.x == nullptr || p.w == nullptr || p.y == nullptr) { cn_set_error("igemm: null operand"); return CN_EINVAL; }
   if (dtype == CN_BF16) return p.out_f32 ? ig_launch<bf16_t, true>(p, stream) : ig_launch<bf16_t, false>(p, stream);
   if (dtype == CN_F32) { p.out_f32 = 1; return ig_launch<float, true>(p, stream); }
   cn_set_error("igemm: bad dtype %d", dtype);

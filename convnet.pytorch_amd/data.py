@@ -1,0 +1,319 @@
+"""Input pipeline for real image folders: the host side of the reference's `data.py` + `preprocess.py`
+(/root/reference data.py:17-125, preprocess.py:21-161) for the datasets the hot path is benchmarked on.
+
+The reference builds its pipeline from torchvision (`datasets.ImageFolder`, `transforms.*`), which is
+not part of this image; the same steps are re-stated here on PIL + numpy:
+
+    ImageFolder (class sub-directories, sorted)                       data.py:45-53
+    train : RandomResizedCrop(input_size) -> RandomHorizontalFlip
+            -> ToTensor -> Normalize(mean, std)                       preprocess.py:71-77 (inception_preprocess)
+    eval  : Resize(scale_size = input_size*8/7) -> CenterCrop(input_size)
+            -> ToTensor -> Normalize                                  preprocess.py:21-41 (scale_crop)
+    DataRegime: epoch-keyed loader settings, DistributedSampler       data.py:74-125
+
+Batches leave this module exactly as the reference's loader hands them to `Trainer`: fp32 NCHW
+`inputs`, int64 `target`, pinned when asked.  The device side (copy-stream prefetch, fused cast to the
+bf16 NHWC / pixel-pair layout) is trainer.DevicePrefetcher + csrc/pool.hip.
+
+Randomness: every random transform draws from Python's `random` module, seeded per worker by the
+DataLoader (`torch.initial_seed()`), so a seeded run is reproducible; the draws are *not* the same
+stream torchvision would consume (parity of augmentation samples is unpinned - torchvision is absent
+here - the deterministic eval transform is pinned against PIL in tests/test_data.py).
+"""
+import math
+import os
+import random
+from copy import deepcopy
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader, Dataset, Subset
+from torch.utils.data.distributed import DistributedSampler
+
+from .optim import Regime
+
+_IMAGENET_STATS = {'mean': [0.485, 0.456, 0.406], 'std': [0.229, 0.224, 0.225]}   # preprocess.py:7-8
+IMG_EXTENSIONS = ('.jpg', '.jpeg', '.png', '.ppm', '.bmp', '.pgm', '.tif', '.tiff', '.webp')
+
+
+def _pil():
+    from PIL import Image
+    return Image
+
+
+# ---------------------------------------------------------------------------------------------
+# transforms (callables on PIL images / CHW float tensors)
+
+class Compose(object):
+    def __init__(self, transforms):
+        self.transforms = list(transforms)
+
+    def __call__(self, img):
+        for t in self.transforms:
+            img = t(img)
+        return img
+
+    def __repr__(self):
+        return 'Compose(%s)' % ', '.join(repr(t) for t in self.transforms)
+
+
+class Resize(object):
+    """Shorter side -> `size`, aspect ratio kept, bilinear (torchvision.transforms.Resize(int))."""
+
+    def __init__(self, size):
+        self.size = int(size)
+
+    def __call__(self, img):
+        w, h = img.size
+        if (w <= h and w == self.size) or (h <= w and h == self.size):
+            return img
+        if w < h:
+            ow, oh = self.size, int(self.size * h / w)
+        else:
+            oh, ow = self.size, int(self.size * w / h)
+        return img.resize((ow, oh), _pil().BILINEAR)
+
+    def __repr__(self):
+        return 'Resize(%d)' % self.size
+
+
+class CenterCrop(object):
+    def __init__(self, size):
+        self.size = int(size)
+
+    def __call__(self, img):
+        w, h = img.size
+        th = tw = self.size
+        if w < tw or h < th:    # pad symmetrically with zeros, like torchvision
+            Image = _pil()
+            canvas = Image.new(img.mode, (max(w, tw), max(h, th)))
+            canvas.paste(img, ((canvas.size[0] - w) // 2, (canvas.size[1] - h) // 2))
+            img, (w, h) = canvas, canvas.size
+        left, top = int(round((w - tw) / 2.0)), int(round((h - th) / 2.0))
+        return img.crop((left, top, left + tw, top + th))
+
+    def __repr__(self):
+        return 'CenterCrop(%d)' % self.size
+
+
+class RandomResizedCrop(object):
+    """Inception-style crop: area fraction in `scale`, aspect ratio log-uniform in `ratio`, ten
+    attempts then a centre crop clamped to the ratio range; resized to size x size (bilinear)."""
+
+    def __init__(self, size, scale=(0.08, 1.0), ratio=(3.0 / 4.0, 4.0 / 3.0)):
+        self.size, self.scale, self.ratio = int(size), scale, ratio
+
+    def get_params(self, w, h):
+        area = w * h
+        log_ratio = (math.log(self.ratio[0]), math.log(self.ratio[1]))
+        for _ in range(10):
+            target_area = area * random.uniform(*self.scale)
+            aspect = math.exp(random.uniform(*log_ratio))
+            cw = int(round(math.sqrt(target_area * aspect)))
+            ch = int(round(math.sqrt(target_area / aspect)))
+            if 0 < cw <= w and 0 < ch <= h:
+                top, left = random.randint(0, h - ch), random.randint(0, w - cw)
+                return left, top, cw, ch
+        in_ratio = w / float(h)
+        if in_ratio < self.ratio[0]:
+            cw, ch = w, int(round(w / self.ratio[0]))
+        elif in_ratio > self.ratio[1]:
+            ch, cw = h, int(round(h * self.ratio[1]))
+        else:
+            cw, ch = w, h
+        return (w - cw) // 2, (h - ch) // 2, cw, ch
+
+    def __call__(self, img):
+        left, top, cw, ch = self.get_params(*img.size)
+        return img.resize((self.size, self.size), _pil().BILINEAR, box=(left, top, left + cw, top + ch))
+
+    def __repr__(self):
+        return 'RandomResizedCrop(%d)' % self.size
+
+
+class RandomHorizontalFlip(object):
+    def __init__(self, p=0.5):
+        self.p = p
+
+    def __call__(self, img):
+        if random.random() < self.p:
+            return img.transpose(_pil().FLIP_LEFT_RIGHT)
+        return img
+
+    def __repr__(self):
+        return 'RandomHorizontalFlip(%g)' % self.p
+
+
+class ToTensor(object):
+    """PIL image -> float32 CHW in [0, 1]."""
+
+    def __call__(self, img):
+        a = np.asarray(img, dtype=np.uint8)
+        if a.ndim == 2:
+            a = a[:, :, None]
+        return torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1))).float().div_(255.0)
+
+    def __repr__(self):
+        return 'ToTensor()'
+
+
+class Normalize(object):
+    def __init__(self, mean, std):
+        self.mean = torch.tensor(mean, dtype=torch.float32).view(-1, 1, 1)
+        self.std = torch.tensor(std, dtype=torch.float32).view(-1, 1, 1)
+
+    def __call__(self, t):
+        return (t - self.mean) / self.std
+
+    def __repr__(self):
+        return 'Normalize(mean=%s, std=%s)' % (self.mean.flatten().tolist(), self.std.flatten().tolist())
+
+
+def scale_crop(input_size, scale_size=None, normalize=None):
+    """Evaluation transform (preprocess.py:21-41, num_crops = 1)."""
+    normalize = normalize or _IMAGENET_STATS
+    t = [CenterCrop(input_size), ToTensor(), Normalize(**normalize)]
+    if scale_size != input_size:
+        t = [Resize(scale_size)] + t
+    return Compose(t)
+
+
+def inception_preprocess(input_size, normalize=None):
+    """Training transform (preprocess.py:71-77)."""
+    normalize = normalize or _IMAGENET_STATS
+    return Compose([RandomResizedCrop(input_size), RandomHorizontalFlip(), ToTensor(), Normalize(**normalize)])
+
+
+def get_transform(transform_name='imagenet', input_size=None, scale_size=None, normalize=None, augment=True,
+                  cutout=None, autoaugment=False, padding=None, duplicates=1, num_crops=1):
+    """preprocess.get_transform (preprocess.py:115-161) for the ImageNet family; the research
+    augmentations (autoaugment, cutout, duplicates, multi-crop) are outside the hot path."""
+    if 'imagenet' not in transform_name:
+        raise NotImplementedError('transform %r: only the ImageNet pipeline is built' % transform_name)
+    if autoaugment or cutout is not None or duplicates != 1 or num_crops != 1:
+        raise NotImplementedError('autoaugment / cutout / duplicates / multi-crop are not part of the hot path')
+    input_size = input_size or 224
+    scale_size = scale_size or int(input_size * 8 / 7)
+    if augment:
+        return inception_preprocess(input_size, normalize=normalize)
+    return scale_crop(input_size=input_size, scale_size=scale_size, normalize=normalize)
+
+
+# ---------------------------------------------------------------------------------------------
+# datasets
+
+class ImageFolder(Dataset):
+    """root/<class>/<image>: classes = sorted sub-directory names, samples sorted by path
+    (torchvision.datasets.ImageFolder semantics, data.py:45-53)."""
+
+    def __init__(self, root, transform=None, target_transform=None):
+        root = os.path.expanduser(root)
+        if not os.path.isdir(root):
+            raise FileNotFoundError('image folder %r does not exist' % root)
+        self.root = root
+        self.classes = sorted(d.name for d in os.scandir(root) if d.is_dir())
+        if not self.classes:
+            raise FileNotFoundError('no class folders under %r' % root)
+        self.class_to_idx = {c: i for i, c in enumerate(self.classes)}
+        self.samples = []
+        for c in self.classes:
+            for dirpath, _, files in sorted(os.walk(os.path.join(root, c), followlinks=True)):
+                for f in sorted(files):
+                    if f.lower().endswith(IMG_EXTENSIONS):
+                        self.samples.append((os.path.join(dirpath, f), self.class_to_idx[c]))
+        if not self.samples:
+            raise FileNotFoundError('no images under %r' % root)
+        self.targets = [t for _, t in self.samples]
+        self.transform, self.target_transform = transform, target_transform
+
+    def __len__(self):
+        return len(self.samples)
+
+    def __getitem__(self, i):
+        path, target = self.samples[i]
+        with open(path, 'rb') as f:
+            img = _pil().open(f).convert('RGB')
+        if self.transform is not None:
+            img = self.transform(img)
+        if self.target_transform is not None:
+            target = self.target_transform(target)
+        return img, target
+
+
+def get_dataset(name, split='train', transform=None, target_transform=None, download=True,
+                datasets_path='~/Datasets'):
+    """data.get_dataset (data.py:17-70) for `imagenet`: <datasets_path>/imagenet/{train,val}/<class>/*."""
+    if name != 'imagenet':
+        raise NotImplementedError('dataset %r: the folder pipeline is built for "imagenet"' % name)
+    root = os.path.join(os.path.expanduser(datasets_path), name, 'train' if split == 'train' else 'val')
+    return ImageFolder(root, transform=transform, target_transform=target_transform)
+
+
+_DATA_ARGS = {'name', 'split', 'transform', 'target_transform', 'download', 'datasets_path'}
+_DATALOADER_ARGS = {'batch_size', 'shuffle', 'sampler', 'batch_sampler', 'num_workers', 'collate_fn', 'pin_memory',
+                    'drop_last', 'timeout', 'worker_init_fn'}
+_TRANSFORM_ARGS = {'transform_name', 'input_size', 'scale_size', 'normalize', 'augment', 'cutout', 'duplicates',
+                   'num_crops', 'autoaugment'}
+_OTHER_ARGS = {'distributed'}
+
+
+def _seed_worker(worker_id):
+    seed = torch.initial_seed() % 2 ** 32
+    random.seed(seed)
+    np.random.seed(seed)
+
+
+class DataRegime(object):
+    """Epoch-keyed data settings -> DataLoader (data.py:74-125): the same setting groups, the same
+    `get_loader / set_epoch / get / __len__` surface main.py drives (main.py:264-310)."""
+
+    def __init__(self, regime, defaults={}):
+        self.regime = Regime(regime, deepcopy(defaults))
+        self.epoch = 0
+        self.steps = None
+        self._sampler = None
+        self.get_loader(True)
+
+    def get_setting(self):
+        setting = self.regime.setting
+        out = {'data': {k: v for k, v in setting.items() if k in _DATA_ARGS},
+               'loader': {k: v for k, v in setting.items() if k in _DATALOADER_ARGS},
+               'transform': {k: v for k, v in setting.items() if k in _TRANSFORM_ARGS},
+               'other': {k: v for k, v in setting.items() if k in _OTHER_ARGS}}
+        out['transform'].setdefault('transform_name', out['data']['name'])
+        return out
+
+    def get(self, key, default=None):
+        return self.regime.setting.get(key, default)
+
+    def get_loader(self, force_update=False, override_settings=None, subset_indices=None):
+        if force_update or self.regime.update(self.epoch, self.steps):
+            setting = self.get_setting()
+            if override_settings is not None:
+                setting.update(override_settings)
+            self._transform = get_transform(**setting['transform'])
+            setting['data'].setdefault('transform', self._transform)
+            self._data = get_dataset(**setting['data'])
+            if subset_indices is not None:
+                self._data = Subset(self._data, subset_indices)
+            loader = dict(setting['loader'])
+            if setting['other'].get('distributed', False):
+                loader['sampler'] = DistributedSampler(self._data)
+                loader['shuffle'] = None
+            self._sampler = loader.get('sampler', None)
+            if loader.get('num_workers', 0) > 0:
+                loader.setdefault('worker_init_fn', _seed_worker)
+                loader.setdefault('persistent_workers', True)
+            self._loader = DataLoader(self._data, **loader)
+        return self._loader
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+        if self._sampler is not None and hasattr(self._sampler, 'set_epoch'):
+            self._sampler.set_epoch(epoch)
+
+    def __len__(self):
+        return len(self._data)
+
+    def __repr__(self):
+        return str(self.regime.setting)

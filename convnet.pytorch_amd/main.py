@@ -254,21 +254,44 @@ def main_worker(args):
                       mixup=args.mixup, cutmix=args.cutmix, loss_scale=args.loss_scale, grad_clip=args.grad_clip,
                       adapt_grad_norm=args.adapt_grad_norm)
 
-    if 'synthetic' not in args.dataset:
-        raise NotImplementedError("dataset %r: only the synthetic ImageNet-shaped dataset is built; the JPEG "
-                                  "pipeline is under 'next' in DESIGN.md" % args.dataset)
-    is_mnist = args.model == 'mnist'
-    size = args.input_size or (28 if is_mnist else 224)
-    classes, channels = (10, 1) if is_mnist else (model_config.get('num_classes', 1000), 3)
     args.eval_batch_size = args.eval_batch_size if args.eval_batch_size > 0 else args.batch_size
-    rank = max(args.local_rank, 0)
-    val_data = SyntheticLoader(args.val_steps, args.eval_batch_size, size, classes, channels, args.seed + 10000)
+    if 'synthetic' in args.dataset:
+        is_mnist = args.model == 'mnist'
+        size = args.input_size or (28 if is_mnist else 224)
+        classes, channels = (10, 1) if is_mnist else (model_config.get('num_classes', 1000), 3)
+        rank = max(args.local_rank, 0)
+        val_data = SyntheticLoader(args.val_steps, args.eval_batch_size, size, classes, channels, args.seed + 10000)
+        val_loader = lambda: val_data                                   # noqa: E731
+        if not args.evaluate:
+            train_data = SyntheticLoader(args.steps_per_epoch, args.batch_size, size, classes, channels,
+                                         args.seed + 1 + rank)
+            train_loader = lambda: train_data                           # noqa: E731
+    else:
+        # real image folders through DataRegime, exactly the settings of main.py:264-293
+        from .data import DataRegime
+        if hasattr(model, 'sampled_data_regime'):
+            raise NotImplementedError('sampled (mixed-size) data regimes are not part of the hot path')
+        val_data = DataRegime(getattr(model, 'data_eval_regime', None),
+                              defaults={'datasets_path': args.datasets_dir, 'name': args.dataset, 'split': 'val',
+                                        'augment': False, 'input_size': args.input_size,
+                                        'batch_size': args.eval_batch_size, 'shuffle': False,
+                                        'num_workers': args.workers, 'pin_memory': True, 'drop_last': False})
+        val_loader = val_data.get_loader
+        if not args.evaluate:
+            train_data = DataRegime(getattr(model, 'data_regime', None),
+                                    defaults={'datasets_path': args.datasets_dir, 'name': args.dataset,
+                                              'split': 'train', 'augment': True, 'input_size': args.input_size,
+                                              'batch_size': args.batch_size, 'shuffle': True,
+                                              'num_workers': args.workers, 'pin_memory': True, 'drop_last': True,
+                                              'distributed': args.distributed, 'duplicates': args.duplicates,
+                                              'autoaugment': args.autoaugment,
+                                              'cutout': {'holes': 1, 'length': 16} if args.cutout else None})
+            train_loader = train_data.get_loader
+            logging.info('data regime: %s', train_data)
     if args.evaluate:
-        res = trainer.validate(val_data)
+        res = trainer.validate(val_loader())
         logging.info(res)
         return res
-    train_data = SyntheticLoader(args.steps_per_epoch, args.batch_size, size, classes, channels,
-                                 args.seed + 1 + rank)
 
     logging.info('optimization regime: %s', optim_regime)
     args.start_epoch = max(args.start_epoch, 0)
@@ -278,8 +301,11 @@ def main_worker(args):
         trainer.epoch = epoch
         logging.info('\nStarting Epoch: {0}\n'.format(epoch + 1))
         t0 = time.time()
-        train_results = trainer.train(train_data, chunk_batch=args.chunk_batch)
-        val_results = trainer.validate(val_data)
+        if hasattr(train_data, 'set_epoch'):   # main.py:301-302
+            train_data.set_epoch(epoch)
+            val_data.set_epoch(epoch)
+        train_results = trainer.train(train_loader(), chunk_batch=args.chunk_batch)
+        val_results = trainer.validate(val_loader())
         if not main_rank:
             continue
         is_best = val_results['prec1'] > best_prec1
@@ -292,7 +318,7 @@ def main_worker(args):
                      'Training Prec@5 {train[prec5]:.3f} \tValidation Loss {val[loss]:.4f} \t'
                      'Validation Prec@1 {val[prec1]:.3f} \tValidation Prec@5 {val[prec5]:.3f} \t'
                      '[{ips:.0f} img/s]\n'.format(epoch + 1, train=train_results, val=val_results,
-                                                  ips=len(train_data) * args.batch_size / (time.time() - t0)))
+                                                  ips=len(train_loader()) * args.batch_size / (time.time() - t0)))
         values = dict(epoch=epoch + 1, steps=trainer.training_steps)
         values.update({'training ' + k: v for k, v in train_results.items()})
         values.update({'validation ' + k: v for k, v in val_results.items()})

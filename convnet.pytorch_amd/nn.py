@@ -162,6 +162,9 @@ class Linear(_ArenaModule):
     def forward(self, x):
         self._require_prepared()
         B = x.shape[0]
+        if self.out_features % _lib.chunk_elems(self.compute_dtype) != 0:
+            # ragged width (e.g. a 3- or 10-way classifier): plain dot products from the fp32 master
+            return ops.SmallLinearFunction.apply(x.reshape(B, self.in_features), self.weight, self.bias, self)
         y = ops.Conv2dFunction.apply(x.reshape(B, 1, 1, self.in_features), self.weight, self.bias, self)
         return y.view(B, self.out_features)
 

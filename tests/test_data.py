@@ -1,0 +1,142 @@
+"""Input pipeline (convnet.pytorch_amd/data.py; the reference's data.py / preprocess.py re-stated on
+PIL + numpy because torchvision is not installed here).
+
+Pinned: the deterministic evaluation transform against an independent PIL + numpy computation, the
+ImageFolder class / sample ordering, the DataRegime -> DataLoader plumbing (shapes, dtypes, labels,
+epoch-keyed settings) and a CLI run of `main.py --dataset imagenet` on a tiny folder through the
+TEST-ONLY emulator.  Unpinned (stated in data.py): the random draws of the training augmentation -
+only their invariants are tested (crop inside the image, area / ratio ranges, output size, flips)."""
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import ROOT  # noqa: F401  (puts the repo root on sys.path)
+
+PIL = pytest.importorskip('PIL')
+from PIL import Image  # noqa: E402
+
+
+def _make_folder(root, classes=('cat', 'apple', 'bird'), per_class=3, size=(40, 52), seed=0):
+    rng = np.random.RandomState(seed)
+    for split in ('train', 'val'):
+        for ci, c in enumerate(classes):
+            d = os.path.join(root, 'imagenet', split, c)
+            os.makedirs(d, exist_ok=True)
+            for i in range(per_class):
+                w, h = size[0] + 7 * i, size[1] - 5 * ci
+                arr = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+                Image.fromarray(arr).save(os.path.join(d, 'img_%d.png' % i))
+    return os.path.join(root, 'imagenet')
+
+
+def test_imagefolder_ordering_and_eval_transform(tmp_path):
+    import convnet_amd as ca
+    from convnet_amd import data as D
+    root = _make_folder(str(tmp_path))
+    tf = D.get_transform('imagenet', input_size=28, augment=False)          # Resize(32) -> CenterCrop(28)
+    ds = D.get_dataset('imagenet', split='val', transform=tf, datasets_path=str(tmp_path))
+    assert ds.classes == ['apple', 'bird', 'cat'] and ds.class_to_idx['cat'] == 2
+    assert len(ds) == 9 and [t for _, t in ds.samples] == [0, 0, 0, 1, 1, 1, 2, 2, 2]
+    assert [os.path.basename(p) for p, _ in ds.samples[:3]] == ['img_0.png', 'img_1.png', 'img_2.png']
+    x, t = ds[4]
+    assert x.dtype == torch.float32 and tuple(x.shape) == (3, 28, 28) and t == 1
+    # independent computation of the same deterministic pipeline
+    img = Image.open(ds.samples[4][0]).convert('RGB')
+    w, h = img.size
+    scale = int(28 * 8 / 7)
+    if w < h:
+        ow, oh = scale, int(scale * h / w)
+    else:
+        oh, ow = scale, int(scale * w / h)
+    r = img.resize((ow, oh), Image.BILINEAR)
+    left, top = int(round((ow - 28) / 2.0)), int(round((oh - 28) / 2.0))
+    a = np.asarray(r.crop((left, top, left + 28, top + 28)), dtype=np.float32) / 255.0
+    mean, std = np.array([0.485, 0.456, 0.406], np.float32), np.array([0.229, 0.224, 0.225], np.float32)
+    ref = torch.from_numpy(((a - mean) / std).transpose(2, 0, 1).copy())
+    assert torch.allclose(x, ref, atol=1e-6)
+    assert ca is not None
+
+
+def test_random_resized_crop_invariants():
+    from convnet_amd import data as D
+    random.seed(3)
+    rrc = D.RandomResizedCrop(24)
+    w, h = 90, 60
+    for _ in range(200):
+        left, top, cw, ch = rrc.get_params(w, h)
+        assert 0 <= left and 0 <= top and left + cw <= w and top + ch <= h and cw > 0 and ch > 0
+        assert 0.08 * w * h * 0.9 <= cw * ch <= w * h
+        assert 3.0 / 4.0 * 0.9 <= cw / float(ch) <= 4.0 / 3.0 * 1.1
+    img = Image.fromarray(np.arange(60 * 90 * 3, dtype=np.uint32).reshape(60, 90, 3).astype(np.uint8))
+    out = rrc(img)
+    assert out.size == (24, 24)
+    flip = D.RandomHorizontalFlip(p=1.0)
+    assert np.array_equal(np.asarray(flip(img)), np.asarray(img)[:, ::-1])
+    # seeded runs reproduce the same crops
+    random.seed(11)
+    a = [rrc.get_params(w, h) for _ in range(5)]
+    random.seed(11)
+    assert a == [rrc.get_params(w, h) for _ in range(5)]
+
+
+def test_data_regime_loader_and_epoch_keyed_settings(tmp_path):
+    from convnet_amd import data as D
+    _make_folder(str(tmp_path))
+    regime = [{'epoch': 0, 'input_size': 16}, {'epoch': 2, 'input_size': 24, 'batch_size': 2}]
+    dr = D.DataRegime(regime, defaults={'datasets_path': str(tmp_path), 'name': 'imagenet', 'split': 'train',
+                                        'augment': True, 'input_size': None, 'batch_size': 4, 'shuffle': True,
+                                        'num_workers': 0, 'pin_memory': False, 'drop_last': True})
+    assert len(dr) == 9
+    torch.manual_seed(0)
+    batches = list(dr.get_loader())
+    assert len(batches) == 2
+    x, t = batches[0]
+    assert tuple(x.shape) == (4, 3, 16, 16) and x.dtype == torch.float32 and t.dtype == torch.int64
+    assert int(t.min()) >= 0 and int(t.max()) <= 2
+    dr.set_epoch(2)
+    x, t = next(iter(dr.get_loader()))
+    assert tuple(x.shape) == (2, 3, 24, 24)            # the epoch-2 phase of the regime took over
+    assert dr.get('input_size') == 24
+
+
+def test_cli_trains_on_an_image_folder(tmp_path):
+    """`main.py --dataset imagenet --datasets-dir ...` end to end on a tiny folder (emulator)."""
+    from conftest import HAS_GPU
+    if HAS_GPU:
+        pytest.skip('emulator CLI run is for GPU-less hosts')
+    _make_folder(str(tmp_path), per_class=4)
+    from convnet_amd.main import main
+    out = main(['--dataset', 'imagenet', '--datasets-dir', str(tmp_path), '--model', 'resnet',
+                '--model-config', "{'depth': 18, 'width': [8, 16, 32, 64], 'inplanes': 8, 'num_classes': 3}",
+                '--input-size', '32', '-b', '4', '--epochs', '1', '--workers', '0', '--device', 'cpu',
+                '--dtype', 'float', '--results-dir', str(tmp_path / 'results'), '--save', 'run', '--print-freq', '1'])
+    assert out is not None
+    ck = torch.load(tmp_path / 'results' / 'run' / 'checkpoint.pth.tar', map_location='cpu')
+    assert ck['epoch'] == 1 and 'conv1.weight' in ck['state_dict']
+
+
+@pytest.mark.gpu
+def test_folder_pipeline_feeds_the_gpu_trainer(tmp_path):
+    """Image folder -> worker processes -> pinned fp32 NCHW batches -> copy-stream prefetch -> fused
+    layout cast -> two bf16 training steps on the MI355X (finite loss, parameters move)."""
+    import convnet_amd as ca
+    from convnet_amd import data as D
+    assert not ca._lib.is_emulated()
+    _make_folder(str(tmp_path), per_class=6, size=(70, 64))
+    dr = D.DataRegime(None, defaults={'datasets_path': str(tmp_path), 'name': 'imagenet', 'split': 'train',
+                                      'augment': True, 'input_size': 64, 'batch_size': 8, 'shuffle': True,
+                                      'num_workers': 2, 'pin_memory': True, 'drop_last': True})
+    torch.manual_seed(123)
+    model = ca.models.resnet(dataset='imagenet', depth=18, num_classes=8)
+    tr = ca.Trainer(model, ca.CrossEntropyLoss(), ca.OptimRegime(model, model.regime), device='cuda:0',
+                    dtype=torch.bfloat16, print_freq=10 ** 9)
+    w0 = model.fc.weight.detach().float().cpu().clone()
+    res = tr.train(dr.get_loader())
+    assert res['loss'] == res['loss'] and 0 < res['loss'] < 20       # finite
+    assert not torch.equal(model.fc.weight.detach().float().cpu(), w0)
+    val = tr.validate(dr.get_loader())
+    assert val['loss'] == val['loss']
