@@ -609,7 +609,10 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
   // variant: 1 = register-staged single buffer, 2 = register-staged double buffer, 3 = LDS-DMA double
   // buffer, 4 = LDS-DMA 4-deep ring (4 waves), 5 = LDS-DMA 4-deep ring with 8 waves; 0 / unset = heuristic (tuning knob "igemm_variant", profiles/r01_conv_layers*)
   int variant = cn_get_option("igemm_variant", 0);
-  if (variant < 1 || variant > 6) variant = cn_get_option("igemm_default_variant", nkt < 24 ? 1 : 3);
+  // short reductions: register-staged single buffer (more workgroups per CU); from "igemm_dma_min_nkt" K tiles
+  // on: LDS-DMA double buffer (measured per layer, profiles/r01_conv_layers_b256_bf16.txt)
+  if (variant < 1 || variant > 6)
+    variant = cn_get_option("igemm_default_variant", nkt < cn_get_option("igemm_dma_min_nkt", 24) ? 1 : 3);
   if ((p.stats != nullptr || p.bn_y != nullptr || p.addend != nullptr) && variant == 6) variant = 3;   // 128-pixel tiles   // statistics rows are defined per 128-pixel tile
   const bool epi = p.addend != nullptr || p.bn_y != nullptr;
   // EPI launches on wide outputs can run on 64-pixel tiles (32 accumulator registers, half the prefetch

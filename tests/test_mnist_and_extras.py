@@ -91,3 +91,27 @@ def test_calibrate_bn_cumulative_statistics(mode):
     for k in ('bn1.running_mean', 'bn1.running_var', 'layer3.0.downsample.1.running_var', 'layer4.1.bn2.running_mean'):
         assert rel_l2(sd[k].float().cpu(), rsd[k]) < 1e-4, k
     assert int(sd['bn1.num_batches_tracked']) == 3
+
+
+@pytest.mark.gpu
+def test_resnet_learns_a_separable_task_bf16():
+    """End-to-end learning sanity on the MI355X with every fusion on (beyond the few-step trajectory
+    parity): ResNet-18 bf16 on 8 classes of noisy class templates must fit the training set."""
+    import convnet_amd as ca
+    dev = 'cuda:0'
+    torch.manual_seed(123)
+    model = ca.models.resnet(dataset='imagenet', depth=18, num_classes=8)
+    tr = ca.Trainer(model, ca.CrossEntropyLoss(), ca.OptimRegime(model, model.regime), device=dev,
+                    dtype=torch.bfloat16, print_freq=10 ** 9)
+    g = torch.Generator().manual_seed(5)
+    templates = torch.randn(8, 3, 64, 64, generator=g)
+    def batch():
+        t = torch.randint(0, 8, (64,), generator=g)
+        return templates[t] * 0.7 + torch.randn(64, 3, 64, 64, generator=g), t
+    first = tr.train([batch() for _ in range(5)])
+    for _ in range(5):
+        last = tr.train([batch() for _ in range(10)])
+    assert first['loss'] > 1.5
+    assert last['loss'] < 0.35 and last['prec1'] > 90.0, (first, last)
+    val = tr.validate([batch() for _ in range(4)])
+    assert val['prec1'] > 85.0, val
