@@ -409,7 +409,7 @@ struct WgradPlan {
   int BI, BJ, BKP, n_itiles, n_jtiles, nsplit, m_per_split, ncols;
 };
 
-static WgradPlan wg_plan(int M, int Co, int ntaps, int Ci, int dtype) {
+static WgradPlan wg_plan(int M, int Co, int ntaps, int Ci, int dtype, bool simple) {
   WgradPlan pl;
   pl.ncols = ntaps * Ci;
   pl.BI = Co <= 64 ? 64 : 128;
@@ -420,10 +420,11 @@ static WgradPlan wg_plan(int M, int Co, int ntaps, int Ci, int dtype) {
   int tiles = pl.n_itiles * pl.n_jtiles;
   int stages = (M + pl.BKP - 1) / pl.BKP;
   // workgroups per launch: ~2 per CU for the 128-wide tile (fewer, longer splits = less partial traffic),
-  // ~4 per CU for the 64-wide one (small LDS / register footprint; measured per layer, profiles/README.md).
+  // ~4 per CU for the 64-wide one when it gathers (3x3 / 7x7: small LDS / register footprint; identity-gather
+  // 64-wide layers measured better at 512: profiles/r01_conv_layers_b256_bf16.txt).
   // Tuning knob "wgrad_target_wgs" overrides both.
   int target = cn_get_option("wgrad_target_wgs", 0);
-  if (target <= 0) target = pl.BI == 64 ? 1024 : 512;
+  if (target <= 0) target = (pl.BI == 64 && !simple) ? 1024 : 512;
   int want = (target + tiles - 1) / tiles;
   int max_split = (stages + 7) / 8;               // at least 8 stages per split
   if (max_split < 1) max_split = 1;
@@ -440,7 +441,8 @@ extern "C" size_t cn_conv2d_wgrad_workspace(int N, int H, int W, int C, int K, i
   const int P = (H + 2 * pad_h - R) / stride_h + 1;
   const int Q = (W + 2 * pad_w - S) / stride_w + 1;
   if (P <= 0 || Q <= 0 || N <= 0) return 0;
-  WgradPlan pl = wg_plan(N * P * Q, K, R * S, C, dtype);
+  const bool simple = R == 1 && S == 1 && stride_h == 1 && stride_w == 1 && pad_h == 0 && pad_w == 0;
+  WgradPlan pl = wg_plan(N * P * Q, K, R * S, C, dtype, simple);
   return (size_t)pl.nsplit * (size_t)K * (size_t)pl.ncols * sizeof(float);
 }
 
@@ -476,7 +478,8 @@ extern "C" int cn_conv2d_wgrad(const void* x, const void* dy, float* dw_krsc, in
   }
   if (R * S > WG_MAX_TAPS) { cn_set_error("conv2d_wgrad: too many taps"); return CN_ESHAPE; }
   if (C_real <= 0 || C_real > C) { cn_set_error("conv2d_wgrad: bad C_real"); return CN_EINVAL; }
-  WgradPlan pl = wg_plan(N * P * Q, K, R * S, C, dtype);
+  const bool simple_gather = R == 1 && S == 1 && stride_h == 1 && stride_w == 1 && pad_h == 0 && pad_w == 0;
+  WgradPlan pl = wg_plan(N * P * Q, K, R * S, C, dtype, simple_gather);
   size_t need = (size_t)pl.nsplit * (size_t)K * (size_t)pl.ncols * sizeof(float);
   if (ws_bytes < need || workspace == nullptr) {
     cn_set_error("conv2d_wgrad: workspace %zu < %zu bytes", ws_bytes, need);
