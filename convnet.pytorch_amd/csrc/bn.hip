@@ -111,6 +111,19 @@ __device__ __forceinline__ void bn_sum_partials(const float* partial, int nrb, i
   double s = 0.0, q = 0.0;
   if (c < C) {
     int r = part;
+    for (; r + 15 * BN_FP < nrb; r += 16 * BN_FP) {   // 32 independent loads in flight: 512 rows = one round trip
+      float a[16], b[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        a[u] = partial[(size_t)(r + BN_FP * u) * 2 * C + c];
+        b[u] = partial[(size_t)(r + BN_FP * u) * 2 * C + C + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; u += 4) {
+        s += ((double)a[u] + (double)a[u + 1]) + ((double)a[u + 2] + (double)a[u + 3]);
+        q += ((double)b[u] + (double)b[u + 1]) + ((double)b[u + 2] + (double)b[u + 3]);
+      }
+    }
     for (; r + 7 * BN_FP < nrb; r += 8 * BN_FP) {   // 16 independent loads in flight per thread
       float a[8], b[8];
 #pragma unroll
@@ -172,6 +185,13 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* partial, 
   const int c = blockIdx.x * BN_FC + (threadIdx.x % BN_FC);
   const int part = threadIdx.x / BN_FC;
   if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked != nullptr) *num_batches_tracked += 1;
+  // per-channel parameters are requested before the partial reduction (one memory round trip less on a
+  // kernel that is nothing but latency)
+  const bool owner = c < C && part == 0;
+  const float g_pre = (owner && gamma != nullptr) ? gamma[c] : 1.f;
+  const float b_pre = (owner && beta != nullptr) ? beta[c] : 0.f;
+  const float rm_pre = (owner && running_mean != nullptr) ? running_mean[c] : 0.f;
+  const float rv_pre = (owner && running_mean != nullptr) ? running_var[c] : 0.f;
   double s, q;
   bn_sum_partials(partial, nrb, C, c, part, red, s, q);
   if (c >= C || part != 0) return;
@@ -183,14 +203,12 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* partial, 
   save_invstd[c] = invstd;
   if (running_mean != nullptr) {
     const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
-    running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
-    running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+    running_mean[c] = (float)((1.0 - (double)momentum) * (double)rm_pre + (double)momentum * mean);
+    running_var[c] = (float)((1.0 - (double)momentum) * (double)rv_pre + (double)momentum * unbiased);
   }
-  const float g = gamma != nullptr ? gamma[c] : 1.f;
-  const float b = beta != nullptr ? beta[c] : 0.f;
-  const float sc = g * invstd;
+  const float sc = g_pre * invstd;
   scale[c] = sc;
-  shift[c] = b - (float)mean * sc;
+  shift[c] = b_pre - (float)mean * sc;
 }
 
 // Inference coefficients from the running statistics.
@@ -349,17 +367,22 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* parti
   __shared__ double red[512];
   const int c = blockIdx.x * BN_FC + (threadIdx.x % BN_FC);
   const int part = threadIdx.x / BN_FC;
+  const bool owner = c < C && part == 0;   // operands requested before the partial reduction (latency)
+  const float g = (owner && gamma != nullptr) ? gamma[c] : 1.f;
+  const float is_pre = owner ? invstd[c] : 0.f;
+  const float mu_pre = owner ? mean[c] : 0.f;
+  const float dg_pre = (owner && dgamma != nullptr && beta_acc != 0.f) ? dgamma[c] : 0.f;
+  const float db_pre = (owner && dbeta != nullptr && beta_acc != 0.f) ? dbeta[c] : 0.f;
   double s1, s2;
   bn_sum_partials(partial, nrb, C, c, part, red, s1, s2);
   if (c >= C || part != 0) return;
-  const float g = gamma != nullptr ? gamma[c] : 1.f;
-  if (dgamma != nullptr) dgamma[c] = (beta_acc != 0.f ? beta_acc * dgamma[c] : 0.f) + (float)s2 * gscale;
-  if (dbeta != nullptr) dbeta[c] = (beta_acc != 0.f ? beta_acc * dbeta[c] : 0.f) + (float)s1 * gscale;
-  const double k = (double)g * (double)invstd[c];
-  const double a2 = k * (double)invstd[c] * s2 / (double)M;
+  if (dgamma != nullptr) dgamma[c] = (beta_acc != 0.f ? beta_acc * dg_pre : 0.f) + (float)s2 * gscale;
+  if (dbeta != nullptr) dbeta[c] = (beta_acc != 0.f ? beta_acc * db_pre : 0.f) + (float)s1 * gscale;
+  const double k = (double)g * (double)is_pre;
+  const double a2 = k * (double)is_pre * s2 / (double)M;
   coef[c] = (float)k;
   coef[C + c] = (float)(-a2);
-  coef[2 * C + c] = (float)(a2 * (double)mean[c] - k * s1 / (double)M);
+  coef[2 * C + c] = (float)(a2 * (double)mu_pre - k * s1 / (double)M);
 }
 
 template <typename T>
