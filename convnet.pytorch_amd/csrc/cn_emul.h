@@ -50,6 +50,7 @@ inline int lane() { return (int)(g_tid.x & 63u); }
 #define gridDim (cn_emul::g_gdim)
 #define __syncthreads() cn_emul::sync_threads()
 
+static inline void __threadfence() {}
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }

@@ -17,6 +17,7 @@ echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 
 echo "== layers"; timeout 600 python tools/bench_layers.py 2>&1 | tail -30 | tee $OUT/layers.txt
 echo "== bench"; timeout 900 python bench.py --steps ${BENCH_STEPS:-10} --warmup 3 2>&1 | tail -5 | tee $OUT/bench.txt
 echo "== host overhead (B=8: GPU work is small, step time ~ host launch cost)"; timeout 300 python bench.py --batch 8 --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-profile 2>&1 | grep '"metric"' | tee $OUT/bench_b8.txt | cut -c1-330
+echo "== PCIe-inclusive rate (pinned host batches, H2D inside the timed loop; never the contract value)"; timeout 300 python bench.py --host-inputs --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-profile 2>&1 | grep '"metric"' | tee $OUT/bench_host_inputs.txt | cut -c1-330
 echo "== world-1 RCCL path"; BENCH_FORCE_DIST=1 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-profile 2>&1 | grep '"metric"' | tee $OUT/bench_dist1.txt | cut -c1-330
 echo "== ResNet-18 fp32 b=256 (BASELINE config 1, parity-test case)"; timeout 600 python bench.py --depth 18 --dtype f32 --steps 5 --warmup 2 --no-cpu-baseline 2>&1 | grep '"metric"' | tee $OUT/bench_r18_f32.txt | cut -c1-400
 echo "== epilogue fusions per layer"; timeout 600 python tools/bench_fusion.py 2>&1 | grep -v amdgpu.ids | tail -26 | tee $OUT/fusion.txt
