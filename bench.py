@@ -95,7 +95,10 @@ def main():
 
     def fence():
         if distributed:
-            dist.barrier()
+            if dist.get_backend() == 'nccl':
+                dist.barrier(device_ids=[local_rank])   # RCCL barrier on this rank's own device
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     tr.train(loader(args.warmup))          # W untimed warm-up steps
@@ -103,9 +106,7 @@ def main():
     t0 = time.perf_counter()
     res = tr.train(loader(args.steps))     # EXACTLY K timed steps
     torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-        torch.cuda.synchronize()
+    fence()
     elapsed = time.perf_counter() - t0
     if distributed:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
