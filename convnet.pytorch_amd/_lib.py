@@ -15,7 +15,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB = os.path.join(_HERE, 'libconvnet_hip.so')
+# CONVNET_AMD_HIP_LIB: alternative build of the same library for A/B measurement (csrc/build.sh CN_LIB_NAME)
+HIP_LIB = os.path.join(_HERE, os.environ.get('CONVNET_AMD_HIP_LIB', 'libconvnet_hip.so'))
 EMUL_LIB = os.path.join(_HERE, 'libconvnet_emul.so')
 
 F32, BF16 = 0, 1

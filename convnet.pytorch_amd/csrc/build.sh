@@ -6,9 +6,11 @@ cd "$(dirname "$0")"
 SRCS="runtime.hip igemm.hip wgrad.hip bn.hip pool.hip loss.hip optim.hip probe.hip"
 OUT=..
 if [ "$1" != "emul-only" ]; then
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-result \
-      $SRCS -o $OUT/libconvnet_hip.so
-  echo "built $OUT/libconvnet_hip.so"
+  # CN_EXTRA_FLAGS / CN_LIB_NAME: A/B builds (e.g. CN_EXTRA_FLAGS=-DCN_NT_STORES CN_LIB_NAME=libconvnet_hip_nt.so)
+  LIB=${CN_LIB_NAME:-libconvnet_hip.so}
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-result $CN_EXTRA_FLAGS \
+      $SRCS -o $OUT/$LIB
+  echo "built $OUT/$LIB"
 fi
 if [ "$1" = "emul" ] || [ "$1" = "emul-only" ]; then
   CXX=/opt/rocm/lib/llvm/bin/clang++

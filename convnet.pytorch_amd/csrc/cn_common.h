@@ -276,6 +276,10 @@ __device__ __forceinline__ cn_buf_t cn_make_buf(const void* p, unsigned int nbyt
 __device__ __forceinline__ u32x4 cn_buf_ld16(cn_buf_t b, unsigned int off) {
   return __builtin_amdgcn_raw_buffer_load_b128(b, (int)off, 0, 0);
 }
+// same with the non-temporal cache policy (aux = 2): operands every element of which is read by one workgroup only
+__device__ __forceinline__ u32x4 cn_buf_ld16_nt(cn_buf_t b, unsigned int off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(b, (int)off, 0, 2);
+}
 #else
 struct cn_buf_t { const char* p; unsigned int n; };
 static inline cn_buf_t cn_make_buf(const void* p, unsigned int nbytes) {
@@ -286,6 +290,7 @@ static inline u32x4 cn_buf_ld16(cn_buf_t b, unsigned int off) {
   if ((unsigned long long)off + 16ull <= (unsigned long long)b.n) return *(const u32x4*)(b.p + off);
   return z;
 }
+static inline u32x4 cn_buf_ld16_nt(cn_buf_t b, unsigned int off) { return cn_buf_ld16(b, off); }
 #endif
 
 // Direct-to-LDS DMA form (buffer_load_dwordx4 ... lds): the 64 lanes of the wave write one
@@ -324,6 +329,26 @@ static inline void cn_sched_fence() {}
 // 16-byte global / LDS accessors
 __host__ __device__ __forceinline__ u32x4 cn_ld16(const void* p) { return *(const u32x4*)p; }
 __host__ __device__ __forceinline__ void cn_st16(void* p, const u32x4& v) { *(u32x4*)p = v; }
+// streaming 16-byte global store (big activation / gradient tensors written once and read back only after
+// they have left the L2): a non-temporal store; -DCN_NO_NT_STORES makes it a plain store (A/B: +0.45 % on the
+// ResNet-50 step, profiles/README.md).
+__host__ __device__ __forceinline__ void cn_st16_stream(void* p, const u32x4& v) {
+#if !defined(CN_NO_NT_STORES) && defined(__HIP_DEVICE_COMPILE__) && !defined(CN_EMULATE)
+  __builtin_nontemporal_store(v, (u32x4*)p);
+#else
+  *(u32x4*)p = v;
+#endif
+}
+// streaming 16-byte global load (read-once passes over big tensors: BatchNorm apply / reduce, epilogue
+// operands): non-temporal, so the pass does not evict what the next kernels re-read from L2 / Infinity Cache;
+// -DCN_NO_NT_LOADS makes it a plain load (A/B: +1.5 % on the ResNet-50 step, profiles/README.md).
+__host__ __device__ __forceinline__ u32x4 cn_ld16_stream(const void* p) {
+#if !defined(CN_NO_NT_LOADS) && defined(__HIP_DEVICE_COMPILE__) && !defined(CN_EMULATE)
+  return __builtin_nontemporal_load((const u32x4*)p);
+#else
+  return *(const u32x4*)p;
+#endif
+}
 __host__ __device__ __forceinline__ u32x4 cn_zero16() {
   u32x4 z = {0u, 0u, 0u, 0u};
   return z;

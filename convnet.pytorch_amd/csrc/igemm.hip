@@ -49,6 +49,7 @@ struct IgemmParams {
                     // 1 = pixel tiles fastest (share one filter slab in the XCD's L2; weight-heavy layers)
   unsigned int x_bytes, w_bytes;   // extents of the gather source / filter tensors (buffer descriptors)
   int simple;                      // 1: no tap of a valid row ever leaves the image (skip bounds tests)
+  int x_nt;                        // 1: every gathered element is read by one workgroup only -> non-temporal loads
   FastDiv div_hw, div_w, div_cpt;
   int tap_dhdw[IG_MAX_TAPS];
   int tap_woff[IG_MAX_TAPS];
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
       for (int i = 0; i < NPR; ++i) {
         const unsigned int o = (prow[i] | kb) >= CN_OOB ? CN_OOB : prow[i] + xofs;
         if (GLDS) cn_buf_ld16_lds(xbuf, o, dp_ + i * RS * 128);
-        else preg[i] = cn_buf_ld16(xbuf, o);
+        else preg[i] = p.x_nt ? cn_buf_ld16_nt(xbuf, o) : cn_buf_ld16(xbuf, o);
       }
     } else {
       const int dh = (int)(short)(dhdw & 0xffff);
@@ -526,7 +527,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
               v = Chunk<TO>::pack(fv);
             }
           }
-          cn_st16(dst, v);
+          cn_st16_stream(dst, v);
         } else {   // ragged channel count: element-wise tail (never combined with the BN reduction)
           for (int e = 0; e < epc && c_first + e < p.Co; ++e) {
             if (OEB == 4) {
@@ -617,7 +618,10 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
   const bool epi = p.addend != nullptr || p.bn_y != nullptr;
   // EPI launches on wide outputs can run on 64-pixel tiles (32 accumulator registers, half the prefetch
   // registers: 3 workgroups per CU instead of 2); knob "igemm_epi_bm64"
-  const bool bm64 = epi && p.Co > 64 && ig_epi_bm64();
+  // plain launches without the statistics epilogue (inner dgrads) can also run on 64-pixel tiles for short
+  // reductions: knob "igemm_plain_bm64_max_nkt" (0 = off)
+  const bool bm64_plain = !epi && p.stats == nullptr && p.Co > 64 && nkt <= cn_get_option("igemm_plain_bm64_max_nkt", 0);
+  const bool bm64 = (epi && p.Co > 64 && ig_epi_bm64()) || bm64_plain;
   const int BM = bm64 ? 64 : ((variant == 6 && p.Co > 64) ? 256 : 128), BN = p.Co <= 64 ? 64 : 128;
   p.n_ntiles = (p.Co + BN - 1) / BN;
   const int n_mtiles = (p.M + BM - 1) / BM;
@@ -628,6 +632,8 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
     (void)wbytes;   // pixel-tiles-fastest for weight-heavy layers measured 1-2 % slower (profiles/README.md)
     p.mt_fastest = order > 0 ? 1 : 0;
   }
+  // a 1x1 gather whose output fits one channel tile reads every input element exactly once
+  p.x_nt = (cn_get_option("igemm_x_nt", 0) != 0 && p.ntaps == 1 && p.n_ntiles == 1 && p.simple) ? 1 : 0;
   dim3 grid((unsigned)(p.n_ntiles * n_mtiles));
   // EPI: epilogue with global-side operands (residual-branch addend, fused BN-backward reduction)
 #define IG_GO2(WC, WP, TI, TJ, EP)                                                                              \
@@ -648,7 +654,8 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
   }
   if (variant >= 4) variant = 3;
   if (p.Co <= 64) IG_GO(1, 4, 2, 1);
-  else if (bm64) IG_GO2(2, 2, 2, 1, true);
+  else if (bm64 && epi) IG_GO2(2, 2, 2, 1, true);
+  else if (bm64) IG_GO2(2, 2, 2, 1, false);
   else IG_GO(2, 2, 2, 2);
 #undef IG_GO
 #undef IG_GO2

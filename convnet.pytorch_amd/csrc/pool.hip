@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const char* dy, const 
         for (int e = 0; e < CH; ++e)
           if ((int)((pk >> (8 * e)) & 0xffull) == t) acc[e] += g[e];
       }
-    cn_st16(dx + (((size_t)row * W + w) * C + (size_t)col * CH) * EB, Chunk<T>::pack(acc));
+    cn_st16_stream(dx + (((size_t)row * W + w) * C + (size_t)col * CH) * EB, Chunk<T>::pack(acc));
   }
 }
 
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void nchw_to_pairs_kernel(const float* x, char
       for (int c = 0; c < 4; ++c)
         f[j * 4 + c] = (in && c < C) ? x[(((size_t)n * C + c) * H + h) * W + w] : 0.f;
     }
-    cn_st16(y + (size_t)id * 16, Chunk<bf16_t>::pack(f));
+    cn_st16_stream(y + (size_t)id * 16, Chunk<bf16_t>::pack(f));
   }
 }
 
