@@ -332,8 +332,12 @@ __host__ __device__ __forceinline__ void cn_st16(void* p, const u32x4& v) { *(u3
 // streaming 16-byte global store (big activation / gradient tensors written once and read back only after
 // they have left the L2): a non-temporal store; -DCN_NO_NT_STORES makes it a plain store (A/B: +0.45 % on the
 // ResNet-50 step, profiles/README.md).
+template <int SITE = 0>
 __host__ __device__ __forceinline__ void cn_st16_stream(void* p, const u32x4& v) {
 #if !defined(CN_NO_NT_STORES) && defined(__HIP_DEVICE_COMPILE__) && !defined(CN_EMULATE)
+#ifdef CN_PLAIN_STORE_SITE   /* A/B builds: one site back to a plain store */
+  if (SITE == CN_PLAIN_STORE_SITE) { *(u32x4*)p = v; return; }
+#endif
   __builtin_nontemporal_store(v, (u32x4*)p);
 #else
   *(u32x4*)p = v;
@@ -342,8 +346,12 @@ __host__ __device__ __forceinline__ void cn_st16_stream(void* p, const u32x4& v)
 // streaming 16-byte global load (read-once passes over big tensors: BatchNorm apply / reduce, epilogue
 // operands): non-temporal, so the pass does not evict what the next kernels re-read from L2 / Infinity Cache;
 // -DCN_NO_NT_LOADS makes it a plain load (A/B: +1.5 % on the ResNet-50 step, profiles/README.md).
+template <int SITE = 0>
 __host__ __device__ __forceinline__ u32x4 cn_ld16_stream(const void* p) {
 #if !defined(CN_NO_NT_LOADS) && defined(__HIP_DEVICE_COMPILE__) && !defined(CN_EMULATE)
+#ifdef CN_PLAIN_LOAD_SITE   /* A/B builds: one site back to a plain load */
+  if (SITE == CN_PLAIN_LOAD_SITE) return *(const u32x4*)p;
+#endif
   return __builtin_nontemporal_load((const u32x4*)p);
 #else
   return *(const u32x4*)p;

@@ -527,7 +527,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
               v = Chunk<TO>::pack(fv);
             }
           }
-          cn_st16_stream(dst, v);
+          cn_st16(dst, v);   // plain store: a non-temporal one measured neutral here (profiles/README.md)
         } else {   // ragged channel count: element-wise tail (never combined with the BN reduction)
           for (int e = 0; e < epc && c_first + e < p.Co; ++e) {
             if (OEB == 4) {
