@@ -301,9 +301,16 @@ __device__ __forceinline__ void cn_buf_ld16_lds(cn_buf_t b, unsigned int off, vo
   __builtin_amdgcn_raw_ptr_buffer_load_lds(b, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)off,
                                            0, 0, 0);
 }
+__device__ __forceinline__ void cn_buf_ld16_lds_nt(cn_buf_t b, unsigned int off, void* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(b, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)off,
+                                           0, 0, 2);
+}
 #else
 static inline void cn_buf_ld16_lds(cn_buf_t b, unsigned int off, void* lds_wave_base) {
   *(u32x4*)((char*)lds_wave_base + cn_emul::lane() * 16) = cn_buf_ld16(b, off);
+}
+static inline void cn_buf_ld16_lds_nt(cn_buf_t b, unsigned int off, void* lds_wave_base) {
+  cn_buf_ld16_lds(b, off, lds_wave_base);
 }
 #endif
 

@@ -29,6 +29,7 @@ struct WgradParams {
   int n_itiles, n_jtiles;
   unsigned int x_bytes, dy_bytes;
   int simple;   // 1x1, stride 1, no padding: the gather is the identity (row m of x)
+  int nt;       // cache policy A/B knob "wgrad_nt": bit 0 = non-temporal x loads, bit 1 = non-temporal dy loads
   FastDiv div_hw, div_w, div_cpt;
   int tap_dhdw[WG_MAX_TAPS];
 };
@@ -100,14 +101,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     for (int i = 0; i < NI; ++i) {
       const int m = mb + rowI0 + i * RI;
       const bool ok = m < m_end && colI_b < CN_OOB;
-      regI[i] = cn_buf_ld16(dybuf, ok ? (unsigned int)m * rowI_pitch + colI_b : CN_OOB);
+      const unsigned int oI = ok ? (unsigned int)m * rowI_pitch + colI_b : CN_OOB;
+      regI[i] = (p.nt & 2) ? cn_buf_ld16_nt(dybuf, oI) : cn_buf_ld16(dybuf, oI);
     }
     if (p.simple) {
 #pragma unroll
       for (int i = 0; i < NJ; ++i) {
         const int m = mb + rowJ0 + i * RJ;
         const bool ok = m < m_end && colJ_b < CN_OOB;
-        regJ[i] = cn_buf_ld16(xbuf, ok ? (unsigned int)m * rowJ_pitch + colJ_b : CN_OOB);
+        const unsigned int oJ = ok ? (unsigned int)m * rowJ_pitch + colJ_b : CN_OOB;
+        regJ[i] = (p.nt & 1) ? cn_buf_ld16_nt(xbuf, oJ) : cn_buf_ld16(xbuf, oJ);
       }
     } else {
 #pragma unroll
@@ -121,7 +124,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
         const int wo = rem - ho * p.Wo;
         const int hi = ho * p.stride_h + dh, wq = wo * p.stride_w + dw;
         ok = ok && (unsigned)hi < (unsigned)p.Hi && (unsigned)wq < (unsigned)p.Wi;
-        regJ[i] = cn_buf_ld16(xbuf, ok ? (unsigned int)((n * p.Hi + hi) * p.Wi + wq) * rowJ_pitch + colJ_b : CN_OOB);
+        const unsigned int oJ = ok ? (unsigned int)((n * p.Hi + hi) * p.Wi + wq) * rowJ_pitch + colJ_b : CN_OOB;
+        regJ[i] = (p.nt & 1) ? cn_buf_ld16_nt(xbuf, oJ) : cn_buf_ld16(xbuf, oJ);
       }
     }
   };
@@ -276,7 +280,9 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(WgradParams p) {
       const int blk = i * 4 + wave;
       const int m = mb + blk * (1024 / RBI) + rI;
       const bool ok = m < m_end && colI_b < CN_OOB;
-      cn_buf_ld16_lds(dybuf, ok ? (unsigned int)m * rowI_pitch + colI_b : CN_OOB, baseI + blk * 1024);
+      const unsigned int oI = ok ? (unsigned int)m * rowI_pitch + colI_b : CN_OOB;
+      if (p.nt & 2) cn_buf_ld16_lds_nt(dybuf, oI, baseI + blk * 1024);
+      else cn_buf_ld16_lds(dybuf, oI, baseI + blk * 1024);
     }
 #pragma unroll
     for (int i = 0; i < NJ; ++i) {
@@ -296,7 +302,8 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(WgradParams p) {
         ok = ok && (unsigned)hi < (unsigned)p.Hi && (unsigned)wq < (unsigned)p.Wi;
         off = (unsigned int)((n * p.Hi + hi) * p.Wi + wq) * rowJ_pitch + colJ_b;
       }
-      cn_buf_ld16_lds(xbuf, ok ? off : CN_OOB, baseJ + blk * 1024);
+      if (p.nt & 1) cn_buf_ld16_lds_nt(xbuf, ok ? off : CN_OOB, baseJ + blk * 1024);
+      else cn_buf_ld16_lds(xbuf, ok ? off : CN_OOB, baseJ + blk * 1024);
     }
   };
 
@@ -500,6 +507,7 @@ extern "C" int cn_conv2d_wgrad(const void* x, const void* dy, float* dw_krsc, in
   }
   p.x_bytes = (unsigned int)xb; p.dy_bytes = (unsigned int)dyb;
   p.simple = (R == 1 && S == 1 && stride_h == 1 && stride_w == 1 && pad_h == 0 && pad_w == 0) ? 1 : 0;
+  p.nt = cn_get_option("wgrad_nt", 0);
   p.M = N * P * Q; p.m_per_split = pl.m_per_split; p.nsplit = pl.nsplit;
   p.n_itiles = pl.n_itiles; p.n_jtiles = pl.n_jtiles;
   p.div_hw = cn_make_fastdiv((unsigned)(P * Q));
