@@ -90,7 +90,10 @@ class SideStream(object):
     def get(self, device):
         s = self._streams.get(device)
         if s is None:
-            s = torch.cuda.Stream(device)
+            # CONVNET_AMD_WGRAD_STREAM_PRIO: HIP stream priority of the side stream (A/B knob; default = the
+            # runtime's default priority)
+            prio = os.environ.get('CONVNET_AMD_WGRAD_STREAM_PRIO')
+            s = torch.cuda.Stream(device, priority=int(prio)) if prio is not None else torch.cuda.Stream(device)
             self._streams[device] = s
         return s
 

