@@ -36,6 +36,11 @@ static BnMap bn_map(int cpr) {
   m.rpp = 256 >> l;
   return m;
 }
+// bit 1 of the kernels' `rev` argument: tensors below "bn_nt_min_mb" MB use cached instead of non-temporal accesses
+static int bn_cached_flag(long long M, int C, int dtype) {
+  const long long bytes = M * C * (dtype == CN_BF16 ? 2 : 4);
+  return bytes < (long long)cn_get_option("bn_nt_min_mb", 0) * (1ll << 20) ? 2 : 0;
+}
 static int bn_row_blocks(long long M, const BnMap& m, int target_blocks) {
   long long passes = (M + m.rpp - 1) / m.rpp;
   long long nb = target_blocks / m.gy;
@@ -246,15 +251,15 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const char* y, const char
   const int step = gridDim.x * rpp;
 #pragma unroll 4
   for (int it = blockIdx.x * rpp + rsub; it < M; it += step) {
-    const int row = rev ? M - 1 - it : it;   // rev: sweep back to front (the producer's freshest rows first)
+    const int row = (rev & 1) ? M - 1 - it : it;   // bit 0: sweep back to front; bit 1: cached (plain) accesses
     const size_t off = ((size_t)row * C + (size_t)col * CH) * EB;
     float f[CH];
-    Chunk<T>::unpack(cn_ld16_stream<1>(y + off), f);
+    Chunk<T>::unpack((rev & 2) ? cn_ld16(y + off) : cn_ld16_stream<1>(y + off), f);
 #pragma unroll
     for (int e = 0; e < CH; ++e) f[e] = fmaf(f[e], sc[e], sh[e]);
     if (res != nullptr) {
       float r[CH];
-      Chunk<T>::unpack(cn_ld16_stream<2>(res + off), r);
+      Chunk<T>::unpack((rev & 2) ? cn_ld16(res + off) : cn_ld16_stream<2>(res + off), r);
 #pragma unroll
       for (int e = 0; e < CH; ++e) f[e] += r[e];
     }
@@ -327,7 +332,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const char* dz, cons
       unsigned int bits[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int row = rev ? M - 1 - (it + u * step) : it + u * step;
+        const int row = (rev & 1) ? M - 1 - (it + u * step) : it + u * step;
         gz[u] = cn_ld16(dz + (size_t)row * rb + cb);
         vy[u] = cn_ld16(y + (size_t)row * rb + cb);
         if (relu && zmask != nullptr) bits[u] = zmask[(size_t)row * cpr + col];
@@ -336,7 +341,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const char* dz, cons
       for (int u = 0; u < 4; ++u) accum(gz[u], vy[u], bits[u]);
     }
     for (; it < M; it += step) {
-      const int row = rev ? M - 1 - it : it;
+      const int row = (rev & 1) ? M - 1 - it : it;
       unsigned int bits = 0u;
       if (relu && zmask != nullptr) bits = zmask[(size_t)row * cpr + col];
       accum(cn_ld16(dz + (size_t)row * rb + cb), cn_ld16(y + (size_t)row * rb + cb), bits);
@@ -409,11 +414,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char* dz, const
   const int step = gridDim.x * rpp;
 #pragma unroll 2
   for (int it = blockIdx.x * rpp + rsub; it < M; it += step) {
-    const int row = rev ? M - 1 - it : it;
+    const int row = (rev & 1) ? M - 1 - it : it;
     const size_t off = ((size_t)row * C + (size_t)col * CH) * EB;
     float g[CH], v[CH];
-    Chunk<T>::unpack(cn_ld16_stream<3>(dz + off), g);
-    Chunk<T>::unpack(cn_ld16_stream<4>(y + off), v);
+    Chunk<T>::unpack((rev & 2) ? cn_ld16(dz + off) : cn_ld16_stream<3>(dz + off), g);
+    Chunk<T>::unpack((rev & 2) ? cn_ld16(y + off) : cn_ld16_stream<4>(y + off), v);
     if (relu) {
       if (zmask != nullptr) {
         const unsigned int bits = zmask[(size_t)row * cpr + col];
@@ -424,11 +429,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char* dz, const
         for (int e = 0; e < CH; ++e) g[e] = fmaf(v[e], sc[e], sh[e]) > 0.f ? g[e] : 0.f;
       }
     }
-    if (dres != nullptr) cn_st16_stream<3>(dres + off, Chunk<T>::pack(g));
+    if (dres != nullptr) { if (rev & 2) cn_st16(dres + off, Chunk<T>::pack(g)); else cn_st16_stream<3>(dres + off, Chunk<T>::pack(g)); }
     float o[CH];
 #pragma unroll
     for (int e = 0; e < CH; ++e) o[e] = fmaf(c1[e], g[e], fmaf(c2[e], v[e], c3[e]));
-    cn_st16_stream<3>(dy + off, Chunk<T>::pack(o));
+    if (rev & 2) cn_st16(dy + off, Chunk<T>::pack(o)); else cn_st16_stream<3>(dy + off, Chunk<T>::pack(o));
   }
 }
 
@@ -649,7 +654,7 @@ static int bn_fwd_tail(const float* partial, int nrb, const void* y, const void*
   if (z == nullptr) return cn_check_launch("bn_fwd_train");   // statistics only (the consumer applies them itself)
   int nab = bn_row_blocks(M, m, cn_get_option("bn_apply_blocks", BN_APPLY_BLOCKS));
   dim3 agrid((unsigned)nab, (unsigned)m.gy);
-  const int rev = cn_get_option("bn_reverse", BN_REVERSE_DEFAULT) & 1;
+  const int rev = (cn_get_option("bn_reverse", BN_REVERSE_DEFAULT) & 1) | bn_cached_flag(M, C, dtype);
   if (dtype == CN_BF16)
     CN_LAUNCH(bn_apply_kernel<bf16_t>, agrid, dim3(256), stream, (const char*)y, (const char*)residual,
               (char*)z, relu_mask, (const float*)(stats_out + 2 * C), (const float*)(stats_out + 3 * C), M, C,
@@ -731,7 +736,7 @@ extern "C" int cn_bn_fwd_infer(const void* y, const void* residual, void* z, con
             running_mean, running_var, eps, coeffs, coeffs + C);
   int nab = bn_row_blocks(M, m, cn_get_option("bn_apply_blocks", BN_APPLY_BLOCKS));
   dim3 agrid((unsigned)nab, (unsigned)m.gy);
-  const int rev = cn_get_option("bn_reverse", BN_REVERSE_DEFAULT) & 1;
+  const int rev = (cn_get_option("bn_reverse", BN_REVERSE_DEFAULT) & 1) | bn_cached_flag(M, C, dtype);
   if (dtype == CN_BF16)
     CN_LAUNCH(bn_apply_kernel<bf16_t>, agrid, dim3(256), stream, (const char*)y, (const char*)residual,
               (char*)z, (unsigned char*)nullptr, (const float*)coeffs, (const float*)(coeffs + C), M, C, relu,
@@ -767,7 +772,7 @@ extern "C" int cn_bn_bwd(const void* dz, const void* y, const unsigned char* rel
   const float* shift = stats + 3 * C;
   dim3 grid((unsigned)nrb, (unsigned)m.gy);
   const int revopt = cn_get_option("bn_reverse", BN_REVERSE_DEFAULT);
-  const int rev_r = (revopt >> 1) & 1, rev_a = (revopt >> 2) & 1;
+  const int rev_r = (revopt >> 1) & 1, rev_a = ((revopt >> 2) & 1) | bn_cached_flag(M, C, dtype);
   if (dtype == CN_BF16)
     CN_LAUNCH(bn_bwd_reduce_kernel<bf16_t>, grid, dim3(256), stream, (const char*)dz, (const char*)y,
               relu_mask, mean, invstd, scale, shift, partial, M, C, relu, m.tpr_log2, rev_r);
@@ -822,7 +827,7 @@ extern "C" int cn_bn_bwd_partials(const void* g, const void* y, const float* gam
             mean, invstd, dgamma, dbeta, beta_acc, gscale, coef_scratch);
   int nab = bn_row_blocks(M, m, cn_get_option("bn_apply_blocks", BN_APPLY_BLOCKS));
   dim3 agrid((unsigned)nab, (unsigned)m.gy);
-  const int rev_a = (cn_get_option("bn_reverse", BN_REVERSE_DEFAULT) >> 2) & 1;
+  const int rev_a = ((cn_get_option("bn_reverse", BN_REVERSE_DEFAULT) >> 2) & 1) | bn_cached_flag(M, C, dtype);
   if (dtype == CN_BF16)
     CN_LAUNCH(bn_bwd_apply_kernel<bf16_t>, agrid, dim3(256), stream, (const char*)g, (const char*)y,
               (const unsigned char*)nullptr, scale, shift, (const float*)coef_scratch, (char*)dy, (char*)nullptr, M,
