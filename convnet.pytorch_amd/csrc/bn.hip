@@ -110,10 +110,9 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const char* y, float* par
 // dependent L2 round trips: measured 0.5 ms per launch at 2048 partials; with 8 threads per channel
 // 512 rows still took 4 dependent rounds, with 32 it is one or two.)
 #define BN_FC 8     /* channels per workgroup */
-#define BN_FP_MAX 128   /* row slices (threads per channel) = blockDim.x / BN_FC: 32 (256 threads) or 128 (1024) */
+#define BN_FP 32    /* row slices (threads per channel) */
 __device__ __forceinline__ void bn_sum_partials(const float* partial, int nrb, int C, int c, int part,
-                                                double* red /*[2][BN_FP_MAX][BN_FC]*/, double& s_out, double& q_out) {
-  const int BN_FP = (int)blockDim.x / BN_FC;
+                                                double* red /*[2][BN_FP][BN_FC]*/, double& s_out, double& q_out) {
   double s = 0.0, q = 0.0;
   if (c < C) {
     int r = part;
@@ -149,24 +148,45 @@ __device__ __forceinline__ void bn_sum_partials(const float* partial, int nrb, i
   }
   const int lc = threadIdx.x % BN_FC;
   red[part * BN_FC + lc] = s;
-  red[BN_FP_MAX * BN_FC + part * BN_FC + lc] = q;
+  red[BN_FP * BN_FC + part * BN_FC + lc] = q;
   __syncthreads();
   s = 0.0;
   q = 0.0;
-  for (int k = 0; k < BN_FP; ++k) { s += red[k * BN_FC + lc]; q += red[BN_FP_MAX * BN_FC + k * BN_FC + lc]; }
+#pragma unroll
+  for (int k = 0; k < BN_FP; ++k) { s += red[k * BN_FC + lc]; q += red[BN_FP * BN_FC + k * BN_FC + lc]; }
   s_out = s;
   q_out = q;
 }
 
+// out[r2][col] = sum of the G consecutive partial rows r2*G .. r2*G+G-1 (fixed order).  Brings the
+// per-pixel-tile partials a convolution epilogue emitted (thousands of rows for the 56x56 layers) down
+// to the few hundred rows bn_finalize_kernel walks.
+__global__ __launch_bounds__(256) void bn_partials_compress_kernel(const float* in, float* out, int nrb, int G,
+                                                                  int W) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= W) return;
+  int r = blockIdx.y * G;
+  const int re = r + G < nrb ? r + G : nrb;
+  float acc = 0.f;
+  for (; r + 7 < re; r += 8) {
+    float a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = in[(size_t)(r + u) * W + col];
+    acc += ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  }
+  for (; r < re; ++r) acc += in[(size_t)r * W + col];
+  out[(size_t)blockIdx.y * W + col] = acc;
+}
+
 // BN_FC channels per workgroup: statistics, running-stat update and the fused scale/shift the apply
 // kernel consumes.
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* partial, int nrb, int M, int C,
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* partial, int nrb, int M, int C,
                                                          const float* gamma, const float* beta,
                                                          float* running_mean, float* running_var,
                                                          long long* num_batches_tracked, float momentum,
                                                          float eps, float* save_mean, float* save_invstd,
                                                          float* scale, float* shift) {
-  __shared__ double red[2 * BN_FP_MAX * BN_FC];
+  __shared__ double red[512];
   const int c = blockIdx.x * BN_FC + (threadIdx.x % BN_FC);
   const int part = threadIdx.x / BN_FC;
   if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked != nullptr) *num_batches_tracked += 1;
@@ -344,12 +364,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const char* dz, cons
 
 // dgamma/dbeta (optionally accumulated) and the three per-channel coefficients of
 //   dy = c1*g + c2*y + c3     ( = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)) )
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* partial, int nrb, int M, int C,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* partial, int nrb, int M, int C,
                                                              const float* gamma, const float* mean,
                                                              const float* invstd, float* dgamma,
                                                              float* dbeta, float beta_acc, float gscale,
                                                              float* coef) {
-  __shared__ double red[2 * BN_FP_MAX * BN_FC];
+  __shared__ double red[512];
   const int c = blockIdx.x * BN_FC + (threadIdx.x % BN_FC);
   const int part = threadIdx.x / BN_FC;
   const bool owner = c < C && part == 0;   // operands requested before the partial reduction (latency)
@@ -628,9 +648,9 @@ static int bn_fwd_tail(const float* partial, int nrb, const void* y, const void*
                        unsigned char* relu_mask, const float* gamma, const float* beta, float* running_mean,
                        float* running_var, long long* num_batches_tracked, float momentum, float eps,
                        float* stats_out, int M, int C, int relu, int dtype, const BnMap& m, hipStream_t stream) {
-  CN_LAUNCH(bn_finalize_kernel, dim3((unsigned)((C + BN_FC - 1) / BN_FC)), dim3(nrb > BN_TARGET_BLOCKS ? 1024 : 256),
-            stream, partial, nrb, M, C, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
-            stats_out, stats_out + C, stats_out + 2 * C, stats_out + 3 * C);
+  CN_LAUNCH(bn_finalize_kernel, dim3((unsigned)((C + BN_FC - 1) / BN_FC)), dim3(256), stream, partial, nrb,
+            M, C, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, stats_out,
+            stats_out + C, stats_out + 2 * C, stats_out + 3 * C);
   if (z == nullptr) return cn_check_launch("bn_fwd_train");   // statistics only (the consumer applies them itself)
   int nab = bn_row_blocks(M, m, cn_get_option("bn_apply_blocks", BN_APPLY_BLOCKS));
   dim3 agrid((unsigned)nab, (unsigned)m.gy);
@@ -687,9 +707,18 @@ extern "C" int cn_bn_fwd_train_partials(const void* y, const void* residual, voi
   hipStream_t stream = (hipStream_t)stream_;
   const int CH = dtype == CN_BF16 ? 8 : 4;
   BnMap m = bn_map(C / CH);
-  // more than 512 rows (the 56x56 / 28x28 layers): the finalize runs with 1024 threads = 128 row slices per
-  // channel instead of a separate row-compression launch (a kernel boundary costs ~5 us on this machine)
-  (void)workspace; (void)ws_bytes;
+  if (nrb > BN_TARGET_BLOCKS) {
+    const int G = (nrb + BN_TARGET_BLOCKS - 1) / BN_TARGET_BLOCKS;
+    const int nr2 = (nrb + G - 1) / G;
+    if (workspace == nullptr || ws_bytes < (size_t)nr2 * 2 * C * sizeof(float)) {
+      cn_set_error("bn_fwd_train_partials: workspace too small");
+      return CN_EWORKSPACE;
+    }
+    CN_LAUNCH(bn_partials_compress_kernel, dim3((unsigned)((2 * C + 255) / 256), (unsigned)nr2), dim3(256), stream,
+              partial, (float*)workspace, nrb, G, 2 * C);
+    partial = (const float*)workspace;
+    nrb = nr2;
+  }
   return bn_fwd_tail(partial, nrb, y, residual, z, relu_mask, gamma, beta, running_mean, running_var,
                      num_batches_tracked, momentum, eps, stats_out, M, C, relu, dtype, m, stream);
 }
@@ -778,13 +807,24 @@ extern "C" int cn_bn_bwd_partials(const void* g, const void* y, const float* gam
   hipStream_t stream = (hipStream_t)stream_;
   const int CH = dtype == CN_BF16 ? 8 : 4;
   BnMap m = bn_map(C / CH);
-  (void)workspace; (void)ws_bytes;   // > 512 rows: 1024-thread finalize instead of a row-compression launch
+  if (nrb > BN_TARGET_BLOCKS) {
+    const int G = (nrb + BN_TARGET_BLOCKS - 1) / BN_TARGET_BLOCKS;
+    const int nr2 = (nrb + G - 1) / G;
+    if (workspace == nullptr || ws_bytes < (size_t)nr2 * 2 * C * sizeof(float)) {
+      cn_set_error("bn_bwd_partials: workspace too small");
+      return CN_EWORKSPACE;
+    }
+    CN_LAUNCH(bn_partials_compress_kernel, dim3((unsigned)((2 * C + 255) / 256), (unsigned)nr2), dim3(256), stream,
+              partial, (float*)workspace, nrb, G, 2 * C);
+    partial = (const float*)workspace;
+    nrb = nr2;
+  }
   const float* mean = stats;
   const float* invstd = stats + C;
   const float* scale = stats + 2 * C;
   const float* shift = stats + 3 * C;
-  CN_LAUNCH(bn_bwd_finalize_kernel, dim3((unsigned)((C + BN_FC - 1) / BN_FC)), dim3(nrb > BN_TARGET_BLOCKS ? 1024 : 256),
-            stream, partial, nrb, M, C, gamma, mean, invstd, dgamma, dbeta, beta_acc, gscale, coef_scratch);
+  CN_LAUNCH(bn_bwd_finalize_kernel, dim3((unsigned)((C + BN_FC - 1) / BN_FC)), dim3(256), stream, partial, nrb, M, C, gamma,
+            mean, invstd, dgamma, dbeta, beta_acc, gscale, coef_scratch);
   int nab = bn_row_blocks(M, m, cn_get_option("bn_apply_blocks", BN_APPLY_BLOCKS));
   dim3 agrid((unsigned)nab, (unsigned)m.gy);
   const int rev_a = ((cn_get_option("bn_reverse", BN_REVERSE_DEFAULT) >> 2) & 1) | bn_cached_flag(M, C, dtype);

@@ -532,7 +532,7 @@ class BatchNormActFunction(Function):
                                          ptr(stats), M, C, int(relu), code, ptr(sums), M * world, stream_of(y)),
                   'cn_bn_fwd_train_sums')
         elif ps is not None:   # statistics came out of the producing convolution's epilogue: no pass over y
-            PROFILER.run('bn_finalize+bn_apply (stats from conv epilogue)', 2, 0.0,
+            PROFILER.run('bn_finalize+bn_apply (stats from conv epilogue)', 2 if ps.rows <= 512 else 3, 0.0,
                          nb * (3 if residual is not None else 2) + (mask.numel() if mask is not None else 0)
                          + ps.partial.numel() * 4,
                          lambda: check(L.cn_bn_fwd_train_partials(
@@ -604,7 +604,7 @@ class BatchNormActFunction(Function):
             _, _, partial, rows = pp
             COUNTERS['bn_bwd_fused'] += 1
             dres = dz if want_res else None       # the residual branch's gradient is g itself
-            PROFILER.run('bn_bwd_finalize+bn_bwd_apply (reduce in dgrad epilogue)', 2, 0.0,
+            PROFILER.run('bn_bwd_finalize+bn_bwd_apply (reduce in dgrad epilogue)', 2 if rows <= 512 else 3, 0.0,
                          nb * 3 + partial.numel() * 4,
                          lambda: check(L.cn_bn_bwd_partials(ptr(dz), ptr(y), ptr(mod.weight), ptr(stats), ptr(dy),
                                                             ptr(mod.grad_view('weight')), ptr(mod.grad_view('bias')),
