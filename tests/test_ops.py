@@ -390,6 +390,56 @@ def test_stem_bn_relu_maxpool_fused_equals_chain(mode, dtype):
 
 
 @pytest.mark.parametrize('mode', MODES)
+def test_batchnorm_from_many_partial_rows(mode):
+    """cn_bn_fwd_train_partials / cn_bn_bwd_partials with more than 512 partial rows (the 1024-thread
+    finalize that replaces a separate row-compression launch) against the standalone passes."""
+    dev = _dev(mode)
+    import convnet_amd as ca
+    lib, L, ops = ca._lib, ca._lib.load(), ca.ops
+    dtype, code = torch.float32, ca._lib.F32
+    C, rows, per = 16, 1300, 2
+    M = rows * per
+    g = torch.Generator().manual_seed(1)
+    y = (torch.randn(M, C, generator=g) * 1.7 + 0.4).to(dev)
+    dz = torch.randn(M, C, generator=g).to(dev)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.1).to(dev)
+    ws = ops.workspace(L.cn_bn_workspace(M, C, code), dev)
+    yr = y.view(rows, per, C)
+    partial = torch.cat([yr.sum(1), (yr * yr).sum(1)], dim=1).contiguous()       # [rows][2C]
+    outs = []
+    for use_partials in (True, False):
+        z = torch.empty_like(y)
+        st = torch.empty(4 * C, device=dev)
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        if use_partials:
+            lib.check(L.cn_bn_fwd_train_partials(lib.ptr(y), None, lib.ptr(z), None, lib.ptr(gamma), lib.ptr(beta),
+                                                 lib.ptr(rm), lib.ptr(rv), None, 0.1, 1e-5, lib.ptr(st), M, C, 1, code,
+                                                 lib.ptr(partial), rows, lib.ptr(ws), ws.numel() * 4, lib.stream_of(y)))
+        else:
+            lib.check(L.cn_bn_fwd_train(lib.ptr(y), None, lib.ptr(z), None, lib.ptr(gamma), lib.ptr(beta), lib.ptr(rm),
+                                        lib.ptr(rv), None, 0.1, 1e-5, lib.ptr(st), M, C, 1, code, lib.ptr(ws),
+                                        ws.numel() * 4, lib.stream_of(y)))
+        # backward: g = dz * relu mask, partial rows of [sum g | sum g*xhat]
+        mean, invstd = st[:C], st[C:2 * C]
+        gm = torch.where(z > 0, dz, torch.zeros_like(dz))
+        dy = torch.empty_like(y)
+        dg, db, coef = torch.zeros(C, device=dev), torch.zeros(C, device=dev), torch.empty(3 * C, device=dev)
+        if use_partials:
+            xhat = (y - mean) * invstd
+            bp = torch.cat([gm.view(rows, per, C).sum(1), (gm * xhat).view(rows, per, C).sum(1)], dim=1).contiguous()
+            lib.check(L.cn_bn_bwd_partials(lib.ptr(gm), lib.ptr(y), lib.ptr(gamma), lib.ptr(st), lib.ptr(dy), lib.ptr(dg),
+                                           lib.ptr(db), 0.0, 1.0, lib.ptr(coef), M, C, code, lib.ptr(bp), rows,
+                                           lib.ptr(ws), ws.numel() * 4, lib.stream_of(y)))
+        else:
+            lib.check(L.cn_bn_bwd(lib.ptr(dz), lib.ptr(y), None, lib.ptr(gamma), lib.ptr(st), lib.ptr(dy), None,
+                                  lib.ptr(dg), lib.ptr(db), 0.0, 1.0, lib.ptr(coef), M, C, 1, code, lib.ptr(ws),
+                                  ws.numel() * 4, lib.stream_of(y)))
+        outs.append([t.float().cpu() for t in (z, st, rm, rv, dy, dg, db)])
+    for a, b in zip(*outs):
+        assert rel_l2(a, b) < 2e-5
+
+
+@pytest.mark.parametrize('mode', MODES)
 def test_wgrad_accumulates_and_scales(mode):
     dev = _dev(mode)
     import convnet_amd as ca
