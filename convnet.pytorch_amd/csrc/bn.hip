@@ -36,10 +36,25 @@ static BnMap bn_map(int cpr) {
   m.rpp = 256 >> l;
   return m;
 }
-// bit 1 of the kernels' `rev` argument: tensors below "bn_nt_min_mb" MB use cached instead of non-temporal accesses
-static int bn_cached_flag(long long M, int C, int dtype) {
+// 1 = the apply passes use non-temporal accesses (default; tensors below "bn_nt_min_mb" MB and
+// "bn_nt" = 0 use the cached policy: whole-step A/B knobs)
+static int bn_nt_flag(long long M, int C, int dtype) {
+  if (cn_get_option("bn_nt", 1) == 0) return 0;
   const long long bytes = M * C * (dtype == CN_BF16 ? 2 : 4);
-  return bytes < (long long)cn_get_option("bn_nt_min_mb", 0) * (1ll << 20) ? 2 : 0;
+  return bytes < (long long)cn_get_option("bn_nt_min_mb", 0) * (1ll << 20) ? 0 : 1;
+}
+// Cache policy of the streaming passes is a COMPILE-TIME parameter of the kernels (NT): a run-time select
+// between a plain and a non-temporal access of the same address is folded by LLVM into one plain access
+// (round 1 shipped exactly that; tools/check_nt.sh now greps the code object for the `nt` accesses).
+template <bool NT, int SITE>
+__device__ __forceinline__ u32x4 bn_ld(const void* p) {
+  if constexpr (NT) return cn_ld16_stream<SITE>(p);
+  else return cn_ld16(p);
+}
+template <bool NT, int SITE>
+__device__ __forceinline__ void bn_st(void* p, const u32x4& v) {
+  if constexpr (NT) cn_st16_stream<SITE>(p, v);
+  else cn_st16(p, v);
 }
 static int bn_row_blocks(long long M, const BnMap& m, int target_blocks) {
   long long passes = (M + m.rpp - 1) / m.rpp;
@@ -233,7 +248,7 @@ __global__ __launch_bounds__(256) void bn_infer_coeffs_kernel(int C, const float
 // z = act(y*scale[c] + shift[c] (+ residual)).  When `mask` is given (ReLU after a residual add) one
 // byte per 16-byte chunk records which outputs were positive, so backward reads M*C/CH bytes instead
 // of re-reading z (the mask cannot be recomputed from y alone once a residual was added).
-template <typename T>
+template <typename T, bool NT>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const char* y, const char* res, char* z,
                                                       unsigned char* mask, const float* scale,
                                                       const float* shift, int M, int C, int relu,
@@ -251,15 +266,15 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const char* y, const char
   const int step = gridDim.x * rpp;
 #pragma unroll 4
   for (int it = blockIdx.x * rpp + rsub; it < M; it += step) {
-    const int row = (rev & 1) ? M - 1 - it : it;   // bit 0: sweep back to front; bit 1: cached (plain) accesses
+    const int row = (rev & 1) ? M - 1 - it : it;   // bit 0: sweep back to front
     const size_t off = ((size_t)row * C + (size_t)col * CH) * EB;
     float f[CH];
-    Chunk<T>::unpack((rev & 2) ? cn_ld16(y + off) : cn_ld16_stream<1>(y + off), f);
+    Chunk<T>::unpack(bn_ld<NT, 1>(y + off), f);
 #pragma unroll
     for (int e = 0; e < CH; ++e) f[e] = fmaf(f[e], sc[e], sh[e]);
     if (res != nullptr) {
       float r[CH];
-      Chunk<T>::unpack((rev & 2) ? cn_ld16(res + off) : cn_ld16_stream<2>(res + off), r);
+      Chunk<T>::unpack(bn_ld<NT, 2>(res + off), r);
 #pragma unroll
       for (int e = 0; e < CH; ++e) f[e] += r[e];
     }
@@ -279,7 +294,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const char* y, const char
 // Per-channel sum(g) and sum(g * xhat), g = dz * relu_mask.
 //   mask source: the byte mask written by bn_apply (needed when a residual was added) or, when
 //   mask == nullptr and relu != 0, recomputed from y*scale+shift > 0.
-template <typename T>
+template <typename T, bool NT>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const char* dz, const char* y, const unsigned char* zmask,
                                                            const float* mean, const float* invstd,
                                                            const float* scale, const float* shift,
@@ -333,8 +348,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const char* dz, cons
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int row = (rev & 1) ? M - 1 - (it + u * step) : it + u * step;
-        gz[u] = cn_ld16(dz + (size_t)row * rb + cb);
-        vy[u] = cn_ld16(y + (size_t)row * rb + cb);
+        gz[u] = bn_ld<NT, 5>(dz + (size_t)row * rb + cb);
+        vy[u] = bn_ld<NT, 6>(y + (size_t)row * rb + cb);
         if (relu && zmask != nullptr) bits[u] = zmask[(size_t)row * cpr + col];
       }
 #pragma unroll
@@ -344,7 +359,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const char* dz, cons
       const int row = (rev & 1) ? M - 1 - it : it;
       unsigned int bits = 0u;
       if (relu && zmask != nullptr) bits = zmask[(size_t)row * cpr + col];
-      accum(cn_ld16(dz + (size_t)row * rb + cb), cn_ld16(y + (size_t)row * rb + cb), bits);
+      accum(bn_ld<NT, 5>(dz + (size_t)row * rb + cb), bn_ld<NT, 6>(y + (size_t)row * rb + cb), bits);
     }
   }
 #pragma unroll
@@ -390,7 +405,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* parti
   coef[2 * C + c] = (float)(a2 * (double)mu_pre - k * s1 / (double)M);
 }
 
-template <typename T>
+template <typename T, bool NT>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char* dz, const char* y, const unsigned char* zmask,
                                                           const float* scale, const float* shift,
                                                           const float* coef, char* dy, char* dres, int M,
@@ -417,8 +432,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char* dz, const
     const int row = (rev & 1) ? M - 1 - it : it;
     const size_t off = ((size_t)row * C + (size_t)col * CH) * EB;
     float g[CH], v[CH];
-    Chunk<T>::unpack((rev & 2) ? cn_ld16(dz + off) : cn_ld16_stream<3>(dz + off), g);
-    Chunk<T>::unpack((rev & 2) ? cn_ld16(y + off) : cn_ld16_stream<4>(y + off), v);
+    Chunk<T>::unpack(bn_ld<NT, 3>(dz + off), g);
+    Chunk<T>::unpack(bn_ld<NT, 4>(y + off), v);
     if (relu) {
       if (zmask != nullptr) {
         const unsigned int bits = zmask[(size_t)row * cpr + col];
@@ -429,11 +444,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char* dz, const
         for (int e = 0; e < CH; ++e) g[e] = fmaf(v[e], sc[e], sh[e]) > 0.f ? g[e] : 0.f;
       }
     }
-    if (dres != nullptr) { if (rev & 2) cn_st16(dres + off, Chunk<T>::pack(g)); else cn_st16_stream<3>(dres + off, Chunk<T>::pack(g)); }
+    if (dres != nullptr) bn_st<NT, 3>(dres + off, Chunk<T>::pack(g));
     float o[CH];
 #pragma unroll
     for (int e = 0; e < CH; ++e) o[e] = fmaf(c1[e], g[e], fmaf(c2[e], v[e], c3[e]));
-    if (rev & 2) cn_st16(dy + off, Chunk<T>::pack(o)); else cn_st16_stream<3>(dy + off, Chunk<T>::pack(o));
+    bn_st<NT, 3>(dy + off, Chunk<T>::pack(o));
   }
 }
 
@@ -618,6 +633,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(BnPoolGeom geo, 
 // Inference-mode backward is not part of the reference hot path (validate() runs under no_grad).
 
 // ------------------------------------------------------------------------------------------------
+// (dtype, cache policy) -> kernel instantiation
+#define BN_DISPATCH(kern, dtype, nt, grid, stream, ...)                                            \
+  do {                                                                                             \
+    if ((dtype) == CN_BF16) {                                                                      \
+      if (nt) CN_LAUNCH((kern<bf16_t, true>), grid, dim3(256), stream, __VA_ARGS__);                \
+      else CN_LAUNCH((kern<bf16_t, false>), grid, dim3(256), stream, __VA_ARGS__);                  \
+    } else {                                                                                       \
+      if (nt) CN_LAUNCH((kern<float, true>), grid, dim3(256), stream, __VA_ARGS__);                 \
+      else CN_LAUNCH((kern<float, false>), grid, dim3(256), stream, __VA_ARGS__);                   \
+    }                                                                                              \
+  } while (0)
+
 #define BN_TARGET_BLOCKS 512   /* reduction kernels: partial rows per channel (kept small) */
 #define BN_APPLY_BLOCKS 2048   /* pure streaming kernels */
 /* Sweep direction of the streaming kernels, bit 0: forward apply, bit 1: backward reduce, bit 2: backward
@@ -654,15 +681,8 @@ static int bn_fwd_tail(const float* partial, int nrb, const void* y, const void*
   if (z == nullptr) return cn_check_launch("bn_fwd_train");   // statistics only (the consumer applies them itself)
   int nab = bn_row_blocks(M, m, cn_get_option("bn_apply_blocks", BN_APPLY_BLOCKS));
   dim3 agrid((unsigned)nab, (unsigned)m.gy);
-  const int rev = (cn_get_option("bn_reverse", BN_REVERSE_DEFAULT) & 1) | bn_cached_flag(M, C, dtype);
-  if (dtype == CN_BF16)
-    CN_LAUNCH(bn_apply_kernel<bf16_t>, agrid, dim3(256), stream, (const char*)y, (const char*)residual,
-              (char*)z, relu_mask, (const float*)(stats_out + 2 * C), (const float*)(stats_out + 3 * C), M, C,
-              relu, m.tpr_log2, rev);
-  else
-    CN_LAUNCH(bn_apply_kernel<float>, agrid, dim3(256), stream, (const char*)y, (const char*)residual, (char*)z,
-              relu_mask, (const float*)(stats_out + 2 * C), (const float*)(stats_out + 3 * C), M, C, relu,
-              m.tpr_log2, rev);
+  const int rev = (cn_get_option("bn_reverse", BN_REVERSE_DEFAULT) & 1);
+  BN_DISPATCH(bn_apply_kernel, dtype, bn_nt_flag(M, C, dtype), agrid, stream, (const char*)y, (const char*)residual, (char*)z, relu_mask, (const float*)(stats_out + 2 * C), (const float*)(stats_out + 3 * C), M, C, relu, m.tpr_log2, rev);
   return cn_check_launch("bn_fwd_train");
 }
 
@@ -736,15 +756,8 @@ extern "C" int cn_bn_fwd_infer(const void* y, const void* residual, void* z, con
             running_mean, running_var, eps, coeffs, coeffs + C);
   int nab = bn_row_blocks(M, m, cn_get_option("bn_apply_blocks", BN_APPLY_BLOCKS));
   dim3 agrid((unsigned)nab, (unsigned)m.gy);
-  const int rev = (cn_get_option("bn_reverse", BN_REVERSE_DEFAULT) & 1) | bn_cached_flag(M, C, dtype);
-  if (dtype == CN_BF16)
-    CN_LAUNCH(bn_apply_kernel<bf16_t>, agrid, dim3(256), stream, (const char*)y, (const char*)residual,
-              (char*)z, (unsigned char*)nullptr, (const float*)coeffs, (const float*)(coeffs + C), M, C, relu,
-              m.tpr_log2, rev);
-  else
-    CN_LAUNCH(bn_apply_kernel<float>, agrid, dim3(256), stream, (const char*)y, (const char*)residual, (char*)z,
-              (unsigned char*)nullptr, (const float*)coeffs, (const float*)(coeffs + C), M, C, relu, m.tpr_log2,
-              rev);
+  const int rev = (cn_get_option("bn_reverse", BN_REVERSE_DEFAULT) & 1);
+  BN_DISPATCH(bn_apply_kernel, dtype, bn_nt_flag(M, C, dtype), agrid, stream, (const char*)y, (const char*)residual, (char*)z, (unsigned char*)nullptr, (const float*)coeffs, (const float*)(coeffs + C), M, C, relu, m.tpr_log2, rev);
   return cn_check_launch("bn_fwd_infer");
 }
 
@@ -772,25 +785,13 @@ extern "C" int cn_bn_bwd(const void* dz, const void* y, const unsigned char* rel
   const float* shift = stats + 3 * C;
   dim3 grid((unsigned)nrb, (unsigned)m.gy);
   const int revopt = cn_get_option("bn_reverse", BN_REVERSE_DEFAULT);
-  const int rev_r = (revopt >> 1) & 1, rev_a = ((revopt >> 2) & 1) | bn_cached_flag(M, C, dtype);
-  if (dtype == CN_BF16)
-    CN_LAUNCH(bn_bwd_reduce_kernel<bf16_t>, grid, dim3(256), stream, (const char*)dz, (const char*)y,
-              relu_mask, mean, invstd, scale, shift, partial, M, C, relu, m.tpr_log2, rev_r);
-  else
-    CN_LAUNCH(bn_bwd_reduce_kernel<float>, grid, dim3(256), stream, (const char*)dz, (const char*)y,
-              relu_mask, mean, invstd, scale, shift, partial, M, C, relu, m.tpr_log2, rev_r);
+  const int rev_r = (revopt >> 1) & 1, rev_a = ((revopt >> 2) & 1);
+  BN_DISPATCH(bn_bwd_reduce_kernel, dtype, (cn_get_option("bn_reduce_nt", 0) != 0), grid, stream, (const char*)dz, (const char*)y, relu_mask, mean, invstd, scale, shift, partial, M, C, relu, m.tpr_log2, rev_r);
   CN_LAUNCH(bn_bwd_finalize_kernel, dim3((unsigned)((C + BN_FC - 1) / BN_FC)), dim3(256), stream, (const float*)partial,
             nrb, M, C, gamma, mean, invstd, dgamma, dbeta, beta_acc, gscale, coef_scratch);
   int nab = bn_row_blocks(M, m, cn_get_option("bn_apply_blocks", BN_APPLY_BLOCKS));
   dim3 agrid((unsigned)nab, (unsigned)m.gy);
-  if (dtype == CN_BF16)
-    CN_LAUNCH(bn_bwd_apply_kernel<bf16_t>, agrid, dim3(256), stream, (const char*)dz, (const char*)y,
-              relu_mask, scale, shift, (const float*)coef_scratch, (char*)dy, (char*)dres, M, C, relu,
-              m.tpr_log2, rev_a);
-  else
-    CN_LAUNCH(bn_bwd_apply_kernel<float>, agrid, dim3(256), stream, (const char*)dz, (const char*)y,
-              relu_mask, scale, shift, (const float*)coef_scratch, (char*)dy, (char*)dres, M, C, relu,
-              m.tpr_log2, rev_a);
+  BN_DISPATCH(bn_bwd_apply_kernel, dtype, bn_nt_flag(M, C, dtype), agrid, stream, (const char*)dz, (const char*)y, relu_mask, scale, shift, (const float*)coef_scratch, (char*)dy, (char*)dres, M, C, relu, m.tpr_log2, rev_a);
   return cn_check_launch("bn_bwd");
 }
 
@@ -827,15 +828,8 @@ extern "C" int cn_bn_bwd_partials(const void* g, const void* y, const float* gam
             mean, invstd, dgamma, dbeta, beta_acc, gscale, coef_scratch);
   int nab = bn_row_blocks(M, m, cn_get_option("bn_apply_blocks", BN_APPLY_BLOCKS));
   dim3 agrid((unsigned)nab, (unsigned)m.gy);
-  const int rev_a = ((cn_get_option("bn_reverse", BN_REVERSE_DEFAULT) >> 2) & 1) | bn_cached_flag(M, C, dtype);
-  if (dtype == CN_BF16)
-    CN_LAUNCH(bn_bwd_apply_kernel<bf16_t>, agrid, dim3(256), stream, (const char*)g, (const char*)y,
-              (const unsigned char*)nullptr, scale, shift, (const float*)coef_scratch, (char*)dy, (char*)nullptr, M,
-              C, 0, m.tpr_log2, rev_a);
-  else
-    CN_LAUNCH(bn_bwd_apply_kernel<float>, agrid, dim3(256), stream, (const char*)g, (const char*)y,
-              (const unsigned char*)nullptr, scale, shift, (const float*)coef_scratch, (char*)dy, (char*)nullptr, M,
-              C, 0, m.tpr_log2, rev_a);
+  const int rev_a = ((cn_get_option("bn_reverse", BN_REVERSE_DEFAULT) >> 2) & 1);
+  BN_DISPATCH(bn_bwd_apply_kernel, dtype, bn_nt_flag(M, C, dtype), agrid, stream, (const char*)g, (const char*)y, (const unsigned char*)nullptr, scale, shift, (const float*)coef_scratch, (char*)dy, (char*)nullptr, M, C, 0, m.tpr_log2, rev_a);
   return cn_check_launch("bn_bwd_partials");
 }
 
@@ -962,14 +956,7 @@ extern "C" int cn_bn_fwd_train_sums(const void* y, const void* residual, void* z
             stats_out + 2 * C, stats_out + 3 * C);
   int nab = bn_row_blocks(M, m, cn_get_option("bn_apply_blocks", BN_APPLY_BLOCKS));
   dim3 agrid((unsigned)nab, (unsigned)m.gy);
-  if (dtype == CN_BF16)
-    CN_LAUNCH(bn_apply_kernel<bf16_t>, agrid, dim3(256), stream, (const char*)y, (const char*)residual,
-              (char*)z, relu_mask, (const float*)(stats_out + 2 * C), (const float*)(stats_out + 3 * C), M, C,
-              relu, m.tpr_log2, 0);
-  else
-    CN_LAUNCH(bn_apply_kernel<float>, agrid, dim3(256), stream, (const char*)y, (const char*)residual, (char*)z,
-              relu_mask, (const float*)(stats_out + 2 * C), (const float*)(stats_out + 3 * C), M, C, relu,
-              m.tpr_log2, 0);
+  BN_DISPATCH(bn_apply_kernel, dtype, bn_nt_flag(M, C, dtype), agrid, stream, (const char*)y, (const char*)residual, (char*)z, relu_mask, (const float*)(stats_out + 2 * C), (const float*)(stats_out + 3 * C), M, C, relu, m.tpr_log2, 0);
   return cn_check_launch("bn_fwd_train_sums");
 }
 
@@ -990,12 +977,7 @@ extern "C" int cn_bn_bwd_local_sums(const void* dz, const void* y, const unsigne
       return CN_EWORKSPACE;
     }
     dim3 grid((unsigned)nrb, (unsigned)m.gy);
-    if (dtype == CN_BF16)
-      CN_LAUNCH(bn_bwd_reduce_kernel<bf16_t>, grid, dim3(256), stream, (const char*)dz, (const char*)y, relu_mask,
-                stats, stats + C, stats + 2 * C, stats + 3 * C, (float*)workspace, M, C, relu, m.tpr_log2, 0);
-    else
-      CN_LAUNCH(bn_bwd_reduce_kernel<float>, grid, dim3(256), stream, (const char*)dz, (const char*)y, relu_mask,
-                stats, stats + C, stats + 2 * C, stats + 3 * C, (float*)workspace, M, C, relu, m.tpr_log2, 0);
+    BN_DISPATCH(bn_bwd_reduce_kernel, dtype, (cn_get_option("bn_reduce_nt", 0) != 0), grid, stream, (const char*)dz, (const char*)y, relu_mask, stats, stats + C, stats + 2 * C, stats + 3 * C, (float*)workspace, M, C, relu, m.tpr_log2, 0);
     partial = (const float*)workspace;
   }
   CN_LAUNCH(bn_partials_total_kernel, dim3((unsigned)((2 * C + 31) / 32)), dim3(256), stream, partial, nrb, 2 * C, sums);
@@ -1028,12 +1010,7 @@ extern "C" int cn_bn_bwd_sums(const void* dz, const void* y, const unsigned char
   dim3 agrid((unsigned)nab, (unsigned)m.gy);
   const int arelu = pre_masked ? 0 : relu;
   const unsigned char* amask = pre_masked ? nullptr : relu_mask;
-  if (dtype == CN_BF16)
-    CN_LAUNCH(bn_bwd_apply_kernel<bf16_t>, agrid, dim3(256), stream, (const char*)dz, (const char*)y, amask, scale,
-              shift, (const float*)coef_scratch, (char*)dy, (char*)dres, M, C, arelu, m.tpr_log2, 0);
-  else
-    CN_LAUNCH(bn_bwd_apply_kernel<float>, agrid, dim3(256), stream, (const char*)dz, (const char*)y, amask, scale,
-              shift, (const float*)coef_scratch, (char*)dy, (char*)dres, M, C, arelu, m.tpr_log2, 0);
+  BN_DISPATCH(bn_bwd_apply_kernel, dtype, bn_nt_flag(M, C, dtype), agrid, stream, (const char*)dz, (const char*)y, amask, scale, shift, (const float*)coef_scratch, (char*)dy, (char*)dres, M, C, arelu, m.tpr_log2, 0);
   return cn_check_launch("bn_bwd_sums");
 }
 

@@ -1,0 +1,51 @@
+"""Build guard: the shipped gfx950 code objects contain the instructions the design claims
+(tools/isa_check.py disassembles libconvnet_hip.so; no GPU needed).  Round 1 shipped a library whose
+"non-temporal" BatchNorm loads had been folded into plain loads by a run-time select; this test pins
+the cache policy, the MFMA / LDS-DMA / transpose-read core of the GEMM kernels and the absence of
+anything but our own kernels."""
+import os
+import sys
+
+import pytest
+
+from helpers import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+HIP_LIB = os.path.join(ROOT, 'convnet.pytorch_amd', 'libconvnet_hip.so')
+
+
+@pytest.fixture(scope='module')
+def table():
+    import isa_check
+    if not os.path.exists(HIP_LIB):
+        import __graft_entry__ as g
+        g.build()
+    return isa_check.kernel_table(HIP_LIB)
+
+
+def _find(table, *needles):
+    hits = [(k, v) for k, v in table.items() if all(n in k for n in needles)]
+    assert hits, 'no kernel matching %r in the library' % (needles,)
+    return hits
+
+
+def test_bn_streaming_passes_really_use_nontemporal_accesses(table):
+    # NT = true instantiations: the activation loads are `nt`, the plain ones left are coefficient loads
+    for kern, sites in (('bn_apply_kernel', 'nt_load16'), ('bn_bwd_apply_kernel', 'nt_load16'),
+                        ('bn_bwd_apply_kernel', 'nt_store16'), ('bn_bwd_reduce_kernel', 'nt_load16')):
+        for name, c in _find(table, kern + '<', ', true>'):
+            assert c[sites] > 0, (name, c)
+        for name, c in _find(table, kern + '<', ', false>'):
+            assert c['nt_load16'] == 0 and c['nt_store16'] == 0, (name, c)
+    # z is stored with the default policy in both instantiations (its consumer follows at once)
+    for name, c in _find(table, 'bn_apply_kernel'):
+        assert c['nt_store16'] == 0 and c['plain_store16'] > 0, (name, c)
+
+
+def test_gemm_kernels_are_mfma_lds_dma_and_transpose_reads(table):
+    ig = _find(table, 'igemm_kernel', 'bf16_t')
+    assert all(c['mfma'] >= 8 for _, c in ig), [(n, c['mfma']) for n, c in ig]
+    assert any(c['lds_dma'] > 0 for _, c in ig)
+    wg = _find(table, 'wgrad', 'kernel')
+    assert any(c['tr_read'] > 0 and c['mfma'] > 0 for _, c in wg)
+    assert any(c['lds_dma'] > 0 for _, c in wg)
