@@ -18,17 +18,23 @@ from . import _lib
 from ._lib import check, dtype_code, ptr, stream_of
 
 # ---------------------------------------------------------------------------------------------
-# workspaces: one grow-only scratch buffer per (device, tag); kernels on one stream are ordered,
-# so reuse across ops is safe.
+# workspaces: one grow-only scratch buffer per (device, tag, stream).  Kernels on one stream are ordered,
+# so reuse across ops on that stream is safe; keying by stream keeps a buffer from being shared (or, when
+# it is replaced by a bigger one, recycled by the caching allocator) across streams without an event.
 _WS = {}
 
 
 def workspace(nbytes, device, tag='main'):
-    key = (str(device), tag)
+    dev = torch.device(device)
+    sid = torch.cuda.current_stream(dev).cuda_stream if dev.type == 'cuda' else 0
+    key = (str(dev), tag, sid)
     buf = _WS.get(key)
     if buf is None or buf.numel() * 4 < nbytes:
         n = max(int(nbytes + 3) // 4, 1024)
-        buf = torch.empty(n, dtype=torch.float32, device=device)
+        old = buf
+        buf = torch.empty(n, dtype=torch.float32, device=dev)
+        if old is not None and dev.type == 'cuda':
+            old.record_stream(torch.cuda.current_stream(dev))   # kernels still reading the old block finish first
         _WS[key] = buf
     return buf
 

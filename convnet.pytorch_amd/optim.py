@@ -215,19 +215,34 @@ class OptimRegime(Regime):
                 'regime_phase': self.current_regime_phase}
 
     def load_state_dict(self, state):
+        """Restores the momentum buffers (and the hyper-parameters as a starting point).  The regime
+        position is deliberately NOT restored: `setting` is cumulative over all phases passed so far
+        (e.g. the WeightDecay regulariser only appears in phase 0 of the ResNet regime,
+        models/resnet.py:250-256), so the first `update(epoch, steps)` after a resume replays the
+        regime from the start exactly as a fresh OptimRegime at that epoch would.  Only this
+        implementation's own format is understood: a foreign optimizer state (e.g. the reference's
+        torch.optim state) is refused loudly instead of silently starting from zero momentum."""
         self._bind()
+        bufs = state.get('momentum_buffer') if isinstance(state, dict) else None
+        if bufs is None:
+            raise _lib.ConvNetHipError(
+                "OptimRegime.load_state_dict: no 'momentum_buffer' entry - not a checkpoint of this engine "
+                "(only the model state_dict is interchangeable with the reference)")
+        missing = [s.name for s in self.arena.slots if s.name not in bufs]
+        if missing:
+            raise _lib.ConvNetHipError('OptimRegime.load_state_dict: momentum buffers missing for %s%s'
+                                       % (missing[:4], ' ...' if len(missing) > 4 else ''))
         for s in self.arena.slots:
-            if s.name in state.get('momentum_buffer', {}):
-                src = state['momentum_buffer'][s.name].to(self.arena.device, torch.float32)
-                seg = self.momentum_buf[s.offset:s.offset + s.numel]
-                p = s.param
-                if s.is_filter and p.dim() == 4:
-                    O, I, R, S_ = p.shape
-                    seg.view(O, R, S_, I).permute(0, 3, 1, 2).copy_(src)
-                else:
-                    seg.view(p.shape).copy_(src)
+            src = bufs[s.name].to(self.arena.device, torch.float32)
+            seg = self.momentum_buf[s.offset:s.offset + s.numel]
+            p = s.param
+            if s.is_filter and p.dim() == 4:
+                O, I, R, S_ = p.shape
+                seg.view(O, R, S_, I).permute(0, 3, 1, 2).copy_(src)
+            else:
+                seg.view(p.shape).copy_(src)
         self.hyper.update(state.get('hyper', {}))
-        self.current_regime_phase = state.get('regime_phase', None)
+        self.reset()          # current_regime_phase = None, setting = defaults: next update() replays the regime
         self._runs = None
 
 

@@ -115,3 +115,39 @@ def test_resnet_learns_a_separable_task_bf16():
     assert last['loss'] < 0.35 and last['prec1'] > 90.0, (first, last)
     val = tr.validate([batch() for _ in range(4)])
     assert val['prec1'] > 85.0, val
+
+
+def test_optimizer_resume_past_a_regime_boundary_keeps_weight_decay(device):
+    """a checkpoint saved after the first LR boundary (epoch >= 30 of models/resnet.py:250-256)
+    must resume with the cumulative regime setting - in particular the WeightDecay regulariser that only
+    phase 0 names - exactly like a fresh OptimRegime started at that epoch."""
+    import convnet_amd as ca
+    kw = dict(depth=18, width=(8, 16, 32, 64), inplanes=8, num_classes=16)
+    torch.manual_seed(1)
+    model = ca.models.resnet(**kw)
+    ca.engine.prepare(model, device, torch.float32)
+    opt = ca.OptimRegime(model, model.regime)
+    for ep in (0, 29, 30, 31):
+        opt.update(ep, ep * 10)
+    assert opt.hyper['lr'] == pytest.approx(0.01) and opt.regularizer_cfg
+    opt._bind()
+    opt.momentum_buf.fill_(0.25)
+    state = opt.state_dict()
+
+    torch.manual_seed(1)
+    model2 = ca.models.resnet(**kw)
+    ca.engine.prepare(model2, device, torch.float32)
+    opt2 = ca.OptimRegime(model2, model2.regime)
+    opt2.load_state_dict(state)
+    opt2.update(31, 310)
+    fresh = ca.OptimRegime(model2, model2.regime)
+    fresh.update(31, 310)
+    assert opt2.hyper['lr'] == pytest.approx(fresh.hyper['lr']) == pytest.approx(0.01)
+    assert [r['name'] for r in opt2.regularizer_cfg] == ['WeightDecay']
+    opt2._build_runs()
+    wds = {wd for _, _, wd in opt2._runs}
+    assert 1e-4 in wds and 0.0 in wds          # conv / fc weights decayed, BN + bias not
+    assert float(opt2.momentum_buf[:8].mean()) == pytest.approx(0.25)
+    # a foreign optimizer state (e.g. the reference's torch.optim dict) is refused, not silently ignored
+    with pytest.raises(ca._lib.ConvNetHipError):
+        opt2.load_state_dict({'state': {}, 'param_groups': []})
