@@ -52,18 +52,34 @@ def main():
     ap.add_argument('--no-kernel-profile', action='store_true')
     args = ap.parse_args()
 
-    import convnet_amd as ca
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: there is no CPU fallback for the measured path')
+    share = os.environ.get('BENCH_SHARE_GPU') == '1'   # protocol test of the N > 1 flow on a 1-GPU box (gloo)
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU,
+        # the same command line the driver uses) and hand over to them
+        if torch.cuda.device_count() < args.gpus and not share:
+            raise SystemExit('bench.py: --gpus %d but only %d device(s) visible' % (args.gpus, torch.cuda.device_count()))
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+    import convnet_amd as ca
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    if args.gpus != world and rank == 0:
-        print('bench.py: --gpus %d but WORLD_SIZE=%d (launch through torch.distributed.run for N > 1)'
-              % (args.gpus, world), file=sys.stderr)
+    if args.gpus != world:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     distributed = world > 1 or os.environ.get('BENCH_FORCE_DIST') == '1'   # world-1 RCCL smoke test
-    if os.environ.get('BENCH_SHARE_GPU') == '1':   # protocol test of the N > 1 flow on a 1-GPU box (with gloo)
+    if share:
         local_rank = 0
+        os.environ.setdefault('BENCH_DIST_BACKEND', 'gloo')   # RCCL refuses two ranks on one device
+    elif torch.cuda.device_count() <= local_rank:
+        raise SystemExit('bench.py: rank %d has no device (%d visible)' % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if distributed:
@@ -183,8 +199,10 @@ def main():
             'data': 'synthetic' + (' (host batches, H2D inside the timed loop)' if args.host_inputs else ''),
             'config': {'workload': 'ResNet-%d (depth:%d) synthetic 3x224x224 b=%d/GPU %s, SGD+momentum, '
                                    '%s' % (args.depth, args.depth, B, args.dtype,
-                                           'dp%d RCCL all-reduce' % world if world > 1 else '1 MI355X'),
-                       'global_batch': B * world, 'final_loss': round(float(res['loss']), 4)},
+                                           'dp%d gradient all-reduce' % world if world > 1 else '1 MI355X'),
+                       'global_batch': B * world, 'final_loss': round(float(res['loss']), 4),
+                       'parallelism': 'dp%d' % world,
+                       'transport': tr.reducer.describe() if tr.reducer is not None else None},
             'mfma_frac_whole_step': round(step_tflops / (elapsed / args.steps) / PEAK_TFLOPS[args.dtype], 4)
             if step_tflops else None,
             'roofline': roof, 'cpu_baseline': cpu, 'kernels': kernels,

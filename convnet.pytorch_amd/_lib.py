@@ -75,6 +75,14 @@ _SIGNATURES = {
     'cn_small_linear': (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     'cn_cast_from_f32': (c_i, [c_p, c_p, c_ll, c_i, c_p]),
     'cn_fill_f32': (c_i, [c_p, c_ll, c_f, c_p]),
+    'cn_comm_unique_id': (c_i, [c_p]),
+    'cn_comm_init': (c_i, [c_p, c_p, c_i, c_i]),
+    'cn_comm_info': (c_i, [c_p, c_p, c_p, c_p]),
+    'cn_comm_allreduce_bucket': (c_i, [c_p, c_p, c_ll, c_p, c_p, c_i]),
+    'cn_comm_join': (c_i, [c_p, c_p]),
+    'cn_comm_allreduce': (c_i, [c_p, c_p, c_ll, c_i, c_p]),
+    'cn_comm_broadcast': (c_i, [c_p, c_p, c_ll, c_i, c_p]),
+    'cn_comm_destroy': (c_i, [c_p]),
     'cn_probe_mfma_bf16': (c_i, [c_p, c_p, c_p, c_p]),
     'cn_probe_mfma_f32': (c_i, [c_p, c_p, c_p, c_p]),
     'cn_probe_tr16': (c_i, [c_p, c_p, c_p]),

@@ -3,13 +3,13 @@
 # library used by the `-m "not gpu"` kernel-logic tests.
 set -e
 cd "$(dirname "$0")"
-SRCS="runtime.hip igemm.hip wgrad.hip bn.hip pool.hip loss.hip optim.hip probe.hip"
+SRCS="runtime.hip igemm.hip wgrad.hip bn.hip pool.hip loss.hip optim.hip probe.hip comm.hip"
 OUT=..
 if [ "$1" != "emul-only" ]; then
   # CN_EXTRA_FLAGS / CN_LIB_NAME: A/B builds (e.g. CN_EXTRA_FLAGS=-DCN_NT_STORES CN_LIB_NAME=libconvnet_hip_nt.so)
   LIB=${CN_LIB_NAME:-libconvnet_hip.so}
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-result $CN_EXTRA_FLAGS \
-      $SRCS -o $OUT/$LIB
+      $SRCS -ldl -o $OUT/$LIB
   echo "built $OUT/$LIB"
 fi
 if [ "$1" = "emul" ] || [ "$1" = "emul-only" ]; then

@@ -20,6 +20,7 @@
 #define CN_ESHAPE (-2)
 #define CN_EHIP (-3)
 #define CN_EWORKSPACE (-4)
+#define CN_ERCCL (-5)
 
 // dtype codes of the C ABI
 #define CN_F32 0

@@ -190,27 +190,63 @@ class ParamArena(object):
 
 
 class BucketReducer(object):
-    """Bucketed gradient all-reduce overlapped with backward (RCCL when the process group backend is
-    'nccl' on ROCm, gloo in the CPU tests).  Sums only; the 1/world_size average is folded into the
-    optimizer kernel (ParamArena consumers read `grad_divisor`)."""
+    """Bucketed gradient all-reduce overlapped with backward.  Transport: the direct-RCCL communicator
+    (comm.RcclCommunicator over cn_comm_*: its own high-priority HIP stream, ordered behind the producer
+    streams by events) when the ranks own HIP devices; torch.distributed collectives (gloo) in the CPU
+    tests.  Sums only; the 1/world_size average is folded into the optimizer kernel."""
 
     def __init__(self, arena, process_group=None):
+        from . import comm as _comm
         self.arena = arena
         self.pg = process_group
         self.world = dist.get_world_size(process_group)
+        self.comm = _comm.create_default(arena.device, process_group) if _comm.wanted(arena.device, process_group) \
+            else None
         self.enabled = True
         self._pending = None
         self._works = []
         self.reset()
         arena.reducer = self
 
+    def describe(self):
+        return self.comm.describe() if self.comm is not None else \
+            'torch.distributed (%s), %d ranks' % (dist.get_backend(self.pg), self.world)
+
     def reset(self):
         self._pending = [len(members) for (_, _, members) in self.arena.buckets]
         self._works = []
 
+    def broadcast_(self, t, src=0):
+        if self.comm is not None and t.is_cuda and t.is_contiguous():
+            self.comm.broadcast_(t, src)
+        else:
+            dist.broadcast(t, src=src, group=self.pg)
+
     def broadcast_parameters(self, src=0):
-        dist.broadcast(self.arena.params, src=src, group=self.pg)
+        self.broadcast_(self.arena.params, src)
         self.arena.bump_version()
+
+    def _reduce(self, b):
+        start, length, _ = self.arena.buckets[b]
+        view = self.arena.grads[start:start + length]
+        dev = self.arena.device
+        side_used = dev.type == 'cuda' and ops.SIDE.enabled and ops.SIDE.used
+        if self.comm is not None:
+            # The bucket's weight gradients are queued on the wgrad side stream, its BN / bias gradients on
+            # the main stream: the communicator's stream waits for both (events), neither is stalled.
+            streams = [torch.cuda.current_stream(dev).cuda_stream]
+            if side_used:
+                streams.append(ops.SIDE.get(dev).cuda_stream)
+            self.comm.allreduce_bucket(view, streams)
+        elif side_used:
+            # torch.distributed: issue the collective from the side stream after making IT wait for the
+            # main stream, so the main stream (dgrad / BN chain) is never stalled at a bucket boundary
+            side = ops.SIDE.get(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        else:
+            self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def slot_ready(self, slot):
         if not self.enabled:
@@ -218,20 +254,7 @@ class BucketReducer(object):
         b = slot.bucket
         self._pending[b] -= 1
         if self._pending[b] == 0:
-            start, length, _ = self.arena.buckets[b]
-            view = self.arena.grads[start:start + length]
-            dev = self.arena.device
-            if dev.type == 'cuda' and ops.SIDE.enabled and ops.SIDE.used:
-                # The bucket's weight gradients are queued on the wgrad side stream, its BN / bias gradients
-                # on the main stream.  Issue the collective from the side stream after making IT wait for
-                # the main stream: the communication stream then depends on both, while the main stream
-                # (dgrad / BN chain) is never stalled at a bucket boundary.  finish() joins everything.
-                side = ops.SIDE.get(dev)
-                side.wait_stream(torch.cuda.current_stream(dev))
-                with torch.cuda.stream(side):
-                    self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
-            else:
-                self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            self._reduce(b)
 
     def finish(self):
         """Flush buckets that never filled (unused parameters) and wait for all reductions."""
@@ -239,9 +262,9 @@ class BucketReducer(object):
         if self.enabled:
             for b, left in enumerate(self._pending):
                 if left > 0:
-                    start, length, _ = self.arena.buckets[b]
-                    view = self.arena.grads[start:start + length]
-                    self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                    self._reduce(b)
+            if self.comm is not None:
+                self.comm.join(torch.cuda.current_stream(self.arena.device).cuda_stream)
             for w in self._works:
                 w.wait()
         self.reset()

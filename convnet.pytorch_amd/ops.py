@@ -449,6 +449,17 @@ def _sync_group(mod):
     return (group, world) if world > 1 else None
 
 
+def _sync_all_reduce(t, group, world):
+    """SyncBatchNorm statistics exchange: one in-stream RCCL all-reduce on the compute stream when the
+    direct communicator spans this group (no stream hop, no host-side work object), else torch.distributed."""
+    from . import comm as _comm
+    c = _comm.default()
+    if c is not None and t.is_cuda and c.world == world and (group is None or group is c.pg):
+        c.allreduce_(t)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
 class StemPairConvFunction(Function):
     """The stride-2 stem convolution on the pixel-pair image (ops.nchw_to_pairs): same result as
     Conv2dFunction on the channel-padded NHWC image, with ceil(S/2) instead of S reduction chunks per
@@ -530,7 +541,7 @@ class BatchNormActFunction(Function):
             check(L.cn_bn_local_sums(ptr(y), M, C, code, ptr(ps.partial) if ps is not None else None,
                                      ps.rows if ps is not None else 0, ptr(sums), ptr(ws), ws.numel() * 4,
                                      stream_of(y)), 'cn_bn_local_sums')
-            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+            _sync_all_reduce(sums, group, world)
             check(L.cn_bn_fwd_train_sums(ptr(y), ptr(residual), ptr(z), ptr(mask), ptr(gamma), ptr(beta),
                                          ptr(mod.running_mean) if track else None,
                                          ptr(mod.running_var) if track else None,
@@ -595,7 +606,7 @@ class BatchNormActFunction(Function):
                                          ptr(pp[2]) if fused_in else None, pp[3] if fused_in else 0, ptr(local),
                                          ptr(ws), ws.numel() * 4, stream_of(y)), 'cn_bn_bwd_local_sums')
             glob = local.clone()
-            dist.all_reduce(glob, op=dist.ReduceOp.SUM, group=group)
+            _sync_all_reduce(glob, group, world)
             if fused_in:
                 dres = dz if want_res else None
             else:

@@ -127,7 +127,7 @@ class Trainer(object):
         if self.reducer is None:
             return
         for buf in self._model.buffers():
-            dist.broadcast(buf, src=0, group=self.reducer.pg)
+            self.reducer.broadcast_(buf, 0)
 
     def _to_device(self, inputs, target):
         target = target.to(self.device, non_blocking=True)

@@ -30,6 +30,7 @@ extern "C" {
 #define CN_ESHAPE (-2)
 #define CN_EHIP (-3)
 #define CN_EWORKSPACE (-4)
+#define CN_ERCCL (-5)
 #define CN_F32 0
 #define CN_BF16 1
 
@@ -201,6 +202,28 @@ int cn_small_linear(int mode, const void* x, const float* w, const float* bias, 
                     int B, int C, int K, int dtype, void* stream);
 int cn_cast_from_f32(const float* x, void* y, long long n, int dtype, void* stream);
 int cn_fill_f32(float* x, long long n, float v, void* stream);
+
+/* ---- data-parallel exchange step, directly on RCCL (trainer.py:79-82 DistributedDataParallel; main.py:190-191
+ * SyncBatchNorm) ---------------------------------------------------------------------------------
+ * One communicator handle per process (= per GPU).  The handle is the ONLY state the library keeps for the
+ * caller: an ncclComm_t, one high-priority HIP stream for the gradient buckets and a ring of events.
+ * Rendezvous is the caller's job: rank 0 calls cn_comm_unique_id and ships the 128 bytes to the other ranks
+ * (torch.distributed's store, MPI, a file ...), then every rank calls cn_comm_init with its HIP device current.
+ * RCCL is bound at run time (the process's librccl.so.1). */
+int cn_comm_unique_id(char* id128 /* HOST, 128 bytes */);
+int cn_comm_init(void** handle /* HOST */, const char* id128 /* HOST */, int rank, int world);
+int cn_comm_info(void* handle, int* rank, int* world, int* rccl_version /* HOST, any may be NULL */);
+/* in-place SUM all-reduce of one fp32 gradient bucket on the handle's own stream, ordered after everything
+ * queued so far on the first n_after (0..2) producer streams after_a, after_b; producers are not stalled */
+int cn_comm_allreduce_bucket(void* handle, float* buf, long long count, void* after_a, void* after_b,
+                             int n_after);
+/* `stream` waits for every bucket queued so far (call before the optimizer step) */
+int cn_comm_join(void* handle, void* stream);
+/* in-stream, in-place SUM all-reduce; dtype 0 = fp32, 2 = fp64 (SyncBatchNorm sums) */
+int cn_comm_allreduce(void* handle, void* buf, long long count, int dtype, void* stream);
+/* in-stream broadcast of nbytes bytes from rank `root` (parameter arena at construction, BN buffers) */
+int cn_comm_broadcast(void* handle, void* buf, long long nbytes, int root, void* stream);
+int cn_comm_destroy(void* handle);
 
 /* ---- hardware lane-map probes (tests only) -------------------------------------------------- */
 int cn_probe_mfma_bf16(const unsigned short* A /*32x16*/, const unsigned short* B /*16x32*/, float* D /*32x32*/,

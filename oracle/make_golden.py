@@ -144,7 +144,20 @@ def mnist_eval():
     print('mnist_eval', y[0, :4])
 
 
+def big():
+    """Headline-size goldens: the reference Trainer at the batch sizes BASELINE.json
+    quotes (configs[1] ResNet-18 fp32 b=256, configs[2] ResNet-50 b=256) plus ResNet-50 b=64.
+    ~22 GB of activations and ~15 s per ResNet-50 b=256 step on 8 cores."""
+    trajectory('r50_b64', dict(depth=50), B=64, size=224, classes=1000, steps=2, seed=23)
+    trajectory('r18_b256', dict(depth=18), B=256, size=224, classes=1000, steps=2, seed=25)
+    trajectory('r50_b256', dict(depth=50), B=256, size=224, classes=1000, steps=2, seed=24)
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'big':
+        big()
+        assert not os.path.exists(os.path.join(REF, '__pycache__')), 'bytecode leaked into the reference tree'
+        sys.exit(0)
     structure()
     trajectory('r50s', dict(depth=50, **SMALL), B=8, size=32, classes=16, steps=4, seed=11)
     trajectory('r18s', dict(depth=18, **SMALL), B=8, size=32, classes=16, steps=4, seed=12)
@@ -154,4 +167,5 @@ if __name__ == '__main__':
     trajectory('r50_full', dict(depth=50), B=4, size=224, classes=1000, steps=2, seed=22)
     mnist_eval()
     mnist_trajectory()
+    big()
     assert not os.path.exists(os.path.join(REF, '__pycache__')), 'bytecode leaked into the reference tree'

@@ -1,7 +1,11 @@
-"""Host-logic tests that run without a GPU (kernel sources through the TEST-ONLY emulator):
-the main.py CLI surface + checkpoint round trip, and the data-parallel path on 2 gloo ranks
-against an oracle-side restatement of DistributedDataParallel semantics (per-rank BN statistics,
-gradients averaged over ranks, SURVEY.md section 8e / level T4)."""
+"""The main.py CLI surface + checkpoint round trip, and the data-parallel path on 2 ranks against an
+oracle-side restatement of DistributedDataParallel semantics (per-rank BN statistics, gradients averaged
+over ranks, SURVEY.md section 8e / level T4).
+
+Every test exists in two modes: 'emul' (no GPU: kernel sources through the TEST-ONLY emulator, gloo) and
+'gpu' (`-m gpu`: libconvnet_hip.so on cuda:0; the two ranks share the one device of the test box, so their
+process group is gloo - RCCL refuses two ranks on one device - while the world-1 RCCL tests in
+tests/test_rccl_gpu.py cover the direct-RCCL transport)."""
 import json
 import os
 import subprocess
@@ -13,15 +17,25 @@ import torch
 from conftest import HAS_GPU
 from helpers import ROOT, rel_l2
 
-pytestmark = pytest.mark.skipif(HAS_GPU, reason='emulator-mode host tests')
+MODES = [pytest.param('emul'), pytest.param('gpu', marks=pytest.mark.gpu)]
+
+
+def _mode(mode):
+    if mode == 'emul' and HAS_GPU:
+        pytest.skip('emulator mode is for GPU-less hosts')
+    if mode == 'gpu' and not HAS_GPU:
+        pytest.skip('no GPU')
+    return 'cuda' if mode == 'gpu' else 'cpu'
 
 SMALL = "{'depth': 18, 'width': [8, 16, 32, 64], 'inplanes': 8, 'num_classes': 16}"
 
 
-def test_cli_train_checkpoint_resume(tmp_path):
+@pytest.mark.parametrize('mode', MODES)
+def test_cli_train_checkpoint_resume(mode, tmp_path):
+    dev = _mode(mode)
     import convnet_amd as ca
     from convnet_amd.main import main
-    common = ['--model', 'resnet', '--model-config', SMALL, '--input-size', '32', '-b', '4',
+    common = ['--model', 'resnet', '--model-config', SMALL, '--input-size', '32', '-b', '4', '--device', dev,
               '--steps-per-epoch', '2', '--val-steps', '1', '--results-dir', str(tmp_path), '--print-freq', '1']
     out = main(common + ['--save', 'run', '--epochs', '1'])
     run = tmp_path / 'run'
@@ -51,13 +65,16 @@ def test_cli_train_checkpoint_resume(tmp_path):
 DP_WORKER = r'''
 import os, sys, json, torch, torch.distributed as dist
 sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, 'tests'))
-os.environ['CONVNET_AMD_EMULATE'] = '1'
 import convnet_amd as ca
+DEV = %(dev)r
+if DEV != 'cpu':
+    torch.cuda.set_device(0)
+    assert not ca._lib.is_emulated()
 rank = int(os.environ['RANK'])
 dist.init_process_group('gloo', init_method='env://')
 torch.manual_seed(123 + 7 * rank)          # different initial weights per rank: the broadcast must fix that
 model = ca.models.resnet(depth=18, width=(8, 16, 32, 64), inplanes=8, num_classes=16)
-tr = ca.Trainer(model, ca.CrossEntropyLoss(), ca.OptimRegime(model, model.regime), device='cpu',
+tr = ca.Trainer(model, ca.CrossEntropyLoss(), ca.OptimRegime(model, model.regime), device=DEV,
                 dtype=torch.float32, distributed=True, local_rank=rank, grad_clip=1e9, print_freq=10**9,
                 bucket_mb=0.05)
 g = torch.Generator().manual_seed(77)
@@ -72,12 +89,19 @@ dist.destroy_process_group()
 '''
 
 
-def test_data_parallel_two_ranks_gloo(tmp_path):
+def _worker_env(dev, port):
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE='2', OMP_NUM_THREADS='2')
+    env['CONVNET_AMD_EMULATE'] = '1' if dev == 'cpu' else '0'
+    return env
+
+
+@pytest.mark.parametrize('mode', MODES)
+def test_data_parallel_two_ranks_gloo(mode, tmp_path):
+    dev = _mode(mode)
     script = tmp_path / 'dp_worker.py'
     out_pat = str(tmp_path / 'rank%d.pt')
-    script.write_text(DP_WORKER % {'root': ROOT, 'out': out_pat})
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29531', WORLD_SIZE='2',
-               CONVNET_AMD_EMULATE='1', OMP_NUM_THREADS='2')
+    script.write_text(DP_WORKER % {'root': ROOT, 'out': out_pat, 'dev': dev if dev == 'cpu' else 'cuda:0'})
+    env = _worker_env(dev, 29531)
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)))
              for r in range(2)]
     for p in procs:
@@ -121,18 +145,19 @@ def test_data_parallel_two_ranks_gloo(tmp_path):
         assert rel_l2(outs[0]['sd'][k], ref_sd[k]) < 1e-4, k
 
 
-def test_sync_batchnorm_two_ranks_equals_global_batch(tmp_path):
+@pytest.mark.parametrize('mode', MODES)
+def test_sync_batchnorm_two_ranks_equals_global_batch(mode, tmp_path):
     """--sync-bn (main.py:190-191, nn.SyncBatchNorm): 2 ranks x 4 samples with synchronised batch
     statistics train exactly like one process on the 8-sample batch (statistics, input gradients and,
     after the data-parallel averaging, parameter gradients).  Oracle = the plain-PyTorch model on the
     full batch."""
+    dev = _mode(mode)
     script = tmp_path / 'sync_worker.py'
     out_pat = str(tmp_path / 'sync_rank%d.pt')
     worker = DP_WORKER.replace("tr = ca.Trainer(", "ca.nn.convert_sync_batchnorm(model)\ntr = ca.Trainer(", 1)
     assert worker != DP_WORKER
-    script.write_text(worker % {'root': ROOT, 'out': out_pat})
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', WORLD_SIZE='2',
-               CONVNET_AMD_EMULATE='1', OMP_NUM_THREADS='2')
+    script.write_text(worker % {'root': ROOT, 'out': out_pat, 'dev': dev if dev == 'cpu' else 'cuda:0'})
+    env = _worker_env(dev, 29533)
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)))
              for r in range(2)]
     for p in procs:

@@ -1,0 +1,109 @@
+"""The data-parallel transport on real hardware (`-m gpu`).
+
+* world-1 direct RCCL (cn_comm_* behind engine.BucketReducer): a 1-rank process group must train
+  bit-identically to the non-distributed Trainer - same kernels, the bucket all-reduces are identities,
+  only the stream choreography (communicator stream ordered behind the wgrad side stream and the main
+  stream by events, joined before the optimizer step) differs.  Also bit-identical: the
+  torch.distributed transport (CONVNET_AMD_COMM=torch) on the same group.
+* cn_comm_allreduce (fp64, in-stream) and cn_comm_broadcast on the 1-rank communicator.
+* `bench.py --gpus 2` with no launcher env starts its own ranks (here both on the one device of the
+  test box, BENCH_SHARE_GPU=1 -> gloo) and reports n_gpus = 2.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from helpers import ROOT
+
+pytestmark = pytest.mark.gpu
+
+WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+import convnet_amd as ca
+torch.cuda.set_device(0)
+assert not ca._lib.is_emulated()
+kw = dict(depth=50, width=(16, 32, 64, 128), inplanes=16, num_classes=32)
+g = torch.Generator().manual_seed(5)
+data = [(torch.randn(16, 3, 64, 64, generator=g), torch.randint(0, 32, (16,), generator=g)) for _ in range(3)]
+
+def run(distributed, dtype):
+    torch.manual_seed(123)
+    model = ca.models.resnet(**kw)
+    tr = ca.Trainer(model, ca.CrossEntropyLoss(), ca.OptimRegime(model, model.regime), device='cuda:0',
+                    dtype=dtype, distributed=distributed, local_rank=0, grad_clip=5.0, print_freq=10**9,
+                    bucket_mb=0.25)
+    recs = [tr.train([b]) for b in data]
+    torch.cuda.synchronize()
+    sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    return recs, sd, tr
+
+out = {}
+for dtype in (torch.float32, torch.bfloat16):
+    base_recs, base_sd, _ = run(False, dtype)
+    if not dist.is_initialized():
+        dist.init_process_group('nccl', init_method='env://', world_size=1, rank=0)
+    recs, sd, tr = run(True, dtype)
+    want_direct = os.environ.get('CONVNET_AMD_COMM', 'rccl') != 'torch'
+    assert (tr.reducer.comm is not None) == want_direct, tr.reducer.describe()
+    assert len(tr.arena.buckets) > 2
+    for a, b in zip(base_recs, recs):
+        assert a['loss'] == b['loss'] and a['grad'] == b['grad'] and a['prec1'] == b['prec1'], (a, b)
+    for k in base_sd:
+        assert torch.equal(base_sd[k], sd[k]), k
+    out[str(dtype)] = tr.reducer.describe()
+    if want_direct:
+        c = tr.reducer.comm
+        t = torch.arange(7, dtype=torch.float64, device='cuda:0') * 0.5
+        ref = t.clone()
+        c.allreduce_(t)                       # 1 rank: identity, through ncclAllReduce on the compute stream
+        c.broadcast_(t, 0)
+        torch.cuda.synchronize()
+        assert torch.equal(t, ref)
+        assert c.rccl_version >= 20000, c.rccl_version
+print('TRANSPORT', out)
+ca.comm.destroy_default()
+dist.destroy_process_group()
+'''
+
+
+def _run_worker(tmp_path, extra_env, port):
+    script = tmp_path / 'rccl_worker.py'
+    script.write_text(WORKER % {'root': ROOT})
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), CONVNET_AMD_EMULATE='0', **extra_env)
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return r.stdout
+
+
+def test_world1_direct_rccl_is_bit_identical_to_single_process(tmp_path):
+    out = _run_worker(tmp_path, {}, 29541)
+    assert 'direct RCCL' in out, out
+
+
+def test_world1_torch_distributed_transport_is_bit_identical_too(tmp_path):
+    out = _run_worker(tmp_path, {'CONVNET_AMD_COMM': 'torch'}, 29543)
+    assert 'torch.distributed (nccl)' in out, out
+
+
+def test_bench_self_launches_its_ranks(tmp_path):
+    env = dict(os.environ, BENCH_SHARE_GPU='1', CONVNET_AMD_EMULATE='0')
+    env.pop('WORLD_SIZE', None)
+    env.pop('RANK', None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--batch', '8', '--steps', '2',
+                        '--warmup', '1', '--no-cpu-baseline', '--no-kernel-profile'], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.split('\n') if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['config']['global_batch'] == 16 and rec['scaling'] == 'weak'
+    assert rec['config']['parallelism'] == 'dp2' and 'gloo' in rec['config']['transport']
+    # a launcher environment that disagrees with --gpus is refused instead of silently measuring 1 GPU
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--steps', '1'],
+                        env=dict(env, WORLD_SIZE='1', RANK='0'), capture_output=True, text=True, timeout=300)
+    assert r2.returncode != 0 and 'WORLD_SIZE' in (r2.stdout + r2.stderr)
