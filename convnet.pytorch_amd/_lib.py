@@ -64,7 +64,7 @@ _SIGNATURES = {
     'cn_nhwc_to_nchw': (c_i, [c_p, c_p] + [c_i] * 6 + [c_p]),
     'cn_eltwise': (c_i, [c_i, c_p, c_p, c_p, c_ll, c_i, c_p]),
     'cn_softmax_ce': (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_f, c_p, c_f, c_p]),
-    'cn_sgd_momentum': (c_i, [c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_f, c_p, c_p]),
+    'cn_sgd_momentum': (c_i, [c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_f, c_p, c_p, c_p]),
     'cn_grad_norm_workspace': (c_sz, []),
     'cn_grad_norm_clip': (c_i, [c_p, c_ll, c_f, c_f, c_p, c_p, c_f, c_p, c_p]),
     'cn_weight_prep': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),

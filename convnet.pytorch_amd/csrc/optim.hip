@@ -15,7 +15,8 @@
 // scalar) folds the gradient-clipping factor computed by cn_clip_coef.
 __global__ __launch_bounds__(256) void sgd_kernel(float* p, const float* g, float* buf, long long n, float lr,
                                                  float momentum, float wd, float gscale,
-                                                 const float* clip_coef) {
+                                                 const float* clip_coef, const float* hyper) {
+  if (hyper != nullptr) { lr = hyper[0]; momentum = hyper[1]; }   // device-resident schedule (graph replay)
   const float cs = clip_coef != nullptr ? gscale * clip_coef[0] : gscale;
   const long long n4 = n >> 2;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
@@ -262,14 +263,15 @@ static unsigned opt_grid(long long work, long long cap) {
 }
 
 extern "C" int cn_sgd_momentum(float* p, const float* g, float* buf, long long n, float lr, float momentum,
-                               float weight_decay, float gscale, const float* clip_coef, void* stream) {
+                               float weight_decay, float gscale, const float* clip_coef, const float* hyper_dev,
+                               void* stream) {
   if (n <= 0) return CN_OK;
   if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)buf) & 15) != 0) {
     cn_set_error("sgd_momentum: buffers must be 16-byte aligned");
     return CN_EINVAL;
   }
   CN_LAUNCH(sgd_kernel, dim3(opt_grid(n / 4 + 1, 4096)), dim3(256), (hipStream_t)stream, p, g, buf, n, lr,
-            momentum, weight_decay, gscale, clip_coef);
+            momentum, weight_decay, gscale, clip_coef, hyper_dev);
   return cn_check_launch("sgd_momentum");
 }
 

@@ -236,12 +236,12 @@ class BucketReducer(object):
             # the main stream: the communicator's stream waits for both (events), neither is stalled.
             streams = [torch.cuda.current_stream(dev).cuda_stream]
             if side_used:
-                streams.append(ops.SIDE.get(dev).cuda_stream)
+                streams.append(ops.SIDE.gather(dev).cuda_stream)
             self.comm.allreduce_bucket(view, streams)
         elif side_used:
             # torch.distributed: issue the collective from the side stream after making IT wait for the
             # main stream, so the main stream (dgrad / BN chain) is never stalled at a bucket boundary
-            side = ops.SIDE.get(dev)
+            side = ops.SIDE.gather(dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
                 self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))

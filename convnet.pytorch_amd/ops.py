@@ -88,28 +88,47 @@ class SideStream(object):
     optimizer step; while the KernelProfiler is recording everything stays on one stream."""
 
     def __init__(self):
-        import os
         self.enabled = os.environ.get('CONVNET_AMD_WGRAD_STREAM', '1') == '1'
+        # CONVNET_AMD_WGRAD_STREAMS: number of side streams the weight-gradient launches rotate over (A/B knob)
+        self.nstreams = max(1, int(os.environ.get('CONVNET_AMD_WGRAD_STREAMS', '1')))
         self._streams = {}
+        self._rr = 0
         self.used = False
 
-    def get(self, device):
-        s = self._streams.get(device)
-        if s is None:
+    def _all(self, device):
+        ss = self._streams.get(device)
+        if ss is None:
             # CONVNET_AMD_WGRAD_STREAM_PRIO: HIP stream priority of the side stream (A/B knob; default = the
             # runtime's default priority)
             prio = os.environ.get('CONVNET_AMD_WGRAD_STREAM_PRIO')
-            s = torch.cuda.Stream(device, priority=int(prio)) if prio is not None else torch.cuda.Stream(device)
-            self._streams[device] = s
-        return s
+            ss = [torch.cuda.Stream(device, priority=int(prio)) if prio is not None else torch.cuda.Stream(device)
+                  for _ in range(self.nstreams)]
+            self._streams[device] = ss
+        return ss
+
+    def get(self, device):
+        """The side stream the next weight-gradient launch goes to (stream 0 when there is only one)."""
+        ss = self._all(device)
+        if len(ss) == 1:
+            return ss[0]
+        self._rr = (self._rr + 1) % len(ss)
+        return ss[self._rr]
+
+    def gather(self, device):
+        """Stream 0 after it has been made to wait for the other side streams: the one stream a collective
+        (or a join) has to order itself behind."""
+        ss = self._all(device)
+        for s in ss[1:]:
+            ss[0].wait_stream(s)
+        return ss[0]
 
     def active(self, t):
         return self.enabled and t.is_cuda and not PROFILER.enabled
 
     def join(self, device):
-        """Make the current stream wait for everything queued on the side stream."""
+        """Make the current stream wait for everything queued on the side stream(s)."""
         if self.used and device.type == 'cuda':
-            torch.cuda.current_stream(device).wait_stream(self.get(device))
+            torch.cuda.current_stream(device).wait_stream(self.gather(device))
             self.used = False
 
 

@@ -101,6 +101,8 @@ class OptimRegime(Regime):
         # set by Trainer each step
         self.grad_scale = 1.0     # 1/loss_scale (and 1/world_size for data parallel)
         self.clip_coef = None     # device scalar written by cn_grad_norm_clip, or None
+        self.hyper_dev = None     # device copy of (lr, momentum): read by the SGD kernel, so a captured step
+        self._hyper_pushed = None  # (HIP graph) follows the schedule; refreshed by push_hyper() when it changes
 
     # -- binding to the device arena ------------------------------------------------------
     def _bind(self):
@@ -183,15 +185,35 @@ class OptimRegime(Regime):
         L = _lib.load()
         a = self.arena
         lr, mu = float(self.hyper['lr']), float(self.hyper['momentum'])
+        self.push_hyper()
         for start, end, wd in self._runs:
             n = end - start
             ops.PROFILER.run('sgd_momentum', 1, 0.0, 20.0 * n,
                              lambda: check(L.cn_sgd_momentum(ptr(a.params[start:]), ptr(a.grads[start:]),
                                                              ptr(self.momentum_buf[start:]), n, lr, mu, float(wd),
                                                              float(self.grad_scale), ptr(self.clip_coef),
-                                                             stream_of(a.params)), 'cn_sgd_momentum'),
+                                                             ptr(self.hyper_dev), stream_of(a.params)),
+                                               'cn_sgd_momentum'),
                              a.device)
         a.bump_version()
+
+    def push_hyper(self):
+        """Device copy of (lr, momentum) for the SGD kernel; one tiny H2D copy whenever the schedule moves."""
+        self._bind()
+        cur = (float(self.hyper['lr']), float(self.hyper['momentum']))
+        if self.hyper_dev is None:
+            self.hyper_dev = torch.zeros(2, dtype=torch.float32, device=self.arena.device)
+            self._hyper_pushed = None
+        if cur != self._hyper_pushed:
+            self.hyper_dev.copy_(torch.tensor(cur, dtype=torch.float32), non_blocking=False)
+            self._hyper_pushed = cur
+
+    def runs_signature(self):
+        """What a captured step bakes in besides lr / momentum (weight-decay runs)."""
+        self._bind()
+        if self._runs is None:
+            self._build_runs()
+        return tuple(self._runs)
 
     def get_value(self, key):
         return [self.hyper.get(key)]

@@ -108,6 +108,14 @@ class Trainer(object):
         self.arena = engine.prepare(model, self.device, dtype, bucket_mb=bucket_mb)
         self.reducer = None
         self._main_stream = None   # high-priority HIP stream of the step loop (created lazily on a GPU)
+        # CONVNET_AMD_GRAPH: 'auto' (default) captures only when the eager step is host-bound, 1 = always, 0 = never
+        self._graph_mode = os.environ.get('CONVNET_AMD_GRAPH', 'auto')
+        self._use_graph = self._graph_mode != '0'
+        self._graph_dp = os.environ.get('CONVNET_AMD_GRAPH_DP', '0') == '1'   # capture RCCL buckets too (opt-in)
+        self._graph, self._graph_seen = None, {}
+        from . import nn as cnn
+        # a captured step replays the SAME kernels: host-drawn Dropout masks (models/mnist.py) rule it out
+        self._graph_model_ok = not any(isinstance(m, cnn.Dropout) and m.p > 0 for m in model.modules())
         self.world_size = 1
         if distributed:
             if not dist.is_initialized():
@@ -137,13 +145,23 @@ class Trainer(object):
     def _step(self, inputs_batch, target_batch, training=False, average_output=False, chunk_batch=1):
         if average_output:
             raise NotImplementedError('average_output (duplicates) is outside the MI355X hot path')
+        if training:
+            # host side of trainer.py:111-112 (the regime moves lr / momentum; nothing here touches the device
+            # except a tiny H2D copy when the schedule changes)
+            self.optimizer.update(self.epoch, self.training_steps)
+            if self._graph_ok(inputs_batch, target_batch):
+                return self._graph_step(inputs_batch, target_batch, chunk_batch)
+        return self._body(inputs_batch, target_batch, training, chunk_batch)
+
+    def _body(self, inputs_batch, target_batch, training, chunk_batch):
+        """Device side of one step (trainer.py:106-177): everything here is a stream of kernel launches with
+        no host synchronisation, which is what lets `_graph_step` capture it into one HIP graph."""
         outputs = []
         total_loss = None
         grad = None
 
         if training:
             self.optimizer.zero_grad()
-            self.optimizer.update(self.epoch, self.training_steps)
             if self.reducer is not None:
                 self.reducer.reset()
 
@@ -199,6 +217,79 @@ class Trainer(object):
 
         outputs = outputs[0] if len(outputs) == 1 else torch.cat(outputs, dim=0)
         return outputs, total_loss, grad
+
+    # -- whole-step HIP graph ------------------------------------------------------------------
+    # The eager step issues ~520 kernel launches through ctypes + the autograd tape (about 10 ms of host time
+    # for ResNet-50, profiles/r01_bench_line_b8_host_overhead.json).  The launches never depend on host
+    # values - meters, the clip coefficient and (lr, momentum) live in device memory, workspaces are
+    # caller-owned - so after two eager warm-up steps of a given shape the whole device side of the step
+    # (layout cast, forward, loss + meters, backward on both streams, bucket all-reduces, clip, SGD) is
+    # captured once and replayed: one graph launch per step.  CONVNET_AMD_GRAPH=0 keeps the eager path.
+    def _graph_ok(self, inputs, target):
+        if not self._use_graph or self.device.type != 'cuda' or ops.PROFILER.enabled:
+            return False
+        if not (inputs.is_cuda and target.is_cuda and inputs.dtype == torch.float32):
+            return False
+        if not isinstance(self.criterion, CrossEntropyLoss) or not self._graph_model_ok:
+            return False
+        if self.reducer is not None and (self.reducer.comm is None or not self._graph_dp):
+            return False
+        return True
+
+    def _graph_step(self, inputs, target, chunk_batch):
+        opt = self.optimizer
+        opt.push_hyper()
+        key = (tuple(inputs.shape), tuple(target.shape), chunk_batch, float(self.grad_clip), self.loss_scale,
+               self.grad_scale, opt.runs_signature(), self.criterion.smooth_eps, self.world_size)
+        st = self._graph
+        if st is None or st['key'] != key:
+            if self._graph_seen.get('key') != key:
+                self._graph_seen = {'key': key, 'n': 0}
+                self._graph = None
+            if self._graph_seen['n'] < 2:          # eager warm-up (lazy workspace growth, allocator warm)
+                self._graph_seen['n'] += 1
+                if self._graph_seen['n'] < 2 or self._graph_mode != 'auto':
+                    return self._body(inputs, target, True, chunk_batch)
+                # second warm-up step, mode 'auto': is the eager step bound by the host (launch time ~ device
+                # time) or by the device?  A replayed graph removes the host cost but measured 5 % SLOWER than the
+                # eager two-stream schedule when the device is the limit (ResNet-50 b=256: 22.1 vs 21.0 ms), and
+                # 1.55x faster when the host is (b=8: 5.5 vs 8.6 ms) - profiles/README.md.
+                torch.cuda.synchronize(self.device)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0 = time.perf_counter()
+                e0.record()
+                res = self._body(inputs, target, True, chunk_batch)
+                e1.record()
+                host_ms = (time.perf_counter() - t0) * 1e3
+                e1.synchronize()
+                dev_ms = e0.elapsed_time(e1)
+                self._graph_seen['use'] = host_ms > 0.75 * dev_ms
+                logging.debug('step: host %.2f ms, device %.2f ms -> %s', host_ms, dev_ms,
+                              'HIP graph' if self._graph_seen['use'] else 'eager launches')
+                return res
+            if not self._graph_seen.get('use', True):
+                return self._body(inputs, target, True, chunk_batch)
+            st = self._capture(inputs, target, chunk_batch, key)
+        st['x'].copy_(inputs, non_blocking=True)
+        st['t'].copy_(target, non_blocking=True)
+        st['graph'].replay()
+        self.arena.bump_version()      # what optimizer.step() does on the host: master weights moved
+        self.training_steps += 1
+        return st['out'], st['loss'], st['grad']
+
+    def _capture(self, inputs, target, chunk_batch, key):
+        cur = torch.cuda.current_stream(self.device)
+        x, t = torch.empty_like(inputs), torch.empty_like(target)
+        x.copy_(inputs)
+        t.copy_(target)
+        steps_before = self.training_steps
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=cur, capture_error_mode='thread_local'):
+            out, loss, grad = self._body(x, t, True, chunk_batch)
+        self.training_steps = steps_before     # capture executes nothing: the replay is the step
+        self._graph = {'key': key, 'graph': g, 'x': x, 't': t, 'out': out, 'loss': loss, 'grad': grad}
+        logging.debug('captured the training step as one HIP graph (%s)', (key[0],))
+        return self._graph
 
     # ------------------------------------------------------------------------------------
     def forward(self, data_loader, num_steps=None, training=False, average_output=False, chunk_batch=1):

@@ -176,8 +176,11 @@ int cn_softmax_ce(const float* logits, const long long* target, void* dlogits, i
                   void* stream);
 
 /* ---- optimizer.step / grad clipping / filter preparation (trainer.py:165-173) --------------- */
+/* hyper_dev (optional, DEVICE, 2 floats {lr, momentum}): when given it overrides the lr / momentum arguments, so
+ * a step captured in a HIP graph follows the learning-rate schedule without being re-captured */
 int cn_sgd_momentum(float* p, const float* g, float* buf, long long n, float lr, float momentum,
-                    float weight_decay, float gscale, const float* clip_coef, void* stream);
+                    float weight_decay, float gscale, const float* clip_coef, const float* hyper_dev,
+                    void* stream);
 size_t cn_grad_norm_workspace(void);
 /* out2[0] = ||g||_2 * gscale, out2[1] = min(1, max_norm/(norm+1e-6)) (1 when max_norm <= 0). */
 int cn_grad_norm_clip(const float* g, long long n, float gscale, float max_norm, float* out2, float* meters2,

@@ -37,7 +37,7 @@ def rel_l2(a, b):
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
-def run_engine_trajectory(meta, dtype, device, steps=None):
+def run_engine_trajectory(meta, dtype, device, steps=None, graph=True):
     """Train our engine exactly as oracle/make_golden.py trained the reference; returns
     (per-step records, validate dict, model)."""
     import convnet_amd as ca
@@ -48,6 +48,8 @@ def run_engine_trajectory(meta, dtype, device, steps=None):
     opt = ca.OptimRegime(model, model.regime)
     tr = ca.Trainer(model, crit, opt, device=str(device), dtype=dtype, loss_scale=meta['loss_scale'],
                     grad_clip=meta['grad_clip'], print_freq=10 ** 9)
+    if not graph:
+        tr._use_graph = False     # eager launches only (tests that count Python-side fusion decisions per step)
     data = golden_batches(meta)
     if steps is not None:
         data = data[:steps]

@@ -1,0 +1,80 @@
+"""Whole-step HIP graph (Trainer._graph_step; `-m gpu`): after two eager warm-up steps the device side of
+the training step is captured once and replayed.  Replays must be bit-identical to the eager launches -
+same kernels, same order, same streams - including across a learning-rate change (lr / momentum live in
+device memory, so the schedule moves without a re-capture) and with the gradient all-reduce of a 1-rank
+direct-RCCL group inside the graph."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from helpers import ROOT
+
+pytestmark = pytest.mark.gpu
+
+WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+import convnet_amd as ca
+torch.cuda.set_device(0)
+kw = dict(depth=50, width=(16, 32, 64, 128), inplanes=16, num_classes=32)
+g = torch.Generator().manual_seed(9)
+data = [(torch.randn(16, 3, 64, 64, generator=g).cuda(), torch.randint(0, 32, (16,), generator=g).cuda())
+        for _ in range(7)]
+DIST = os.environ.get('TEST_DIST') == '1'
+if DIST:
+    dist.init_process_group('nccl', init_method='env://', world_size=1, rank=0)
+
+def run(graph, dtype, clip):
+    torch.manual_seed(123)
+    model = ca.models.resnet(**kw)
+    tr = ca.Trainer(model, ca.CrossEntropyLoss(smooth_eps=0.1), ca.OptimRegime(model, model.regime),
+                    device='cuda:0', dtype=dtype, distributed=DIST, local_rank=0, grad_clip=clip, loss_scale=4.0,
+                    print_freq=10**9, bucket_mb=0.25)
+    tr._use_graph = graph
+    tr._graph_mode = '1' if graph else '0'     # force the capture (the default 'auto' decides by host vs device time)
+    recs = []
+    for i, b in enumerate(data):
+        if i == 4:
+            tr.epoch = 30            # models/resnet.py:253: lr 0.1 -> 0.01 at epoch 30
+        r = tr.train([b])
+        recs.append((r['loss'], r['prec1'], r.get('grad')))
+    val = tr.validate(data[:2])      # eager evaluation right after replays must see the updated weights
+    torch.cuda.synchronize()
+    sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    return recs, val, sd, tr
+
+for dtype in (torch.float32, torch.bfloat16):
+    for clip in (-1, 5.0):
+        e_recs, e_val, e_sd, _ = run(False, dtype, clip)
+        g_recs, g_val, g_sd, tr = run(True, dtype, clip)
+        assert tr._graph is not None, 'the step was never captured'
+        assert tr.optimizer.hyper['lr'] == 0.01
+        assert e_recs == g_recs, (e_recs, g_recs)
+        assert e_val['loss'] == g_val['loss'] and e_val['prec1'] == g_val['prec1']
+        for k in e_sd:
+            assert torch.equal(e_sd[k], g_sd[k]), k
+print('GRAPH_OK', 'dist' if DIST else 'single')
+if DIST:
+    ca.comm.destroy_default()
+    dist.destroy_process_group()
+'''
+
+
+def _run(tmp_path, env_extra, port):
+    script = tmp_path / 'graph_worker.py'
+    script.write_text(WORKER % {'root': ROOT})
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), CONVNET_AMD_EMULATE='0', **env_extra)
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return r.stdout
+
+
+def test_graph_replay_is_bit_identical_to_eager(tmp_path):
+    assert 'GRAPH_OK single' in _run(tmp_path, {}, 29551)
+
+
+def test_graph_with_world1_rccl_buckets_inside(tmp_path):
+    assert 'GRAPH_OK dist' in _run(tmp_path, {'TEST_DIST': '1', 'CONVNET_AMD_GRAPH_DP': '1'}, 29553)

@@ -635,7 +635,10 @@ def test_sgd_momentum_weight_decay_clip(mode):
         gr[:n] = gs.to(dev)
         check(load().cn_grad_norm_clip(ptr(gr), npad, 1.0 / 8.0, 5.0, ptr(norm_out), None, 0.0, ptr(ws), None
                                        if dev.type == 'cpu' else torch.cuda.current_stream().cuda_stream))
-        check(load().cn_sgd_momentum(ptr(p), ptr(gr), ptr(buf), n, 0.1, 0.9, 1e-4, 1.0 / 8.0, ptr(norm_out[1:]),
+        # device-resident (lr, momentum) on odd steps: same arithmetic
+        hyp = torch.tensor([0.1, 0.9], device=dev) if step % 2 else None
+        check(load().cn_sgd_momentum(ptr(p), ptr(gr), ptr(buf), n, 0.1 if hyp is None else 7.0, 0.9 if hyp is None else 0.0,
+                                     1e-4, 1.0 / 8.0, ptr(norm_out[1:]), ptr(hyp),
                                      None if dev.type == 'cpu' else torch.cuda.current_stream().cuda_stream))
         assert float(norm_out[0]) == pytest.approx(float(total), rel=1e-4)   # fp32 vs double summation
         assert rel_l2(p[:n].cpu(), pr.detach()) < 1e-6
