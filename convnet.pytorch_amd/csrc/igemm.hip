@@ -341,7 +341,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
       // Every thread issues exactly NWR+NPR DMA instructions per tile, so "tile kt has landed" is a
       // counted wait: at most (tiles issued after kt) * (NWR+NPR) operations may remain outstanding.
       constexpr int L = NWR + NPR;
-      static_assert(!(GLDS && STAGES == 4) || L == 8 || L == 6 || L == 4, "wait immediates below assume 4, 6 or 8 DMA instructions per tile");
+      static_assert(L == 8 || L == 6 || L == 4, "wait immediates below assume 4, 6 or 8 DMA instructions per tile");
       if (nkt > 1) load_tile(1, 1);
       if (nkt > 2) load_tile(2, 2);
       for (int kt = 0; kt < nkt; ++kt) {
@@ -612,7 +612,7 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
   int variant = cn_get_option("igemm_variant", 0);
   // short reductions: register-staged single buffer (more workgroups per CU); from "igemm_dma_min_nkt" K tiles
   // on: LDS-DMA double buffer (measured per layer, profiles/r01_conv_layers_b256_bf16.txt)
-  if (variant < 1 || variant > 10)
+  if (variant < 1 || variant > 6)
     variant = cn_get_option("igemm_default_variant", nkt < cn_get_option("igemm_dma_min_nkt", 24) ? 1 : 3);
   if ((p.stats != nullptr || p.bn_y != nullptr || p.addend != nullptr) && variant == 6) variant = 3;   // 128-pixel tiles   // statistics rows are defined per 128-pixel tile
   const bool epi = p.addend != nullptr || p.bn_y != nullptr;
@@ -643,25 +643,6 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
     else CN_LAUNCH((igemm_kernel<T, WC, WP, TI, TJ, 2, OUTF32, true, false, EP>), grid, dim3(256), stream, p);        \
   } while (0)
 #define IG_GO(WC, WP, TI, TJ) do { if (epi) IG_GO2(WC, WP, TI, TJ, true); else IG_GO2(WC, WP, TI, TJ, false); } while (0)
-  if constexpr (std::is_same<T, bf16_t>::value && !OUTF32) {
-    // 7 / 8: 256 pixels x 128 channels with 128x64 wave tiles (6 fragments per 8 MFMAs instead of 4 per 4:
-    //        3/4 of the LDS reads and of the L2->LDS bytes per flop), register-staged single buffer / LDS-DMA
-    //        double buffer; 9 / 10: 128 pixels x 256 channels likewise (wide-N layers re-read the activation
-    //        tile half as often)
-    if (variant >= 7 && variant <= 10 && p.Co > 64 && !epi && p.stats == nullptr) {
-      const bool wide_n = variant >= 9;
-      const int bm = wide_n ? 128 : 256, bn = wide_n ? 256 : 128;
-      p.n_ntiles = (p.Co + bn - 1) / bn;
-      p.n_mtiles = (p.M + bm - 1) / bm;
-      dim3 g2((unsigned)(p.n_ntiles * p.n_mtiles));
-      if (variant == 7) CN_LAUNCH((igemm_kernel<T, 2, 2, 2, 4, 1, false, false, false, false>), g2, dim3(256), stream, p);
-      else if (variant == 8) CN_LAUNCH((igemm_kernel<T, 2, 2, 2, 4, 2, false, true, false, false>), g2, dim3(256), stream, p);
-      else if (variant == 9) CN_LAUNCH((igemm_kernel<T, 4, 1, 2, 4, 1, false, false, false, false>), g2, dim3(256), stream, p);
-      else CN_LAUNCH((igemm_kernel<T, 4, 1, 2, 4, 2, false, true, false, false>), g2, dim3(256), stream, p);
-      return cn_check_launch("igemm");
-    }
-  }
-  if (variant >= 7) variant = cn_get_option("igemm_default_variant", nkt < cn_get_option("igemm_dma_min_nkt", 24) ? 1 : 3);
   if (variant >= 4 && p.Co > 64 && !epi) {
     // 4 / 5: experimental 4-deep DMA rings (4 or 8 waves), measured slower than variant 3, kept for A/B;
     // 6: 256-pixel x 128-channel tile, 8 waves, LDS-DMA double buffer with register-double-buffered
