@@ -14,6 +14,7 @@ from . import ops             # noqa: F401
 from . import nn              # noqa: F401
 from . import engine          # noqa: F401
 from . import comm            # noqa: F401
+from . import quant           # noqa: F401
 from . import models          # noqa: F401
 from .trainer import Trainer  # noqa: F401
 from .optim import OptimRegime, Regime  # noqa: F401

@@ -26,6 +26,7 @@ c_i = ctypes.c_int
 c_f = ctypes.c_float
 c_ll = ctypes.c_longlong
 c_sz = ctypes.c_size_t
+c_ull = ctypes.c_ulonglong
 
 # name -> (restype, argtypes); mirrors include/convnet_hip.h one to one
 _SIGNATURES = {
@@ -75,6 +76,14 @@ _SIGNATURES = {
     'cn_small_linear': (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     'cn_cast_from_f32': (c_i, [c_p, c_p, c_ll, c_i, c_p]),
     'cn_fill_f32': (c_i, [c_p, c_ll, c_f, c_p]),
+    'cn_minmax_workspace': (c_sz, [c_i, c_ll]),
+    'cn_minmax_rows': (c_i, [c_p, c_i, c_ll, c_i, c_p, c_p, c_sz, c_p]),
+    'cn_qparams': (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_f, c_p]),
+    'cn_quantize': (c_i, [c_p, c_p, c_ll, c_i, c_p, c_p, c_i, c_p, c_i, c_ull, c_p]),
+    'cn_quantize_rows': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
+    'cn_rangebn_workspace': (c_sz, [c_i, c_i, c_i]),
+    'cn_rangebn_fwd': (c_i, [c_p] * 7 + [c_f, c_f, c_i, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
+    'cn_rangebn_bwd': (c_i, [c_p] * 8 + [c_i, c_i, c_i, c_f, c_i, c_p, c_sz, c_p]),
     'cn_comm_unique_id': (c_i, [c_p]),
     'cn_comm_init': (c_i, [c_p, c_p, c_i, c_i]),
     'cn_comm_info': (c_i, [c_p, c_p, c_p, c_p]),

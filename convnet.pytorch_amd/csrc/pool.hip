@@ -271,6 +271,12 @@ __global__ __launch_bounds__(256) void eltwise_kernel(char* a, const char* b, co
       Chunk<T>::unpack(cn_ld16(c + id * 16), fc);
 #pragma unroll
       for (int e = 0; e < CH; ++e) fa[e] = fc[e] > 0.f ? fb[e] : 0.f;
+    } else if (OP == 4) {  // a = relu(b + c)   (residual junction of the unfused quantised blocks)
+      float fc[CH];
+      Chunk<T>::unpack(cn_ld16(b + id * 16), fb);
+      Chunk<T>::unpack(cn_ld16(c + id * 16), fc);
+#pragma unroll
+      for (int e = 0; e < CH; ++e) { const float v = fb[e] + fc[e]; fa[e] = v > 0.f ? v : 0.f; }
     } else {  // a = b * c   (dropout: c is the pre-scaled keep mask)
       float fc[CH];
       Chunk<T>::unpack(cn_ld16(b + id * 16), fb);
@@ -418,11 +424,11 @@ extern "C" int cn_eltwise(int op, void* a, const void* b, const void* c, long lo
 #define ELT(T, OP) CN_LAUNCH((eltwise_kernel<T, OP>), grid, dim3(256), s, (char*)a, (const char*)b, (const char*)c, nch)
   if (dtype == CN_BF16) {
     if (op == 0) ELT(bf16_t, 0); else if (op == 1) ELT(bf16_t, 1); else if (op == 2) ELT(bf16_t, 2);
-    else if (op == 3) ELT(bf16_t, 3);
+    else if (op == 3) ELT(bf16_t, 3); else if (op == 4) ELT(bf16_t, 4);
     else { cn_set_error("eltwise: bad op"); return CN_EINVAL; }
   } else {
     if (op == 0) ELT(float, 0); else if (op == 1) ELT(float, 1); else if (op == 2) ELT(float, 2);
-    else if (op == 3) ELT(float, 3);
+    else if (op == 3) ELT(float, 3); else if (op == 4) ELT(float, 4);
     else { cn_set_error("eltwise: bad op"); return CN_EINVAL; }
   }
 #undef ELT

@@ -1,0 +1,573 @@
+// quant.hip -- the simulated-8-bit training operators of BASELINE config 5 (ResNet {'quantize': True}), gfx950.
+//
+// Replaces (reference, /root/reference models/modules/quantize.py): calculate_qparams (:19-38),
+// UniformQuantize.forward (:41-76), UniformQuantizeGrad.backward (:101-112), QuantMeasure (:140-182), the
+// per-output-channel weight quantiser of QConv2d / QLinear (:201-203, :239-240) and RangeBN (:256-330) with
+// the gradient autograd derives for it (mean path + max / min routing).  Like the reference this is
+// *simulated* integer arithmetic: tensors are snapped to the 2^bits-level grid and stay floating point, the
+// convolutions themselves run on the ordinary MFMA kernels (igemm.hip / wgrad.hip).
+//
+// All of these are streaming (HBM-bound) passes: 16-byte coalesced accesses, grid-stride loops, two-stage
+// fixed-order reductions (deterministic).  Arithmetic follows the reference's operation order in fp32 and is
+// compiled without FMA contraction, so an fp32 run lands on the same quantisation levels as the CPU oracle.
+#pragma clang fp contract(off)
+#include "cn_common.h"
+#include "cn_api_internal.h"
+#include <math.h>
+
+#define Q_NT 256
+
+// ------------------------------------------------------------------------------------------------ reductions
+__device__ __forceinline__ void q_block_minmax(float& mn, float& mx, float* red /* [8] */) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    mn = fminf(mn, cn_shfl_xor(mn, m));
+    mx = fmaxf(mx, cn_shfl_xor(mx, m));
+  }
+  const int tid = threadIdx.x;
+  __syncthreads();
+  if ((tid & 63) == 0) { red[tid >> 6] = mn; red[4 + (tid >> 6)] = mx; }
+  __syncthreads();
+  mn = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+  mx = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+}
+
+// Stage 1: block (split s, row r) scans its slice of row r.  partial[(r*splits + s)*2] = {min, max}.
+template <typename T>
+__global__ __launch_bounds__(Q_NT) void minmax_partial_kernel(const T* x, long long row_len, int splits, int vec,
+                                                             float* partial) {
+  __shared__ float red[8];
+  constexpr int CH = ElemTraits<T>::kChunk;
+  const int s = blockIdx.x, r = blockIdx.y, tid = threadIdx.x;
+  const T* row = x + (size_t)r * (size_t)row_len;
+  float mn = INFINITY, mx = -INFINITY;
+  if (vec) {   // rows are whole 16-byte chunks
+    const long long nch = row_len / CH;
+    const long long per = (nch + splits - 1) / splits;
+    const long long c0 = (long long)s * per, c1 = c0 + per < nch ? c0 + per : nch;
+    for (long long c = c0 + tid; c < c1; c += Q_NT) {
+      float f[CH];
+      Chunk<T>::unpack(cn_ld16((const char*)row + c * 16), f);
+#pragma unroll
+      for (int e = 0; e < CH; ++e) { mn = fminf(mn, f[e]); mx = fmaxf(mx, f[e]); }
+    }
+  } else {
+    const long long per = (row_len + splits - 1) / splits;
+    const long long e0 = (long long)s * per, e1 = e0 + per < row_len ? e0 + per : row_len;
+    for (long long e = e0 + tid; e < e1; e += Q_NT) {
+      const float v = cn_load_elem<T>(row + e);
+      mn = fminf(mn, v);
+      mx = fmaxf(mx, v);
+    }
+  }
+  q_block_minmax(mn, mx, red);
+  if (tid == 0) {
+    partial[((size_t)r * splits + s) * 2] = mn;
+    partial[((size_t)r * splits + s) * 2 + 1] = mx;
+  }
+}
+
+__global__ __launch_bounds__(Q_NT) void minmax_final_kernel(const float* partial, int rows, int splits, float* minmax) {
+  const int r = blockIdx.x * Q_NT + threadIdx.x;
+  if (r >= rows) return;
+  float mn = INFINITY, mx = -INFINITY;
+  for (int s = 0; s < splits; ++s) {
+    mn = fminf(mn, partial[((size_t)r * splits + s) * 2]);
+    mx = fmaxf(mx, partial[((size_t)r * splits + s) * 2 + 1]);
+  }
+  minmax[2 * r] = mn;
+  minmax[2 * r + 1] = mx;
+}
+
+static int q_splits(int rows, long long row_len) {
+  long long s = (row_len + 16383) / 16384;          // >= 16 Ki elements per block
+  const long long cap = rows >= 1024 ? 1 : (1024 + rows - 1) / rows;
+  if (s > cap) s = cap;
+  if (s > 256) s = 256;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
+extern "C" size_t cn_minmax_workspace(int rows, long long row_len) {
+  return (size_t)rows * (size_t)q_splits(rows, row_len) * 2 * sizeof(float);
+}
+
+// Per-row minimum / maximum of `rows` contiguous rows of `row_len` elements: minmax[r] = {min, max}.
+// (calculate_qparams' x.flatten(1).min(-1) / .max(-1), quantize.py:21-27.)
+extern "C" int cn_minmax_rows(const void* x, int rows, long long row_len, int dtype, float* minmax, float* ws,
+                              size_t ws_bytes, void* stream_) {
+  if (rows <= 0 || row_len <= 0 || x == nullptr || minmax == nullptr) { cn_set_error("minmax_rows: bad arguments"); return CN_EINVAL; }
+  if (rows > 65535) { cn_set_error("minmax_rows: %d rows > 65535", rows); return CN_ESHAPE; }
+  if (ws == nullptr || ws_bytes < cn_minmax_workspace(rows, row_len)) { cn_set_error("minmax_rows: workspace too small"); return CN_EWORKSPACE; }
+  hipStream_t stream = (hipStream_t)stream_;
+  const int splits = q_splits(rows, row_len);
+  dim3 grid((unsigned)splits, (unsigned)rows);
+  if (dtype == CN_BF16) {
+    const int vec = row_len % 8 == 0 && ((uintptr_t)x & 15) == 0;
+    CN_LAUNCH(minmax_partial_kernel<bf16_t>, grid, dim3(Q_NT), stream, (const bf16_t*)x, row_len, splits, vec, ws);
+  } else if (dtype == CN_F32) {
+    const int vec = row_len % 4 == 0 && ((uintptr_t)x & 15) == 0;
+    CN_LAUNCH(minmax_partial_kernel<float>, grid, dim3(Q_NT), stream, (const float*)x, row_len, splits, vec, ws);
+  } else { cn_set_error("minmax_rows: bad dtype %d", dtype); return CN_EINVAL; }
+  CN_LAUNCH(minmax_final_kernel, dim3((unsigned)((rows + Q_NT - 1) / Q_NT)), dim3(Q_NT), stream, (const float*)ws, rows,
+            splits, minmax);
+  return cn_check_launch("minmax_rows");
+}
+
+// ------------------------------------------------------------------------------------------------ qparams
+// mode 0: zero_point = mean_r min_r, range = mean_r max_r - mean_r min_r   (reduce_type 'mean', activations)
+// mode 1: zero_point = min_r min_r,  range = max_r max_r - min_r min_r     (reduce_type 'extreme', gradients)
+// A zero range is reported as 1 (the quantiser is then the identity on that constant tensor; the reference
+// divides by zero there -- documented repair, oracle/make_golden_quant.py).  Optional running update
+// (QuantMeasure, quantize.py:169-172): running = running * momentum + new * (1 - momentum).
+__global__ __launch_bounds__(Q_NT) void qparams_kernel(const float* minmax, int rows, int mode, float* qp,
+                                                      float* running_zp, float* running_range, float momentum) {
+  __shared__ double sred[2 * Q_NT];
+  const int tid = threadIdx.x;
+  double a = mode == 0 ? 0.0 : (double)INFINITY, b = mode == 0 ? 0.0 : -(double)INFINITY;
+  for (int r = tid; r < rows; r += Q_NT) {
+    const double mn = minmax[2 * r], mx = minmax[2 * r + 1];
+    if (mode == 0) { a += mn; b += mx; } else { a = mn < a ? mn : a; b = mx > b ? mx : b; }
+  }
+  sred[tid] = a;
+  sred[Q_NT + tid] = b;
+  __syncthreads();
+  if (tid == 0) {
+    for (int t = 1; t < Q_NT; ++t) {   // fixed order
+      if (mode == 0) { a += sred[t]; b += sred[Q_NT + t]; }
+      else { a = sred[t] < a ? sred[t] : a; b = sred[Q_NT + t] > b ? sred[Q_NT + t] : b; }
+    }
+    float zp, mxv;
+    if (mode == 0) { zp = (float)(a / rows); mxv = (float)(b / rows); } else { zp = (float)a; mxv = (float)b; }
+    float range = mxv - zp;
+    if (range == 0.f) range = 1.f;
+    qp[0] = zp;
+    qp[1] = range;
+    if (running_zp != nullptr) {
+      const float keep = 1.f - momentum;
+      running_zp[0] = running_zp[0] * momentum + zp * keep;
+      running_range[0] = running_range[0] * momentum + range * keep;
+    }
+  }
+}
+
+extern "C" int cn_qparams(const float* minmax, int rows, int mode, float* qp, float* running_zp, float* running_range,
+                          float momentum, void* stream) {
+  if (minmax == nullptr || qp == nullptr || rows <= 0 || (mode != 0 && mode != 1)) { cn_set_error("qparams: bad arguments"); return CN_EINVAL; }
+  if ((running_zp == nullptr) != (running_range == nullptr)) { cn_set_error("qparams: both running buffers or none"); return CN_EINVAL; }
+  CN_LAUNCH(qparams_kernel, dim3(1), dim3(Q_NT), (hipStream_t)stream, minmax, rows, mode, qp, running_zp, running_range,
+            momentum);
+  return cn_check_launch("qparams");
+}
+
+// ------------------------------------------------------------------------------------------------ quantise
+// Counter-based uniform noise in (-0.5, 0.5) for stochastic rounding when no noise tensor is supplied.
+__host__ __device__ __forceinline__ float q_hash_noise(unsigned long long seed, unsigned long long idx) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return ((float)(unsigned int)(z >> 40) + 0.5f) * (1.0f / 16777216.0f) - 0.5f;
+}
+
+// UniformQuantize.forward, unsigned, dequantised (quantize.py:55-76), operation for operation:
+//   t = (x + (-zp)) / scale  [+ noise];  t = round_half_even(clamp(t, 0, qmax));  y = t * scale + zp
+__host__ __device__ __forceinline__ float q_snap(float x, float zp, float scale, float qmax, float noise) {
+  float t = (x + (-zp)) / scale;
+  t = t + noise;
+  t = fminf(fmaxf(t, 0.f), qmax);
+  t = rintf(t);
+  return t * scale + zp;
+}
+
+template <typename T>
+__global__ __launch_bounds__(Q_NT) void quantize_kernel(const T* x, T* y, long long n, const float* zero_point,
+                                                       const float* range, float qmax, const float* noise,
+                                                       int stochastic, unsigned long long seed) {
+  constexpr int CH = ElemTraits<T>::kChunk;
+  const float zp = zero_point[0];
+  const float scale = (range[0] == 0.f ? 1.f : range[0]) / qmax;
+  const long long nch = n / CH;
+  for (long long c = (long long)blockIdx.x * Q_NT + threadIdx.x; c < nch; c += (long long)gridDim.x * Q_NT) {
+    float f[CH];
+    Chunk<T>::unpack(cn_ld16((const char*)x + c * 16), f);
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+      const long long i = c * CH + e;
+      const float nz = noise != nullptr ? noise[i] : (stochastic ? q_hash_noise(seed, (unsigned long long)i) : 0.f);
+      f[e] = q_snap(f[e], zp, scale, qmax, nz);
+    }
+    cn_st16((char*)y + c * 16, Chunk<T>::pack(f));
+  }
+  // ragged tail (tensors that are not whole chunks: biases, the 3-channel image)
+  for (long long i = nch * CH + (long long)blockIdx.x * Q_NT + threadIdx.x; i < n; i += (long long)gridDim.x * Q_NT) {
+    const float nz = noise != nullptr ? noise[i] : (stochastic ? q_hash_noise(seed, (unsigned long long)i) : 0.f);
+    cn_store_elem<T>(y + i, q_snap(cn_load_elem<T>(x + i), zp, scale, qmax, nz));
+  }
+}
+
+static unsigned q_grid(long long work_items) {
+  long long nb = (work_items + Q_NT - 1) / Q_NT;
+  if (nb > 8192) nb = 8192;
+  if (nb < 1) nb = 1;
+  return (unsigned)nb;
+}
+
+// y = quantise-dequantise(x) with the two scalars zero_point / range read on the device; 2^num_bits levels.
+// Rounding noise: `noise` (fp32, one value per element, U(-0.5, 0.5)) when given, else the counter-based
+// generator keyed by (seed, element index) when stochastic != 0, else none (deterministic rounding).
+extern "C" int cn_quantize(const void* x, void* y, long long n, int dtype, const float* zero_point, const float* range,
+                           int num_bits, const float* noise, int stochastic, unsigned long long seed, void* stream_) {
+  if (n <= 0) return CN_OK;
+  if (x == nullptr || y == nullptr || zero_point == nullptr || range == nullptr || num_bits < 1 || num_bits > 23) { cn_set_error("quantize: bad arguments"); return CN_EINVAL; }
+  if (((uintptr_t)x & 15) != 0 || ((uintptr_t)y & 15) != 0) { cn_set_error("quantize: buffers must be 16-byte aligned"); return CN_EINVAL; }
+  hipStream_t stream = (hipStream_t)stream_;
+  const float qmax = (float)((1 << num_bits) - 1);
+  if (dtype == CN_BF16)
+    CN_LAUNCH(quantize_kernel<bf16_t>, dim3(q_grid((n + 7) / 8)), dim3(Q_NT), stream, (const bf16_t*)x, (bf16_t*)y, n,
+              zero_point, range, qmax, noise, stochastic, seed);
+  else if (dtype == CN_F32)
+    CN_LAUNCH(quantize_kernel<float>, dim3(q_grid((n + 3) / 4)), dim3(Q_NT), stream, (const float*)x, (float*)y, n,
+              zero_point, range, qmax, noise, stochastic, seed);
+  else { cn_set_error("quantize: bad dtype %d", dtype); return CN_EINVAL; }
+  return cn_check_launch("quantize");
+}
+
+// Per-row quantisation of an fp32 matrix [rows][row_len] with that row's own min / max (the weight
+// quantiser: one row per output channel, quantize.py:201-203).  One workgroup per row.
+__global__ __launch_bounds__(Q_NT) void quantize_rows_kernel(const float* x, float* y, int row_len, float qmax) {
+  __shared__ float red[8];
+  const int r = blockIdx.x, tid = threadIdx.x;
+  const float* row = x + (size_t)r * row_len;
+  float mn = INFINITY, mx = -INFINITY;
+  for (int e = tid; e < row_len; e += Q_NT) { mn = fminf(mn, row[e]); mx = fmaxf(mx, row[e]); }
+  q_block_minmax(mn, mx, red);
+  float range = mx - mn;
+  if (range == 0.f) range = 1.f;
+  const float scale = range / qmax;
+  for (int e = tid; e < row_len; e += Q_NT) y[(size_t)r * row_len + e] = q_snap(row[e], mn, scale, qmax, 0.f);
+}
+
+extern "C" int cn_quantize_rows(const float* x, float* y, int rows, int row_len, int num_bits, void* stream) {
+  if (rows <= 0 || row_len <= 0) return CN_OK;
+  if (x == nullptr || y == nullptr || num_bits < 1 || num_bits > 23) { cn_set_error("quantize_rows: bad arguments"); return CN_EINVAL; }
+  CN_LAUNCH(quantize_rows_kernel, dim3((unsigned)rows), dim3(Q_NT), (hipStream_t)stream, x, y, row_len,
+            (float)((1 << num_bits) - 1));
+  return cn_check_launch("quantize_rows");
+}
+
+// ------------------------------------------------------------------------------------------------ RangeBN
+// Activations NHWC [M][C]; the reference's view(C, chunks, M/chunks) of the (b, h, w)-ordered values is the
+// split of the M pixels into `chunks` consecutive ranges.  Each range is cut further into `sub` slices so the
+// launch fills the chip; slices are merged in order, so ties resolve to the FIRST maximal / minimal element
+// exactly as torch.max / torch.min do.
+struct RbnPartial {   // one per (chunk, slice, channel)
+  float mx, mn, sum;
+  int imx, imn;
+};
+
+template <typename T>
+__global__ __launch_bounds__(Q_NT) void rangebn_stats_kernel(const T* x, int M, int C, int chunks, int sub, int cols,
+                                                            RbnPartial* part) {
+  constexpr int CH = ElemTraits<T>::kChunk;
+  __shared__ float s_mx[Q_NT * CH], s_mn[Q_NT * CH], s_sum[Q_NT * CH];
+  __shared__ int s_imx[Q_NT * CH], s_imn[Q_NT * CH];
+  const int tid = threadIdx.x;
+  const int lanes = Q_NT / cols;            // pixel lanes per chunk column
+  const int col = tid % cols, lane = tid / cols;
+  const int CC = C / CH;
+  const int cc = blockIdx.x * cols + col;   // chunk column of this thread
+  const int slice = blockIdx.y;             // chunk * sub + s
+  const int chunk = slice / sub, s = slice - chunk * sub;
+  const int L = M / chunks;
+  const int per = (L + sub - 1) / sub;
+  const int p0 = chunk * L + s * per;
+  int p1 = p0 + per;
+  if (p1 > (chunk + 1) * L) p1 = (chunk + 1) * L;
+  float mx[CH], mn[CH], sm[CH];
+  int imx[CH], imn[CH];
+#pragma unroll
+  for (int e = 0; e < CH; ++e) { mx[e] = -INFINITY; mn[e] = INFINITY; sm[e] = 0.f; imx[e] = 0x7fffffff; imn[e] = 0x7fffffff; }
+  if (cc < CC) {
+    for (int p = p0 + lane; p < p1; p += lanes) {
+      float f[CH];
+      Chunk<T>::unpack(cn_ld16((const char*)x + ((size_t)p * CC + cc) * 16), f);
+#pragma unroll
+      for (int e = 0; e < CH; ++e) {
+        if (f[e] > mx[e]) { mx[e] = f[e]; imx[e] = p; }
+        if (f[e] < mn[e]) { mn[e] = f[e]; imn[e] = p; }
+        sm[e] += f[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < CH; ++e) {
+    s_mx[tid * CH + e] = mx[e]; s_mn[tid * CH + e] = mn[e]; s_sum[tid * CH + e] = sm[e];
+    s_imx[tid * CH + e] = imx[e]; s_imn[tid * CH + e] = imn[e];
+  }
+  __syncthreads();
+  if (lane == 0 && cc < CC) {
+    for (int e = 0; e < CH; ++e) {
+      float bmx = -INFINITY, bmn = INFINITY, bs = 0.f;
+      int bimx = 0x7fffffff, bimn = 0x7fffffff;
+      for (int l = 0; l < lanes; ++l) {   // lanes hold interleaved pixels: ties go to the smaller index
+        const int t = (l * cols + col) * CH + e;
+        if (s_mx[t] > bmx || (s_mx[t] == bmx && s_imx[t] < bimx)) { bmx = s_mx[t]; bimx = s_imx[t]; }
+        if (s_mn[t] < bmn || (s_mn[t] == bmn && s_imn[t] < bimn)) { bmn = s_mn[t]; bimn = s_imn[t]; }
+        bs += s_sum[t];
+      }
+      RbnPartial o;
+      o.mx = bmx; o.mn = bmn; o.sum = bs; o.imx = bimx; o.imn = bimn;
+      part[(size_t)slice * C + cc * CH + e] = o;
+    }
+  }
+}
+
+// Per channel: merge the slices, then mean, scale = (mean of chunk maxima - mean of chunk minima) * scale_fix,
+// running statistics (running = running * momentum + new * (1 - momentum), quantize.py:300-305).
+// stats[c] = mean, stats[C + c] = scale + eps;  arg[c][2*chunks] = pixel index of each chunk's first max / min.
+__global__ __launch_bounds__(Q_NT) void rangebn_finalize_kernel(const RbnPartial* part, int M, int C, int chunks, int sub,
+                                                               float scale_fix, float eps, float momentum,
+                                                               float* running_mean, float* running_var, float* stats,
+                                                               int* arg) {
+  const int c = blockIdx.x * Q_NT + threadIdx.x;
+  if (c >= C) return;
+  double total = 0.0;
+  float smx = 0.f, smn = 0.f;
+  for (int j = 0; j < chunks; ++j) {
+    float bmx = -INFINITY, bmn = INFINITY;
+    int bimx = 0, bimn = 0;
+    for (int s = 0; s < sub; ++s) {
+      const RbnPartial o = part[(size_t)(j * sub + s) * C + c];
+      if (o.mx > bmx) { bmx = o.mx; bimx = o.imx; }
+      if (o.mn < bmn) { bmn = o.mn; bimn = o.imn; }
+      total += (double)o.sum;
+    }
+    smx += bmx;
+    smn += bmn;
+    arg[(size_t)c * 2 * chunks + j] = bimx;
+    arg[(size_t)c * 2 * chunks + chunks + j] = bimn;
+  }
+  const float mean = (float)(total / (double)M);
+  const float scale = (smx / (float)chunks - smn / (float)chunks) * scale_fix;
+  stats[c] = mean;
+  stats[C + c] = scale + eps;
+  if (running_mean != nullptr) {
+    const float keep = 1.f - momentum;
+    running_mean[c] = running_mean[c] * momentum + mean * keep;
+    running_var[c] = running_var[c] * momentum + scale * keep;
+  }
+}
+
+// inference statistics: stats = {running_mean, running_var + eps}
+__global__ __launch_bounds__(Q_NT) void rangebn_infer_stats_kernel(const float* running_mean, const float* running_var,
+                                                                  float eps, int C, float* stats) {
+  const int c = blockIdx.x * Q_NT + threadIdx.x;
+  if (c >= C) return;
+  stats[c] = running_mean[c];
+  stats[C + c] = running_var[c] + eps;
+}
+
+// z = act(((x - mean) / (scale + eps)) * w + b [+ residual])   (quantize.py:312-325, then the block's add / ReLU)
+template <typename T>
+__global__ __launch_bounds__(Q_NT) void rangebn_apply_kernel(const T* x, const T* residual, T* z, const float* stats,
+                                                            const float* weight, const float* bias, long long nch,
+                                                            int C, int relu) {
+  constexpr int CH = ElemTraits<T>::kChunk;
+  const int CC = C / CH;
+  for (long long id = (long long)blockIdx.x * Q_NT + threadIdx.x; id < nch; id += (long long)gridDim.x * Q_NT) {
+    const int c0 = (int)(id % CC) * CH;
+    float f[CH], r[CH];
+    Chunk<T>::unpack(cn_ld16((const char*)x + id * 16), f);
+    if (residual != nullptr) Chunk<T>::unpack(cn_ld16((const char*)residual + id * 16), r);
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+      float v = (f[e] - stats[c0 + e]) / stats[C + c0 + e];
+      v = v * weight[c0 + e];
+      v = v + bias[c0 + e];
+      if (residual != nullptr) v = v + r[e];
+      if (relu) v = v > 0.f ? v : 0.f;
+      f[e] = v;
+    }
+    cn_st16((char*)z + id * 16, Chunk<T>::pack(f));
+  }
+}
+
+extern "C" size_t cn_rangebn_workspace(int M, int C, int chunks) {
+  if (M <= 0 || C <= 0 || chunks <= 0) return 0;
+  int sub = (M / chunks + 2047) / 2048;   // >= 2 Ki pixels per slice
+  if (sub < 1) sub = 1;
+  if (sub > 64) sub = 64;
+  const size_t stats = (size_t)chunks * sub * C * sizeof(RbnPartial);
+  const size_t bwd = ((size_t)((M + 1023) / 1024) * 2 * C + 3 * (size_t)C) * sizeof(float);
+  return stats > bwd ? stats : bwd;
+}
+static int rbn_sub(int M, int chunks) {
+  int sub = (M / chunks + 2047) / 2048;
+  if (sub < 1) sub = 1;
+  if (sub > 64) sub = 64;
+  return sub;
+}
+static int rbn_cols(int CC) {
+  int cols = 1;
+  while (cols * 2 <= CC && cols < 32) cols *= 2;
+  return cols;
+}
+
+// RangeBN forward on an already input-quantised x [M][C].  training != 0: batch statistics (mean; scale from
+// `chunks` chunk-wise max - min, M % chunks == 0 as the reference's view() requires), running statistics
+// updated, stats[2C] = {mean | scale + eps} and arg[C][2*chunks] saved for the backward pass.  training == 0:
+// running statistics.  z = act(affine(normalised x) [+ residual]).
+extern "C" int cn_rangebn_fwd(const void* x, const void* residual, void* z, const float* weight, const float* bias,
+                              float* running_mean, float* running_var, float momentum, float eps, int chunks,
+                              float scale_fix, float* stats, int* arg, int M, int C, int relu, int training, int dtype,
+                              float* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int CH = dtype == CN_BF16 ? 8 : 4;
+  if (dtype != CN_BF16 && dtype != CN_F32) { cn_set_error("rangebn_fwd: bad dtype"); return CN_EINVAL; }
+  if (M <= 0 || C <= 0 || C % CH != 0) { cn_set_error("rangebn_fwd: M=%d C=%d (C must be a multiple of %d)", M, C, CH); return CN_ESHAPE; }
+  if (x == nullptr || z == nullptr || weight == nullptr || bias == nullptr || stats == nullptr) { cn_set_error("rangebn_fwd: null operand"); return CN_EINVAL; }
+  const int CC = C / CH;
+  if (training) {
+    if (chunks <= 0 || M % chunks != 0) { cn_set_error("rangebn_fwd: %d values per channel do not split into %d chunks", M, chunks); return CN_ESHAPE; }
+    if (arg == nullptr) { cn_set_error("rangebn_fwd: training needs the arg buffer"); return CN_EINVAL; }
+    if (ws == nullptr || ws_bytes < cn_rangebn_workspace(M, C, chunks)) { cn_set_error("rangebn_fwd: workspace too small"); return CN_EWORKSPACE; }
+    const int sub = rbn_sub(M, chunks), cols = rbn_cols(CC);
+    dim3 grid((unsigned)((CC + cols - 1) / cols), (unsigned)(chunks * sub));
+    if (dtype == CN_BF16)
+      CN_LAUNCH(rangebn_stats_kernel<bf16_t>, grid, dim3(Q_NT), stream, (const bf16_t*)x, M, C, chunks, sub, cols, (RbnPartial*)ws);
+    else
+      CN_LAUNCH(rangebn_stats_kernel<float>, grid, dim3(Q_NT), stream, (const float*)x, M, C, chunks, sub, cols, (RbnPartial*)ws);
+    CN_LAUNCH(rangebn_finalize_kernel, dim3((unsigned)((C + Q_NT - 1) / Q_NT)), dim3(Q_NT), stream, (const RbnPartial*)ws, M,
+              C, chunks, sub, scale_fix, eps, momentum, running_mean, running_var, stats, arg);
+  } else {
+    if (running_mean == nullptr || running_var == nullptr) { cn_set_error("rangebn_fwd: inference needs the running statistics"); return CN_EINVAL; }
+    CN_LAUNCH(rangebn_infer_stats_kernel, dim3((unsigned)((C + Q_NT - 1) / Q_NT)), dim3(Q_NT), stream,
+              (const float*)running_mean, (const float*)running_var, eps, C, stats);
+  }
+  const long long nch = (long long)M * CC;
+  if (dtype == CN_BF16)
+    CN_LAUNCH(rangebn_apply_kernel<bf16_t>, dim3(q_grid(nch)), dim3(Q_NT), stream, (const bf16_t*)x, (const bf16_t*)residual,
+              (bf16_t*)z, (const float*)stats, weight, bias, nch, C, relu);
+  else
+    CN_LAUNCH(rangebn_apply_kernel<float>, dim3(q_grid(nch)), dim3(Q_NT), stream, (const float*)x, (const float*)residual,
+              (float*)z, (const float*)stats, weight, bias, nch, C, relu);
+  return cn_check_launch("rangebn_fwd");
+}
+
+// ---- backward.  g = the (already quantised) gradient of the RangeBN output, x = its quantised input.
+//   S1 = sum g, S2 = sum g * (x - mean), r = 1 / (scale + eps):
+//   dbias += S1;  dweight += r * S2;  dx = g * (w r) - (w r) S1 / M
+//   dL/dscale = -w r^2 S2 reaches x through the chunk maxima / minima: scale = fix/chunks * sum_j (max_j - min_j)
+//   => dx[first argmax of chunk j] += dL/dscale * fix / chunks,  dx[first argmin of chunk j] -= the same.
+template <typename T>
+__global__ __launch_bounds__(Q_NT) void rangebn_bwd_reduce_kernel(const T* g, const T* x, const float* stats, int M, int C,
+                                                                 int rows_per, int cols, float* partial) {
+  constexpr int CH = ElemTraits<T>::kChunk;
+  __shared__ float s1[Q_NT * CH], s2[Q_NT * CH];
+  const int tid = threadIdx.x, CC = C / CH;
+  const int lanes = Q_NT / cols, col = tid % cols, lane = tid / cols;
+  const int cc = blockIdx.x * cols + col;
+  const int p0 = blockIdx.y * rows_per;
+  const int p1 = p0 + rows_per < M ? p0 + rows_per : M;
+  float a1[CH], a2[CH], mean[CH];
+#pragma unroll
+  for (int e = 0; e < CH; ++e) { a1[e] = 0.f; a2[e] = 0.f; mean[e] = cc < CC ? stats[cc * CH + e] : 0.f; }
+  if (cc < CC) {
+    for (int p = p0 + lane; p < p1; p += lanes) {
+      float fg[CH], fx[CH];
+      Chunk<T>::unpack(cn_ld16((const char*)g + ((size_t)p * CC + cc) * 16), fg);
+      Chunk<T>::unpack(cn_ld16((const char*)x + ((size_t)p * CC + cc) * 16), fx);
+#pragma unroll
+      for (int e = 0; e < CH; ++e) { a1[e] += fg[e]; a2[e] += fg[e] * (fx[e] - mean[e]); }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < CH; ++e) { s1[tid * CH + e] = a1[e]; s2[tid * CH + e] = a2[e]; }
+  __syncthreads();
+  if (lane == 0 && cc < CC) {
+    for (int e = 0; e < CH; ++e) {
+      float t1 = 0.f, t2 = 0.f;
+      for (int l = 0; l < lanes; ++l) { t1 += s1[(l * cols + col) * CH + e]; t2 += s2[(l * cols + col) * CH + e]; }
+      partial[(size_t)blockIdx.y * 2 * C + cc * CH + e] = t1;
+      partial[(size_t)blockIdx.y * 2 * C + C + cc * CH + e] = t2;
+    }
+  }
+}
+
+// coef[c] = w r, coef[C + c] = -(w r) S1 / M, coef[2C + c] = -w r^2 S2 * fix / chunks; parameter gradients accumulated.
+__global__ __launch_bounds__(Q_NT) void rangebn_bwd_finalize_kernel(const float* partial, int rows, int M, int C,
+                                                                   const float* weight, const float* stats, float route,
+                                                                   float* dweight, float* dbias, float* coef) {
+  const int c = blockIdx.x * Q_NT + threadIdx.x;
+  if (c >= C) return;
+  double S1 = 0.0, S2 = 0.0;
+  for (int r = 0; r < rows; ++r) { S1 += (double)partial[(size_t)r * 2 * C + c]; S2 += (double)partial[(size_t)r * 2 * C + C + c]; }
+  const float r = 1.f / stats[C + c];
+  const float w = weight[c];
+  const float s1 = (float)S1, s2 = (float)S2;
+  dbias[c] += s1;
+  dweight[c] += r * s2;
+  coef[c] = w * r;
+  coef[C + c] = -(w * r * s1) / (float)M;
+  coef[2 * C + c] = (-w * r * r * s2) * route;
+}
+
+template <typename T>
+__global__ __launch_bounds__(Q_NT) void rangebn_bwd_apply_kernel(const T* g, T* dx, const float* coef, long long nch, int C) {
+  constexpr int CH = ElemTraits<T>::kChunk;
+  const int CC = C / CH;
+  for (long long id = (long long)blockIdx.x * Q_NT + threadIdx.x; id < nch; id += (long long)gridDim.x * Q_NT) {
+    const int c0 = (int)(id % CC) * CH;
+    float f[CH];
+    Chunk<T>::unpack(cn_ld16((const char*)g + id * 16), f);
+#pragma unroll
+    for (int e = 0; e < CH; ++e) f[e] = f[e] * coef[c0 + e] + coef[C + c0 + e];
+    cn_st16((char*)dx + id * 16, Chunk<T>::pack(f));
+  }
+}
+
+// one thread per channel walks its 2 * chunks routed positions (distinct channels never share an element)
+template <typename T>
+__global__ __launch_bounds__(Q_NT) void rangebn_bwd_route_kernel(T* dx, const float* coef, const int* arg, int C, int chunks) {
+  const int c = blockIdx.x * Q_NT + threadIdx.x;
+  if (c >= C) return;
+  const float d = coef[2 * C + c];
+  for (int j = 0; j < chunks; ++j) {
+    T* pm = dx + (size_t)arg[(size_t)c * 2 * chunks + j] * C + c;
+    cn_store_elem<T>(pm, cn_load_elem<T>(pm) + d);
+    T* pn = dx + (size_t)arg[(size_t)c * 2 * chunks + chunks + j] * C + c;
+    cn_store_elem<T>(pn, cn_load_elem<T>(pn) - d);
+  }
+}
+
+extern "C" int cn_rangebn_bwd(const void* g, const void* x, const float* weight, const float* stats, const int* arg,
+                              void* dx, float* dweight, float* dbias, int M, int C, int chunks, float scale_fix,
+                              int dtype, float* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int CH = dtype == CN_BF16 ? 8 : 4;
+  if (dtype != CN_BF16 && dtype != CN_F32) { cn_set_error("rangebn_bwd: bad dtype"); return CN_EINVAL; }
+  if (M <= 0 || C <= 0 || C % CH != 0 || chunks <= 0) { cn_set_error("rangebn_bwd: bad shape"); return CN_ESHAPE; }
+  if (g == nullptr || x == nullptr || weight == nullptr || stats == nullptr || arg == nullptr || dx == nullptr ||
+      dweight == nullptr || dbias == nullptr) { cn_set_error("rangebn_bwd: null operand"); return CN_EINVAL; }
+  if (ws == nullptr || ws_bytes < cn_rangebn_workspace(M, C, chunks)) { cn_set_error("rangebn_bwd: workspace too small"); return CN_EWORKSPACE; }
+  const int CC = C / CH, cols = rbn_cols(CC);
+  const int rows = (M + 1023) / 1024;
+  float* partial = ws;
+  float* coef = ws + (size_t)rows * 2 * C;
+  dim3 grid((unsigned)((CC + cols - 1) / cols), (unsigned)rows);
+  const long long nch = (long long)M * CC;
+  const float route = scale_fix / (float)chunks;
+  if (dtype == CN_BF16) {
+    CN_LAUNCH(rangebn_bwd_reduce_kernel<bf16_t>, grid, dim3(Q_NT), stream, (const bf16_t*)g, (const bf16_t*)x, stats, M, C, 1024, cols, partial);
+    CN_LAUNCH(rangebn_bwd_finalize_kernel, dim3((unsigned)((C + Q_NT - 1) / Q_NT)), dim3(Q_NT), stream, (const float*)partial, rows, M, C, weight, stats, route, dweight, dbias, coef);
+    CN_LAUNCH(rangebn_bwd_apply_kernel<bf16_t>, dim3(q_grid(nch)), dim3(Q_NT), stream, (const bf16_t*)g, (bf16_t*)dx, (const float*)coef, nch, C);
+    CN_LAUNCH(rangebn_bwd_route_kernel<bf16_t>, dim3((unsigned)((C + Q_NT - 1) / Q_NT)), dim3(Q_NT), stream, (bf16_t*)dx, (const float*)coef, arg, C, chunks);
+  } else {
+    CN_LAUNCH(rangebn_bwd_reduce_kernel<float>, grid, dim3(Q_NT), stream, (const float*)g, (const float*)x, stats, M, C, 1024, cols, partial);
+    CN_LAUNCH(rangebn_bwd_finalize_kernel, dim3((unsigned)((C + Q_NT - 1) / Q_NT)), dim3(Q_NT), stream, (const float*)partial, rows, M, C, weight, stats, route, dweight, dbias, coef);
+    CN_LAUNCH(rangebn_bwd_apply_kernel<float>, dim3(q_grid(nch)), dim3(Q_NT), stream, (const float*)g, (float*)dx, (const float*)coef, nch, C);
+    CN_LAUNCH(rangebn_bwd_route_kernel<float>, dim3((unsigned)((C + Q_NT - 1) / Q_NT)), dim3(Q_NT), stream, (float*)dx, (const float*)coef, arg, C, chunks);
+  }
+  return cn_check_launch("rangebn_bwd");
+}

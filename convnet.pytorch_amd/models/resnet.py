@@ -3,8 +3,10 @@
 Same factory surface, module tree / ``state_dict`` keys, initialisation and optimisation regimes
 as /root/reference models/resnet.py (factory :385-431, ResNet_imagenet :216-317, blocks :81-165,
 init_model :16-31, weight-decay filter :34-40), re-expressed as a declarative stage table instead
-of hand-written block classes.  Out of scope here (not reachable from the BASELINE configs):
-ResNet_cifar, resnet_se, mixed-size "sampled" regimes, checkpoint_segments, quantize / bn_norm.
+of hand-written block classes.  ``quantize=True`` (BASELINE config 5; the reference rebinds torch.nn's
+Conv2d / Linear / BatchNorm2d to its simulated-8-bit classes, :387-391) builds the same tree from
+``convnet.pytorch_amd.quant``'s QConv2d / QLinear / RangeBN.  Out of scope here (not reachable from the
+BASELINE configs): ResNet_cifar, resnet_se, mixed-size "sampled" regimes, checkpoint_segments, bn_norm.
 
 Module construction order and registration order deliberately match the reference, so seeding
 torch's RNG and building ``resnet(depth=50)`` yields bit-identical initial weights.
@@ -52,19 +54,22 @@ class ResidualBlock(tnn.Module):
     """BasicBlock / Bottleneck of the reference (models/resnet.py:81-165) built from a branch plan.
     The last BN of the branch fuses `+ residual` and the final ReLU; inner BNs fuse their ReLU."""
 
-    def __init__(self, kind, inplanes, planes, stride, expansion, downsample):
+    def __init__(self, kind, inplanes, planes, stride, expansion, downsample, op_classes=None):
         super().__init__()
         self.kind = kind
+        self.quantized = op_classes is not None
+        Conv, Norm = op_classes[:2] if self.quantized else (cnn.Conv2d, cnn.BatchNorm2d)
         widths = {'planes': planes, 'out': planes * expansion}
         cin = inplanes
         self.n_convs = len(_BRANCH[kind])
         for i, (k, wkey, strided) in enumerate(_BRANCH[kind], start=1):
             cout = widths[wkey]
-            setattr(self, 'conv%d' % i, cnn.Conv2d(cin, cout, kernel_size=k, stride=stride if strided else 1,
-                                                   padding=k // 2, bias=False))
-            setattr(self, 'bn%d' % i, cnn.BatchNorm2d(cout))
-            getattr(self, 'conv%d' % i).feeds_batchnorm = True   # BN statistics come out of the conv epilogue
-            if i > 1:   # this conv reads relu(bn_{i-1}(.)): its dgrad epilogue does that BN's backward reduction
+            setattr(self, 'conv%d' % i, Conv(cin, cout, kernel_size=k, stride=stride if strided else 1,
+                                             padding=k // 2, bias=False))
+            setattr(self, 'bn%d' % i, Norm(cout))
+            if not self.quantized:
+                getattr(self, 'conv%d' % i).feeds_batchnorm = True   # BN statistics come out of the conv epilogue
+            if i > 1 and not self.quantized:   # this conv reads relu(bn_{i-1}(.)): its dgrad epilogue does that BN's backward reduction
                 # (instance dict, not setattr: the BN must not become a registered sub-module of the conv)
                 getattr(self, 'conv%d' % i).__dict__['input_bn'] = getattr(self, 'bn%d' % (i - 1))
             if i == 1 and kind == 'basic':
@@ -78,6 +83,9 @@ class ResidualBlock(tnn.Module):
             self.dropout = cnn.Dropout(0)
         self.stride = stride
         self.expansion = expansion
+        if self.quantized:   # plain operator chain: no cross-operator fusion in the simulated-8-bit model
+            self._holder = None
+            return
         # the two gradients meeting at the block input are summed inside a dgrad epilogue
         from ..ops import ResGradHolder
         self._holder = ResGradHolder()
@@ -94,6 +102,8 @@ class ResidualBlock(tnn.Module):
     def set_input_bn(self, bn):
         """The block input is the output of `bn` (the previous block's last BN, ReLU and residual fused):
         whichever of conv1 / downsample conv completes the input gradient reduces it for that BN."""
+        if self.quantized:
+            return
         self.conv1.__dict__['input_bn'] = bn
         if self.downsample is not None:
             self.downsample[0].__dict__['input_bn'] = bn
@@ -106,6 +116,12 @@ class ResidualBlock(tnn.Module):
             out = getattr(self, 'bn%d' % i)(out, relu=True)
         out = getattr(self, 'conv%d' % self.n_convs)(out)
         residual = xb
+        if self.quantized:   # bn -> (downsample) -> add -> relu as separate operators, in the reference's order
+            out = self.last_bn()(out)
+            if self.downsample is not None:
+                residual = self.downsample[1](self.downsample[0](xb))
+            from ..quant import add_relu
+            return add_relu(out, residual)
         if self.downsample is not None:
             residual = self.downsample[1](self.downsample[0](xb))
         return self.last_bn()(out, residual=residual, relu=True)
@@ -133,13 +149,18 @@ class ResNetImagenet(tnn.Module):
 
     def __init__(self, num_classes=1000, inplanes=64, block='bottleneck', layers=(3, 4, 23, 3),
                  width=(64, 128, 256, 512), expansion=4, regime='normal', scale_lr=1, ramp_up_lr=True,
-                 ramp_up_epochs=5, epochs=90, base_devices=4, base_device_batch=64):
+                 ramp_up_epochs=5, epochs=90, base_devices=4, base_device_batch=64, quantize=False):
         super().__init__()
         self.inplanes = inplanes
-        self.conv1 = cnn.Conv2d(3, inplanes, kernel_size=7, stride=2, padding=3, bias=False)
+        self.op_classes = None
+        if quantize:
+            from .. import quant
+            self.op_classes = (quant.QConv2d, quant.RangeBN, quant.QLinear)
+        Conv, Norm, Dense = self.op_classes or (cnn.Conv2d, cnn.BatchNorm2d, cnn.Linear)
+        self.conv1 = Conv(3, inplanes, kernel_size=7, stride=2, padding=3, bias=False)
         self.conv1.needs_dgrad = False  # network input needs no gradient
-        self.conv1.feeds_batchnorm = True
-        self.bn1 = cnn.BatchNorm2d(inplanes)
+        self.conv1.feeds_batchnorm = not quantize
+        self.bn1 = Norm(inplanes)
         self.relu = cnn.ReLU(inplace=True)
         self.maxpool = cnn.MaxPool2d(kernel_size=3, stride=2, padding=1)
         for i, nblocks in enumerate(layers):
@@ -152,7 +173,7 @@ class ResNetImagenet(tnn.Module):
                     m.set_input_bn(prev.last_bn())
                 prev = m
         self.avgpool = cnn.AdaptiveAvgPool2d(1)
-        self.fc = cnn.Linear(width[-1] * expansion, num_classes)
+        self.fc = Dense(width[-1] * expansion, num_classes)
         init_model(self)
 
         batch_size = base_devices * base_device_batch
@@ -188,13 +209,14 @@ class ResNetImagenet(tnn.Module):
         out_planes = planes * expansion
         downsample = None
         if stride != 1 or self.inplanes != out_planes:  # models/resnet.py:176-181
+            Conv, Norm = (self.op_classes or (cnn.Conv2d, cnn.BatchNorm2d))[:2]
             downsample = tnn.Sequential(
-                cnn.Conv2d(self.inplanes, out_planes, kernel_size=1, stride=stride, bias=False),
-                cnn.BatchNorm2d(out_planes))
-        stage = [ResidualBlock(kind, self.inplanes, planes, stride, expansion, downsample)]
+                Conv(self.inplanes, out_planes, kernel_size=1, stride=stride, bias=False),
+                Norm(out_planes))
+        stage = [ResidualBlock(kind, self.inplanes, planes, stride, expansion, downsample, self.op_classes)]
         self.inplanes = out_planes
         for _ in range(1, blocks):
-            stage.append(ResidualBlock(kind, self.inplanes, planes, 1, expansion, None))
+            stage.append(ResidualBlock(kind, self.inplanes, planes, 1, expansion, None, self.op_classes))
         return tnn.Sequential(*stage)
 
     def features(self, x):
@@ -218,9 +240,9 @@ class ResNetImagenet(tnn.Module):
 def resnet(**config):
     """Factory with the reference's call shape: resnet(dataset=..., depth=..., **kw)."""
     dataset = config.pop('dataset', 'imagenet')
-    for unsupported in ('quantize', 'bn_norm'):
-        if config.pop(unsupported, None):
-            raise NotImplementedError("resnet(%s=...) is not part of the MI355X hot path yet" % unsupported)
+    if config.pop('bn_norm', None):
+        raise NotImplementedError("resnet(bn_norm=...) is not part of the MI355X hot path")
+    config['quantize'] = bool(config.pop('quantize', False))
     if 'imagenet' not in dataset:
         raise NotImplementedError("only the ImageNet ResNet variant is built natively (dataset=%r)" % dataset)
     config.setdefault('num_classes', 1000)

@@ -272,7 +272,7 @@ def bn_relu_maxpool(bn, pool, y):
     otherwise (eval mode, synchronised BatchNorm, non-square pooling arguments)."""
     simple = all(isinstance(v, int) for v in (pool.kernel_size, pool.stride, pool.padding)) \
         and pool.kernel_size <= 2 * pool.stride
-    if (ops.FUSE_STEM_POOL and simple and bn._arena is not None and (bn.training or not bn.track_running_stats)
+    if (ops.FUSE_STEM_POOL and simple and type(bn) is BatchNorm2d and bn._arena is not None and (bn.training or not bn.track_running_stats)
             and ops._sync_group(bn) is None):
         fn = ops.BnReluMaxPoolFunction.apply
         if torch.is_grad_enabled():

@@ -1,0 +1,371 @@
+"""Simulated 8-bit training operators of BASELINE config 5 (``resnet(quantize=True)``) on the HIP kernels.
+
+Same classes, constructor signatures, ``state_dict`` keys and arithmetic as /root/reference
+models/modules/quantize.py (QuantMeasure :140-182, QConv2d :185-220, QLinear :223-253, RangeBN :256-330), which
+models/resnet.py:387-391 swaps in for Conv2d / Linear / BatchNorm2d.  Like the reference this is *simulated*
+integer training: activations, weights and gradients are snapped to 2^bits-level grids (cn_quantize*,
+cn_rangebn_* in csrc/quant.hip) and stay floating point; the convolutions run on the ordinary MFMA kernels.
+
+Semantics kept from the reference (restated and pinned in oracle/quant_oracle.py):
+  * activations: per-tensor asymmetric 8 bit, zero point / range = batch mean of the per-sample min / (max-min),
+    tracked as running = running*0.1 + new*0.9 for eval mode; straight-through gradient;
+  * weights: 8 bit per output channel; classifier bias 16 bit over its global range;
+  * "bi-precision" backward: the weight gradient sees the full-precision dy, the input gradient sees dy
+    quantised to 8 bits over its global min / max with stochastic rounding;
+  * RangeBN: statistics from 16 chunk-wise (max - min), gradient routed through the maxima / minima, output
+    gradient quantised like a convolution's.
+Deviations (both documented in oracle/make_golden_quant.py, the reference does not run without them on this
+torch): a zero quantisation range makes the quantiser the identity instead of dividing by zero, and the
+gradient quantiser's forward is a copy instead of an alias.
+
+Stochastic rounding noise: by default the kernels' own counter-based generator (seeded per call from
+``manual_seed``); tests install ``set_noise_source`` to feed the very U(-0.5, 0.5) stream the reference draws
+from torch's CPU generator (one draw per gradient tensor, NCHW element order, in backward execution order).
+"""
+import math
+
+import torch
+import torch.nn as tnn
+from torch.autograd import Function
+
+from . import _lib, nn as cnn, ops
+from ._lib import check, dtype_code, ptr, stream_of
+
+_NOISE_SOURCE = None
+_SEED = [0x5EED5EED]
+
+
+def set_noise_source(fn):
+    """fn(shape) -> CPU fp32 tensor of U(-0.5, 0.5) noise in the reference's element order (NCHW for 4-d
+    gradients); None restores the in-kernel generator."""
+    global _NOISE_SOURCE
+    _NOISE_SOURCE = fn
+
+
+def manual_seed(seed):
+    _SEED[0] = int(seed) & 0xFFFFFFFFFFFF
+
+
+def _next_seed():
+    _SEED[0] = (_SEED[0] * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+    return _SEED[0]
+
+
+def _L():
+    return _lib.load()
+
+
+def minmax_rows(x, rows):
+    """[rows][2] = per-row {min, max} of a contiguous tensor viewed as [rows][numel/rows]."""
+    L = _L()
+    row_len = x.numel() // rows
+    out = torch.empty(rows * 2, dtype=torch.float32, device=x.device)
+    ws = ops.workspace(L.cn_minmax_workspace(rows, row_len), x.device, 'quant')
+    check(L.cn_minmax_rows(ptr(x), rows, row_len, dtype_code(x.dtype), ptr(out), ptr(ws), ws.numel() * 4,
+                           stream_of(x)), 'cn_minmax_rows')
+    return out
+
+
+def qparams(minmax, rows, mode, running_zp=None, running_range=None, momentum=0.1):
+    qp = torch.empty(2, dtype=torch.float32, device=minmax.device)
+    check(_L().cn_qparams(ptr(minmax), rows, mode, ptr(qp), ptr(running_zp), ptr(running_range), momentum,
+                          stream_of(minmax)), 'cn_qparams')
+    return qp
+
+
+def quantize(x, zp, rng, num_bits=8, noise=None, stochastic=False):
+    """zp / rng: one-element fp32 device tensors (or views)."""
+    y = torch.empty_like(x)
+    check(_L().cn_quantize(ptr(x), ptr(y), x.numel(), dtype_code(x.dtype), ptr(zp), ptr(rng), num_bits, ptr(noise),
+                           int(stochastic), _next_seed() if (stochastic and noise is None) else 0, stream_of(x)),
+          'cn_quantize')
+    return y
+
+
+def _noise_like(g):
+    """Reference-ordered rounding noise for gradient tensor g (NHWC or 2-d), or None (in-kernel generator)."""
+    if _NOISE_SOURCE is None:
+        return None
+    if g.dim() == 4:
+        N, H, W, C = g.shape
+        n = _NOISE_SOURCE((N, C, H, W)).to(device=g.device, dtype=torch.float32)
+        return ops.nchw_to_nhwc(n, torch.float32, C)
+    return _NOISE_SOURCE(tuple(g.shape)).to(device=g.device, dtype=torch.float32).contiguous()
+
+
+def quantize_grad(g, num_bits=8):
+    """UniformQuantizeGrad.backward (quantize.py:101-112): global min / max, stochastic rounding."""
+    g = g.contiguous()
+    rows = g.shape[0]
+    qp = qparams(minmax_rows(g, rows), rows, 1)
+    return quantize(g, qp[0:1], qp[1:2], num_bits, noise=_noise_like(g), stochastic=True)
+
+
+class QuantMeasure(tnn.Module):
+    """quantize.py:140-182 (measure=False): running zero point / range, quantises its input."""
+    no_graph = True   # per-call seeds / host-side noise: the step is not captured into a HIP graph
+
+    def __init__(self, num_bits=8, shape_measure=(1,), flatten_dims=(1, -1), inplace=False, dequantize=True,
+                 stochastic=False, momentum=0.1, measure=False):
+        super().__init__()
+        if measure or not dequantize or stochastic or tuple(flatten_dims) != (1, -1):
+            raise NotImplementedError('QuantMeasure: only the configuration QConv2d / QLinear / RangeBN use')
+        self.register_buffer('running_zero_point', torch.zeros(*shape_measure))
+        self.register_buffer('running_range', torch.zeros(*shape_measure))
+        self.num_bits, self.momentum = num_bits, momentum
+
+    def forward(self, x, training=None):
+        """x: contiguous activation whose leading dimension is the batch."""
+        training = self.training if training is None else training
+        if training:
+            rows = x.shape[0]
+            qp = qparams(minmax_rows(x, rows), rows, 0, self.running_zero_point, self.running_range, self.momentum)
+            return quantize(x, qp[0:1], qp[1:2], self.num_bits)
+        return quantize(x, self.running_zero_point, self.running_range, self.num_bits)
+
+
+def _quantize_filters(mod, num_bits):
+    """Per-output-channel quantisation of the fp32 master filter into the compute-dtype KRSC / CRSK copies."""
+    mod.ensure_prepared()
+    K = mod.out_channels
+    taps = mod.kernel_size[0] * mod.kernel_size[1]
+    c_real = mod.in_channels
+    master = mod.master_view('weight')
+    tmp = torch.empty_like(master)
+    check(_L().cn_quantize_rows(ptr(master), ptr(tmp), K, taps * c_real, num_bits, stream_of(master)),
+          'cn_quantize_rows')
+    c_pad = mod.w_krsc.numel() // (K * taps)
+    ops.weight_prep(tmp, mod.w_krsc, mod.w_crsk, K, taps, c_real, c_pad)
+
+
+class QConv2dFunction(Function):
+    @staticmethod
+    def forward(ctx, x, weight, mod, prequantized):
+        qx = x if prequantized else mod.quantize_input(x)
+        _quantize_filters(mod, mod.num_bits_weight)
+        y = ops.conv2d_fwd(qx, mod.w_krsc, None, mod.out_channels, mod.kernel_size[0], mod.kernel_size[1],
+                           mod.stride, mod.padding)
+        ctx.mod = mod
+        ctx.save_for_backward(qx)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (qx,) = ctx.saved_tensors
+        mod = ctx.mod
+        dy = dy.contiguous()
+        R, S = mod.kernel_size
+        ops.conv2d_wgrad(qx, dy, mod.grad_view('weight'), mod.in_channels, mod.out_channels, R, S, mod.stride,
+                         mod.padding)
+        mod._notify_grad_ready()
+        dx = None
+        if ctx.needs_input_grad[0]:   # (the stem never gets here: no noise is drawn for it, as in the reference)
+            gq = quantize_grad(dy, mod.num_bits_grad)
+            dx = ops.conv2d_dgrad(gq, mod.w_crsk, qx.shape, mod.out_channels, R, S, mod.stride, mod.padding)
+        return dx, None, None, None
+
+
+class QConv2d(cnn.Conv2d):
+    """quantize.py:185-220 (biprecision=True, the default and what models/resnet.py uses)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 num_bits=8, num_bits_weight=8, num_bits_grad=8, biprecision=True):
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias)
+        if bias or not biprecision or num_bits_grad is None:
+            raise NotImplementedError('QConv2d: bias-free bi-precision configuration only (what ResNet uses)')
+        self.num_bits, self.num_bits_weight, self.num_bits_grad = num_bits, num_bits_weight or num_bits, num_bits_grad
+        self.quantize_input = QuantMeasure(num_bits, shape_measure=(1, 1, 1, 1), flatten_dims=(1, -1))
+        self.biprecision = biprecision
+
+    def pair_eligible(self, x_nchw):
+        return False
+
+    def forward(self, x):
+        self._require_prepared()
+        return QConv2dFunction.apply(x, self.weight, self, False)
+
+    def forward_from_nchw(self, x_nchw):
+        """The network input is quantised in its fp32 NCHW form (channel padding must stay zero), then laid out."""
+        self._require_prepared()
+        qx = self.quantize_input(x_nchw.contiguous())
+        x = ops.nchw_to_nhwc(qx, self.compute_dtype, self.padded_in_channels())
+        return QConv2dFunction.apply(x, self.weight, self, True)
+
+
+class QLinearFunction(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, mod):
+        B = x.shape[0]
+        qx = mod.quantize_input(x.contiguous())
+        _quantize_filters(mod, mod.num_bits_weight)
+        b32 = mod.master_view('bias')
+        bq = qparams(minmax_rows(b32, 1), 1, 1)
+        qb = quantize(b32, bq[0:1], bq[1:2], mod.num_bits_weight + mod.num_bits)
+        y = ops.conv2d_fwd(qx.view(B, 1, 1, mod.in_features), mod.w_krsc, qb, mod.out_features, 1, 1, (1, 1), (0, 0),
+                           out_f32=True)
+        ctx.mod = mod
+        ctx.save_for_backward(qx)
+        return y.view(B, mod.out_features)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (qx,) = ctx.saved_tensors
+        mod = ctx.mod
+        B = qx.shape[0]
+        dy = dy.contiguous()
+        dyc = dy if dy.dtype == qx.dtype else ops.cast_from_f32(dy, qx.dtype)
+        ops.conv2d_wgrad(qx.view(B, 1, 1, mod.in_features), dyc.view(B, 1, 1, mod.out_features),
+                         mod.grad_view('weight'), mod.in_features, mod.out_features, 1, 1, (1, 1), (0, 0))
+        ops.colsum(dy.view(B, mod.out_features), mod.grad_view('bias'))
+        mod._notify_grad_ready()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            gq = quantize_grad(dy, mod.num_bits_grad)
+            gqc = gq if gq.dtype == qx.dtype else ops.cast_from_f32(gq, qx.dtype)
+            dx = ops.conv2d_dgrad(gqc.view(B, 1, 1, mod.out_features), mod.w_crsk, (B, 1, 1, mod.in_features),
+                                  mod.out_features, 1, 1, (1, 1), (0, 0)).view(B, mod.in_features)
+        return dx, None, None, None
+
+
+class QLinear(cnn.Linear):
+    """quantize.py:223-253."""
+
+    def __init__(self, in_features, out_features, bias=True, num_bits=8, num_bits_weight=8, num_bits_grad=8,
+                 biprecision=True):
+        super().__init__(in_features, out_features, bias)
+        if not bias or not biprecision or num_bits_grad is None:
+            raise NotImplementedError('QLinear: biased bi-precision configuration only (what ResNet uses)')
+        self.num_bits, self.num_bits_weight, self.num_bits_grad = num_bits, num_bits_weight or num_bits, num_bits_grad
+        self.biprecision = biprecision
+        self.quantize_input = QuantMeasure(num_bits)
+
+    def forward(self, x):
+        self._require_prepared()
+        if self.out_features % _lib.chunk_elems(self.compute_dtype) != 0:
+            raise NotImplementedError('QLinear: out_features must be a multiple of the 16-byte chunk')
+        return QLinearFunction.apply(x.reshape(x.shape[0], self.in_features), self.weight, self.bias, self)
+
+
+def _scale_fix(values_per_chunk):
+    """quantize.py:295-296."""
+    return (0.5 * 0.35) * (1 + (math.pi * math.log(4)) ** 0.5) / ((2 * math.log(values_per_chunk)) ** 0.5)
+
+
+class RangeBNFunction(Function):
+    @staticmethod
+    def forward(ctx, y, weight, bias, mod, relu):
+        N, H, W, C = y.shape
+        M = N * H * W
+        L = _L()
+        code = dtype_code(y.dtype)
+        qy = mod.quantize_input(y.contiguous())
+        if M % mod.num_chunks != 0 or M // mod.num_chunks < 2:
+            raise _lib.ConvNetHipError('RangeBN: %d values per channel do not split into %d chunks of >= 2'
+                                       % (M, mod.num_chunks))
+        fix = _scale_fix(M // mod.num_chunks)
+        z = torch.empty_like(qy)
+        stats = torch.empty(2 * C, dtype=torch.float32, device=y.device)
+        arg = torch.empty(C * 2 * mod.num_chunks, dtype=torch.int32, device=y.device)
+        ws = ops.workspace(L.cn_rangebn_workspace(M, C, mod.num_chunks), y.device, 'quant')
+        check(L.cn_rangebn_fwd(ptr(qy), None, ptr(z), ptr(weight), ptr(bias), ptr(mod.running_mean),
+                               ptr(mod.running_var), mod.momentum, mod.eps, mod.num_chunks, fix, ptr(stats), ptr(arg),
+                               M, C, int(relu), 1, code, ptr(ws), ws.numel() * 4, stream_of(y)), 'cn_rangebn_fwd')
+        ctx.mod, ctx.relu, ctx.fix = mod, relu, fix
+        ctx.save_for_backward(qy, weight, stats, arg, *((z,) if relu else ()))
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        saved = ctx.saved_tensors
+        qy, weight, stats, arg = saved[:4]
+        mod = ctx.mod
+        N, H, W, C = qy.shape
+        M = N * H * W
+        L = _L()
+        dz = dz.contiguous()
+        if ctx.relu:     # the ReLU that follows the output-gradient quantiser in the reference
+            g0 = torch.empty_like(dz)
+            check(L.cn_eltwise(2, ptr(g0), ptr(dz), ptr(saved[4]), dz.numel(), dtype_code(dz.dtype), stream_of(dz)),
+                  'cn_eltwise')
+        else:
+            g0 = dz
+        gq = quantize_grad(g0, mod.num_bits_grad)
+        dx = torch.empty_like(qy)
+        ws = ops.workspace(L.cn_rangebn_workspace(M, C, mod.num_chunks), qy.device, 'quant')
+        check(L.cn_rangebn_bwd(ptr(gq), ptr(qy), ptr(weight), ptr(stats), ptr(arg), ptr(dx), ptr(mod.grad_view('weight')),
+                               ptr(mod.grad_view('bias')), M, C, mod.num_chunks, ctx.fix, dtype_code(qy.dtype), ptr(ws),
+                               ws.numel() * 4, stream_of(qy)), 'cn_rangebn_bwd')
+        mod._notify_grad_ready()
+        return dx, None, None, None, None
+
+
+class RangeBN(cnn.BatchNorm2d):
+    """quantize.py:256-330.  Subclasses the HIP BatchNorm2d so that the reference's `isinstance(m,
+    nn.BatchNorm2d)` tests (init_model, weight-decay filter -- nn.BatchNorm2d *is* RangeBN there after the
+    rebinding of models/resnet.py:391) keep their meaning; none of the parent's state is created."""
+
+    def __init__(self, num_features, dim=1, momentum=0.1, affine=True, num_chunks=16, eps=1e-5, num_bits=8,
+                 num_bits_grad=8):
+        cnn._ArenaModule.__init__(self)
+        if not affine or num_bits_grad is None:
+            raise NotImplementedError('RangeBN: affine with a quantised output gradient (the reference default)')
+        self.num_features = num_features
+        self.register_buffer('running_mean', torch.zeros(num_features))
+        self.register_buffer('running_var', torch.zeros(num_features))
+        self.momentum, self.dim, self.eps, self.num_chunks = momentum, dim, eps, num_chunks
+        self.bias = tnn.Parameter(torch.empty(num_features))
+        self.weight = tnn.Parameter(torch.empty(num_features))
+        self.num_bits, self.num_bits_grad = num_bits, num_bits_grad
+        self.quantize_input = QuantMeasure(num_bits, inplace=True, shape_measure=(1, 1, 1, 1), flatten_dims=(1, -1))
+        self.affine, self.track_running_stats, self.sync_group = True, True, None
+        self.weight.data.uniform_()   # reset_params (quantize.py:277-281): same RNG consumption as the reference
+        self.bias.data.zero_()
+
+    def forward(self, y, residual=None, relu=False):
+        self._require_prepared()
+        if residual is not None:
+            raise NotImplementedError('RangeBN: the residual junction is a separate add + ReLU (reference order)')
+        if self.training:
+            fn = RangeBNFunction.apply
+            if torch.is_grad_enabled():
+                return fn(y, self.weight, self.bias, self, relu)
+            with torch.no_grad():
+                return fn(y, self.weight, self.bias, self, relu)
+        N, H, W, C = y.shape
+        L = _L()
+        qy = self.quantize_input(y.contiguous())
+        z = torch.empty_like(qy)
+        stats = torch.empty(2 * C, dtype=torch.float32, device=y.device)
+        check(L.cn_rangebn_fwd(ptr(qy), None, ptr(z), ptr(self.weight), ptr(self.bias), ptr(self.running_mean),
+                               ptr(self.running_var), self.momentum, self.eps, self.num_chunks, 0.0, ptr(stats), None,
+                               N * H * W, C, int(relu), 0, dtype_code(y.dtype), None, 0, stream_of(y)), 'cn_rangebn_fwd')
+        return z
+
+    def extra_repr(self):
+        return '{}, eps={}, momentum={}, num_chunks={}'.format(self.num_features, self.eps, self.momentum,
+                                                               self.num_chunks)
+
+
+class AddReLUFunction(Function):
+    """relu(a + b): the residual junction of the quantised blocks (models/resnet.py:162-163), kept apart from
+    the last RangeBN so that the backward pass visits the operators in the reference's order."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        z = torch.empty_like(a)
+        check(_L().cn_eltwise(4, ptr(z), ptr(a.contiguous()), ptr(b.contiguous()), a.numel(), dtype_code(a.dtype),
+                              stream_of(a)), 'cn_eltwise')
+        ctx.save_for_backward(z)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        (z,) = ctx.saved_tensors
+        dz = dz.contiguous()
+        g = torch.empty_like(dz)
+        check(_L().cn_eltwise(2, ptr(g), ptr(dz), ptr(z), dz.numel(), dtype_code(dz.dtype), stream_of(dz)), 'cn_eltwise')
+        return g, g
+
+
+def add_relu(a, b):
+    return AddReLUFunction.apply(a, b)

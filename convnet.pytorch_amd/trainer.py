@@ -115,7 +115,8 @@ class Trainer(object):
         self._graph, self._graph_seen = None, {}
         from . import nn as cnn
         # a captured step replays the SAME kernels: host-drawn Dropout masks (models/mnist.py) rule it out
-        self._graph_model_ok = not any(isinstance(m, cnn.Dropout) and m.p > 0 for m in model.modules())
+        self._graph_model_ok = not any((isinstance(m, cnn.Dropout) and m.p > 0) or getattr(m, 'no_graph', False)
+                                       for m in model.modules())
         self.world_size = 1
         if distributed:
             if not dist.is_initialized():

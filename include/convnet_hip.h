@@ -163,7 +163,8 @@ int cn_weight_prep_pairs(const float* master_krsc, void* out_pairs, int K, int R
 int cn_wgrad_unpack_pairs(const float* packed, float* dw_krsc, int K, int R, int S, int C, float beta, void* stream);
 int cn_nhwc_to_nchw(const void* x_nhwc, float* y_nchw, int N, int C, int H, int W, int Cpad, int dtype,
                     void* stream);
-/* op 0: a += b;  1: a = relu(b);  2: a = b * (c > 0);  3: a = b * c.  n elements (multiple of the chunk). */
+/* op 0: a += b;  1: a = relu(b);  2: a = b * (c > 0);  3: a = b * c;  4: a = relu(b + c).  n elements (multiple of
+ * the chunk). */
 int cn_eltwise(int op, void* a, const void* b, const void* c, long long n, int dtype, void* stream);
 
 /* ---- criterion + accuracy + meters (main.py:231-235; trainer.py:143,153,224-229) ------------ */
@@ -205,6 +206,46 @@ int cn_small_linear(int mode, const void* x, const float* w, const float* bias, 
                     int B, int C, int K, int dtype, void* stream);
 int cn_cast_from_f32(const float* x, void* y, long long n, int dtype, void* stream);
 int cn_fill_f32(float* x, long long n, float v, void* stream);
+
+/* ---- simulated 8-bit training operators, BASELINE config 5 `{'quantize': True}` (models/modules/quantize.py,
+ * switched in by models/resnet.py:387-391).  Tensors are snapped to a 2^bits-level grid and stay floating
+ * point, as in the reference; the convolutions run on cn_conv2d_*.  A zero quantisation range is treated as 1
+ * (identity on a constant tensor) where the reference divides by zero (quantize.py:64-66). --------------- */
+size_t cn_minmax_workspace(int rows, long long row_len);
+/* calculate_qparams' per-sample x.flatten(1).min(-1)/.max(-1) (quantize.py:19-27): minmax[r] = {min, max} of
+ * row r of a contiguous [rows][row_len] tensor */
+int cn_minmax_rows(const void* x, int rows, long long row_len, int dtype, float* minmax, float* workspace,
+                   size_t workspace_bytes, void* stream);
+/* qp[0] = zero_point, qp[1] = range from the per-row min/max: mode 0 = batch mean (activations,
+ * quantize.py:28-30), 1 = extremes (gradients, :31-33); optional QuantMeasure running update
+ * running = running*momentum + new*(1-momentum) (quantize.py:163-172) */
+int cn_qparams(const float* minmax, int rows, int mode, float* qp, float* running_zero_point, float* running_range,
+               float momentum, void* stream);
+/* UniformQuantize.forward, unsigned + dequantised (quantize.py:41-76): y = round(clamp((x - zp)/scale + noise,
+ * 0, 2^bits-1))*scale + zp, scale = range/(2^bits-1); zero_point / range are device scalars (cn_qparams' qp and
+ * qp + 1, or QuantMeasure's running buffers in eval mode).  noise: optional fp32 U(-0.5,0.5)
+ * per element (quantize.py:67-69); else the built-in counter-based generator keyed by (seed, index) when
+ * stochastic != 0; else deterministic rounding. */
+int cn_quantize(const void* x, void* y, long long n, int dtype, const float* zero_point, const float* range,
+                int num_bits, const float* noise, int stochastic, unsigned long long seed, void* stream);
+/* per-row (= per output channel) quantisation of an fp32 filter matrix with the row's own min / max
+ * (QConv2d / QLinear weights, quantize.py:201-203,239-240) */
+int cn_quantize_rows(const float* x, float* y, int rows, int row_len, int num_bits, void* stream);
+/* RangeBN (quantize.py:256-330) on an input-quantised x[M][C]: per channel mean and
+ * scale = (mean of `chunks` chunk maxima - mean of chunk minima) * scale_fix over the M values in (n,h,w) order;
+ * z = act(((x - mean)/(scale + eps))*weight + bias [+ residual]).  training: running statistics updated
+ * (running = running*momentum + new*(1-momentum)), stats[2C] = {mean | scale+eps} and arg[C][2*chunks] (pixel index
+ * of every chunk's first maximum / minimum) are kept for cn_rangebn_bwd.  training == 0: running statistics. */
+size_t cn_rangebn_workspace(int M, int C, int chunks);
+int cn_rangebn_fwd(const void* x, const void* residual, void* z, const float* weight, const float* bias,
+                   float* running_mean, float* running_var, float momentum, float eps, int chunks, float scale_fix,
+                   float* stats, int* arg, int M, int C, int relu, int training, int dtype, float* workspace,
+                   size_t workspace_bytes, void* stream);
+/* gradient of the above for an already quantised output gradient g: dx (mean path + routing of the scale
+ * gradient to the chunk maxima / minima), dweight += sum g*(x-mean)/(scale+eps), dbias += sum g */
+int cn_rangebn_bwd(const void* g, const void* x, const float* weight, const float* stats, const int* arg, void* dx,
+                   float* dweight, float* dbias, int M, int C, int chunks, float scale_fix, int dtype,
+                   float* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- data-parallel exchange step, directly on RCCL (trainer.py:79-82 DistributedDataParallel; main.py:190-191
  * SyncBatchNorm) ---------------------------------------------------------------------------------

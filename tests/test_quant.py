@@ -1,0 +1,229 @@
+"""BASELINE config 5 (`resnet(quantize=True)`, simulated 8-bit training) through the HIP kernels of
+csrc/quant.hip, against (a) per-operator vectors recorded from the reference's own
+models/modules/quantize.py (tests/golden/quant_ops.pt) and (b) training trajectories of the reference
+Trainer (tests/golden/traj_r{18,50}s_quant.json), with the CPU oracle (oracle/quant_oracle.py, pinned on the
+same fixtures in fp32 and float64) run beside it on the same noise stream.
+
+The stochastic-rounding noise of the gradient quantisers is the reference's own stream: the tests install a
+noise source that draws `torch.empty(shape).uniform_(-0.5, 0.5)` from torch's global CPU generator in the
+order the backward pass runs, which is the order the reference draws in.
+
+Tolerances.  The primitives are bit-exact in fp32 (same operation order, no FMA contraction).  Whole-network
+quantities pass through quantisers that turn a one-ulp difference into a full quantisation step
+(range / 255), so fp32 trajectories are compared at loss abs 2e-2 / grad-norm rel 3e-2 -- the same band in
+which the fp32 oracle follows the fp32 reference (tests/test_quant_oracle.py; in float64 it follows to 1e-7).
+"""
+import json
+import os
+
+import pytest
+import torch
+
+from conftest import HAS_GPU
+from helpers import GOLDEN, rel_l2
+
+MODES = [pytest.param('emul'), pytest.param('gpu', marks=pytest.mark.gpu)]
+SMALL = dict(num_classes=16, inplanes=8, width=[8, 16, 32, 64])
+
+
+def _dev(mode):
+    if mode == 'emul' and HAS_GPU:
+        pytest.skip('emulator mode is for GPU-less hosts')
+    if mode == 'gpu' and not HAS_GPU:
+        pytest.skip('no GPU')
+    return torch.device('cuda', 0) if mode == 'gpu' else torch.device('cpu')
+
+
+def _nhwc(x, dev):
+    return x.permute(0, 2, 3, 1).contiguous().to(dev)
+
+
+def _nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def _cpu_noise(shape):
+    return torch.empty(shape).uniform_(-0.5, 0.5)
+
+
+@pytest.fixture()
+def reference_noise():
+    import convnet_amd as ca
+    ca.quant.set_noise_source(_cpu_noise)
+    yield
+    ca.quant.set_noise_source(None)
+
+
+@pytest.mark.parametrize('mode', MODES)
+def test_quantisers_are_bit_exact_against_the_reference_vectors(mode):
+    dev = _dev(mode)
+    import convnet_amd as ca
+    Q = ca.quant
+    g = torch.load(os.path.join(GOLDEN, 'quant_ops.pt'))
+    qm = Q.QuantMeasure(8, shape_measure=(1, 1, 1, 1), flatten_dims=(1, -1)).to(dev)
+    qm.train()
+    x = g['qm_x'].to(dev)                       # per-sample rows: any memory order with the batch leading
+    assert torch.equal(qm(x).cpu(), g['qm_train_y'])
+    assert torch.equal(qm.running_range.cpu(), g['qm_running_range'])
+    assert torch.equal(qm.running_zero_point.cpu(), g['qm_running_zero_point'])
+    qm.eval()
+    assert torch.equal(qm((g['qm_x'] * 1.5).to(dev)).cpu(), g['qm_eval_y'])
+    # per-output-channel weight quantiser
+    w = g['w'].to(dev)
+    wq = torch.empty_like(w)
+    ca._lib.check(ca._lib.load().cn_quantize_rows(w.data_ptr(), wq.data_ptr(), 8, 36, 8, ca._lib.stream_of(w)))
+    assert torch.equal(wq.cpu(), g['w_q'])
+    # 16-bit bias quantiser over the global range
+    b = g['b'].to(dev)
+    qp = Q.qparams(Q.minmax_rows(b, 1), 1, 1)
+    assert torch.equal(Q.quantize(b, qp[0:1], qp[1:2], 16).cpu(), g['b_q16'])
+    # bf16 storage: the same grid, rounded to bf16 on store
+    xb = g['qm_x'].to(dev).to(torch.bfloat16)
+    qp = Q.qparams(Q.minmax_rows(xb, 4), 4, 0)
+    zp, rng = qp.cpu().tolist()
+    ref = (((xb.float().cpu() - zp) / (rng / 255.)).clamp(0, 255).round() * (rng / 255.) + zp).to(torch.bfloat16)
+    assert torch.equal(Q.quantize(xb, qp[0:1], qp[1:2]).cpu(), ref)
+    # the built-in generator: unbiased stochastic rounding onto the same grid
+    big = torch.linspace(-1, 1, 4096, device=dev).view(4, 1024).contiguous()
+    qp = Q.qparams(Q.minmax_rows(big, 4), 4, 1)
+    acc = torch.zeros_like(big)
+    for _ in range(8):
+        y = Q.quantize(big, qp[0:1], qp[1:2], 4, stochastic=True)
+        lv = (y - (-1)) / (2 / 15.)
+        assert (lv - lv.round()).abs().max() < 1e-4
+        acc += y
+    assert (acc / 8 - big).abs().mean() < 0.02
+
+
+def _prepare(mod, dev, dtype=torch.float32):
+    import convnet_amd as ca
+    ca.engine.prepare(mod, dev, dtype)
+    return mod
+
+
+@pytest.mark.parametrize('mode', MODES)
+def test_rangebn_forward_backward_against_the_reference_vectors(mode, reference_noise):
+    dev = _dev(mode)
+    import convnet_amd as ca
+    g = torch.load(os.path.join(GOLDEN, 'quant_ops.pt'))
+    bn = ca.quant.RangeBN(8)
+    with torch.no_grad():
+        bn.weight.copy_(g['rbn_w'])
+        bn.bias.copy_(g['rbn_b'])
+    _prepare(bn, dev)
+    bn.train()
+    x = _nhwc(g['rbn_x'], dev).requires_grad_(True)
+    torch.manual_seed(77)
+    y = bn(x)
+    y.backward(_nhwc(g['rbn_gy'], dev))
+    assert rel_l2(_nchw(y.detach()), g['rbn_y']) < 1e-6
+    assert rel_l2(_nchw(x.grad), g['rbn_dx']) < 1e-5
+    assert rel_l2(bn.weight.grad.cpu(), g['rbn_dw']) < 1e-5
+    assert rel_l2(bn.bias.grad.cpu(), g['rbn_db']) < 1e-5
+    assert rel_l2(bn.running_mean.cpu(), g['rbn_running_mean']) < 1e-5   # (the kernel sums in double)
+    assert rel_l2(bn.running_var.cpu(), g['rbn_running_var']) < 1e-5
+    assert rel_l2(bn.quantize_input.running_range.cpu(), g['rbn_qi_range']) < 1e-6   # batch mean summed in double
+    # eval mode: running statistics, no autograd
+    bn.eval()
+    with torch.no_grad():
+        ye = _nchw(bn(_nhwc(g['rbn_x'], dev)))
+    qi = bn.quantize_input
+    zp, rng = float(qi.running_zero_point), float(qi.running_range)
+    xq = ((g['rbn_x'] - zp) / (rng / 255.)).clamp(0, 255).round() * (rng / 255.) + zp
+    ref = (xq - bn.running_mean.cpu().view(1, -1, 1, 1)) / (bn.running_var.cpu().view(1, -1, 1, 1) + bn.eps) \
+        * g['rbn_w'].view(1, -1, 1, 1) + g['rbn_b'].view(1, -1, 1, 1)
+    assert rel_l2(ye, ref) < 1e-6
+
+
+@pytest.mark.parametrize('mode', MODES)
+def test_qconv_and_qlinear_against_the_reference_vectors(mode, reference_noise):
+    dev = _dev(mode)
+    import convnet_amd as ca
+    g = torch.load(os.path.join(GOLDEN, 'quant_ops.pt'))
+    conv = ca.quant.QConv2d(8, 16, 3, stride=1, padding=1, bias=False)
+    with torch.no_grad():
+        conv.weight.copy_(g['qc_w'])
+    _prepare(conv, dev)
+    conv.train()
+    x = _nhwc(g['qc_x'], dev).requires_grad_(True)
+    torch.manual_seed(78)
+    y = conv(x)
+    y.backward(_nhwc(g['qc_gy'], dev))
+    assert rel_l2(_nchw(y.detach()), g['qc_y']) < 1e-6
+    assert rel_l2(_nchw(x.grad), g['qc_dx']) < 1e-5
+    assert rel_l2(conv.weight.grad.cpu(), g['qc_dw']) < 1e-5
+    lin = ca.quant.QLinear(32, 16)
+    with torch.no_grad():
+        lin.weight.copy_(g['ql_w'])
+        lin.bias.copy_(g['ql_b'])
+    _prepare(lin, dev)
+    lin.train()
+    x = g['ql_x'].to(dev).requires_grad_(True)
+    torch.manual_seed(79)
+    y = lin(x)
+    y.backward(g['ql_gy'].to(dev))
+    assert rel_l2(y.detach().cpu(), g['ql_y']) < 1e-6
+    assert rel_l2(x.grad.cpu(), g['ql_dx']) < 1e-5
+    assert rel_l2(lin.weight.grad.cpu(), g['ql_dw']) < 1e-5
+    assert rel_l2(lin.bias.grad.cpu(), g['ql_db']) < 1e-5
+
+
+def _engine_trajectory(meta, depth, dev, dtype, steps):
+    import convnet_amd as ca
+    from helpers import golden_batches   # noqa: F401  (same generator as the fixture)
+    torch.manual_seed(123)
+    model = ca.models.resnet(dataset='imagenet', quantize=True, depth=depth, **SMALL)
+    sd = model.state_dict()
+    assert set(sd.keys()) == set(meta['keys'].keys())
+    for k, v in sd.items():
+        assert list(v.shape) == meta['keys'][k], k
+        if v.dtype.is_floating_point:    # seeded construction reproduces the reference's initial weights
+            assert abs(float(v.double().sum()) - meta['init_sums'][k][0]) <= 1e-6 * max(1.0, meta['init_sums'][k][1]), k
+    tr = ca.Trainer(model, ca.CrossEntropyLoss(), ca.OptimRegime(model, model.regime), device=str(dev), dtype=dtype,
+                    grad_clip=1e9, print_freq=10 ** 9)
+    g = torch.Generator().manual_seed(meta['seed'])
+    data = [(torch.randn(meta['B'], 3, meta['size'], meta['size'], generator=g),
+             torch.randint(0, meta['classes'], (meta['B'],), generator=g)) for _ in range(meta['steps'])][:steps]
+    recs = []
+    for x, t in data:
+        r = tr.train([(x, t)])
+        recs.append({k: float(r[k]) for k in ('loss', 'prec1', 'prec5', 'grad')})
+    return recs, tr, model, data
+
+
+@pytest.mark.parametrize('mode', MODES)
+@pytest.mark.parametrize('tag,depth', [('r18s_quant', 18), ('r50s_quant', 50)])
+def test_quantised_fp32_trajectory_follows_the_reference(mode, tag, depth, reference_noise):
+    dev = _dev(mode)
+    meta = json.load(open(os.path.join(GOLDEN, 'traj_%s.json' % tag)))
+    if mode == 'emul' and depth != 18:
+        pytest.skip('emulated suite: one ResNet-18 step only (the GPU run does all steps of both depths)')
+    steps = meta['steps'] if mode == 'gpu' else 1
+    recs, tr, model, data = _engine_trajectory(meta, depth, dev, torch.float32, steps)
+    for i, (r, gr) in enumerate(zip(recs, meta['records'])):
+        assert r['loss'] == pytest.approx(gr['loss'], abs=1e-4 if i == 0 else 2e-2), (i, r, gr)
+        assert r['grad'] == pytest.approx(gr['grad'], rel=3e-2), (i, r, gr)
+        if i == 0:
+            assert r['prec1'] == gr['prec1'] and r['prec5'] == gr['prec5']
+    if steps == meta['steps']:
+        final = torch.load(os.path.join(GOLDEN, 'traj_%s_final.pt' % tag))
+        sd = model.state_dict()
+        for k, v in final.items():
+            assert rel_l2(sd[k].float().cpu(), v) < 2e-2, k
+        val = tr.validate(data[:2])     # eval mode: running ranges / statistics
+        assert val['loss'] == pytest.approx(meta['validate']['loss'], abs=5e-2)
+
+
+@pytest.mark.gpu
+def test_quantised_bf16_step_and_builtin_noise():
+    """bf16 storage with the kernels' own rounding-noise generator (the production configuration): the first
+    step's loss matches the fp32 reference (forward only depends on the deterministic quantisers), the
+    gradient norm is within the quantisation noise band, training stays finite."""
+    dev = _dev('gpu')
+    import convnet_amd as ca
+    meta = json.load(open(os.path.join(GOLDEN, 'traj_r50s_quant.json')))
+    ca.quant.manual_seed(1)
+    recs, tr, model, data = _engine_trajectory(meta, 50, dev, torch.bfloat16, 3)
+    assert recs[0]['loss'] == pytest.approx(meta['records'][0]['loss'], abs=5e-2)
+    assert recs[0]['grad'] == pytest.approx(meta['records'][0]['grad'], rel=1e-1)
+    assert all(torch.isfinite(torch.tensor([r['loss'], r['grad']])).all() for r in recs)
