@@ -35,6 +35,16 @@ if ROOT not in sys.path:
 PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 TRAIN_GFLOP_PER_IMG = {50: 24.2991, 18: 10.6484}
+# compulsory HBM traffic per image of the SURVEY.md section 8(d) traffic model (MB): the whole-step HBM roofline
+MODEL_MB_PER_IMG = {(50, 'bf16'): 347.7, (18, 'f32'): 151.4}
+
+
+def roof_fraction(records, dtype):
+    """sum_i max(bytes_i / HBM peak, flops_i / MFMA peak) / sum_i measured time_i over (ms, flops, bytes) records:
+    how far a set of launches sits from whichever roof binds each of them."""
+    ideal = sum(max(b / (PEAK_HBM_GBS * 1e9), f / (PEAK_TFLOPS[dtype] * 1e12)) for _, f, b in records)
+    meas = sum(ms for ms, _, _ in records) * 1e-3
+    return round(ideal / meas, 4) if meas > 0 else None
 
 
 def main():
@@ -48,6 +58,9 @@ def main():
     ap.add_argument('--pool', type=int, default=4, help='distinct pre-staged device batches')
     ap.add_argument('--host-inputs', action='store_true',
                     help='feed pinned HOST batches (PCIe-inclusive rate, for DESIGN.md; never the contract value)')
+    ap.add_argument('--quantize', action='store_true',
+                    help="BASELINE config 5: resnet(quantize=True), the simulated-8-bit operators (a parity-test "
+                         "configuration, not the contract workload)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
     args = ap.parse_args()
@@ -91,7 +104,7 @@ def main():
 
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
     torch.manual_seed(123)
-    model = ca.models.resnet(dataset='imagenet', depth=args.depth)
+    model = ca.models.resnet(dataset='imagenet', depth=args.depth, quantize=args.quantize)
     crit = ca.CrossEntropyLoss()
     opt = ca.OptimRegime(model, model.regime)
     tr = ca.Trainer(model, crit, opt, device=str(device), dtype=dtype, distributed=distributed,
@@ -130,7 +143,7 @@ def main():
         elapsed = float(t.item())
 
     # ---- live per-kernel timing (separate profiled pass, HIP events on the launch stream) ----
-    kernels, roof = {}, None
+    kernels, layers, roof = {}, {}, None
     nprof = 2
     if not args.no_kernel_profile:
         # every rank runs the profiled steps (they contain the gradient all-reduce: a rank-0-only pass would
@@ -152,7 +165,19 @@ def main():
                 'avg_us_per_launch': round(a['ms'] * 1e3 / max(a['launches'], 1), 2),
                 'tflops': round(a['flops'] / sec / 1e12, 2) if a['flops'] else None,
                 'gbs': round(a['bytes'] / sec / 1e9, 1),
+                # launches priced one by one against the roof that binds each (HBM-bound 1x1 and MFMA-bound 3x3
+                # layers share kernel names): sum of max(bytes/8 TB/s, flops/peak) over the measured time
+                'roof_frac': roof_fraction(a['records'], args.dtype),
             }
+        # the same per convolution layer shape (fwd / dgrad / wgrad): which roof binds it and how close it runs
+        for det, a in sorted(ca.ops.PROFILER.summary(by_detail=True).items(), key=lambda kv: -kv[1]['ms']):
+            sec = a['ms'] * 1e-3
+            t_hbm = a['bytes'] / (PEAK_HBM_GBS * 1e9)
+            t_mfma = a['flops'] / (PEAK_TFLOPS[args.dtype] * 1e12)
+            layers[det] = {'n': a['calls'] // nprof, 'us': round(a['ms'] * 1e3 / a['calls'], 1),
+                           'tflops': round(a['flops'] / sec / 1e12, 1), 'gbs': round(a['bytes'] / sec / 1e9, 1),
+                           'bound': 'mfma' if t_mfma >= t_hbm else 'hbm',
+                           'roof_frac': round(max(t_hbm, t_mfma) / sec, 3)}
         # the dominant single HIP kernel ('+' names are multi-kernel C-ABI calls, reported in `kernels`)
         dom = next(k for k in kernels if '+' not in k)
         k = kernels[dom]
@@ -164,8 +189,11 @@ def main():
                     'frac': round(k['gbs'] / PEAK_HBM_GBS, 4), 'traffic': None}
         roof['avg_us_per_launch'] = k['avg_us_per_launch']
         roof['launches_per_step'] = k['launches_per_step']
-        # HBM traffic per launch from the committed PMC passes (profiles/*_pmc_traffic.json), if the
-        # dominant kernel was covered by them
+        roof['frac_per_launch_roof'] = k['roof_frac']   # each launch against max(HBM, MFMA) time instead of one blended bound
+        roof['timing'] = ('HIP events around every launch of a separate pass with the wgrad side stream folded into '
+                          'the main stream (kernels run alone); rocprofv3 of the overlapped step: profiles/')
+        # HBM traffic per launch: NOT measured in this run (PMC counters need rocprofv3 passes of their own);
+        # the latest committed PMC result (profiles/*_pmc_traffic.json) is quoted and tagged as static
         try:
             cands = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('pmc_traffic.json'))
             pm = json.load(open(os.path.join(ROOT, 'profiles', cands[-1])))
@@ -173,6 +201,7 @@ def main():
                 if kn.replace('void ', '').startswith(dom.split(' (')[0]):
                     roof['traffic'] = round(kv['hbm_bytes_per_launch'])
                     roof['traffic_unit'] = 'bytes/launch (avg), ' + pm['source'] + ', ' + cands[-1]
+                    roof['traffic_source'] = 'static: committed rocprofv3 --pmc passes (%s), not this run' % cands[-1]
                     roof['algorithmic_bytes_per_launch'] = round(
                         agg[dom]['bytes'] / max(agg[dom]['launches'], 1))
                     break
@@ -191,8 +220,8 @@ def main():
         img_s = B * world * args.steps / elapsed
         step_tflops = TRAIN_GFLOP_PER_IMG.get(args.depth, 0.0) * B * 1e-3
         out = {
-            'metric': 'images/sec ResNet-%d %s 3x224x224 b=%d/GPU training (fwd+bwd+SGD)' % (
-                args.depth, args.dtype, B),
+            'metric': 'images/sec ResNet-%d %s%s 3x224x224 b=%d/GPU training (fwd+bwd+SGD)' % (
+                args.depth, args.dtype, ' quantize=True (simulated 8-bit)' if args.quantize else '', B),
             'value': round(img_s, 1), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
@@ -205,7 +234,10 @@ def main():
                        'transport': tr.reducer.describe() if tr.reducer is not None else None},
             'mfma_frac_whole_step': round(step_tflops / (elapsed / args.steps) / PEAK_TFLOPS[args.dtype], 4)
             if step_tflops else None,
-            'roofline': roof, 'cpu_baseline': cpu, 'kernels': kernels,
+            'hbm_frac_whole_step': round(MODEL_MB_PER_IMG[(args.depth, args.dtype)] * 1e6 * B / (elapsed / args.steps)
+                                         / (PEAK_HBM_GBS * 1e9), 4)
+            if (args.depth, args.dtype) in MODEL_MB_PER_IMG and not args.quantize else None,
+            'roofline': roof, 'cpu_baseline': cpu, 'kernels': kernels, 'conv_layers': layers,
         }
         print(json.dumps(out))
     if distributed:

@@ -32,6 +32,7 @@ c_ull = ctypes.c_ulonglong
 _SIGNATURES = {
     'cn_last_error': (ctypes.c_char_p, []),
     'cn_build_info': (ctypes.c_char_p, []),
+    'cn_last_kernel_name': (ctypes.c_char_p, []),
     'cn_is_emulator': (c_i, []),
     'cn_set_option': (c_i, [ctypes.c_char_p, c_i]),
     'cn_conv2d_fwd': (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 11 + [c_i, c_i, c_i, c_p]),

@@ -29,6 +29,7 @@
 void cn_set_error(const char* fmt, ...);
 int cn_check_launch(const char* what);
 int cn_get_option(const char* name, int dflt);
+void cn_set_last_kernel(const char* fmt, ...);
 
 // ---------------------------------------------------------------- launch macro
 #ifdef CN_EMULATE

@@ -635,9 +635,13 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
   // a 1x1 gather whose output fits one channel tile reads every input element exactly once
   p.x_nt = (cn_get_option("igemm_x_nt", 0) != 0 && p.ntaps == 1 && p.n_ntiles == 1 && p.simple) ? 1 : 0;
   dim3 grid((unsigned)(p.n_ntiles * n_mtiles));
+  const char* tname = std::is_same<T, float>::value ? "float" : "bf16_t";
   // EPI: epilogue with global-side operands (residual-branch addend, fused BN-backward reduction)
 #define IG_GO2(WC, WP, TI, TJ, EP)                                                                              \
   do {                                                                                                         \
+    cn_set_last_kernel("igemm_kernel<%s, %d, %d, %d, %d, %d, %s, %s, false, %s>", tname, WC, WP, TI, TJ,      \
+                       variant == 1 ? 1 : 2, OUTF32 ? "true" : "false", variant >= 3 ? "true" : "false",      \
+                       EP ? "true" : "false");                                                                 \
     if (variant == 1) CN_LAUNCH((igemm_kernel<T, WC, WP, TI, TJ, 1, OUTF32, false, false, EP>), grid, dim3(256), stream, p); \
     else if (variant == 2) CN_LAUNCH((igemm_kernel<T, WC, WP, TI, TJ, 2, OUTF32, false, false, EP>), grid, dim3(256), stream, p); \
     else CN_LAUNCH((igemm_kernel<T, WC, WP, TI, TJ, 2, OUTF32, true, false, EP>), grid, dim3(256), stream, p);        \
@@ -647,6 +651,7 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
     // 4 / 5: experimental 4-deep DMA rings (4 or 8 waves), measured slower than variant 3, kept for A/B;
     // 6: 256-pixel x 128-channel tile, 8 waves, LDS-DMA double buffer with register-double-buffered
     //    fragments (fewer operand bytes per flop; not faster either, profiles/README.md)
+    cn_set_last_kernel("igemm_kernel<%s, experimental variant %d>", tname, variant);
     if (variant == 4) CN_LAUNCH((igemm_kernel<T, 2, 2, 2, 2, 4, OUTF32, true, false, false>), grid, dim3(256), stream, p);
     else if (variant == 5) CN_LAUNCH((igemm_kernel<T, 2, 4, 2, 1, 4, OUTF32, true, false, false>), grid, dim3(512), stream, p);
     else CN_LAUNCH((igemm_kernel<T, 2, 4, 2, 2, 2, OUTF32, true, true, false>), grid, dim3(512), stream, p);

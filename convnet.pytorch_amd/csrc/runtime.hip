@@ -31,6 +31,18 @@ int cn_check_launch(const char* what) {
 
 extern "C" const char* cn_last_error(void) { return g_err; }
 
+// Name (as rocprofv3 prints it, without "void " and the parameter list) of the GEMM-class kernel the most recent
+// cn_conv2d_* / cn_conv2d_wgrad call of this thread launched: the dispatchers choose an instantiation per
+// shape, and measurement code labels its timings with this instead of mirroring the heuristics.
+static thread_local char g_kernel[160] = "";
+void cn_set_last_kernel(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* cn_last_kernel_name(void) { return g_kernel; }
+
 // Tuning knobs (kernel variant selection for A/B measurements; never change results).
 #include <string.h>
 #define CN_MAX_OPTS 16

@@ -15,6 +15,7 @@
 // writing the KRSC gradient (optionally accumulating, for chunked batches).
 #include "cn_common.h"
 #include "cn_api_internal.h"
+#include <type_traits>
 
 #define WG_MAX_TAPS 64
 
@@ -462,10 +463,12 @@ static void wg_launch(const WgradParams& p, const WgradPlan& pl, hipStream_t str
   // 2 = LDS-DMA everywhere.
   const int wv = cn_get_option("wgrad_variant", 0);
   if (sizeof(T) == 2 && (wv == 2 || (wv == 0 && p.simple))) {
+    cn_set_last_kernel("wgrad_dma_kernel<%d>", pl.BI == 64 ? 64 : 128);
     if (pl.BI == 64) CN_LAUNCH((wgrad_dma_kernel<64>), grid, dim3(256), stream, p);
     else CN_LAUNCH((wgrad_dma_kernel<128>), grid, dim3(256), stream, p);
     return;
   }
+  cn_set_last_kernel("wgrad_kernel<%s, %d, 128>", std::is_same<T, float>::value ? "float" : "bf16_t", pl.BI == 64 ? 64 : 128);
   if (pl.BI == 64) CN_LAUNCH((wgrad_kernel<T, 64, 128>), grid, dim3(256), stream, p);
   else CN_LAUNCH((wgrad_kernel<T, 128, 128>), grid, dim3(256), stream, p);
 }

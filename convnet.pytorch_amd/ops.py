@@ -52,7 +52,9 @@ class KernelProfiler(object):
         self.enabled = False
         self.records = []
 
-    def run(self, name, launches, flops, nbytes, fn, device):
+    def run(self, name, launches, flops, nbytes, fn, device, detail=None):
+        """name: label, or a callable evaluated AFTER fn() (the library reports which kernel instantiation its
+        dispatcher picked: cn_last_kernel_name); detail: optional per-shape label (conv layers)."""
         if not self.enabled or device.type != 'cuda':
             return fn()
         s = torch.cuda.Event(enable_timing=True)
@@ -60,19 +62,26 @@ class KernelProfiler(object):
         s.record()
         out = fn()
         e.record()
-        self.records.append((name, launches, flops, nbytes, s, e))
+        if callable(name):
+            name = name()
+        self.records.append((name, launches, flops, nbytes, s, e, detail))
         return out
 
-    def summary(self):
+    def summary(self, by_detail=False):
         torch.cuda.synchronize()
         agg = {}
-        for name, launches, flops, nbytes, s, e in self.records:
-            a = agg.setdefault(name, {'calls': 0, 'launches': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0})
+        for name, launches, flops, nbytes, s, e, detail in self.records:
+            if by_detail and detail is None:
+                continue
+            a = agg.setdefault(detail if by_detail else name,
+                               {'calls': 0, 'launches': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0, 'records': []})
+            ms = s.elapsed_time(e)
             a['calls'] += 1
             a['launches'] += launches
-            a['ms'] += s.elapsed_time(e)
+            a['ms'] += ms
             a['flops'] += flops
             a['bytes'] += nbytes
+            a['records'].append((ms, flops, nbytes))
         return agg
 
 
@@ -139,18 +148,13 @@ def _esize(t):
     return t.element_size()
 
 
-def _igemm_name(dtype, co, taps, c_red, out_f32=False, epi=False):
-    """Name of the igemm_kernel instantiation the C dispatcher picks (mirrors ig_launch): used only
-    to label profiler records with the names rocprofv3 reports.  Template arguments:
-    <T, WC, WP, TI, TJ, STAGES, OUTF32, GLDS, FRAGDB, EPI>."""
-    ch = 4 if dtype == torch.float32 else 8
-    nkt = (taps * (c_red // ch) + 7) // 8
-    glds = nkt >= 24
-    t = 'float' if dtype == torch.float32 else 'bf16_t'
-    shape = '1, 4, 2, 1' if co <= 64 else '2, 2, 2, 2'
-    outf = 'true' if (out_f32 or dtype == torch.float32) else 'false'
-    return 'igemm_kernel<%s, %s, %d, %s, %s, false, %s>' % (t, shape, 2 if glds else 1, outf,
-                                                            'true' if glds else 'false', 'true' if epi else 'false')
+def _last_kernel(suffix=''):
+    """Label of the kernel the library's dispatcher just launched (cn_last_kernel_name)."""
+    return lambda: _L().cn_last_kernel_name().decode() + suffix
+
+
+def _conv_detail(kind, C, H, K, R, stride):
+    return '%s %d,%d->%d %dx%d/%d' % (kind, C, H, K, R, R, stride[0])
 
 
 def conv_out_hw(H, W, R, S, stride, pad):
@@ -217,23 +221,23 @@ def conv2d_fwd(x, w_krsc, bias, K, R, S, stride, pad, out_f32=False, relu=False,
         L = _L()
         rows = L.cn_conv2d_bnstats_rows(N * P * Q)
         partial = torch.empty((rows, 2 * K), dtype=torch.float32, device=x.device)
-        PROFILER.run(_igemm_name(x.dtype, K, R * S, C, out_f32),
+        PROFILER.run(_last_kernel(),
                      1, 2.0 * N * P * Q * K * C * R * S,
                      x.numel() * _esize(x) + y.numel() * _esize(y) + K * R * S * C * _esize(x) + partial.numel() * 4,
                      lambda: check(L.cn_conv2d_fwd_bnstats(ptr(x), ptr(w_krsc), ptr(y), ptr(bias), N, H, W, C, K, R, S,
                                                            stride[0], stride[1], pad[0], pad[1], dtype_code(x.dtype),
                                                            int(relu), ptr(partial), rows, stream_of(x)),
                                    'cn_conv2d_fwd_bnstats'),
-                     x.device)
+                     x.device, detail=_conv_detail('fwd', C, H, K, R, stride))
         _park_stats(y, partial, rows)
         return y
-    PROFILER.run(_igemm_name(x.dtype, K, R * S, C, out_f32),
+    PROFILER.run(_last_kernel(),
                  1, 2.0 * N * P * Q * K * C * R * S,
                  x.numel() * _esize(x) + y.numel() * _esize(y) + K * R * S * C * _esize(x),
                  lambda: check(_L().cn_conv2d_fwd(ptr(x), ptr(w_krsc), ptr(y), ptr(bias), N, H, W, C, K, R, S,
                                                   stride[0], stride[1], pad[0], pad[1], dtype_code(x.dtype),
                                                   int(out_f32), int(relu), stream_of(x)), 'cn_conv2d_fwd'),
-                 x.device)
+                 x.device, detail=_conv_detail('fwd', C, H, K, R, stride))
     return y
 
 
@@ -242,8 +246,8 @@ def conv2d_dgrad(dy, w_crsk, x_shape, K, R, S, stride, pad, addend=None, bn=None
     reduction half of that BatchNorm's backward: returns (g = dx*relu_mask, partial, rows)."""
     N, H, W, C = x_shape
     dx = torch.empty((N, H, W, C), dtype=dy.dtype, device=dy.device)
-    name = _igemm_name(dy.dtype, C, max(1, -(-R // stride[0]) * -(-S // stride[1])), K,
-                       epi=addend is not None or bn is not None)
+    name = _last_kernel()
+    detail = _conv_detail('dgrad', C, H, K, R, stride)
     flops = 2.0 * dy.numel() * C * R * S
     nbytes = dy.numel() * _esize(dy) + dx.numel() * _esize(dx) * (2 if addend is not None else 1) \
         + K * R * S * C * _esize(dy)
@@ -252,7 +256,7 @@ def conv2d_dgrad(dy, w_crsk, x_shape, K, R, S, stride, pad, addend=None, bn=None
                      lambda: check(_L().cn_conv2d_dgrad(ptr(dy), ptr(w_crsk), ptr(dx), ptr(addend), N, H, W, C, K, R, S,
                                                         stride[0], stride[1], pad[0], pad[1], dtype_code(dy.dtype), 0,
                                                         stream_of(dy)), 'cn_conv2d_dgrad'),
-                     dy.device)
+                     dy.device, detail=detail)
         return dx
     bn_y, bn_mask, bn_stats, bn_relu = bn
     L = _L()
@@ -263,7 +267,7 @@ def conv2d_dgrad(dy, w_crsk, x_shape, K, R, S, stride, pad, addend=None, bn=None
                                                        stride[0], stride[1], pad[0], pad[1], dtype_code(dy.dtype),
                                                        ptr(bn_y), ptr(bn_mask), ptr(bn_stats), int(bn_relu),
                                                        ptr(partial), rows, stream_of(dy)), 'cn_conv2d_dgrad_bnbwd'),
-                 dy.device)
+                 dy.device, detail=detail)
     return dx, partial, rows
 
 
@@ -274,18 +278,13 @@ def conv2d_wgrad(x, dy, dw_krsc, c_real, K, R, S, stride, pad, beta=1.0, scale=1
     L = _L()
     need = L.cn_conv2d_wgrad_workspace(N, H, W, C, K, R, S, stride[0], stride[1], pad[0], pad[1], code)
     ws = workspace(need, x.device, tag)
-    if x.dtype == torch.bfloat16 and R == 1 and S == 1 and tuple(stride) == (1, 1) and tuple(pad) == (0, 0):
-        kname = 'wgrad_dma_kernel<%d> (+wgrad_reduce)' % (64 if K <= 64 else 128)      # identity gather: LDS-DMA variant
-    else:
-        kname = 'wgrad_kernel<%s, %d, 128> (+wgrad_reduce)' % ('float' if x.dtype == torch.float32 else 'bf16_t',
-                                                               64 if K <= 64 else 128)
-    PROFILER.run(kname,
+    PROFILER.run(_last_kernel(' (+wgrad_reduce)'),
                  2, 2.0 * dy.numel() * C * R * S,
                  x.numel() * _esize(x) + dy.numel() * _esize(dy) + K * R * S * C * 4,
                  lambda: check(L.cn_conv2d_wgrad(ptr(x), ptr(dy), ptr(dw_krsc), c_real, N, H, W, C, K, R, S,
                                                  stride[0], stride[1], pad[0], pad[1], code, beta, scale, ptr(ws),
                                                  ws.numel() * 4, stream_of(x)), 'cn_conv2d_wgrad'),
-                 x.device)
+                 x.device, detail=_conv_detail('wgrad', C, H, K, R, stride))
 
 
 def weight_prep(w_master_krsc, w_krsc, w_crsk, Co, taps, c_real, c_pad):

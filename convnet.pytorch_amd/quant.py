@@ -61,8 +61,9 @@ def minmax_rows(x, rows):
     row_len = x.numel() // rows
     out = torch.empty(rows * 2, dtype=torch.float32, device=x.device)
     ws = ops.workspace(L.cn_minmax_workspace(rows, row_len), x.device, 'quant')
-    check(L.cn_minmax_rows(ptr(x), rows, row_len, dtype_code(x.dtype), ptr(out), ptr(ws), ws.numel() * 4,
-                           stream_of(x)), 'cn_minmax_rows')
+    ops.PROFILER.run('quant: minmax_rows', 2, 0.0, x.numel() * x.element_size(),
+                     lambda: check(L.cn_minmax_rows(ptr(x), rows, row_len, dtype_code(x.dtype), ptr(out), ptr(ws),
+                                                    ws.numel() * 4, stream_of(x)), 'cn_minmax_rows'), x.device)
     return out
 
 
@@ -76,9 +77,11 @@ def qparams(minmax, rows, mode, running_zp=None, running_range=None, momentum=0.
 def quantize(x, zp, rng, num_bits=8, noise=None, stochastic=False):
     """zp / rng: one-element fp32 device tensors (or views)."""
     y = torch.empty_like(x)
-    check(_L().cn_quantize(ptr(x), ptr(y), x.numel(), dtype_code(x.dtype), ptr(zp), ptr(rng), num_bits, ptr(noise),
-                           int(stochastic), _next_seed() if (stochastic and noise is None) else 0, stream_of(x)),
-          'cn_quantize')
+    seed = _next_seed() if (stochastic and noise is None) else 0
+    ops.PROFILER.run('quant: quantize', 1, 0.0, 2 * x.numel() * x.element_size(),
+                     lambda: check(_L().cn_quantize(ptr(x), ptr(y), x.numel(), dtype_code(x.dtype), ptr(zp), ptr(rng),
+                                                    num_bits, ptr(noise), int(stochastic), seed, stream_of(x)),
+                                   'cn_quantize'), x.device)
     return y
 
 
@@ -267,9 +270,12 @@ class RangeBNFunction(Function):
         stats = torch.empty(2 * C, dtype=torch.float32, device=y.device)
         arg = torch.empty(C * 2 * mod.num_chunks, dtype=torch.int32, device=y.device)
         ws = ops.workspace(L.cn_rangebn_workspace(M, C, mod.num_chunks), y.device, 'quant')
-        check(L.cn_rangebn_fwd(ptr(qy), None, ptr(z), ptr(weight), ptr(bias), ptr(mod.running_mean),
-                               ptr(mod.running_var), mod.momentum, mod.eps, mod.num_chunks, fix, ptr(stats), ptr(arg),
-                               M, C, int(relu), 1, code, ptr(ws), ws.numel() * 4, stream_of(y)), 'cn_rangebn_fwd')
+        ops.PROFILER.run('quant: rangebn_stats+finalize+apply', 3, 0.0, 3 * qy.numel() * qy.element_size(),
+                         lambda: check(L.cn_rangebn_fwd(ptr(qy), None, ptr(z), ptr(weight), ptr(bias),
+                                                        ptr(mod.running_mean), ptr(mod.running_var), mod.momentum,
+                                                        mod.eps, mod.num_chunks, fix, ptr(stats), ptr(arg), M, C,
+                                                        int(relu), 1, code, ptr(ws), ws.numel() * 4, stream_of(y)),
+                                       'cn_rangebn_fwd'), y.device)
         ctx.mod, ctx.relu, ctx.fix = mod, relu, fix
         ctx.save_for_backward(qy, weight, stats, arg, *((z,) if relu else ()))
         return z
@@ -292,9 +298,11 @@ class RangeBNFunction(Function):
         gq = quantize_grad(g0, mod.num_bits_grad)
         dx = torch.empty_like(qy)
         ws = ops.workspace(L.cn_rangebn_workspace(M, C, mod.num_chunks), qy.device, 'quant')
-        check(L.cn_rangebn_bwd(ptr(gq), ptr(qy), ptr(weight), ptr(stats), ptr(arg), ptr(dx), ptr(mod.grad_view('weight')),
-                               ptr(mod.grad_view('bias')), M, C, mod.num_chunks, ctx.fix, dtype_code(qy.dtype), ptr(ws),
-                               ws.numel() * 4, stream_of(qy)), 'cn_rangebn_bwd')
+        ops.PROFILER.run('quant: rangebn_bwd reduce+finalize+apply+route', 4, 0.0, 4 * qy.numel() * qy.element_size(),
+                         lambda: check(L.cn_rangebn_bwd(ptr(gq), ptr(qy), ptr(weight), ptr(stats), ptr(arg), ptr(dx),
+                                                        ptr(mod.grad_view('weight')), ptr(mod.grad_view('bias')), M, C,
+                                                        mod.num_chunks, ctx.fix, dtype_code(qy.dtype), ptr(ws),
+                                                        ws.numel() * 4, stream_of(qy)), 'cn_rangebn_bwd'), qy.device)
         mod._notify_grad_ready()
         return dx, None, None, None, None
 

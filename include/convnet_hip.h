@@ -36,6 +36,9 @@ extern "C" {
 
 const char* cn_last_error(void);
 const char* cn_build_info(void);
+/* name of the GEMM-class kernel instantiation the last cn_conv2d_* call of this thread launched (as rocprofv3
+ * prints it, minus "void " and the parameter list); measurement code labels its timings with it */
+const char* cn_last_kernel_name(void);
 int cn_is_emulator(void); /* 1 only in the TEST-ONLY CPU emulator build */
 /* kernel-variant tuning knobs for A/B measurement (e.g. "igemm_stages" = 1|2); results never change */
 int cn_set_option(const char* name, int value);
