@@ -85,6 +85,9 @@ _SIGNATURES = {
     'cn_rangebn_workspace': (c_sz, [c_i, c_i, c_i]),
     'cn_rangebn_fwd': (c_i, [c_p] * 7 + [c_f, c_f, c_i, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
     'cn_rangebn_bwd': (c_i, [c_p] * 8 + [c_i, c_i, c_i, c_f, c_i, c_p, c_sz, c_p]),
+    'cn_i8_prepare_activation': (c_i, [c_p] * 5 + [c_i] * 11 + [c_p, c_p, c_p, c_p, c_i, c_p]),
+    'cn_i8_prepare_weight': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
+    'cn_conv2d_fwd_i8': (c_i, [c_p] * 10 + [c_i, c_p] + [c_i] * 12 + [c_p]),
     'cn_comm_unique_id': (c_i, [c_p]),
     'cn_comm_init': (c_i, [c_p, c_p, c_i, c_i]),
     'cn_comm_info': (c_i, [c_p, c_p, c_p, c_p]),
@@ -96,6 +99,7 @@ _SIGNATURES = {
     'cn_probe_mfma_bf16': (c_i, [c_p, c_p, c_p, c_p]),
     'cn_probe_mfma_f32': (c_i, [c_p, c_p, c_p, c_p]),
     'cn_probe_tr16': (c_i, [c_p, c_p, c_p]),
+    'cn_probe_mfma_i8': (c_i, [c_p, c_p, c_p, c_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))

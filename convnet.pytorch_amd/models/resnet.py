@@ -200,6 +200,13 @@ class ResNetImagenet(tnn.Module):
                  'regularizer': weight_decay_config(1e-4),
                  'step_lambda': linear_scale(scale_lr * 1e-1, 0, num_steps_epoch * epochs)},
             ]
+            if ramp_up_lr:
+                # the reference (models/resnet.py:269-276) would start this regime at lr 0 and append a ramp-up
+                # phase, but crashes on `self.regime['step_lambda']` (a list indexed by a string); here the
+                # linear decay runs without warm-up, and says so
+                import logging
+                logging.warning("resnet(regime='linear'): ramp_up_lr is ignored (linear decay from %g without "
+                                "warm-up; the reference raises a TypeError for this combination)", scale_lr * 1e-1)
             ramp_up_lr = False
         if ramp_up_lr and scale_lr > 1:  # learning-rate ramp-up (models/resnet.py:313-317)
             self.regime[0]['step_lambda'] = linear_scale(0.1, 0.1 * scale_lr, ramp_up_steps)

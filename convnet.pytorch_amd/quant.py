@@ -23,6 +23,7 @@ Stochastic rounding noise: by default the kernels' own counter-based generator (
 from torch's CPU generator (one draw per gradient tensor, NCHW element order, in backward execution order).
 """
 import math
+import os
 
 import torch
 import torch.nn as tnn
@@ -117,14 +118,20 @@ class QuantMeasure(tnn.Module):
         self.register_buffer('running_range', torch.zeros(*shape_measure))
         self.num_bits, self.momentum = num_bits, momentum
 
-    def forward(self, x, training=None):
-        """x: contiguous activation whose leading dimension is the batch."""
+    def params(self, x, training=None):
+        """(zero_point, range) one-element device tensors for x; training: measured on x (and folded into the
+        running buffers), else the running buffers."""
         training = self.training if training is None else training
         if training:
             rows = x.shape[0]
             qp = qparams(minmax_rows(x, rows), rows, 0, self.running_zero_point, self.running_range, self.momentum)
-            return quantize(x, qp[0:1], qp[1:2], self.num_bits)
-        return quantize(x, self.running_zero_point, self.running_range, self.num_bits)
+            return qp[0:1], qp[1:2]
+        return self.running_zero_point, self.running_range
+
+    def forward(self, x, training=None):
+        """x: contiguous activation whose leading dimension is the batch."""
+        zp, rng = self.params(x, training)
+        return quantize(x, zp, rng, self.num_bits)
 
 
 def _quantize_filters(mod, num_bits):
@@ -141,9 +148,100 @@ def _quantize_filters(mod, num_bits):
     ops.weight_prep(tmp, mod.w_krsc, mod.w_crsk, K, taps, c_real, c_pad)
 
 
+# ---- true int8 MFMA forward (csrc/qconv_i8.hip) ------------------------------------------------------------
+# CONVNET_AMD_QUANT_INT8=1 (or QConv2d.int8_forward = True): the forward product of every eligible QConv2d
+# (input channels a multiple of 16: everything but the 3-channel stem) runs on v_mfma_i32_32x32x32_i8 instead
+# of the float kernels on dequantised operands.  Same result up to fp32 rounding; backward unchanged.
+INT8_FORWARD = os.environ.get('CONVNET_AMD_QUANT_INT8', '0') == '1'
+_I8_GEOM = {}
+
+
+def _border_classes(n_in, k, stride, pad, n_out):
+    """Per output index: which taps fall inside the image -> (class id per output index, [(lo, hi)] per class)."""
+    ids, pats = [], []
+    for o in range(n_out):
+        lo = max(0, pad - o * stride)
+        hi = min(k - 1, n_in - 1 + pad - o * stride)
+        if (lo, hi) not in pats:
+            pats.append((lo, hi))
+        ids.append(pats.index((lo, hi)))
+    return ids, pats
+
+
+def _i8_geometry(H, W, R, S, stride, pad, device):
+    key = (H, W, R, S, tuple(stride), tuple(pad), str(device))
+    g = _I8_GEOM.get(key)
+    if g is None:
+        P, Q = ops.conv_out_hw(H, W, R, S, stride, pad)
+        rid, rp = _border_classes(H, R, stride[0], pad[0], P)
+        cid, cp = _border_classes(W, S, stride[1], pad[1], Q)
+        mask = torch.zeros(len(rp) * len(cp), R * S, dtype=torch.uint8)
+        for i, (rlo, rhi) in enumerate(rp):
+            for j, (slo, shi) in enumerate(cp):
+                for r in range(rlo, rhi + 1):
+                    for c in range(slo, shi + 1):
+                        mask[i * len(cp) + j, r * S + c] = 1
+        g = (torch.tensor(rid, dtype=torch.uint8).to(device), torch.tensor(cid, dtype=torch.uint8).to(device),
+             len(cp), mask.to(device), len(rp) * len(cp))
+        _I8_GEOM[key] = g
+    return g
+
+
+def int8_eligible(mod, x):
+    return ((INT8_FORWARD or getattr(mod, 'int8_forward', False)) and x.shape[-1] % 16 == 0
+            and mod.in_channels == x.shape[-1] and mod.out_channels % 8 == 0)
+
+
+def conv2d_fwd_int8(x, zp, rng, mod):
+    """QConv2d's forward product on the int8 matrix cores.  x: the UNquantised NHWC input, (zp, rng) its
+    quantisation parameters (device scalars)."""
+    L = _L()
+    N, H, W, C = x.shape
+    K = mod.out_channels
+    R, S = mod.kernel_size
+    P, Q = ops.conv_out_hw(H, W, R, S, mod.stride, mod.padding)
+    dev = x.device
+    rowcls, colcls, ncolcls, clsmask, ncls = _i8_geometry(H, W, R, S, mod.stride, mod.padding, dev)
+    st = stream_of(x)
+    xq = torch.empty((N, H, W, C), dtype=torch.int8, device=dev)
+    chansum = torch.empty(N * H * W, dtype=torch.int32, device=dev)
+    A = torch.empty(N * P * Q, dtype=torch.int32, device=dev)
+    cls = torch.empty(N * P * Q, dtype=torch.uint8, device=dev)
+    ops.PROFILER.run('quant int8: levels+chansum+window', 3, 0.0, x.numel() * (x.element_size() + 2),
+                     lambda: check(L.cn_i8_prepare_activation(ptr(x), ptr(xq), ptr(chansum), ptr(A), ptr(cls), N, H, W, C,
+                                                              R, S, mod.stride[0], mod.stride[1], mod.padding[0],
+                                                              mod.padding[1], dtype_code(x.dtype), ptr(zp), ptr(rng),
+                                                              ptr(rowcls), ptr(colcls), ncolcls, st),
+                                   'cn_i8_prepare_activation'), dev)
+    master = mod.master_view('weight')
+    wq = torch.empty(K * R * S * C, dtype=torch.int8, device=dev)
+    wsum = torch.empty(K * R * S, dtype=torch.int32, device=dev)
+    wpar = torch.empty(K * 2, dtype=torch.float32, device=dev)
+    check(L.cn_i8_prepare_weight(ptr(master), ptr(wq), ptr(wsum), ptr(wpar), K, R * S, C, st), 'cn_i8_prepare_weight')
+    tables = torch.empty((2 + ncls) * K, dtype=torch.float32, device=dev)
+    y = torch.empty((N, P, Q, K), dtype=x.dtype, device=dev)
+    ops.PROFILER.run(lambda: L.cn_last_kernel_name().decode(), 2, 2.0 * N * P * Q * K * C * R * S,
+                     xq.numel() + wq.numel() + y.numel() * y.element_size(),
+                     lambda: check(L.cn_conv2d_fwd_i8(ptr(xq), ptr(wq), ptr(y), ptr(A), ptr(cls), ptr(zp), ptr(rng),
+                                                      ptr(wpar), ptr(wsum), ptr(clsmask), ncls, ptr(tables), N, H, W, C,
+                                                      K, R, S, mod.stride[0], mod.stride[1], mod.padding[0],
+                                                      mod.padding[1], dtype_code(x.dtype), st), 'cn_conv2d_fwd_i8'),
+                     dev, detail='fwd-int8 %d,%d->%d %dx%d/%d' % (C, H, K, R, R, mod.stride[0]))
+    return y
+
+
 class QConv2dFunction(Function):
     @staticmethod
     def forward(ctx, x, weight, mod, prequantized):
+        if not prequantized and int8_eligible(mod, x):
+            x = x.contiguous()
+            zp, rng = mod.quantize_input.params(x)
+            y = conv2d_fwd_int8(x, zp, rng, mod)
+            qx = quantize(x, zp, rng, mod.num_bits)      # float copies of both operands: the backward pass
+            _quantize_filters(mod, mod.num_bits_weight)  # (wgrad / dgrad) runs on the float kernels
+            ctx.mod = mod
+            ctx.save_for_backward(qx)
+            return y
         qx = x if prequantized else mod.quantize_input(x)
         _quantize_filters(mod, mod.num_bits_weight)
         y = ops.conv2d_fwd(qx, mod.w_krsc, None, mod.out_channels, mod.kernel_size[0], mod.kernel_size[1],

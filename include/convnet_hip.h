@@ -250,6 +250,29 @@ int cn_rangebn_bwd(const void* g, const void* x, const float* weight, const floa
                    float* dweight, float* dbias, int M, int C, int chunks, float scale_fix, int dtype,
                    float* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- true int8 MFMA forward product of QConv2d (v_mfma_i32_32x32x32_i8; csrc/qconv_i8.hip).  Both operands of
+ * the reference's simulated convolution (quantize.py:195-219) live on integer grids, so
+ *   y[p,k] = sx*sw[k]*ACC[p,k] + sx*zw'[k]*A[p] + zx'*(sw[k]*B[cls(p)][k] + zw'[k]*n_valid(cls(p))),
+ * ACC = the int8 GEMM of the levels - 128 (exact int32), A = window sums of the activation levels, B = filter
+ * level sums over the taps valid for border class cls (zero padding contributes 0, not the zero point).
+ * Forward only: dgrad reduces across the per-output-channel filter scales and wgrad uses the full-precision dy
+ * (quantize.py:115-121); both stay on the float kernels. */
+/* activation (NHWC, dtype) -> q = level - 128 (int8 NHWC), A[N*P*Q] window sums, cls[N*P*Q] border class =
+ * rowcls[p] * ncolcls + colcls[q]; chansum = int32 scratch [N*H*W]; C % 16 == 0 */
+int cn_i8_prepare_activation(const void* x, signed char* q, int* chansum, int* A, unsigned char* cls, int N, int H,
+                             int W, int C, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w, int dtype,
+                             const float* zero_point, const float* range, const unsigned char* rowcls,
+                             const unsigned char* colcls, int ncolcls, void* stream);
+/* fp32 master filter [K][taps][C] -> q = level - 128 with the row's own min / max (quantize.py:201-203),
+ * wsum[K][taps] = sum_c q, wpar[K][2] = {scale, zero point + 128*scale} */
+int cn_i8_prepare_weight(const float* w_master, signed char* q, int* wsum, float* wpar, int K, int taps, int C,
+                         void* stream);
+/* clsmask[ncls][taps] = 1 where the tap is inside the image for that class; tables = (2 + ncls)*K floats scratch */
+int cn_conv2d_fwd_i8(const signed char* xq, const signed char* wq, void* y, const int* A, const unsigned char* cls,
+                     const float* zero_point, const float* range, const float* wpar, const int* wsum,
+                     const unsigned char* clsmask, int ncls, float* tables, int N, int H, int W, int C, int K, int R,
+                     int S, int stride_h, int stride_w, int pad_h, int pad_w, int out_dtype, void* stream);
+
 /* ---- data-parallel exchange step, directly on RCCL (trainer.py:79-82 DistributedDataParallel; main.py:190-191
  * SyncBatchNorm) ---------------------------------------------------------------------------------
  * One communicator handle per process (= per GPU).  The handle is the ONLY state the library keeps for the
@@ -277,6 +300,7 @@ int cn_probe_mfma_bf16(const unsigned short* A /*32x16*/, const unsigned short* 
                        void* stream);
 int cn_probe_mfma_f32(const float* A /*32x2*/, const float* B /*2x32*/, float* D, void* stream);
 int cn_probe_tr16(const unsigned short* src /*256*/, unsigned short* out /*64x4*/, void* stream);
+int cn_probe_mfma_i8(const signed char* A /*32x32*/, const signed char* B /*32x32*/, int* D /*32x32*/, void* stream);
 
 #ifdef __cplusplus
 }

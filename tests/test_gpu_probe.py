@@ -59,3 +59,16 @@ def test_lds_transpose_read_map(mode):
             exp[l, j] = 4 * src_lane + (i & 3)
     got = out.cpu()
     assert torch.equal(got, exp), 'ds_read_b64_tr_b16 map differs:\n%s' % got[:16].tolist()
+
+
+@pytest.mark.parametrize('mode', MODES)
+def test_mfma_i8_lane_map(mode):
+    """v_mfma_i32_32x32x32_i8 as csrc/qconv_i8.hip assumes it: lane l holds A[l & 31][16*(l >> 5) + e], e = 0..15."""
+    ca, dev, stream = _setup(mode)
+    g = torch.Generator().manual_seed(2)
+    A = torch.randint(-128, 128, (32, 32), generator=g, dtype=torch.int32)     # asymmetric, full int8 range
+    B = torch.randint(-128, 128, (32, 32), generator=g, dtype=torch.int32)
+    Ad, Bd = A.to(torch.int8).to(dev), B.to(torch.int8).to(dev)
+    D = torch.zeros(32, 32, dtype=torch.int32, device=dev)
+    ca._lib.check(ca._lib.load().cn_probe_mfma_i8(Ad.data_ptr(), Bd.data_ptr(), D.data_ptr(), stream))
+    assert torch.equal(D.cpu(), A @ B)

@@ -231,3 +231,54 @@ def test_quantised_bf16_step_and_builtin_noise():
     assert recs[0]['loss'] == pytest.approx(meta['records'][0]['loss'], abs=5e-2)
     assert recs[0]['grad'] == pytest.approx(meta['records'][0]['grad'], rel=1e-1)
     assert all(torch.isfinite(torch.tensor([r['loss'], r['grad']])).all() for r in recs)
+
+
+@pytest.mark.parametrize('mode', MODES)
+@pytest.mark.parametrize('cfg', [(16, 8, 32, 1, 1, 0), (32, 9, 64, 3, 1, 1), (16, 8, 128, 3, 2, 1), (64, 6, 64, 1, 2, 0),
+                                 (48, 7, 136, 3, 1, 1)])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_int8_mfma_forward_equals_the_simulated_convolution(mode, cfg, dtype):
+    """csrc/qconv_i8.hip: the QConv2d forward product on v_mfma_i32_32x32x32_i8 (levels - 128, exact int32
+    accumulation, zero-point / border-class corrections in the epilogue) against (a) the float-kernel path of the
+    same module and (b) the CPU oracle's F.conv2d on the dequantised operands.  fp32 output: rel-L2 1e-5 (the
+    int8 path is the more exact of the two); bf16 output: one bf16 rounding."""
+    dev = _dev(mode)
+    import convnet_amd as ca
+    from oracle import quant_oracle as QO
+    C, H, K, R, stride, pad = cfg
+    g = torch.Generator().manual_seed(C * 131 + K)
+    conv = ca.quant.QConv2d(C, K, R, stride=stride, padding=pad, bias=False)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(K, C, R, R, generator=g) * 0.1)
+    _prepare(conv, dev, dtype)
+    conv.train()
+    x_nchw = torch.randn(4, C, H, H + 1, generator=g)
+    x = _nhwc(x_nchw, dev).to(dtype)
+    with torch.no_grad():
+        conv.int8_forward = False
+        y_sim = conv(x).float()
+        conv.int8_forward = True
+        y_i8 = conv(x).float()
+    xq = x.float().cpu().permute(0, 3, 1, 2)
+    zp, rng = QO.qparams_mean(xq)
+    wzp, wrng = QO.qparams_rows(conv.weight.detach().float().cpu())
+    ref = torch.nn.functional.conv2d(QO.quantize(xq, zp, rng), QO.quantize(conv.weight.detach().float().cpu(), wzp, wrng),
+                                     None, stride, pad)
+    # the oracle averages the per-sample min / max in fp32, the kernel in double: a last-bit difference in the
+    # zero point moves a handful of elements to the neighbouring level (1/255 of the range each)
+    assert rel_l2(_nchw(y_i8), ref) < (2e-3 if dtype == torch.float32 else 8e-3)
+    assert rel_l2(_nchw(y_i8), _nchw(y_sim)) < (1e-5 if dtype == torch.float32 else 8e-3)
+    # and through autograd: same gradients as the float-kernel path (the backward pass IS that path)
+    ca.quant.set_noise_source(lambda shape: torch.zeros(shape))
+    try:
+        grads = []
+        for flag in (False, True):
+            conv.int8_forward = flag
+            conv._arena.zero_grad()     # gradients accumulate into the flat arena
+            xi = x.clone().requires_grad_(True)
+            y = conv(xi)
+            y.backward(torch.ones_like(y))
+            grads.append((xi.grad.float().cpu().clone(), conv.weight.grad.float().cpu().clone()))
+        assert rel_l2(grads[1][0], grads[0][0]) < 1e-6 and rel_l2(grads[1][1], grads[0][1]) < 1e-6
+    finally:
+        ca.quant.set_noise_source(None)
