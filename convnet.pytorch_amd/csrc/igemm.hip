@@ -50,6 +50,7 @@ struct IgemmParams {
   unsigned int x_bytes, w_bytes;   // extents of the gather source / filter tensors (buffer descriptors)
   int simple;                      // 1: no tap of a valid row ever leaves the image (skip bounds tests)
   int x_nt;                        // 1: every gathered element is read by one workgroup only -> non-temporal loads
+  int dbg;                         // measurement only ("igemm_dbg"): 1 = skip the reduction loop, 2 = skip the global stores
   FastDiv div_hw, div_w, div_cpt;
   int tap_dhdw[IG_MAX_TAPS];
   int tap_woff[IG_MAX_TAPS];
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
     }
   };
 
-  if (nkt > 0) {
+  if (nkt > 0 && !(p.dbg & 1)) {
     load_tile(0, 0);
     if (!GLDS) store_tile(0);
     if (!(GLDS && STAGES == 4)) __syncthreads();
@@ -527,7 +528,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
               v = Chunk<TO>::pack(fv);
             }
           }
-          cn_st16(dst, v);   // plain store: a non-temporal one measured neutral here (profiles/README.md)
+          if (!(p.dbg & 2)) cn_st16(dst, v);   // plain store: a non-temporal one measured neutral here (profiles/README.md)
         } else {   // ragged channel count: element-wise tail (never combined with the BN reduction)
           for (int e = 0; e < epc && c_first + e < p.Co; ++e) {
             if (OEB == 4) {
@@ -633,6 +634,7 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
     p.mt_fastest = order > 0 ? 1 : 0;
   }
   // a 1x1 gather whose output fits one channel tile reads every input element exactly once
+  p.dbg = cn_get_option("igemm_dbg", 0);
   p.x_nt = (cn_get_option("igemm_x_nt", 0) != 0 && p.ntaps == 1 && p.n_ntiles == 1 && p.simple) ? 1 : 0;
   dim3 grid((unsigned)(p.n_ntiles * n_mtiles));
   const char* tname = std::is_same<T, float>::value ? "float" : "bf16_t";

@@ -15,10 +15,14 @@ Batches leave this module exactly as the reference's loader hands them to `Train
 `inputs`, int64 `target`, pinned when asked.  The device side (copy-stream prefetch, fused cast to the
 bf16 NHWC / pixel-pair layout) is trainer.DevicePrefetcher + csrc/pool.hip.
 
-Randomness: every random transform draws from Python's `random` module, seeded per worker by the
-DataLoader (`torch.initial_seed()`), so a seeded run is reproducible; the draws are *not* the same
-stream torchvision would consume (parity of augmentation samples is unpinned - torchvision is absent
-here - the deterministic eval transform is pinned against PIL in tests/test_data.py).
+Randomness: the random transforms draw from torch's global generator with exactly the calls, arguments and
+order of torchvision's implementations (>= 0.8: `RandomResizedCrop.get_params`: `torch.empty(1).uniform_(scale)`,
+`torch.empty(1).uniform_(log ratio)`, `torch.randint` for the top / left corner, ten attempts, centre-crop
+fallback; `RandomHorizontalFlip`: `torch.rand(1) < p`), so a DataLoader worker seeded like the reference's
+(base_seed + worker_id -> torch.manual_seed) consumes the same stream and takes the same crops / flips as the
+reference's torchvision pipeline.  torchvision is absent from this image, so this is pinned by construction
+(the algorithm is restated from its published source) plus a recorded draw sequence in tests/test_data.py, not
+by running torchvision; the deterministic eval transform is pinned against PIL there as well.
 """
 import math
 import os
@@ -104,21 +108,23 @@ class RandomResizedCrop(object):
         self.size, self.scale, self.ratio = int(size), scale, ratio
 
     def get_params(self, w, h):
-        area = w * h
-        log_ratio = (math.log(self.ratio[0]), math.log(self.ratio[1]))
+        """torchvision.transforms.RandomResizedCrop.get_params, draw for draw (returns left, top, cw, ch)."""
+        area = h * w
+        log_ratio = torch.log(torch.tensor(self.ratio))
         for _ in range(10):
-            target_area = area * random.uniform(*self.scale)
-            aspect = math.exp(random.uniform(*log_ratio))
+            target_area = area * torch.empty(1).uniform_(self.scale[0], self.scale[1]).item()
+            aspect = torch.exp(torch.empty(1).uniform_(log_ratio[0], log_ratio[1])).item()
             cw = int(round(math.sqrt(target_area * aspect)))
             ch = int(round(math.sqrt(target_area / aspect)))
             if 0 < cw <= w and 0 < ch <= h:
-                top, left = random.randint(0, h - ch), random.randint(0, w - cw)
+                top = torch.randint(0, h - ch + 1, size=(1,)).item()
+                left = torch.randint(0, w - cw + 1, size=(1,)).item()
                 return left, top, cw, ch
-        in_ratio = w / float(h)
-        if in_ratio < self.ratio[0]:
-            cw, ch = w, int(round(w / self.ratio[0]))
-        elif in_ratio > self.ratio[1]:
-            ch, cw = h, int(round(h * self.ratio[1]))
+        in_ratio = float(w) / float(h)
+        if in_ratio < min(self.ratio):
+            cw, ch = w, int(round(w / min(self.ratio)))
+        elif in_ratio > max(self.ratio):
+            ch, cw = h, int(round(h * max(self.ratio)))
         else:
             cw, ch = w, h
         return (w - cw) // 2, (h - ch) // 2, cw, ch
@@ -136,7 +142,7 @@ class RandomHorizontalFlip(object):
         self.p = p
 
     def __call__(self, img):
-        if random.random() < self.p:
+        if torch.rand(1) < self.p:       # torchvision.transforms.RandomHorizontalFlip.forward
             return img.transpose(_pil().FLIP_LEFT_RIGHT)
         return img
 
