@@ -37,6 +37,7 @@ struct IgemmParams {
   const float* bn_coef;          // [mean | invstd | scale | shift], 4*Co floats
   float* bn_partial;             // [rows][2*Co]
   int bn_row0, bn_relu;
+  int stats_rows;                // rows of `stats` (one per 128 pixels)
   int N, Hi, Wi, Ci;
   int Hg, Wg, a_h, a_w;
   int Ho, Wo, Co;
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
       // Every thread issues exactly NWR+NPR DMA instructions per tile, so "tile kt has landed" is a
       // counted wait: at most (tiles issued after kt) * (NWR+NPR) operations may remain outstanding.
       constexpr int L = NWR + NPR;
-      static_assert(L == 8 || L == 6 || L == 4, "wait immediates below assume 4, 6 or 8 DMA instructions per tile");
+      static_assert(!(GLDS && STAGES == 4) || L == 8 || L == 6 || L == 4, "wait immediates below assume 4, 6 or 8 DMA instructions per tile");
       if (nkt > 1) load_tile(1, 1);
       if (nkt > 2) load_tile(2, 2);
       for (int kt = 0; kt < nkt; ++kt) {
@@ -587,7 +588,10 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
         const f32x4 b = red[g * NCOL + tid];
         a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
       }
-      float* dst = p.stats + (size_t)mt * 2 * (size_t)p.Co;
+      // the statistics buffer has one row per 128 pixels (cn_conv2d_bnstats_rows): a 256-pixel tile fills the
+      // first of its two rows and zeroes the second
+      constexpr int RPT = BM / 128 > 0 ? BM / 128 : 1;
+      float* dst = p.stats + (size_t)mt * RPT * 2 * (size_t)p.Co;
       if (OEBc == 4) {
         const int c = n0 + tid;
         if (c < p.Co) { dst[c] = a[0]; dst[p.Co + c] = a[2]; }
@@ -595,6 +599,16 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
         const int c = n0 + 2 * tid;
         if (c < p.Co) { dst[c] = a[0]; dst[p.Co + c] = a[2]; }
         if (c + 1 < p.Co) { dst[c + 1] = a[1]; dst[p.Co + c + 1] = a[3]; }
+      }
+      if (RPT > 1) {
+#pragma unroll
+        for (int x = 1; x < RPT; ++x) {
+          if (mt * RPT + x >= p.stats_rows) break;
+          float* dz = dst + (size_t)x * 2 * (size_t)p.Co;
+          const int c = n0 + (OEBc == 4 ? tid : 2 * tid);
+          if (c < p.Co) { dz[c] = 0.f; dz[p.Co + c] = 0.f; }
+          if (OEBc != 4 && c + 1 < p.Co) { dz[c + 1] = 0.f; dz[p.Co + c + 1] = 0.f; }
+        }
       }
     }
   }
@@ -613,7 +627,7 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
   int variant = cn_get_option("igemm_variant", 0);
   // short reductions: register-staged single buffer (more workgroups per CU); from "igemm_dma_min_nkt" K tiles
   // on: LDS-DMA double buffer (measured per layer, profiles/r01_conv_layers_b256_bf16.txt)
-  if (variant < 1 || variant > 6)
+  if (variant < 1 || variant > 12)
     variant = cn_get_option("igemm_default_variant", nkt < cn_get_option("igemm_dma_min_nkt", 24) ? 1 : 3);
   if ((p.stats != nullptr || p.bn_y != nullptr || p.addend != nullptr) && variant == 6) variant = 3;   // 128-pixel tiles   // statistics rows are defined per 128-pixel tile
   const bool epi = p.addend != nullptr || p.bn_y != nullptr;
@@ -649,6 +663,29 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
     else CN_LAUNCH((igemm_kernel<T, WC, WP, TI, TJ, 2, OUTF32, true, false, EP>), grid, dim3(256), stream, p);        \
   } while (0)
 #define IG_GO(WC, WP, TI, TJ) do { if (epi) IG_GO2(WC, WP, TI, TJ, true); else IG_GO2(WC, WP, TI, TJ, false); } while (0)
+  if constexpr (std::is_same<T, bf16_t>::value && !OUTF32) {
+    // 256 pixels x 256 channels, 8 waves of 128 pixels x 64 channels, LDS-DMA double buffer, fragments double-buffered
+    // in registers, one workgroup per CU: half the L2->LDS bytes per flop of the 128x128 tile.  It wins where the
+    // reduction is long enough to amortise the big tile's ramp (>= 16 K tiles) and the launch still has about a
+    // tile per CU (measured per layer, profiles/r02c_conv_layers_256sq_tile.txt: 256-wide 3x3 at 14x14 690 -> 900
+    // TFLOP/s, 1024 -> 256 1x1 550 -> 760); short reductions and the 7x7 maps (98 tiles) stay on 128x128.
+    const int big = cn_get_option("igemm_256sq", -1);   // -1 heuristic, 0 never, 1 whenever the shape allows it
+    const long long tiles256 = (long long)((p.M + 255) / 256) * ((p.Co + 255) / 256);
+    const bool shape_ok = p.Co >= 256 && p.Co % 128 == 0 && !epi;
+    const bool want = big == 1 || (big < 0 && nkt >= cn_get_option("igemm_256sq_min_nkt", 16) &&
+                                   tiles256 >= cn_get_option("igemm_256sq_min_tiles", 160));
+    if (shape_ok && big != 0 && (variant == 11 || variant == 12 || (cn_get_option("igemm_variant", 0) == 0 && want))) {
+      p.n_ntiles = (p.Co + 255) / 256;
+      p.n_mtiles = (p.M + 255) / 256;
+      dim3 g2((unsigned)(p.n_ntiles * p.n_mtiles));
+      const bool fragdb = variant != 11;
+      cn_set_last_kernel("igemm_kernel<bf16_t, 4, 2, 2, 4, 2, false, true, %s, false>", fragdb ? "true" : "false");
+      if (fragdb) CN_LAUNCH((igemm_kernel<T, 4, 2, 2, 4, 2, false, true, true, false>), g2, dim3(512), stream, p);
+      else CN_LAUNCH((igemm_kernel<T, 4, 2, 2, 4, 2, false, true, false, false>), g2, dim3(512), stream, p);
+      return cn_check_launch("igemm");
+    }
+  }
+  if (variant >= 7) variant = cn_get_option("igemm_default_variant", nkt < cn_get_option("igemm_dma_min_nkt", 24) ? 1 : 3);
   if (variant >= 4 && p.Co > 64 && !epi) {
     // 4 / 5: experimental 4-deep DMA rings (4 or 8 waves), measured slower than variant 3, kept for A/B;
     // 6: 256-pixel x 128-channel tile, 8 waves, LDS-DMA double buffer with register-double-buffered
@@ -726,6 +763,7 @@ static int ig_conv_fwd(const void* x, const void* w_krsc, void* y, const float* 
   IgemmParams p;
   memset(&p, 0, sizeof(p));
   p.x = (const char*)x; p.w = (const char*)w_krsc; p.y = (char*)y; p.bias = bias; p.stats = stats;
+  p.stats_rows = (int)(((long long)N * P * Q + 127) / 128);
   p.N = N; p.Hi = H; p.Wi = W; p.Ci = C;
   p.Hg = P; p.Wg = Q; p.a_h = stride_h; p.a_w = stride_w;
   p.Ho = P; p.Wo = Q; p.Co = K;

@@ -658,3 +658,47 @@ def test_layout_conversion_roundtrip(mode, dtype):
     assert float(xh[..., C:].float().abs().sum()) == 0.0
     back = ca.ops.nhwc_to_nchw(xh, C)
     assert torch.equal(back.cpu(), x.to(dtype).float())
+
+
+@pytest.mark.parametrize('mode', MODES)
+def test_igemm_256x256_tile_is_bit_identical_to_128x128(mode):
+    """The 8-wave 256x256 tile (long reductions on >= 256-channel layers; forced here with the igemm_256sq knob)
+    accumulates every output in the same order as the 128x128 tile: identical y / dx bits, and statistics
+    partial rows that carry each 256-pixel tile's sums in the first of its two 128-pixel rows."""
+    dev = _dev(mode)
+    import convnet_amd as ca
+    ops, L = ca.ops, ca._lib.load()
+    dtype = torch.bfloat16
+    cfgs = [(2, 12, 12, 16, 256, 3, 1, 1), (1, 18, 17, 64, 384, 1, 1, 0)] if mode == 'emul' else \
+        [(8, 14, 14, 256, 256, 3, 1, 1), (6, 14, 14, 1024, 256, 1, 1, 0), (4, 28, 28, 256, 256, 3, 2, 1),
+         (3, 14, 15, 512, 384, 1, 1, 0)]
+    try:
+        for (N, H, W, C, K, R, st, pad) in cfgs:
+            g = torch.Generator().manual_seed(K + H)
+            xh = _nhwc(torch.randn(N, C, H, W, generator=g), dtype, dev)
+            wk = (torch.randn(K, R, R, C, generator=g) * (2.0 / (C * R * R)) ** 0.5).to(dtype).to(dev)
+            res = {}
+            for big in (0, 1):
+                L.cn_set_option(b'igemm_256sq', big)
+                y = ops.conv2d_fwd(xh, wk, None, K, R, R, (st, st), (pad, pad))
+                name = L.cn_last_kernel_name().decode()
+                assert ('4, 2, 2, 4' in name) == bool(big), name
+                ys = ops.conv2d_fwd(xh, wk, None, K, R, R, (st, st), (pad, pad), bn_stats=True)
+                ps = ops.take_pending_stats(ys)
+                # dgrad of the transposed problem: gradient w.r.t. a K-channel input from a C-channel dy
+                dy = _nhwc(torch.randn(N, C, H, W, generator=torch.Generator().manual_seed(5)), dtype, dev)
+                wt = (torch.randn(C, R, R, K, generator=torch.Generator().manual_seed(6)) * 0.05).to(dtype).to(dev)
+                Hin, Win = (H - 1) * st + R - 2 * pad, (W - 1) * st + R - 2 * pad
+                dx = ops.conv2d_dgrad(dy, wt.permute(3, 1, 2, 0).contiguous(), (N, Hin, Win, K), C, R, R, (st, st),
+                                      (pad, pad))
+                res[big] = (y.cpu(), ys.cpu(), ps.partial.cpu().double(), ps.rows, dx.cpu())
+            y0, ys0, p0, r0, dx0 = res[0]
+            y1, ys1, p1, r1, dx1 = res[1]
+            assert torch.equal(y0, y1) and torch.equal(ys0, ys1) and torch.equal(ys1, y1) and torch.equal(dx0, dx1)
+            assert r0 == r1 and rel_l2(p1.sum(0), p0.sum(0)) < 1e-6
+            y2 = ys1.float().double().reshape(-1, K)
+            assert rel_l2(p1[0, :K], y2[:256].sum(0)) < 1e-5 and rel_l2(p1[0, K:], (y2[:256] ** 2).sum(0)) < 1e-5
+            if r1 > 1:
+                assert float(p1[1].abs().max()) == 0.0
+    finally:
+        L.cn_set_option(b'igemm_256sq', -1)
