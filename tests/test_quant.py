@@ -243,6 +243,8 @@ def test_int8_mfma_forward_equals_the_simulated_convolution(mode, cfg, dtype):
     same module and (b) the CPU oracle's F.conv2d on the dequantised operands.  fp32 output: rel-L2 1e-5 (the
     int8 path is the more exact of the two); bf16 output: one bf16 rounding."""
     dev = _dev(mode)
+    if mode == 'emul' and (cfg[2] > 64 or (dtype == torch.bfloat16 and cfg[3] != 3)):
+        pytest.skip('emulated suite: the small shapes only (all of them run on the GPU)')
     import convnet_amd as ca
     from oracle import quant_oracle as QO
     C, H, K, R, stride, pad = cfg
