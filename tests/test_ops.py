@@ -702,3 +702,37 @@ def test_igemm_256x256_tile_is_bit_identical_to_128x128(mode):
                 assert float(p1[1].abs().max()) == 0.0
     finally:
         L.cn_set_option(b'igemm_256sq', -1)
+
+
+@pytest.mark.parametrize('mode', MODES)
+def test_wgrad_256x256_tile_matches_128_tile_and_cpu(mode):
+    """wgrad_dma256_kernel (8 waves, 256 x 256 tile; forced with the wgrad_256sq knob) against the 128-wide
+    kernels and the CPU weight gradient: identity gather (1x1), 3x3 with padding, a strided 3x3, ragged Co."""
+    dev = _dev(mode)
+    import convnet_amd as ca
+    ops, L = ca.ops, ca._lib.load()
+    dtype = torch.bfloat16
+    cfgs = [(2, 9, 10, 256, 256, 1, 1, 0), (1, 10, 9, 32, 384, 3, 1, 1)] if mode == 'emul' else \
+        [(8, 14, 14, 1024, 256, 1, 1, 0), (8, 14, 14, 256, 256, 3, 1, 1), (4, 28, 28, 256, 384, 3, 2, 1),
+         (6, 7, 7, 512, 512, 3, 1, 1)]
+    try:
+        for (N, H, W, C, K, R, st, pad) in cfgs:
+            g = torch.Generator().manual_seed(K + H + R)
+            P, Q = (H + 2 * pad - R) // st + 1, (W + 2 * pad - R) // st + 1
+            x = torch.randn(N, C, H, W, generator=g)
+            dy = torch.randn(N, K, P, Q, generator=g)
+            xh, dyh = _nhwc(x, dtype, dev), _nhwc(dy, dtype, dev)
+            ref = torch.nn.grad.conv2d_weight(xh.float().cpu().permute(0, 3, 1, 2), (K, C, R, R),
+                                              dyh.float().cpu().permute(0, 3, 1, 2), st, pad)
+            outs = {}
+            for big in (0, 1):
+                L.cn_set_option(b'wgrad_256sq', big)
+                dw = torch.zeros(K, R, R, C, device=dev)
+                ops.conv2d_wgrad(xh, dyh, dw, C, K, R, R, (st, st), (pad, pad), beta=0.0)
+                name = L.cn_last_kernel_name().decode()
+                assert ('dma256' in name) == bool(big), name
+                outs[big] = dw.cpu().permute(0, 3, 1, 2)
+            assert rel_l2(outs[1], ref) < 2e-5 and rel_l2(outs[0], ref) < 2e-5
+            assert rel_l2(outs[1], outs[0]) < 1e-5
+    finally:
+        L.cn_set_option(b'wgrad_256sq', 0)
