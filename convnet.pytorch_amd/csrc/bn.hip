@@ -657,6 +657,9 @@ extern "C" size_t cn_bn_workspace(int M, int C, int dtype) {
   if (C % CH != 0 || M <= 0) return 0;
   BnMap m = bn_map(C / CH);
   int nrb = bn_row_blocks(M, m, 2048);   // upper bound over the tunable reduce-grid sizes
+  // ... and room for the row-compressed form of any number of caller-supplied partial rows
+  // (cn_bn_fwd_train_partials / cn_bn_bwd_partials compress > BN_TARGET_BLOCKS rows into <= BN_TARGET_BLOCKS)
+  if (nrb < BN_TARGET_BLOCKS) nrb = BN_TARGET_BLOCKS;
   return (size_t)nrb * 2 * C * sizeof(float);
 }
 

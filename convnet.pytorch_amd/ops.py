@@ -200,8 +200,11 @@ _PENDING = {}   # id(y) -> _PendingStats; a handful of entries at most
 def _park_stats(y, partial, rows):
     ps = _PendingStats()
     ps.ref, ps.partial, ps.rows = weakref.ref(y), partial, rows
-    if len(_PENDING) >= 4:     # never consumed (e.g. the BatchNorm ran in eval mode): drop
-        _PENDING.clear()
+    if len(_PENDING) >= 4:     # entries nobody consumed (their BatchNorm ran in eval mode / the tensor died):
+        for k in [k for k, v in _PENDING.items() if v.ref() is None]:   # dead tensors first,
+            del _PENDING[k]
+        while len(_PENDING) >= 4:                                       # then the oldest (dicts keep insertion order)
+            _PENDING.pop(next(iter(_PENDING)))
     _PENDING[id(y)] = ps
 
 
