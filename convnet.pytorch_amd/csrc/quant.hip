@@ -289,16 +289,25 @@ __global__ __launch_bounds__(Q_NT) void rangebn_stats_kernel(const T* x, int M, 
 #pragma unroll
   for (int e = 0; e < CH; ++e) { mx[e] = -INFINITY; mn[e] = INFINITY; sm[e] = 0.f; imx[e] = 0x7fffffff; imn[e] = 0x7fffffff; }
   if (cc < CC) {
-    for (int p = p0 + lane; p < p1; p += lanes) {
+    auto visit = [&](const u32x4& v, int p) {
       float f[CH];
-      Chunk<T>::unpack(cn_ld16((const char*)x + ((size_t)p * CC + cc) * 16), f);
+      Chunk<T>::unpack(v, f);
 #pragma unroll
       for (int e = 0; e < CH; ++e) {
         if (f[e] > mx[e]) { mx[e] = f[e]; imx[e] = p; }
         if (f[e] < mn[e]) { mn[e] = f[e]; imn[e] = p; }
         sm[e] += f[e];
       }
+    };
+    int p = p0 + lane;
+    for (; p + 3 * lanes < p1; p += 4 * lanes) {   // four loads in flight, visited in increasing pixel order
+      u32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = cn_ld16((const char*)x + ((size_t)(p + u * lanes) * CC + cc) * 16);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) visit(v[u], p + u * lanes);
     }
+    for (; p < p1; p += lanes) visit(cn_ld16((const char*)x + ((size_t)p * CC + cc) * 16), p);
   }
 #pragma unroll
   for (int e = 0; e < CH; ++e) {
@@ -474,13 +483,26 @@ __global__ __launch_bounds__(Q_NT) void rangebn_bwd_reduce_kernel(const T* g, co
 #pragma unroll
   for (int e = 0; e < CH; ++e) { a1[e] = 0.f; a2[e] = 0.f; mean[e] = cc < CC ? stats[cc * CH + e] : 0.f; }
   if (cc < CC) {
-    for (int p = p0 + lane; p < p1; p += lanes) {
+    auto visit = [&](const u32x4& vg, const u32x4& vx) {
       float fg[CH], fx[CH];
-      Chunk<T>::unpack(cn_ld16((const char*)g + ((size_t)p * CC + cc) * 16), fg);
-      Chunk<T>::unpack(cn_ld16((const char*)x + ((size_t)p * CC + cc) * 16), fx);
+      Chunk<T>::unpack(vg, fg);
+      Chunk<T>::unpack(vx, fx);
 #pragma unroll
       for (int e = 0; e < CH; ++e) { a1[e] += fg[e]; a2[e] += fg[e] * (fx[e] - mean[e]); }
+    };
+    int p = p0 + lane;
+    for (; p + 3 * lanes < p1; p += 4 * lanes) {   // eight loads in flight
+      u32x4 vg[4], vx[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        vg[u] = cn_ld16((const char*)g + ((size_t)(p + u * lanes) * CC + cc) * 16);
+        vx[u] = cn_ld16((const char*)x + ((size_t)(p + u * lanes) * CC + cc) * 16);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) visit(vg[u], vx[u]);
     }
+    for (; p < p1; p += lanes)
+      visit(cn_ld16((const char*)g + ((size_t)p * CC + cc) * 16), cn_ld16((const char*)x + ((size_t)p * CC + cc) * 16));
   }
 #pragma unroll
   for (int e = 0; e < CH; ++e) { s1[tid * CH + e] = a1[e]; s2[tid * CH + e] = a2[e]; }

@@ -107,6 +107,9 @@ def trajectory(tag, model_kw, B, size, classes, steps, seed, dtype=torch.float):
             'bn1.running_mean', 'bn1.running_var', 'bn1.quantize_input.running_range', 'layer1.0.conv1.weight',
             'layer1.0.bn3.weight', 'layer2.0.downsample.0.weight', 'layer4.1.bn2.weight',
             'layer4.1.bn2.running_var', 'fc.weight', 'fc.bias', 'fc.quantize_input.running_range']
+    if size > 64:   # full-size model: keep the fixture small
+        keep = ['conv1.weight', 'conv1.quantize_input.running_range', 'bn1.running_mean', 'bn1.running_var',
+                'layer1.0.conv1.weight', 'fc.bias', 'fc.quantize_input.running_range', 'layer4.1.bn2.running_var']
     torch.save({k: sd[k].clone() for k in keep if k in sd}, os.path.join(OUT, 'traj_%s_final.pt' % tag))
     print(tag, recs, 'val', out['validate'])
 
@@ -179,7 +182,16 @@ def op_vectors():
     print('quant_ops.pt', {k: tuple(v.shape) for k, v in out.items()})
 
 
+def full():
+    """Full-size ResNet-50 with quantize=True (2048-channel layers, 7x7 maps with 49-value RangeBN chunks), B=16."""
+    trajectory('r50_quant_full', dict(depth=50), B=16, size=224, classes=1000, steps=2, seed=43)
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'full':
+        full()
+        assert not os.path.exists(os.path.join(REF, '__pycache__')), 'bytecode leaked into the reference tree'
+        sys.exit(0)
     op_vectors()
     trajectory('r50s_quant', dict(depth=50, **SMALL), B=16, size=64, classes=16, steps=3, seed=41)
     trajectory('r18s_quant', dict(depth=18, **SMALL), B=16, size=64, classes=16, steps=3, seed=42)

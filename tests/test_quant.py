@@ -284,3 +284,34 @@ def test_int8_mfma_forward_equals_the_simulated_convolution(mode, cfg, dtype):
         assert rel_l2(grads[1][0], grads[0][0]) < 1e-6 and rel_l2(grads[1][1], grads[0][1]) < 1e-6
     finally:
         ca.quant.set_noise_source(None)
+
+
+@pytest.mark.gpu
+def test_full_size_quantised_resnet50_follows_the_reference(reference_noise):
+    """ResNet-50 at full width (2048-channel layers, 7x7 maps: 49-value RangeBN chunks), B=16, 224x224, fp32,
+    against the reference Trainer's records (tests/golden/traj_r50_quant_full.json), on the reference's noise
+    stream.  Same tolerance band as the small models (quantisers amplify one-ulp differences)."""
+    dev = _dev('gpu')
+    import convnet_amd as ca
+    meta = json.load(open(os.path.join(GOLDEN, 'traj_r50_quant_full.json')))
+    torch.manual_seed(123)
+    model = ca.models.resnet(dataset='imagenet', quantize=True, depth=50)
+    sd = model.state_dict()
+    assert set(sd.keys()) == set(meta['keys'].keys())
+    for k, v in sd.items():
+        if v.dtype.is_floating_point:
+            assert abs(float(v.double().sum()) - meta['init_sums'][k][0]) <= 1e-6 * max(1.0, meta['init_sums'][k][1]), k
+    tr = ca.Trainer(model, ca.CrossEntropyLoss(), ca.OptimRegime(model, model.regime), device=str(dev),
+                    dtype=torch.float32, grad_clip=1e9, print_freq=10 ** 9)
+    g = torch.Generator().manual_seed(meta['seed'])
+    data = [(torch.randn(meta['B'], 3, meta['size'], meta['size'], generator=g),
+             torch.randint(0, meta['classes'], (meta['B'],), generator=g)) for _ in range(meta['steps'])]
+    for i, ((x, t), gr) in enumerate(zip(data, meta['records'])):
+        r = tr.train([(x, t)])
+        assert float(r['loss']) == pytest.approx(gr['loss'], abs=1e-3 if i == 0 else 3e-2), (i, r, gr)
+        assert float(r['grad']) == pytest.approx(gr['grad'], rel=3e-2), (i, r, gr)
+    final = torch.load(os.path.join(GOLDEN, 'traj_r50_quant_full_final.pt'))
+    sd = model.state_dict()
+    for k in ('conv1.weight', 'layer1.0.conv1.weight', 'bn1.running_mean', 'bn1.running_var',
+              'conv1.quantize_input.running_range', 'fc.quantize_input.running_range'):
+        assert rel_l2(sd[k].float().cpu(), final[k]) < 0.15, k
