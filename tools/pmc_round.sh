@@ -5,7 +5,7 @@
 export TMPDIR=/tmp
 OUT=gpurun_out/${1:-pmc1}
 mkdir -p $OUT
-LAYERS="2,3,10,13,16,19,22"
+LAYERS="2,3,10,13,15,16,19,22"
 run() { # name counters... -- cmd
   name=$1; shift; ctrs=$1; shift
   timeout 600 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $OUT/$name -o $name -- "$@" > $OUT/$name.log 2>&1
