@@ -32,7 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_TFLOPS = {'bf16': 2500.0, 'f16': 2500.0, 'f32': 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 TRAIN_GFLOP_PER_IMG = {50: 24.2991, 18: 10.6484}
 # compulsory HBM traffic per image of the SURVEY.md section 8(d) traffic model (MB): the whole-step HBM roofline
@@ -54,7 +54,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=256, help='per-GPU batch (BASELINE: 256)')
     ap.add_argument('--depth', type=int, default=50)
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f16', 'f32'])
     ap.add_argument('--pool', type=int, default=4, help='distinct pre-staged device batches')
     ap.add_argument('--host-inputs', action='store_true',
                     help='feed pinned HOST batches (PCIe-inclusive rate, for DESIGN.md; never the contract value)')
@@ -102,7 +102,7 @@ def main():
                                 world_size=world, rank=rank)
     assert not ca._lib.is_emulated()
 
-    dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    dtype = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[args.dtype]
     torch.manual_seed(123)
     model = ca.models.resnet(dataset='imagenet', depth=args.depth, quantize=args.quantize)
     crit = ca.CrossEntropyLoss()

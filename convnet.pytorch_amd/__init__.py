@@ -24,4 +24,5 @@ from .meters import AverageMeter, accuracy   # noqa: F401
 torch_dtypes = {  # utils.misc.torch_dtypes of the reference (main.py:18,136) + bfloat16
     'float': __import__('torch').float, 'float32': __import__('torch').float32,
     'bfloat16': __import__('torch').bfloat16, 'bf16': __import__('torch').bfloat16,
+    'half': __import__('torch').float16, 'float16': __import__('torch').float16,
 }

@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB = os.path.join(_HERE, os.environ.get('CONVNET_AMD_HIP_LIB', 'libconvnet_hip.so'))
 EMUL_LIB = os.path.join(_HERE, 'libconvnet_emul.so')
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 
 c_p = ctypes.c_void_p
 c_i = ctypes.c_int
@@ -97,6 +97,7 @@ _SIGNATURES = {
     'cn_comm_broadcast': (c_i, [c_p, c_p, c_ll, c_i, c_p]),
     'cn_comm_destroy': (c_i, [c_p]),
     'cn_probe_mfma_bf16': (c_i, [c_p, c_p, c_p, c_p]),
+    'cn_probe_mfma_f16': (c_i, [c_p, c_p, c_p, c_p]),
     'cn_probe_mfma_f32': (c_i, [c_p, c_p, c_p, c_p]),
     'cn_probe_tr16': (c_i, [c_p, c_p, c_p]),
     'cn_probe_mfma_i8': (c_i, [c_p, c_p, c_p, c_p]),
@@ -175,7 +176,9 @@ def dtype_code(dtype):
         return F32
     if dtype == torch.bfloat16:
         return BF16
-    raise ConvNetHipError('unsupported compute dtype %s (float32 / bfloat16 only)' % dtype)
+    if dtype == torch.float16:
+        return F16
+    raise ConvNetHipError('unsupported compute dtype %s (float32 / bfloat16 / float16 only)' % dtype)
 
 
 def chunk_elems(dtype):

@@ -40,7 +40,7 @@ static BnMap bn_map(int cpr) {
 // "bn_nt" = 0 use the cached policy: whole-step A/B knobs)
 static int bn_nt_flag(long long M, int C, int dtype) {
   if (cn_get_option("bn_nt", 1) == 0) return 0;
-  const long long bytes = M * C * (dtype == CN_BF16 ? 2 : 4);
+  const long long bytes = M * C * cn_dtype_bytes(dtype);
   return bytes < (long long)cn_get_option("bn_nt_min_mb", 0) * (1ll << 20) ? 0 : 1;
 }
 // Cache policy of the streaming passes is a COMPILE-TIME parameter of the kernels (NT): a run-time select
@@ -639,6 +639,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(BnPoolGeom geo, 
     if ((dtype) == CN_BF16) {                                                                      \
       if (nt) CN_LAUNCH((kern<bf16_t, true>), grid, dim3(256), stream, __VA_ARGS__);                \
       else CN_LAUNCH((kern<bf16_t, false>), grid, dim3(256), stream, __VA_ARGS__);                  \
+    } else if ((dtype) == CN_F16) {                                                                \
+      if (nt) CN_LAUNCH((kern<f16_t, true>), grid, dim3(256), stream, __VA_ARGS__);                 \
+      else CN_LAUNCH((kern<f16_t, false>), grid, dim3(256), stream, __VA_ARGS__);                   \
     } else {                                                                                       \
       if (nt) CN_LAUNCH((kern<float, true>), grid, dim3(256), stream, __VA_ARGS__);                 \
       else CN_LAUNCH((kern<float, false>), grid, dim3(256), stream, __VA_ARGS__);                   \
@@ -653,7 +656,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(BnPoolGeom geo, 
 #define BN_REVERSE_DEFAULT 0
 
 extern "C" size_t cn_bn_workspace(int M, int C, int dtype) {
-  const int CH = dtype == CN_BF16 ? 8 : 4;
+  const int CH = cn_dtype_chunk(dtype);
   if (C % CH != 0 || M <= 0) return 0;
   BnMap m = bn_map(C / CH);
   int nrb = bn_row_blocks(M, m, 2048);   // upper bound over the tunable reduce-grid sizes
@@ -664,8 +667,8 @@ extern "C" size_t cn_bn_workspace(int M, int C, int dtype) {
 }
 
 static int bn_check(const char* who, int M, int C, int dtype) {
-  if (dtype != CN_BF16 && dtype != CN_F32) { cn_set_error("%s: bad dtype %d", who, dtype); return CN_EINVAL; }
-  const int CH = dtype == CN_BF16 ? 8 : 4;
+  if (!cn_dtype_ok(dtype)) { cn_set_error("%s: bad dtype %d", who, dtype); return CN_EINVAL; }
+  const int CH = cn_dtype_chunk(dtype);
   if (M <= 0 || C <= 0 || C % CH != 0) {
     cn_set_error("%s: need M>0 and C (%d) a multiple of %d", who, C, CH);
     return CN_ESHAPE;
@@ -699,7 +702,7 @@ extern "C" int cn_bn_fwd_train(const void* y, const void* residual, void* z, uns
   int rc = bn_check("bn_fwd_train", M, C, dtype);
   if (rc) return rc;
   hipStream_t stream = (hipStream_t)stream_;
-  const int CH = dtype == CN_BF16 ? 8 : 4;
+  const int CH = cn_dtype_chunk(dtype);
   BnMap m = bn_map(C / CH);
   int nrb = bn_row_blocks(M, m, cn_get_option("bn_reduce_blocks", BN_TARGET_BLOCKS));
   if (workspace == nullptr || ws_bytes < (size_t)nrb * 2 * C * sizeof(float)) {
@@ -708,10 +711,7 @@ extern "C" int cn_bn_fwd_train(const void* y, const void* residual, void* z, uns
   }
   float* partial = (float*)workspace;
   dim3 grid((unsigned)nrb, (unsigned)m.gy);
-  if (dtype == CN_BF16)
-    CN_LAUNCH(bn_stats_kernel<bf16_t>, grid, dim3(256), stream, (const char*)y, partial, M, C, m.tpr_log2);
-  else
-    CN_LAUNCH(bn_stats_kernel<float>, grid, dim3(256), stream, (const char*)y, partial, M, C, m.tpr_log2);
+  CN_DISPATCH_T(dtype, CN_LAUNCH(bn_stats_kernel<TT>, grid, dim3(256), stream, (const char*)y, partial, M, C, m.tpr_log2));
   return bn_fwd_tail(partial, nrb, y, residual, z, relu_mask, gamma, beta, running_mean, running_var,
                      num_batches_tracked, momentum, eps, stats_out, M, C, relu, dtype, m, stream);
 }
@@ -728,7 +728,7 @@ extern "C" int cn_bn_fwd_train_partials(const void* y, const void* residual, voi
   if (rc) return rc;
   if (partial == nullptr || nrb <= 0) { cn_set_error("bn_fwd_train_partials: no partials"); return CN_EINVAL; }
   hipStream_t stream = (hipStream_t)stream_;
-  const int CH = dtype == CN_BF16 ? 8 : 4;
+  const int CH = cn_dtype_chunk(dtype);
   BnMap m = bn_map(C / CH);
   if (nrb > BN_TARGET_BLOCKS) {
     const int G = (nrb + BN_TARGET_BLOCKS - 1) / BN_TARGET_BLOCKS;
@@ -753,7 +753,7 @@ extern "C" int cn_bn_fwd_infer(const void* y, const void* residual, void* z, con
   int rc = bn_check("bn_fwd_infer", M, C, dtype);
   if (rc) return rc;
   hipStream_t stream = (hipStream_t)stream_;
-  const int CH = dtype == CN_BF16 ? 8 : 4;
+  const int CH = cn_dtype_chunk(dtype);
   BnMap m = bn_map(C / CH);
   CN_LAUNCH(bn_infer_coeffs_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), stream, C, gamma, beta,
             running_mean, running_var, eps, coeffs, coeffs + C);
@@ -774,7 +774,7 @@ extern "C" int cn_bn_bwd(const void* dz, const void* y, const unsigned char* rel
   int rc = bn_check("bn_bwd", M, C, dtype);
   if (rc) return rc;
   hipStream_t stream = (hipStream_t)stream_;
-  const int CH = dtype == CN_BF16 ? 8 : 4;
+  const int CH = cn_dtype_chunk(dtype);
   BnMap m = bn_map(C / CH);
   int nrb = bn_row_blocks(M, m, cn_get_option("bn_reduce_blocks", BN_TARGET_BLOCKS));
   if (workspace == nullptr || ws_bytes < (size_t)nrb * 2 * C * sizeof(float)) {
@@ -809,7 +809,7 @@ extern "C" int cn_bn_bwd_partials(const void* g, const void* y, const float* gam
   if (rc) return rc;
   if (partial == nullptr || nrb <= 0) { cn_set_error("bn_bwd_partials: no partials"); return CN_EINVAL; }
   hipStream_t stream = (hipStream_t)stream_;
-  const int CH = dtype == CN_BF16 ? 8 : 4;
+  const int CH = cn_dtype_chunk(dtype);
   BnMap m = bn_map(C / CH);
   if (nrb > BN_TARGET_BLOCKS) {
     const int G = (nrb + BN_TARGET_BLOCKS - 1) / BN_TARGET_BLOCKS;
@@ -924,7 +924,7 @@ extern "C" int cn_bn_local_sums(const void* y, int M, int C, int dtype, const fl
   if (rc) return rc;
   hipStream_t stream = (hipStream_t)stream_;
   if (partial == nullptr) {
-    const int CH = dtype == CN_BF16 ? 8 : 4;
+    const int CH = cn_dtype_chunk(dtype);
     BnMap m = bn_map(C / CH);
     nrb = bn_row_blocks(M, m, cn_get_option("bn_reduce_blocks", BN_TARGET_BLOCKS));
     if (workspace == nullptr || ws_bytes < (size_t)nrb * 2 * C * sizeof(float)) {
@@ -932,10 +932,7 @@ extern "C" int cn_bn_local_sums(const void* y, int M, int C, int dtype, const fl
       return CN_EWORKSPACE;
     }
     dim3 grid((unsigned)nrb, (unsigned)m.gy);
-    if (dtype == CN_BF16)
-      CN_LAUNCH(bn_stats_kernel<bf16_t>, grid, dim3(256), stream, (const char*)y, (float*)workspace, M, C, m.tpr_log2);
-    else
-      CN_LAUNCH(bn_stats_kernel<float>, grid, dim3(256), stream, (const char*)y, (float*)workspace, M, C, m.tpr_log2);
+    CN_DISPATCH_T(dtype, CN_LAUNCH(bn_stats_kernel<TT>, grid, dim3(256), stream, (const char*)y, (float*)workspace, M, C, m.tpr_log2));
     partial = (const float*)workspace;
   }
   CN_LAUNCH(bn_partials_total_kernel, dim3((unsigned)((2 * C + 31) / 32)), dim3(256), stream, partial, nrb, 2 * C, sums);
@@ -952,7 +949,7 @@ extern "C" int cn_bn_fwd_train_sums(const void* y, const void* residual, void* z
   if (rc) return rc;
   if (sums == nullptr || m_total < M) { cn_set_error("bn_fwd_train_sums: bad sums / m_total"); return CN_EINVAL; }
   hipStream_t stream = (hipStream_t)stream_;
-  const int CH = dtype == CN_BF16 ? 8 : 4;
+  const int CH = cn_dtype_chunk(dtype);
   BnMap m = bn_map(C / CH);
   CN_LAUNCH(bn_finalize_sums_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), stream, sums, m_total, C, gamma,
             beta, running_mean, running_var, num_batches_tracked, momentum, eps, stats_out, stats_out + C,
@@ -972,7 +969,7 @@ extern "C" int cn_bn_bwd_local_sums(const void* dz, const void* y, const unsigne
   if (rc) return rc;
   hipStream_t stream = (hipStream_t)stream_;
   if (partial == nullptr) {
-    const int CH = dtype == CN_BF16 ? 8 : 4;
+    const int CH = cn_dtype_chunk(dtype);
     BnMap m = bn_map(C / CH);
     nrb = bn_row_blocks(M, m, cn_get_option("bn_reduce_blocks", BN_TARGET_BLOCKS));
     if (workspace == nullptr || ws_bytes < (size_t)nrb * 2 * C * sizeof(float)) {
@@ -1001,7 +998,7 @@ extern "C" int cn_bn_bwd_sums(const void* dz, const void* y, const unsigned char
     return CN_EINVAL;
   }
   hipStream_t stream = (hipStream_t)stream_;
-  const int CH = dtype == CN_BF16 ? 8 : 4;
+  const int CH = cn_dtype_chunk(dtype);
   BnMap m = bn_map(C / CH);
   const float* mean = stats;
   const float* invstd = stats + C;
@@ -1034,7 +1031,7 @@ extern "C" int cn_bn_bwd_maxpool(const void* dpool, const unsigned char* idx, co
     return CN_ESHAPE;
   }
   hipStream_t stream = (hipStream_t)stream_;
-  const int CH = dtype == CN_BF16 ? 8 : 4;
+  const int CH = cn_dtype_chunk(dtype);
   BnMap m = bn_map(C / CH);
   int nrb = bn_row_blocks(M, m, cn_get_option("bn_reduce_blocks", BN_TARGET_BLOCKS));
   if (workspace == nullptr || ws_bytes < (size_t)nrb * 2 * C * sizeof(float)) {
@@ -1055,21 +1052,13 @@ extern "C" int cn_bn_bwd_maxpool(const void* dpool, const unsigned char* idx, co
   const float* scale = stats + 2 * C;
   const float* shift = stats + 3 * C;
   dim3 grid((unsigned)nrb, (unsigned)m.gy);
-  if (dtype == CN_BF16)
-    CN_LAUNCH(bn_bwd_reduce_pool_kernel<bf16_t>, grid, dim3(256), stream, geo, (const char*)y, mean, invstd, scale,
-              shift, partial, M, C, m.tpr_log2);
-  else
-    CN_LAUNCH(bn_bwd_reduce_pool_kernel<float>, grid, dim3(256), stream, geo, (const char*)y, mean, invstd, scale,
-              shift, partial, M, C, m.tpr_log2);
+  CN_DISPATCH_T(dtype, CN_LAUNCH(bn_bwd_reduce_pool_kernel<TT>, grid, dim3(256), stream, geo, (const char*)y, mean, invstd, scale,
+              shift, partial, M, C, m.tpr_log2));
   CN_LAUNCH(bn_bwd_finalize_kernel, dim3((unsigned)((C + BN_FC - 1) / BN_FC)), dim3(256), stream, (const float*)partial,
             nrb, M, C, gamma, mean, invstd, dgamma, dbeta, beta_acc, gscale, coef_scratch);
   int nab = bn_row_blocks(M, m, cn_get_option("bn_apply_blocks", BN_APPLY_BLOCKS));
   dim3 agrid((unsigned)nab, (unsigned)m.gy);
-  if (dtype == CN_BF16)
-    CN_LAUNCH(bn_bwd_apply_pool_kernel<bf16_t>, agrid, dim3(256), stream, geo, (const char*)y, scale, shift,
-              (const float*)coef_scratch, (char*)dy, M, C, m.tpr_log2);
-  else
-    CN_LAUNCH(bn_bwd_apply_pool_kernel<float>, agrid, dim3(256), stream, geo, (const char*)y, scale, shift,
-              (const float*)coef_scratch, (char*)dy, M, C, m.tpr_log2);
+  CN_DISPATCH_T(dtype, CN_LAUNCH(bn_bwd_apply_pool_kernel<TT>, agrid, dim3(256), stream, geo, (const char*)y, scale, shift,
+              (const float*)coef_scratch, (char*)dy, M, C, m.tpr_log2));
   return cn_check_launch("bn_bwd_maxpool");
 }

@@ -25,11 +25,24 @@
 // dtype codes of the C ABI
 #define CN_F32 0
 #define CN_BF16 1
+#define CN_F16 2   /* IEEE half storage (the reference's --dtype half), fp32 accumulation */
+// storage-type facts by dtype code (the 16-bit types share chunk width and byte size)
+static inline int cn_dtype_ok(int dtype) { return dtype == CN_F32 || dtype == CN_BF16 || dtype == CN_F16; }
+static inline int cn_dtype_bytes(int dtype) { return dtype == CN_F32 ? 4 : 2; }
+static inline int cn_dtype_chunk(int dtype) { return dtype == CN_F32 ? 4 : 8; }
 
 void cn_set_error(const char* fmt, ...);
 int cn_check_launch(const char* what);
 int cn_get_option(const char* name, int dflt);
 void cn_set_last_kernel(const char* fmt, ...);
+
+// dtype code -> storage type: runs the statement(s) with `TT` bound to bf16_t / f16_t / float
+#define CN_DISPATCH_T(dtype, ...)                                          \
+  do {                                                                     \
+    if ((dtype) == CN_BF16) { typedef bf16_t TT; __VA_ARGS__; }            \
+    else if ((dtype) == CN_F16) { typedef f16_t TT; __VA_ARGS__; }         \
+    else { typedef float TT; __VA_ARGS__; }                                \
+  } while (0)
 
 // ---------------------------------------------------------------- launch macro
 #ifdef CN_EMULATE
@@ -52,6 +65,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 struct bf16_t { unsigned short v; };
+struct f16_t { unsigned short v; };
 
 // ---------------------------------------------------------------- bf16 <-> f32 (RNE)
 __host__ __device__ __forceinline__ float cn_bf16_to_f32(unsigned short h) {
@@ -83,7 +97,18 @@ __host__ __device__ __forceinline__ unsigned int cn_pack_bf16x2(float lo, float 
 }
 #endif
 
-// element traits: T = float or bf16_t
+// ---------------------------------------------------------------- fp16 <-> f32 (RNE; v_cvt_f16_f32 / v_cvt_f32_f16)
+__host__ __device__ __forceinline__ float cn_f16_to_f32(unsigned short h) {
+  return (float)__builtin_bit_cast(_Float16, h);
+}
+__host__ __device__ __forceinline__ unsigned short cn_f32_to_f16(float f) {
+  return __builtin_bit_cast(unsigned short, (_Float16)f);
+}
+__host__ __device__ __forceinline__ unsigned int cn_pack_f16x2(float lo, float hi) {
+  return (unsigned int)cn_f32_to_f16(lo) | ((unsigned int)cn_f32_to_f16(hi) << 16);
+}
+
+// element traits: T = float, bf16_t or f16_t
 template <typename T> struct ElemTraits;
 template <> struct ElemTraits<float> {
   static constexpr int kBytes = 4;
@@ -95,6 +120,29 @@ template <> struct ElemTraits<bf16_t> {
   static constexpr int kChunk = 8;
   static constexpr int kCode = CN_BF16;
 };
+template <> struct ElemTraits<f16_t> {
+  static constexpr int kBytes = 2;
+  static constexpr int kChunk = 8;
+  static constexpr int kCode = CN_F16;
+};
+// two fp32 -> one packed dword of T (16-bit storage types), and back
+template <typename T> __host__ __device__ __forceinline__ unsigned int cn_pack2(float lo, float hi);
+template <> __host__ __device__ __forceinline__ unsigned int cn_pack2<bf16_t>(float lo, float hi) { return cn_pack_bf16x2(lo, hi); }
+template <> __host__ __device__ __forceinline__ unsigned int cn_pack2<f16_t>(float lo, float hi) { return cn_pack_f16x2(lo, hi); }
+template <> __host__ __device__ __forceinline__ unsigned int cn_pack2<float>(float lo, float) { return __builtin_bit_cast(unsigned int, lo); }
+template <typename T> __host__ __device__ __forceinline__ void cn_unpack2(unsigned int v, float& lo, float& hi);
+template <> __host__ __device__ __forceinline__ void cn_unpack2<bf16_t>(unsigned int v, float& lo, float& hi) {
+  lo = __builtin_bit_cast(float, v << 16);
+  hi = __builtin_bit_cast(float, v & 0xffff0000u);
+}
+template <> __host__ __device__ __forceinline__ void cn_unpack2<f16_t>(unsigned int v, float& lo, float& hi) {
+  lo = cn_f16_to_f32((unsigned short)(v & 0xffffu));
+  hi = cn_f16_to_f32((unsigned short)(v >> 16));
+}
+template <> __host__ __device__ __forceinline__ void cn_unpack2<float>(unsigned int v, float& lo, float& hi) {
+  lo = __builtin_bit_cast(float, v);
+  hi = 0.f;
+}
 
 // Unpack a 16-byte chunk into floats / pack floats into a chunk.
 template <typename T> struct Chunk;
@@ -130,12 +178,31 @@ template <> struct Chunk<bf16_t> {
   }
 };
 
+template <> struct Chunk<f16_t> {
+  static constexpr int N = 8;
+  __host__ __device__ static __forceinline__ void unpack(const u32x4& c, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = cn_f16_to_f32((unsigned short)(c[i] & 0xffffu));
+      f[2 * i + 1] = cn_f16_to_f32((unsigned short)(c[i] >> 16));
+    }
+  }
+  __host__ __device__ static __forceinline__ u32x4 pack(const float* f) {
+    u32x4 c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c[i] = cn_pack_f16x2(f[2 * i], f[2 * i + 1]);
+    return c;
+  }
+};
+
 template <typename T> __host__ __device__ __forceinline__ float cn_load_elem(const T* p);
 template <> __host__ __device__ __forceinline__ float cn_load_elem<float>(const float* p) { return *p; }
 template <> __host__ __device__ __forceinline__ float cn_load_elem<bf16_t>(const bf16_t* p) {
   return cn_bf16_to_f32(p->v);
 }
+template <> __host__ __device__ __forceinline__ float cn_load_elem<f16_t>(const f16_t* p) { return cn_f16_to_f32(p->v); }
 template <typename T> __host__ __device__ __forceinline__ void cn_store_elem(T* p, float v);
+template <> __host__ __device__ __forceinline__ void cn_store_elem<f16_t>(f16_t* p, float v) { p->v = cn_f32_to_f16(v); }
 template <> __host__ __device__ __forceinline__ void cn_store_elem<float>(float* p, float v) { *p = v; }
 template <> __host__ __device__ __forceinline__ void cn_store_elem<bf16_t>(bf16_t* p, float v) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(CN_EMULATE)
@@ -186,6 +253,12 @@ __device__ __forceinline__ f32x16 cn_mfma_32x32x16_bf16(s16x8 a, s16x8 b, f32x16
 __device__ __forceinline__ f32x16 cn_mfma_32x32x2_f32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
+typedef _Float16 cn_f16x8_native __attribute__((ext_vector_type(8)));
+// same lane map as the bf16 form (pinned by cn_probe_mfma_f16)
+__device__ __forceinline__ f32x16 cn_mfma_32x32x16_f16(s16x8 a, s16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(cn_f16x8_native, a),
+                                                __builtin_bit_cast(cn_f16x8_native, b), c, 0, 0, 0);
+}
 // LDS transpose read (ds_read_b64_tr_b16).  Within each 16-lane group, lane L supplies the
 // address of 4 consecutive 16-bit elements in[L][0..3]; lane i receives
 //   out[i][j] = in[4*j + (i>>2)][i&3]      (i, L = lane & 15; j = 0..3)
@@ -211,6 +284,25 @@ static inline f32x16 cn_mfma_32x32x16_bf16(s16x8 a, s16x8 b, f32x16 c) {
       const P* pa = (const P*)all[i + 32 * (k >> 3)];
       const P* pb = (const P*)all[j + 32 * (k >> 3)];
       acc += cn_bf16_to_f32((unsigned short)pa->a[k & 7]) * cn_bf16_to_f32((unsigned short)pb->b[k & 7]);
+    }
+    d[r] += acc;
+  }
+  cn_emul::wave_release();
+  return d;
+}
+static inline f32x16 cn_mfma_32x32x16_f16(s16x8 a, s16x8 b, f32x16 c) {
+  struct P { s16x8 a, b; } mine{a, b};
+  const void* const* all = cn_emul::wave_gather(&mine);
+  int l = cn_emul::lane();
+  int j = l & 31;
+  f32x16 d = c;
+  for (int r = 0; r < 16; ++r) {
+    int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    float acc = 0.f;
+    for (int k = 0; k < 16; ++k) {
+      const P* pa = (const P*)all[i + 32 * (k >> 3)];
+      const P* pb = (const P*)all[j + 32 * (k >> 3)];
+      acc += cn_f16_to_f32((unsigned short)pa->a[k & 7]) * cn_f16_to_f32((unsigned short)pb->b[k & 7]);
     }
     d[r] += acc;
   }

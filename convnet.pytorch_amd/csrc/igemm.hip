@@ -64,6 +64,10 @@ __device__ __forceinline__ void ig_mma<bf16_t>(const u32x4& a, const u32x4& b, f
   acc = cn_mfma_32x32x16_bf16(__builtin_bit_cast(s16x8, a), __builtin_bit_cast(s16x8, b), acc);
 }
 template <>
+__device__ __forceinline__ void ig_mma<f16_t>(const u32x4& a, const u32x4& b, f32x16& acc) {
+  acc = cn_mfma_32x32x16_f16(__builtin_bit_cast(s16x8, a), __builtin_bit_cast(s16x8, b), acc);
+}
+template <>
 __device__ __forceinline__ void ig_mma<float>(const u32x4& a, const u32x4& b, f32x16& acc) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -431,8 +435,8 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
           *(f32x4*)dst = v;
         } else {
           u32x2 pk;
-          pk[0] = cn_pack_bf16x2(acc[a][b][q * 4], acc[a][b][q * 4 + 1]);
-          pk[1] = cn_pack_bf16x2(acc[a][b][q * 4 + 2], acc[a][b][q * 4 + 3]);
+          pk[0] = cn_pack2<T>(acc[a][b][q * 4], acc[a][b][q * 4 + 1]);
+          pk[1] = cn_pack2<T>(acc[a][b][q * 4 + 2], acc[a][b][q * 4 + 3]);
           *(u32x2*)dst = pk;
         }
       }
@@ -456,7 +460,8 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
         st[0] += f;
         st[2] = fmaf(f, f, st[2]);
       } else {
-        const float lo = __builtin_bit_cast(float, v << 16), hi = __builtin_bit_cast(float, v & 0xffff0000u);
+        float lo, hi;
+        cn_unpack2<T>(v, lo, hi);
         st[0] += lo;
         st[1] += hi;
         st[2] = fmaf(lo, lo, st[2]);
@@ -537,9 +542,9 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
               if (p.addend != nullptr) f += ((const float*)(p.addend + goff))[e];
               ((float*)dst)[e] = f;
             } else {
-              float f = cn_bf16_to_f32(((const unsigned short*)src)[e]);
-              if (p.addend != nullptr) f += cn_bf16_to_f32(((const unsigned short*)(p.addend + goff))[e]);
-              ((unsigned short*)dst)[e] = cn_f32_to_bf16(f);
+              float f = cn_load_elem<T>((const T*)src + e);
+              if (p.addend != nullptr) f += cn_load_elem<T>((const T*)(p.addend + goff) + e);
+              cn_store_elem<T>((T*)dst + e, f);
             }
           }
         }
@@ -651,7 +656,7 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
   p.dbg = cn_get_option("igemm_dbg", 0);
   p.x_nt = (cn_get_option("igemm_x_nt", 0) != 0 && p.ntaps == 1 && p.n_ntiles == 1 && p.simple) ? 1 : 0;
   dim3 grid((unsigned)(p.n_ntiles * n_mtiles));
-  const char* tname = std::is_same<T, float>::value ? "float" : "bf16_t";
+  const char* tname = std::is_same<T, float>::value ? "float" : (std::is_same<T, f16_t>::value ? "f16_t" : "bf16_t");
   // EPI: epilogue with global-side operands (residual-branch addend, fused BN-backward reduction)
 #define IG_GO2(WC, WP, TI, TJ, EP)                                                                              \
   do {                                                                                                         \
@@ -663,7 +668,7 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
     else CN_LAUNCH((igemm_kernel<T, WC, WP, TI, TJ, 2, OUTF32, true, false, EP>), grid, dim3(256), stream, p);        \
   } while (0)
 #define IG_GO(WC, WP, TI, TJ) do { if (epi) IG_GO2(WC, WP, TI, TJ, true); else IG_GO2(WC, WP, TI, TJ, false); } while (0)
-  if constexpr (std::is_same<T, bf16_t>::value && !OUTF32) {
+  if constexpr (sizeof(T) == 2 && !OUTF32) {
     // 256 pixels x 256 channels, 8 waves of 128 pixels x 64 channels, LDS-DMA double buffer, fragments double-buffered
     // in registers, one workgroup per CU: half the L2->LDS bytes per flop of the 128x128 tile.  It wins where the
     // reduction is long enough to amortise the big tile's ramp (>= 16 K tiles) and the launch still has about a
@@ -679,7 +684,7 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
       p.n_mtiles = (p.M + 255) / 256;
       dim3 g2((unsigned)(p.n_ntiles * p.n_mtiles));
       const bool fragdb = variant != 11;
-      cn_set_last_kernel("igemm_kernel<bf16_t, 4, 2, 2, 4, 2, false, true, %s, false>", fragdb ? "true" : "false");
+      cn_set_last_kernel("igemm_kernel<%s, 4, 2, 2, 4, 2, false, true, %s, false>", tname, fragdb ? "true" : "false");
       if (fragdb) CN_LAUNCH((igemm_kernel<T, 4, 2, 2, 4, 2, false, true, true, false>), g2, dim3(512), stream, p);
       else CN_LAUNCH((igemm_kernel<T, 4, 2, 2, 4, 2, false, true, false, false>), g2, dim3(512), stream, p);
       return cn_check_launch("igemm");
@@ -710,13 +715,14 @@ static int ig_dispatch(IgemmParams& p, int dtype, hipStream_t stream) {
   if (p.M <= 0 || p.Co <= 0) return CN_OK;
   if (p.x == nullptr || p.w == nullptr || p.y == nullptr) { cn_set_error("igemm: null operand"); return CN_EINVAL; }
   if (dtype == CN_BF16) return p.out_f32 ? ig_launch<bf16_t, true>(p, stream) : ig_launch<bf16_t, false>(p, stream);
+  if (dtype == CN_F16) return p.out_f32 ? ig_launch<f16_t, true>(p, stream) : ig_launch<f16_t, false>(p, stream);
   if (dtype == CN_F32) { p.out_f32 = 1; return ig_launch<float, true>(p, stream); }
   cn_set_error("igemm: bad dtype %d", dtype);
   return CN_EINVAL;
 }
 
 static int ig_common(IgemmParams& p, int dtype, int Ci, int ntaps) {
-  const int CH = dtype == CN_BF16 ? 8 : 4;
+  const int CH = cn_dtype_chunk(dtype);
   if (Ci % CH != 0) {
     cn_set_error("igemm: reduction channels %d not a multiple of the 16-byte chunk (%d elems)", Ci, CH);
     return CN_ESHAPE;
@@ -732,7 +738,7 @@ static int ig_common(IgemmParams& p, int dtype, int Ci, int ntaps) {
   p.M = p.N * p.Hg * p.Wg;
   p.div_hw = cn_make_fastdiv((unsigned)(p.Hg * p.Wg));
   p.div_w = cn_make_fastdiv((unsigned)p.Wg);
-  const int EB = dtype == CN_BF16 ? 2 : 4;
+  const int EB = cn_dtype_bytes(dtype);
   const long long xb = (long long)p.N * p.Hi * p.Wi * p.Ci * EB;
   const long long wb = (long long)p.Co * p.w_row * EB;
   if (xb >= (1ll << 31) || wb >= (1ll << 31)) {
@@ -909,7 +915,7 @@ extern "C" int cn_conv2d_dgrad_bnbwd(const void* dy, const void* w_crsk, void* g
                                      int pad_w, int dtype, const void* bn_y, const unsigned char* bn_mask,
                                      const float* bn_coef, int bn_relu, float* partial, int partial_rows,
                                      void* stream) {
-  const int CH = dtype == CN_BF16 ? 8 : 4;
+  const int CH = cn_dtype_chunk(dtype);
   if (bn_y == nullptr || bn_coef == nullptr || partial == nullptr || C % CH != 0) {
     cn_set_error("conv2d_dgrad_bnbwd: needs bn_y, bn_coef, partial and C (%d) a multiple of %d", C, CH);
     return CN_EINVAL;

@@ -98,6 +98,9 @@ extern "C" int cn_softmax_ce(const float* logits, const long long* target, void*
   if (dlogits != nullptr && grad_dtype == CN_BF16)
     CN_LAUNCH(softmax_ce_kernel<bf16_t>, dim3((unsigned)B), dim3(256), stream, logits, target, (bf16_t*)dlogits,
               row_scratch, B, K, gscale, gscale_dev, smooth_eps);
+  else if (dlogits != nullptr && grad_dtype == CN_F16)
+    CN_LAUNCH(softmax_ce_kernel<f16_t>, dim3((unsigned)B), dim3(256), stream, logits, target, (f16_t*)dlogits,
+              row_scratch, B, K, gscale, gscale_dev, smooth_eps);
   else
     CN_LAUNCH(softmax_ce_kernel<float>, dim3((unsigned)B), dim3(256), stream, logits, target, (float*)dlogits,
               row_scratch, B, K, gscale, gscale_dev, smooth_eps);

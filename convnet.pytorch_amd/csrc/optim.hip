@@ -296,13 +296,9 @@ extern "C" int cn_weight_prep(const float* w_master, void* w_krsc, void* w_crsk,
     return CN_ESHAPE;
   }
   dim3 grid(opt_grid((long long)Co * taps * Cpad, 2048));
-  if (dtype == CN_BF16)
-    CN_LAUNCH(weight_prep_kernel<bf16_t>, grid, dim3(256), stream, w_master, (bf16_t*)w_krsc, (bf16_t*)w_crsk, Co,
-              taps, Creal, Cpad);
-  else if (dtype == CN_F32)
-    CN_LAUNCH(weight_prep_kernel<float>, grid, dim3(256), stream, w_master, (float*)w_krsc, (float*)w_crsk, Co,
-              taps, Creal, Cpad);
-  else { cn_set_error("weight_prep: bad dtype"); return CN_EINVAL; }
+  if (!cn_dtype_ok(dtype)) { cn_set_error("weight_prep: bad dtype"); return CN_EINVAL; }
+  CN_DISPATCH_T(dtype, CN_LAUNCH(weight_prep_kernel<TT>, grid, dim3(256), stream, w_master, (TT*)w_krsc, (TT*)w_crsk, Co,
+              taps, Creal, Cpad));
   return cn_check_launch("weight_prep");
 }
 
@@ -311,11 +307,8 @@ extern "C" int cn_weight_prep_multi(const float* master, void* wbuf, const long 
   hipStream_t stream = (hipStream_t)stream_;
   if (nd <= 0 || total <= 0) return CN_OK;
   dim3 grid(opt_grid(total, 8192));
-  if (dtype == CN_BF16)
-    CN_LAUNCH(weight_prep_multi_kernel<bf16_t>, grid, dim3(256), stream, master, (bf16_t*)wbuf, desc, nd, total);
-  else if (dtype == CN_F32)
-    CN_LAUNCH(weight_prep_multi_kernel<float>, grid, dim3(256), stream, master, (float*)wbuf, desc, nd, total);
-  else { cn_set_error("weight_prep_multi: bad dtype"); return CN_EINVAL; }
+  if (!cn_dtype_ok(dtype)) { cn_set_error("weight_prep_multi: bad dtype"); return CN_EINVAL; }
+  CN_DISPATCH_T(dtype, CN_LAUNCH(weight_prep_multi_kernel<TT>, grid, dim3(256), stream, master, (TT*)wbuf, desc, nd, total));
   return cn_check_launch("weight_prep_multi");
 }
 
@@ -323,13 +316,9 @@ extern "C" int cn_weight_prep_tiled(const float* master, void* wbuf, const long 
                                     int ntiles, int dtype, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (ntiles <= 0) return CN_OK;
-  if (dtype == CN_BF16)
-    CN_LAUNCH(weight_prep_tiled_kernel<bf16_t>, dim3((unsigned)ntiles), dim3(256), stream, master, (bf16_t*)wbuf,
-              desc, tiles);
-  else if (dtype == CN_F32)
-    CN_LAUNCH(weight_prep_tiled_kernel<float>, dim3((unsigned)ntiles), dim3(256), stream, master, (float*)wbuf, desc,
-              tiles);
-  else { cn_set_error("weight_prep_tiled: bad dtype"); return CN_EINVAL; }
+  if (!cn_dtype_ok(dtype)) { cn_set_error("weight_prep_tiled: bad dtype"); return CN_EINVAL; }
+  CN_DISPATCH_T(dtype, CN_LAUNCH(weight_prep_tiled_kernel<TT>, dim3((unsigned)ntiles), dim3(256), stream, master, (TT*)wbuf,
+              desc, tiles));
   return cn_check_launch("weight_prep_tiled");
 }
 
@@ -359,11 +348,8 @@ extern "C" int cn_colsum(const void* x, float* out, int M, int C, int dtype, flo
   if (M <= 0 || C <= 0) { cn_set_error("colsum: empty"); return CN_ESHAPE; }
   int parts = M < CN_COLSUM_PARTS ? M : CN_COLSUM_PARTS;
   dim3 grid((unsigned)((C + 255) / 256), (unsigned)parts);
-  if (dtype == CN_BF16)
-    CN_LAUNCH(colsum_partial_kernel<bf16_t>, grid, dim3(256), stream, (const bf16_t*)x, workspace, M, C);
-  else if (dtype == CN_F32)
-    CN_LAUNCH(colsum_partial_kernel<float>, grid, dim3(256), stream, (const float*)x, workspace, M, C);
-  else { cn_set_error("colsum: bad dtype"); return CN_EINVAL; }
+  if (!cn_dtype_ok(dtype)) { cn_set_error("colsum: bad dtype"); return CN_EINVAL; }
+  CN_DISPATCH_T(dtype, CN_LAUNCH(colsum_partial_kernel<TT>, grid, dim3(256), stream, (const TT*)x, workspace, M, C));
   CN_LAUNCH(colsum_final_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), stream, (const float*)workspace,
             out, parts, C, beta, scale);
   return cn_check_launch("colsum");
@@ -374,7 +360,7 @@ extern "C" int cn_small_linear(int mode, const void* x, const float* w, const fl
   // mode 0: out = y (fp32) from x;  1: out = dx (T) from x := dy (fp32);  2: dw/db += from x (T), out := dy (fp32)
   hipStream_t stream = (hipStream_t)stream_;
   if (B <= 0 || C <= 0 || K <= 0) { cn_set_error("small_linear: empty"); return CN_ESHAPE; }
-  if (dtype != CN_BF16 && dtype != CN_F32) { cn_set_error("small_linear: bad dtype"); return CN_EINVAL; }
+  if (!cn_dtype_ok(dtype)) { cn_set_error("small_linear: bad dtype"); return CN_EINVAL; }
 #define SL(T)                                                                                                       \
   do {                                                                                                              \
     if (mode == 0)                                                                                                  \
@@ -387,7 +373,7 @@ extern "C" int cn_small_linear(int mode, const void* x, const float* w, const fl
       CN_LAUNCH(small_linear_wgrad_kernel<T>, dim3((unsigned)((K * (C + 1) + 255) / 256)), dim3(256), stream,        \
                 (const T*)x, (const float*)out, dw, db, B, C, K);                                                   \
   } while (0)
-  if (dtype == CN_BF16) SL(bf16_t); else SL(float);
+  if (dtype == CN_BF16) SL(bf16_t); else if (dtype == CN_F16) SL(f16_t); else SL(float);
 #undef SL
   return cn_check_launch("small_linear");
 }
@@ -396,9 +382,8 @@ extern "C" int cn_cast_from_f32(const float* x, void* y, long long n, int dtype,
   hipStream_t stream = (hipStream_t)stream_;
   if (n <= 0) return CN_OK;
   dim3 grid(opt_grid(n, 4096));
-  if (dtype == CN_BF16) CN_LAUNCH(cast_kernel<bf16_t>, grid, dim3(256), stream, x, (bf16_t*)y, n);
-  else if (dtype == CN_F32) CN_LAUNCH(cast_kernel<float>, grid, dim3(256), stream, x, (float*)y, n);
-  else { cn_set_error("cast: bad dtype"); return CN_EINVAL; }
+  if (!cn_dtype_ok(dtype)) { cn_set_error("cast: bad dtype"); return CN_EINVAL; }
+  CN_DISPATCH_T(dtype, CN_LAUNCH(cast_kernel<TT>, grid, dim3(256), stream, x, (TT*)y, n));
   return cn_check_launch("cast");
 }
 

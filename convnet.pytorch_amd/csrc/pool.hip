@@ -296,14 +296,15 @@ static unsigned pool_grid(long long total) {
   return (unsigned)nb;
 }
 static int pool_check(const char* who, int C, int dtype) {
-  if (dtype != CN_BF16 && dtype != CN_F32) { cn_set_error("%s: bad dtype %d", who, dtype); return CN_EINVAL; }
-  const int CH = dtype == CN_BF16 ? 8 : 4;
+  if (!cn_dtype_ok(dtype)) { cn_set_error("%s: bad dtype %d", who, dtype); return CN_EINVAL; }
+  const int CH = cn_dtype_chunk(dtype);
   if (C <= 0 || C % CH != 0) { cn_set_error("%s: C=%d must be a multiple of %d", who, C, CH); return CN_ESHAPE; }
   return CN_OK;
 }
 #define POOL_DISPATCH(kern, grid, stream, ...)                                          \
   do {                                                                                  \
     if (dtype == CN_BF16) CN_LAUNCH(kern<bf16_t>, grid, dim3(256), stream, __VA_ARGS__); \
+    else if (dtype == CN_F16) CN_LAUNCH(kern<f16_t>, grid, dim3(256), stream, __VA_ARGS__); \
     else CN_LAUNCH(kern<float>, grid, dim3(256), stream, __VA_ARGS__);                   \
   } while (0)
 
@@ -313,7 +314,7 @@ extern "C" int cn_maxpool_fwd(const void* x, void* y, unsigned char* idx, int N,
   if (rc) return rc;
   if (k * k > 255 || pad * 2 > k) { cn_set_error("maxpool_fwd: unsupported window"); return CN_ESHAPE; }
   const int P = (H + 2 * pad - k) / stride + 1, Q = (W + 2 * pad - k) / stride + 1;
-  const int CH = dtype == CN_BF16 ? 8 : 4;
+  const int CH = cn_dtype_chunk(dtype);
   const long long rows_f = (long long)N * P;
   dim3 grid((unsigned)((Q * (C / CH) + 255) / 256), (unsigned)(rows_f < 65535 ? rows_f : 65535));
   const FastDiv div_cpr = cn_make_fastdiv((unsigned)(C / CH));
@@ -322,6 +323,7 @@ extern "C" int cn_maxpool_fwd(const void* x, void* y, unsigned char* idx, int N,
             W, C, P, Q, k, stride, pad, div_cpr, SC, SH)
   const float* none = nullptr;
   if (dtype == CN_BF16) { if (k == 3) MP_GO(bf16_t, false, 3, none, none); else MP_GO(bf16_t, false, 0, none, none); }
+  else if (dtype == CN_F16) { if (k == 3) MP_GO(f16_t, false, 3, none, none); else MP_GO(f16_t, false, 0, none, none); }
   else { if (k == 3) MP_GO(float, false, 3, none, none); else MP_GO(float, false, 0, none, none); }
   return cn_check_launch("maxpool_fwd");
 }
@@ -339,11 +341,12 @@ extern "C" int cn_maxpool_fwd_bnrelu(const void* x, const float* scale, const fl
     return CN_ESHAPE;
   }
   const int P = (H + 2 * pad - k) / stride + 1, Q = (W + 2 * pad - k) / stride + 1;
-  const int CH = dtype == CN_BF16 ? 8 : 4;
+  const int CH = cn_dtype_chunk(dtype);
   const long long rows_f = (long long)N * P;
   dim3 grid((unsigned)((Q * (C / CH) + 255) / 256), (unsigned)(rows_f < 65535 ? rows_f : 65535));
   const FastDiv div_cpr = cn_make_fastdiv((unsigned)(C / CH));
   if (dtype == CN_BF16) { if (k == 3) MP_GO(bf16_t, true, 3, scale, shift); else MP_GO(bf16_t, true, 0, scale, shift); }
+  else if (dtype == CN_F16) { if (k == 3) MP_GO(f16_t, true, 3, scale, shift); else MP_GO(f16_t, true, 0, scale, shift); }
   else { if (k == 3) MP_GO(float, true, 3, scale, shift); else MP_GO(float, true, 0, scale, shift); }
 #undef MP_GO
   return cn_check_launch("maxpool_fwd_bnrelu");
@@ -354,7 +357,7 @@ extern "C" int cn_maxpool_bwd(const void* dy, const unsigned char* idx, void* dx
   int rc = pool_check("maxpool_bwd", C, dtype);
   if (rc) return rc;
   const int P = (H + 2 * pad - k) / stride + 1, Q = (W + 2 * pad - k) / stride + 1;
-  const int CH = dtype == CN_BF16 ? 8 : 4;
+  const int CH = cn_dtype_chunk(dtype);
   const long long rows_b = (long long)N * H;
   dim3 grid((unsigned)((W * (C / CH) + 255) / 256), (unsigned)(rows_b < 65535 ? rows_b : 65535));
   const FastDiv div_cpr = cn_make_fastdiv((unsigned)(C / CH));
@@ -366,7 +369,7 @@ extern "C" int cn_maxpool_bwd(const void* dy, const unsigned char* idx, void* dx
 extern "C" int cn_avgpool_fwd(const void* x, void* y, int N, int HW, int C, int dtype, void* stream) {
   int rc = pool_check("avgpool_fwd", C, dtype);
   if (rc) return rc;
-  const int CH = dtype == CN_BF16 ? 8 : 4;
+  const int CH = cn_dtype_chunk(dtype);
   dim3 grid(pool_grid((long long)N * (C / CH)));
   POOL_DISPATCH(avgpool_fwd_kernel, grid, (hipStream_t)stream, (const char*)x, (char*)y, N, HW, C);
   return cn_check_launch("avgpool_fwd");
@@ -375,7 +378,7 @@ extern "C" int cn_avgpool_fwd(const void* x, void* y, int N, int HW, int C, int 
 extern "C" int cn_avgpool_bwd(const void* dy, void* dx, int N, int HW, int C, int dtype, void* stream) {
   int rc = pool_check("avgpool_bwd", C, dtype);
   if (rc) return rc;
-  const int CH = dtype == CN_BF16 ? 8 : 4;
+  const int CH = cn_dtype_chunk(dtype);
   dim3 grid(pool_grid((long long)N * HW * (C / CH)));
   POOL_DISPATCH(avgpool_bwd_kernel, grid, (hipStream_t)stream, (const char*)dy, (char*)dx, N, HW, C);
   return cn_check_launch("avgpool_bwd");
@@ -386,7 +389,7 @@ extern "C" int cn_nchw_to_nhwc(const float* x, void* y, int N, int C, int H, int
   int rc = pool_check("nchw_to_nhwc", Cpad, dtype);
   if (rc) return rc;
   if (Cpad < C) { cn_set_error("nchw_to_nhwc: Cpad < C"); return CN_ESHAPE; }
-  const int CH = dtype == CN_BF16 ? 8 : 4;
+  const int CH = cn_dtype_chunk(dtype);
   dim3 grid(pool_grid((long long)N * H * W * (Cpad / CH)));
   POOL_DISPATCH(nchw_to_nhwc_kernel, grid, (hipStream_t)stream, x, (char*)y, N, C, H * W, Cpad);
   return cn_check_launch("nchw_to_nhwc");
@@ -406,7 +409,7 @@ extern "C" int cn_nchw_to_pairs(const float* x, void* y, int N, int C, int H, in
 
 extern "C" int cn_nhwc_to_nchw(const void* x, float* y, int N, int C, int H, int W, int Cpad, int dtype,
                                void* stream) {
-  if (dtype != CN_BF16 && dtype != CN_F32) { cn_set_error("nhwc_to_nchw: bad dtype"); return CN_EINVAL; }
+  if (!cn_dtype_ok(dtype)) { cn_set_error("nhwc_to_nchw: bad dtype"); return CN_EINVAL; }
   dim3 grid(pool_grid((long long)N * C * H * W));
   POOL_DISPATCH(nhwc_to_nchw_kernel, grid, (hipStream_t)stream, (const char*)x, y, N, C, H * W, Cpad);
   return cn_check_launch("nhwc_to_nchw");
@@ -414,8 +417,8 @@ extern "C" int cn_nhwc_to_nchw(const void* x, float* y, int N, int C, int H, int
 
 // op: 0  a += b;  1  a = relu(b);  2  a = b * (c > 0);  3  a = b * c.   n = element count (multiple of the chunk).
 extern "C" int cn_eltwise(int op, void* a, const void* b, const void* c, long long n, int dtype, void* stream) {
-  if (dtype != CN_BF16 && dtype != CN_F32) { cn_set_error("eltwise: bad dtype"); return CN_EINVAL; }
-  const int CH = dtype == CN_BF16 ? 8 : 4;
+  if (!cn_dtype_ok(dtype)) { cn_set_error("eltwise: bad dtype"); return CN_EINVAL; }
+  const int CH = cn_dtype_chunk(dtype);
   if (n % CH != 0) { cn_set_error("eltwise: n=%lld not a multiple of %d", n, CH); return CN_ESHAPE; }
   if (n == 0) return CN_OK;
   const long long nch = n / CH;
@@ -425,6 +428,10 @@ extern "C" int cn_eltwise(int op, void* a, const void* b, const void* c, long lo
   if (dtype == CN_BF16) {
     if (op == 0) ELT(bf16_t, 0); else if (op == 1) ELT(bf16_t, 1); else if (op == 2) ELT(bf16_t, 2);
     else if (op == 3) ELT(bf16_t, 3); else if (op == 4) ELT(bf16_t, 4);
+    else { cn_set_error("eltwise: bad op"); return CN_EINVAL; }
+  } else if (dtype == CN_F16) {
+    if (op == 0) ELT(f16_t, 0); else if (op == 1) ELT(f16_t, 1); else if (op == 2) ELT(f16_t, 2);
+    else if (op == 3) ELT(f16_t, 3); else if (op == 4) ELT(f16_t, 4);
     else { cn_set_error("eltwise: bad op"); return CN_EINVAL; }
   } else {
     if (op == 0) ELT(float, 0); else if (op == 1) ELT(float, 1); else if (op == 2) ELT(float, 2);

@@ -24,6 +24,22 @@ __global__ __launch_bounds__(64) void probe_mfma_bf16_kernel(const unsigned shor
   }
 }
 
+// the same with v_mfma_f32_32x32x16_f16 (operands as fp16 bit patterns)
+__global__ __launch_bounds__(64) void probe_mfma_f16_kernel(const unsigned short* A, const unsigned short* B,
+                                                           float* D) {
+  const int l = threadIdx.x;
+  s16x8 a, b;
+  for (int e = 0; e < 8; ++e) {
+    const int k = 8 * (l >> 5) + e;
+    a[e] = (short)A[(l & 31) * 16 + k];
+    b[e] = (short)B[k * 32 + (l & 31)];
+  }
+  f32x16 c;
+  for (int r = 0; r < 16; ++r) c[r] = 0.f;
+  c = cn_mfma_32x32x16_f16(a, b, c);
+  for (int r = 0; r < 16; ++r) D[((r & 3) + 8 * (r >> 2) + 4 * (l >> 5)) * 32 + (l & 31)] = c[r];
+}
+
 // D[32][32] = A[32][2] * B[2][32] with one v_mfma_f32_32x32x2_f32.
 __global__ __launch_bounds__(64) void probe_mfma_f32_kernel(const float* A, const float* B, float* D) {
   const int l = threadIdx.x;
@@ -52,6 +68,10 @@ __global__ __launch_bounds__(64) void probe_tr16_kernel(const unsigned short* sr
 extern "C" int cn_probe_mfma_bf16(const unsigned short* A, const unsigned short* B, float* D, void* stream) {
   CN_LAUNCH(probe_mfma_bf16_kernel, dim3(1), dim3(64), (hipStream_t)stream, A, B, D);
   return cn_check_launch("probe_mfma_bf16");
+}
+extern "C" int cn_probe_mfma_f16(const unsigned short* A, const unsigned short* B, float* D, void* stream) {
+  CN_LAUNCH(probe_mfma_f16_kernel, dim3(1), dim3(64), (hipStream_t)stream, A, B, D);
+  return cn_check_launch("probe_mfma_f16");
 }
 extern "C" int cn_probe_mfma_f32(const float* A, const float* B, float* D, void* stream) {
   CN_LAUNCH(probe_mfma_f32_kernel, dim3(1), dim3(64), (hipStream_t)stream, A, B, D);

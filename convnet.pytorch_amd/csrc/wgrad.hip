@@ -161,7 +161,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
 #pragma unroll
         for (int a = 0; a < TI; ++a)
 #pragma unroll
-          for (int b = 0; b < TJ; ++b) acc[a][b] = cn_mfma_32x32x16_bf16(af[a], bfr[b], acc[a][b]);
+          for (int b = 0; b < TJ; ++b) {
+            if constexpr (std::is_same<T, f16_t>::value) acc[a][b] = cn_mfma_32x32x16_f16(af[a], bfr[b], acc[a][b]);
+            else acc[a][b] = cn_mfma_32x32x16_bf16(af[a], bfr[b], acc[a][b]);
+          }
       }
     } else {
 #pragma unroll 4
@@ -606,7 +609,7 @@ static WgradPlan wg_plan(int M, int Co, int ntaps, int Ci, int dtype, bool simpl
   }
   pl.BI = Co <= 64 ? 64 : 128;
   pl.BJ = 128;
-  pl.BKP = dtype == CN_BF16 ? 64 : 32;
+  pl.BKP = dtype == CN_F32 ? 32 : 64;
   pl.n_itiles = (Co + pl.BI - 1) / pl.BI;
   pl.n_jtiles = (pl.ncols + pl.BJ - 1) / pl.BJ;
   int tiles = pl.n_itiles * pl.n_jtiles;
@@ -647,19 +650,20 @@ static void wg_launch(const WgradParams& p, const WgradPlan& pl, hipStream_t str
   // 2 = LDS-DMA everywhere.
   const int wv = cn_get_option("wgrad_variant", 0);
   if (pl.BI == 256) {
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (std::is_same<T, bf16_t>::value) {
       cn_set_last_kernel("wgrad_dma256_kernel");
       CN_LAUNCH(wgrad_dma256_kernel, grid, dim3(512), stream, p);
     }
     return;
   }
-  if (sizeof(T) == 2 && (wv == 2 || (wv == 0 && p.simple))) {
+  if (std::is_same<T, bf16_t>::value && (wv == 2 || (wv == 0 && p.simple))) {   // (the LDS-DMA kernels are bf16 instantiations)
     cn_set_last_kernel("wgrad_dma_kernel<%d>", pl.BI == 64 ? 64 : 128);
     if (pl.BI == 64) CN_LAUNCH((wgrad_dma_kernel<64>), grid, dim3(256), stream, p);
     else CN_LAUNCH((wgrad_dma_kernel<128>), grid, dim3(256), stream, p);
     return;
   }
-  cn_set_last_kernel("wgrad_kernel<%s, %d, 128>", std::is_same<T, float>::value ? "float" : "bf16_t", pl.BI == 64 ? 64 : 128);
+  cn_set_last_kernel("wgrad_kernel<%s, %d, 128>",
+                     std::is_same<T, float>::value ? "float" : (std::is_same<T, f16_t>::value ? "f16_t" : "bf16_t"), pl.BI == 64 ? 64 : 128);
   if (pl.BI == 64) CN_LAUNCH((wgrad_kernel<T, 64, 128>), grid, dim3(256), stream, p);
   else CN_LAUNCH((wgrad_kernel<T, 128, 128>), grid, dim3(256), stream, p);
 }
@@ -671,8 +675,8 @@ extern "C" int cn_conv2d_wgrad(const void* x, const void* dy, float* dw_krsc, in
   const int P = (H + 2 * pad_h - R) / stride_h + 1;
   const int Q = (W + 2 * pad_w - S) / stride_w + 1;
   if (P <= 0 || Q <= 0 || N <= 0) { cn_set_error("conv2d_wgrad: empty output"); return CN_ESHAPE; }
-  const int CH = dtype == CN_BF16 ? 8 : 4;
-  if (dtype != CN_BF16 && dtype != CN_F32) { cn_set_error("conv2d_wgrad: bad dtype"); return CN_EINVAL; }
+  const int CH = cn_dtype_chunk(dtype);
+  if (!cn_dtype_ok(dtype)) { cn_set_error("conv2d_wgrad: bad dtype"); return CN_EINVAL; }
   if (C % CH != 0 || K % CH != 0) {
     cn_set_error("conv2d_wgrad: C=%d / K=%d must be multiples of the 16-byte chunk (%d)", C, K, CH);
     return CN_ESHAPE;
@@ -693,7 +697,7 @@ extern "C" int cn_conv2d_wgrad(const void* x, const void* dy, float* dw_krsc, in
   p.stride_h = stride_h; p.stride_w = stride_w;
   p.ntaps = R * S; p.cpt = C / CH; p.ncols = pl.ncols;
   p.div_cpt = cn_make_fastdiv((unsigned)p.cpt);
-  const long long EBl = dtype == CN_BF16 ? 2 : 4;
+  const long long EBl = cn_dtype_bytes(dtype);
   const long long xb = (long long)N * H * W * C * EBl, dyb = (long long)N * P * Q * K * EBl;
   if (xb >= (1ll << 31) || dyb >= (1ll << 31)) {
     cn_set_error("conv2d_wgrad: operand exceeds the 2 GiB buffer-descriptor window");
@@ -709,6 +713,7 @@ extern "C" int cn_conv2d_wgrad(const void* x, const void* dy, float* dw_krsc, in
   for (int r = 0; r < R; ++r)
     for (int s = 0; s < S; ++s) p.tap_dhdw[r * S + s] = ((r - pad_h) & 0xffff) | ((s - pad_w) << 16);
   if (dtype == CN_BF16) wg_launch<bf16_t>(p, pl, (hipStream_t)stream);
+  else if (dtype == CN_F16) wg_launch<f16_t>(p, pl, (hipStream_t)stream);
   else wg_launch<float>(p, pl, (hipStream_t)stream);
   int rc = cn_check_launch("wgrad");
   if (rc) return rc;

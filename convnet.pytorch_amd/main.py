@@ -4,15 +4,15 @@ re-authored for the MI355X engine:
 
 * `models.__dict__[args.model](**{'dataset': ..., **literal_eval(--model-config)})` registry call,
   model-attached `regime` picked up exactly like main.py:243-253;
-* `--dtype float|bfloat16` (bf16 gets the reference's `half` policy: BN statistics / parameters and
-  master weights in fp32); `--device cuda`; distributed via the launcher env (`--local_rank`,
+* `--dtype float|bfloat16|half` (the 16-bit types get the reference's `half` policy, main.py:239-250: BN
+  statistics / parameters and master weights in fp32; fp16 wants `--loss-scale`, as in the reference); `--device cuda`; distributed via the launcher env (`--local_rank`,
   `--dist-init env://`, `--dist-backend nccl` = RCCL);
 * results dir with `config.json`, `log.txt`, `results.csv`, `checkpoint.pth.tar` /
   `model_best.pth.tar` holding the reference's keys (epoch, model, config, state_dict,
   optim_state_dict, best_prec1); `state_dict` tensors have the reference's OIHW shapes, so
   checkpoints load both ways;
 * data: a synthetic ImageNet-shaped dataset (`--dataset imagenet-synthetic`, the default here);
-  the JPEG input pipeline (data.py / preprocess.py) is listed under "next" in DESIGN.md.
+  `--dataset imagenet --datasets-dir ...` drives the image-folder pipeline of data.py.
 """
 import argparse
 import csv

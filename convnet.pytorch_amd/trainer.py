@@ -83,9 +83,12 @@ class Trainer(object):
                  bucket_mb=25.0, process_group=None):
         if mixup is not None or cutmix is not None or adapt_grad_norm is not None:
             raise NotImplementedError('mixup / cutmix / adapt_grad_norm are outside the MI355X hot path')
-        if dtype in (torch.half, torch.float16):
-            raise NotImplementedError("compute dtype 'half' is not supported on the MI355X path; "
-                                      "use bfloat16 (same BN-in-fp32 / fp32-master policy)")
+        if dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            raise NotImplementedError('compute dtype %s: float32, bfloat16 and float16 (the reference\'s `half`: fp32 '
+                                      'BatchNorm parameters / statistics and fp32 master weights, main.py:239-250) '
+                                      'are built' % dtype)
+        if dtype == torch.float16 and any(getattr(m, 'no_graph', False) for m in model.modules()):
+            raise NotImplementedError('resnet(quantize=True) runs in float32 or bfloat16 storage')
         self._model = model
         self.model = model
         self.criterion = criterion

@@ -16,7 +16,8 @@
  *     thread-local reason.
  *   - Activations are NHWC, filters KRSC ([Co][kh][kw][Ci]); the channel count of every tensor a
  *     kernel vector-loads must be a multiple of the 16-byte chunk (8 bf16 / 4 fp32 elements).
- *   - dtype: CN_F32 = 0, CN_BF16 = 1 (bf16 storage, fp32 accumulation).
+ *   - dtype: CN_F32 = 0, CN_BF16 = 1, CN_F16 = 2 (16-bit storage, fp32 accumulation; the simulated-8-bit and int8
+ *     entry points take CN_F32 / CN_BF16 only).
  */
 #ifndef CONVNET_HIP_H
 #define CONVNET_HIP_H
@@ -33,6 +34,7 @@ extern "C" {
 #define CN_ERCCL (-5)
 #define CN_F32 0
 #define CN_BF16 1
+#define CN_F16 2 /* IEEE half storage, fp32 accumulation (the reference's --dtype half) */
 
 const char* cn_last_error(void);
 const char* cn_build_info(void);
@@ -298,6 +300,8 @@ int cn_comm_destroy(void* handle);
 /* ---- hardware lane-map probes (tests only) -------------------------------------------------- */
 int cn_probe_mfma_bf16(const unsigned short* A /*32x16*/, const unsigned short* B /*16x32*/, float* D /*32x32*/,
                        void* stream);
+int cn_probe_mfma_f16(const unsigned short* A /*32x16*/, const unsigned short* B /*16x32*/, float* D /*32x32*/,
+                      void* stream);
 int cn_probe_mfma_f32(const float* A /*32x2*/, const float* B /*2x32*/, float* D, void* stream);
 int cn_probe_tr16(const unsigned short* src /*256*/, unsigned short* out /*64x4*/, void* stream);
 int cn_probe_mfma_i8(const signed char* A /*32x32*/, const signed char* B /*32x32*/, int* D /*32x32*/, void* stream);

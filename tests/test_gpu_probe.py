@@ -34,6 +34,19 @@ def test_mfma_bf16_lane_map(mode):
 
 
 @pytest.mark.parametrize('mode', MODES)
+def test_mfma_f16_lane_map(mode):
+    ca, dev, stream = _setup(mode)
+    g = torch.Generator().manual_seed(3)
+    A = torch.randint(-4, 5, (32, 16), generator=g).float()
+    B = torch.randint(-4, 5, (16, 32), generator=g).float()
+    Ah = A.to(torch.float16).view(torch.int16).to(dev)
+    Bh = B.to(torch.float16).view(torch.int16).to(dev)
+    D = torch.zeros(32, 32, device=dev)
+    ca._lib.check(ca._lib.load().cn_probe_mfma_f16(Ah.data_ptr(), Bh.data_ptr(), D.data_ptr(), stream))
+    assert torch.equal(D.cpu(), A @ B)
+
+
+@pytest.mark.parametrize('mode', MODES)
 def test_mfma_f32_lane_map(mode):
     ca, dev, stream = _setup(mode)
     g = torch.Generator().manual_seed(1)

@@ -13,7 +13,7 @@ from conftest import HAS_GPU
 from helpers import rel_l2
 
 MODES = [pytest.param('emul'), pytest.param('gpu', marks=pytest.mark.gpu)]
-DTYPES = [torch.float32, torch.bfloat16]
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
 
 
 def _dev(mode):
@@ -29,7 +29,16 @@ def _dev(mode):
 def _tol(dtype, grad=False):
     if dtype == torch.bfloat16:
         return 1e-2
+    if dtype == torch.float16:      # 11 significant bits against bf16's 8
+        return 2e-3
     return 1e-4 if grad else 1e-5
+
+
+def _f16_emul_subset(mode, dtype, keep=False):
+    """fp16 shares every kernel template with bf16: on the emulated (CPU) suite only the conv and BatchNorm tests
+    run it, the GPU suite runs all of them."""
+    if mode == 'emul' and dtype == torch.float16 and not keep:
+        pytest.skip('fp16 on the emulator: conv + BatchNorm tests only')
 
 
 def _q(t, dtype):
@@ -85,10 +94,11 @@ def _conv_case(cfg, dtype, dev, seed=0):
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_conv2d_fwd_dgrad_wgrad(mode, dtype):
     dev = _dev(mode)
+    _f16_emul_subset(mode, dtype, keep=True)
     cases = CONV_EMUL if mode == 'emul' else CONV_GPU
     bad = []
     for cfg in cases:
-        if dtype == torch.bfloat16 and cfg[3] % 8:
+        if dtype != torch.float32 and cfg[3] % 8:
             continue
         ef, ed, ew = _conv_case(cfg, dtype, dev)
         if ef > _tol(dtype) or ed > _tol(dtype, True) or ew > _tol(dtype, True):
@@ -110,10 +120,11 @@ def test_conv_epilogue_bn_statistics(mode, dtype):
     per-channel sum / sum of squares of the stored y, and a BatchNorm fed from those partials that
     matches the BatchNorm that re-reads y (models/resnet.py:141-165 conv -> bn pairs)."""
     dev = _dev(mode)
+    _f16_emul_subset(mode, dtype)
     import convnet_amd as ca
     ops, L = ca.ops, ca._lib.load()
     for (N, H, W, C, K, R, st, pad) in (STATS_EMUL if mode == 'emul' else STATS_GPU):
-        if dtype == torch.bfloat16 and C % 8:
+        if dtype != torch.float32 and C % 8:
             continue
         g = torch.Generator().manual_seed(K + H)
         xh = _nhwc(torch.randn(N, C, H, W, generator=g), dtype, dev)
@@ -162,6 +173,7 @@ def test_dgrad_epilogue_bn_backward_reduction(mode, dtype):
     """cn_conv2d_dgrad_bnbwd + cn_bn_bwd_partials == cn_conv2d_dgrad followed by cn_bn_bwd: the masked
     gradient g, the per-tile partial sums, and the BatchNorm input/parameter gradients."""
     dev = _dev(mode)
+    _f16_emul_subset(mode, dtype)
     import convnet_amd as ca
     ops, L = ca.ops, ca._lib.load()
     ch = ca._lib.chunk_elems(dtype)
@@ -234,6 +246,7 @@ def test_sync_batchnorm_building_blocks(mode, dtype):
     a two-shard split (sums added on the host, as the all-reduce would) reproduces BatchNorm over the
     concatenated batch."""
     dev = _dev(mode)
+    _f16_emul_subset(mode, dtype)
     import convnet_amd as ca
     lib, L, ops = ca._lib, ca._lib.load(), ca.ops
     code = lib.dtype_code(dtype)
@@ -355,6 +368,7 @@ def test_stem_bn_relu_maxpool_fused_equals_chain(mode, dtype):
     backward with the pool's gather folded into the BatchNorm backward) against the separate BatchNorm2d
     and MaxPool2d modules: same pooled map bit for bit, same gradients / statistics."""
     dev = _dev(mode)
+    _f16_emul_subset(mode, dtype)
     import convnet_amd as ca
     shapes = [(2, 16, 9, 11), (3, 8, 12, 12)] if mode == 'emul' else [(4, 64, 112, 112), (3, 72, 17, 13)]
     for (N, C, H, W) in shapes:
@@ -460,6 +474,7 @@ def test_wgrad_accumulates_and_scales(mode):
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_linear_with_bias_fp32_logits(mode, dtype):
     dev = _dev(mode)
+    _f16_emul_subset(mode, dtype)
     import convnet_amd as ca
     g = torch.Generator().manual_seed(1)
     B, C, K = (5, 64, 1000) if mode == 'emul' else (256, 2048, 1000)
@@ -493,6 +508,7 @@ def _bn_ref(y, gamma, beta, res, relu, eps=1e-5, momentum=0.1):
 @pytest.mark.parametrize('relu,use_res', [(False, False), (True, False), (True, True)])
 def test_batchnorm_train_fwd_bwd(mode, dtype, relu, use_res):
     dev = _dev(mode)
+    _f16_emul_subset(mode, dtype, keep=True)
     import convnet_amd as ca
     shapes = [(4, 16, 5, 5), (2, 72, 3, 7)] if mode == 'emul' else [(8, 64, 56, 56), (4, 2048, 7, 7), (3, 136, 9, 5)]
     for (N, C, H, W) in shapes:
@@ -541,6 +557,7 @@ def test_batchnorm_train_fwd_bwd(mode, dtype, relu, use_res):
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_maxpool_fwd_bwd_with_ties(mode, dtype):
     dev = _dev(mode)
+    _f16_emul_subset(mode, dtype)
     import convnet_amd as ca
     shapes = [(2, 8, 9, 9, 3, 2, 1), (1, 16, 8, 8, 2, 2, 0)] if mode == 'emul' else \
         [(4, 64, 112, 112, 3, 2, 1), (2, 32, 26, 26, 2, 2, 0), (3, 8, 13, 13, 2, 2, 0)]
@@ -562,6 +579,7 @@ def test_maxpool_fwd_bwd_with_ties(mode, dtype):
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_global_avgpool_and_fork_and_relu(mode, dtype):
     dev = _dev(mode)
+    _f16_emul_subset(mode, dtype)
     import convnet_amd as ca
     N, C, H, W = (2, 16, 7, 7) if mode == 'emul' else (8, 2048, 7, 7)
     g = torch.Generator().manual_seed(5)
@@ -648,6 +666,7 @@ def test_sgd_momentum_weight_decay_clip(mode):
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_layout_conversion_roundtrip(mode, dtype):
     dev = _dev(mode)
+    _f16_emul_subset(mode, dtype)
     import convnet_amd as ca
     N, C, H, W = (2, 3, 6, 5) if mode == 'emul' else (16, 3, 224, 224)
     x = torch.randn(N, C, H, W)
