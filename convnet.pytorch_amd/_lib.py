@@ -38,6 +38,7 @@ _SIGNATURES = {
     'cn_conv2d_fwd': (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 11 + [c_i, c_i, c_i, c_p]),
     'cn_conv2d_bnstats_rows': (c_i, [c_ll]),
     'cn_conv2d_fwd_bnstats': (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 11 + [c_i, c_i, c_p, c_i, c_p]),
+    'cn_conv2d_fwd_xf': (c_i, [c_p, c_p, c_i, c_p, c_p] + [c_i] * 11 + [c_i, c_p, c_i, c_p]),
     'cn_conv2d_dgrad': (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 11 + [c_i, c_i, c_p]),
     'cn_conv2d_dgrad_bnbwd_rows': (c_i, [c_i] * 6),
     'cn_conv2d_dgrad_bnbwd': (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 11 + [c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_p]),

@@ -51,6 +51,8 @@ struct IgemmParams {
   unsigned int x_bytes, w_bytes;   // extents of the gather source / filter tensors (buffer descriptors)
   int simple;                      // 1: no tap of a valid row ever leaves the image (skip bounds tests)
   int x_nt;                        // 1: every gathered element is read by one workgroup only -> non-temporal loads
+  const float* xf;                 // optional [scale(Ci) | shift(Ci)]: the gathered operand is act(x*scale+shift), applied on load (XF)
+  int xf_relu;
   int dbg;                         // measurement only ("igemm_dbg"): 1 = skip the reduction loop, 2 = skip the global stores
   FastDiv div_hw, div_w, div_cpt;
   int tap_dhdw[IG_MAX_TAPS];
@@ -96,8 +98,14 @@ __device__ __forceinline__ int ig_slot(int row, int chunk) {
 //       variant spends ~416 LDS cycles per K tile on ds_write_b128 against 512 MFMA cycles).
 //       STAGES = 4 with GLDS: a 4-deep DMA ring (3 K tiles in flight across raw barriers, counted
 //       vmcnt waits) for long reductions, one workgroup per CU.
-template <typename T, int WC, int WP, int TI, int TJ, int STAGES, bool OUTF32, bool GLDS, bool FRAGDB, bool EPI>
+// XF: the pixel operand is a BatchNorm input y whose normalisation + ReLU, z = act(y*scale[c] + shift[c]) rounded to T
+//     exactly as bn_apply stores it, is applied between the global load and the LDS store (register-staged variants
+//     only), so the inner BatchNorm's apply pass - one read and one write of the activation - disappears.  Padded taps
+//     stay zero (they are zeros of z, not of y).
+#define IG_XF_MAX 512
+template <typename T, int WC, int WP, int TI, int TJ, int STAGES, bool OUTF32, bool GLDS, bool FRAGDB, bool EPI, bool XF = false>
 __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
+  static_assert(!XF || (!GLDS && !EPI), "operand transform needs the register-staged path");
   static_assert(!GLDS || STAGES == 2 || STAGES == 4, "LDS-DMA needs the double-buffered tile or the 4-deep ring");
   constexpr int BN = WC * TI * 32;  // output channels per block
   constexpr int BM = WP * TJ * 32;  // pixels per block
@@ -110,10 +118,11 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
   constexpr int STAGE = (BM + BN) * 128;
   constexpr int OUT_MAX = BM * (BN * (OUTF32 ? 4 : EB) + 16);
   constexpr int MAIN = (STAGES * STAGE > OUT_MAX) ? STAGES * STAGE : OUT_MAX;
-  constexpr int LDS_BYTES = MAIN + IG_MAX_TAPS * 16 + BM * 4;
+  constexpr int LDS_BYTES = MAIN + IG_MAX_TAPS * 16 + BM * 4 + (XF ? IG_XF_MAX * 8 : 0);
   __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
   int* s_taps = (int*)(lds + MAIN);                       // per tap: {dhdw, woff bytes, x delta bytes, 0}
   int* s_outpix = (int*)(lds + MAIN + IG_MAX_TAPS * 16);
+  float* s_xf = (float*)(lds + MAIN + IG_MAX_TAPS * 16 + BM * 4);   // XF: [scale | shift] of the Ci input channels
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -150,6 +159,9 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
       pix = (n * p.Ho + hg * p.oh_mul + p.oh_off) * p.Wo + wg * p.ow_mul + p.ow_off;
     }
     s_outpix[tid] = pix;
+  }
+  if (XF) {
+    for (int c = tid; c < 2 * p.Ci; c += NT) s_xf[c] = p.xf[c];
   }
 
   // per-thread staging coordinates (fixed for the whole reduction loop)
@@ -249,6 +261,8 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
   const int nkt = (p.nchunks + 7) >> 3;
   const bool simple = p.simple != 0;   // every tap of every valid row is inside the image
 
+  unsigned int xf_ok = 0;   // XF: which of this thread's staged pixel rows hold real data (bit i), and their channel chunk
+  int xf_chunk = 0;
   auto load_tile = [&](int kt, int buf) {
     const int kc = kt * 8 + cg;
     char* dw_ = lds + buf * STAGE + (8 * wave) * 128;             // this wave's KiB of filter rows
@@ -263,10 +277,12 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
     const unsigned int kb = kvalid ? (unsigned int)(cchunk * 16) : CN_OOB;   // 16 bytes per chunk
     const unsigned int wofs = (unsigned int)s_taps[4 * tap + 1] + kb;
     const unsigned int xofs = (unsigned int)s_taps[4 * tap + 2] + kb;
+    if (XF) { xf_ok = 0; xf_chunk = cchunk; }
     if (simple) {
 #pragma unroll
       for (int i = 0; i < NPR; ++i) {
         const unsigned int o = (prow[i] | kb) >= CN_OOB ? CN_OOB : prow[i] + xofs;
+        if (XF) xf_ok |= (o < CN_OOB ? 1u : 0u) << i;
         if (GLDS) cn_buf_ld16_lds(xbuf, o, dp_ + i * RS * 128);
         else preg[i] = p.x_nt ? cn_buf_ld16_nt(xbuf, o) : cn_buf_ld16(xbuf, o);
       }
@@ -278,6 +294,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
         const bool ok = (unsigned)(phin[i] + dh) < (unsigned)p.Hi && (unsigned)(pwin[i] + dw) < (unsigned)p.Wi &&
                         kb < CN_OOB;
         const unsigned int o = ok ? prow[i] + xofs : CN_OOB;
+        if (XF) xf_ok |= (ok ? 1u : 0u) << i;
         if (GLDS) cn_buf_ld16_lds(xbuf, o, dp_ + i * RS * 128);
         else preg[i] = cn_buf_ld16(xbuf, o);
       }
@@ -293,6 +310,24 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
     char* base = lds + buf * STAGE;
 #pragma unroll
     for (int i = 0; i < NWR; ++i) cn_st16(base + st0 + i * RS * 128, wreg[i]);
+    if (XF) {
+      constexpr int CH = ElemTraits<T>::kChunk;
+      float sc[CH], sh[CH];
+#pragma unroll
+      for (int e = 0; e < CH; ++e) { sc[e] = s_xf[xf_chunk * CH + e]; sh[e] = s_xf[p.Ci + xf_chunk * CH + e]; }
+#pragma unroll
+      for (int i = 0; i < NPR; ++i) {
+        float f[CH];
+        Chunk<T>::unpack(preg[i], f);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+          f[e] = fmaf(f[e], sc[e], sh[e]);
+          if (p.xf_relu) f[e] = f[e] > 0.f ? f[e] : 0.f;
+        }
+        const u32x4 v = Chunk<T>::pack(f);
+        preg[i] = ((xf_ok >> i) & 1u) ? v : cn_zero16();
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NPR; ++i) cn_st16(base + st0 + BN * 128 + i * RS * 128, preg[i]);
   };
@@ -668,6 +703,13 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
     else CN_LAUNCH((igemm_kernel<T, WC, WP, TI, TJ, 2, OUTF32, true, false, EP>), grid, dim3(256), stream, p);        \
   } while (0)
 #define IG_GO(WC, WP, TI, TJ) do { if (epi) IG_GO2(WC, WP, TI, TJ, true); else IG_GO2(WC, WP, TI, TJ, false); } while (0)
+  if (p.xf != nullptr) {   // operand transform: register-staged single buffer only
+    if (epi || p.Ci > IG_XF_MAX) { cn_set_error("igemm: operand transform with an epilogue operand / more than %d channels", IG_XF_MAX); return CN_EINVAL; }
+    cn_set_last_kernel("igemm_kernel<%s, %s, 1, %s, false, false, false, true>", tname, p.Co <= 64 ? "1, 4, 2, 1" : "2, 2, 2, 2", OUTF32 ? "true" : "false");
+    if (p.Co <= 64) CN_LAUNCH((igemm_kernel<T, 1, 4, 2, 1, 1, OUTF32, false, false, false, true>), grid, dim3(256), stream, p);
+    else CN_LAUNCH((igemm_kernel<T, 2, 2, 2, 2, 1, OUTF32, false, false, false, true>), grid, dim3(256), stream, p);
+    return cn_check_launch("igemm");
+  }
   if constexpr (sizeof(T) == 2 && !OUTF32) {
     // 256 pixels x 256 channels, 8 waves of 128 pixels x 64 channels, LDS-DMA double buffer, fragments double-buffered
     // in registers, one workgroup per CU: half the L2->LDS bytes per flop of the 128x128 tile.  It wins where the
@@ -762,13 +804,14 @@ static int ig_is_simple(const IgemmParams& p, const int* dhdw, int ntaps) {
 
 static int ig_conv_fwd(const void* x, const void* w_krsc, void* y, const float* bias, float* stats, int N, int H,
                        int W, int C, int K, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w,
-                       int dtype, int out_f32, int relu, void* stream) {
+                       int dtype, int out_f32, int relu, void* stream, const float* xf = nullptr, int xf_relu = 0) {
   const int P = (H + 2 * pad_h - R) / stride_h + 1;
   const int Q = (W + 2 * pad_w - S) / stride_w + 1;
   if (P <= 0 || Q <= 0 || N <= 0) { cn_set_error("conv2d_fwd: empty output"); return CN_ESHAPE; }
   IgemmParams p;
   memset(&p, 0, sizeof(p));
   p.x = (const char*)x; p.w = (const char*)w_krsc; p.y = (char*)y; p.bias = bias; p.stats = stats;
+  p.xf = xf; p.xf_relu = xf_relu;
   p.stats_rows = (int)(((long long)N * P * Q + 127) / 128);
   p.N = N; p.Hi = H; p.Wi = W; p.Ci = C;
   p.Hg = P; p.Wg = Q; p.a_h = stride_h; p.a_w = stride_w;
@@ -813,6 +856,22 @@ extern "C" int cn_conv2d_fwd_bnstats(const void* x, const void* w_krsc, void* y,
   }
   return ig_conv_fwd(x, w_krsc, y, bias, partial, N, H, W, C, K, R, S, stride_h, stride_w, pad_h, pad_w, dtype,
                      0, relu, stream);
+}
+
+// Convolution forward whose input is a BatchNorm *input*: x_op = act(x*scale[c] + shift[c]) (xf = [scale | shift],
+// 2*C floats, e.g. stats_out + 2C of cn_bn_fwd_train*), applied on the operand load, so the BatchNorm between two
+// convolutions needs no apply pass of its own.  partial (optional): the statistics epilogue of cn_conv2d_fwd_bnstats.
+extern "C" int cn_conv2d_fwd_xf(const void* x, const float* xf, int xf_relu, const void* w_krsc, void* y, int N, int H,
+                                int W, int C, int K, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w,
+                                int dtype, float* partial, int partial_rows, void* stream) {
+  if (xf == nullptr) { cn_set_error("conv2d_fwd_xf: no transform table"); return CN_EINVAL; }
+  const long long P = (H + 2 * pad_h - R) / stride_h + 1, Q = (W + 2 * pad_w - S) / stride_w + 1;
+  if (partial != nullptr && partial_rows < cn_conv2d_bnstats_rows((long long)N * P * Q)) {
+    cn_set_error("conv2d_fwd_xf: partial buffer of %d rows is too small", partial_rows);
+    return CN_EWORKSPACE;
+  }
+  return ig_conv_fwd(x, w_krsc, y, nullptr, partial, N, H, W, C, K, R, S, stride_h, stride_w, pad_h, pad_w, dtype, 0, 0,
+                     stream, xf, xf_relu);
 }
 
 struct IgBnBwd {

@@ -244,6 +244,28 @@ def conv2d_fwd(x, w_krsc, bias, K, R, S, stride, pad, out_f32=False, relu=False,
     return y
 
 
+def conv2d_fwd_xf(x, xf, xf_relu, w_krsc, K, R, S, stride, pad, bn_stats=False):
+    """conv(act(x*scale + shift)) with the BatchNorm apply folded into the operand load (cn_conv2d_fwd_xf).
+    xf: fp32 [scale | shift] of the C input channels."""
+    N, H, W, C = x.shape
+    P, Q = conv_out_hw(H, W, R, S, stride, pad)
+    y = torch.empty((N, P, Q, K), dtype=x.dtype, device=x.device)
+    L = _L()
+    partial, rows = None, 0
+    if bn_stats:
+        rows = L.cn_conv2d_bnstats_rows(N * P * Q)
+        partial = torch.empty((rows, 2 * K), dtype=torch.float32, device=x.device)
+    PROFILER.run(_last_kernel(), 1, 2.0 * N * P * Q * K * C * R * S,
+                 x.numel() * _esize(x) + y.numel() * _esize(y) + K * R * S * C * _esize(x),
+                 lambda: check(L.cn_conv2d_fwd_xf(ptr(x), ptr(xf), int(xf_relu), ptr(w_krsc), ptr(y), N, H, W, C, K, R, S,
+                                                  stride[0], stride[1], pad[0], pad[1], dtype_code(x.dtype), ptr(partial),
+                                                  rows, stream_of(x)), 'cn_conv2d_fwd_xf'),
+                 x.device, detail=_conv_detail('fwd-xf', C, H, K, R, stride))
+    if bn_stats:
+        _park_stats(y, partial, rows)
+    return y
+
+
 def conv2d_dgrad(dy, w_crsk, x_shape, K, R, S, stride, pad, addend=None, bn=None):
     """dx (NHWC).  With bn = (bn_y, bn_mask_or_None, bn_stats[4C], relu) the epilogue also does the
     reduction half of that BatchNorm's backward: returns (g = dx*relu_mask, partial, rows)."""

@@ -61,6 +61,13 @@ int cn_conv2d_fwd_bnstats(const void* x, const void* w_krsc, void* y, const floa
                           int dtype, int relu, float* partial, int partial_rows, void* stream);
 /* dx[N,H,W,C] from dy[N,P,Q,K] and the transposed filter w_crsk[C][R][S][K]
  * (written by cn_weight_prep).  Strided convs run one launch per output-parity class. */
+/* conv forward on a BatchNorm INPUT: the operand is act(x*scale[c] + shift[c]) (xf = [scale | shift], 2*C floats =
+ * stats_out + 2C of cn_bn_fwd_train*), rounded to dtype like cn_bn_fwd_train's z and applied on the operand load, so
+ * an inner BatchNorm (models/resnet.py:143-152: bn -> relu -> next conv) needs no apply pass; C <= 512; partial
+ * (optional) as in cn_conv2d_fwd_bnstats */
+int cn_conv2d_fwd_xf(const void* x, const float* xf, int xf_relu, const void* w_krsc, void* y, int N, int H, int W,
+                     int C, int K, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w, int dtype,
+                     float* partial, int partial_rows, void* stream);
 int cn_conv2d_dgrad(const void* dy, const void* w_crsk, void* dx, const void* addend /*optional: dx += addend,
                     the residual-branch gradient of models/resnet.py:162 folded into the epilogue*/, int N, int H,
                     int W, int C, int K, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w,

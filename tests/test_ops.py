@@ -755,3 +755,56 @@ def test_wgrad_256x256_tile_matches_128_tile_and_cpu(mode):
             assert rel_l2(outs[1], outs[0]) < 1e-5
     finally:
         L.cn_set_option(b'wgrad_256sq', 0)
+
+
+@pytest.mark.parametrize('mode', MODES)
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_conv_with_batchnorm_apply_folded_into_the_operand_load(mode, dtype):
+    """cn_conv2d_fwd_xf(y, [scale | shift]) == conv(relu(bn_apply(y))) bit for bit (the transform rounds to the
+    compute dtype exactly like bn_apply stores z; padded taps stay zero), with and without the statistics epilogue."""
+    _f16_emul_subset(mode, dtype)
+    dev = _dev(mode)
+    import convnet_amd as ca
+    ops, L = ca.ops, ca._lib.load()
+    cfgs = [(2, 9, 8, 16, 64, 3, 1, 1), (2, 7, 6, 32, 136, 1, 1, 0), (1, 12, 11, 16, 72, 3, 2, 1)] if mode == 'emul' else \
+        [(8, 56, 56, 64, 64, 3, 1, 1), (8, 56, 56, 64, 256, 1, 1, 0), (4, 56, 56, 128, 128, 3, 2, 1),
+         (8, 14, 14, 256, 1024, 1, 1, 0), (4, 7, 7, 512, 2048, 1, 1, 0), (3, 17, 13, 64, 72, 3, 2, 1)]
+    for (N, H, W, C, K, R, st, pad) in cfgs:
+        if dtype != torch.float32 and C % 8:
+            continue
+        g = torch.Generator().manual_seed(K + H)
+        yh = _nhwc(torch.randn(N, C, H, W, generator=g) * 1.5 + 0.3, dtype, dev)
+        wk = (torch.randn(K, R, R, C, generator=g) * (2.0 / (C * R * R)) ** 0.5).to(dtype).to(dev)
+        bn = ca.nn.BatchNorm2d(C)
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+            bn.bias.copy_(torch.randn(C, generator=g) * 0.2)
+        ca.engine.prepare(torch.nn.Sequential(bn), dev, dtype)
+        bn.train()
+        with torch.no_grad():
+            fn = ops.BatchNormActFunction
+            z = fn.apply(yh, bn.weight, bn.bias, None, bn, True)
+        stats = bn._last_stats if hasattr(bn, '_last_stats') else None
+        # scale / shift of the batch statistics, as cn_bn_fwd_train wrote them (stats_out + 2C)
+        M = N * H * W
+        st4 = torch.empty(4 * C, dtype=torch.float32, device=dev)
+        z2 = torch.empty_like(yh)
+        ws = ops.workspace(L.cn_bn_workspace(M, C, ca._lib.dtype_code(dtype)), dev)
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        ca._lib.check(L.cn_bn_fwd_train(yh.data_ptr(), None, z2.data_ptr(), None, bn.weight.data_ptr(), bn.bias.data_ptr(),
+                                        rm.data_ptr(), rv.data_ptr(), None, 0.1, bn.eps, st4.data_ptr(), M, C, 1,
+                                        ca._lib.dtype_code(dtype), ws.data_ptr(), ws.numel() * 4, ca._lib.stream_of(yh)))
+        assert torch.equal(z2.cpu(), z.cpu())
+        xf = st4[2 * C:]
+        L.cn_set_option(b'igemm_variant', 1)
+        try:
+            ref = ops.conv2d_fwd(z2, wk, None, K, R, R, (st, st), (pad, pad))
+            got = ops.conv2d_fwd_xf(yh, xf, True, wk, K, R, R, (st, st), (pad, pad))
+            assert torch.equal(got.cpu(), ref.cpu()), (N, H, W, C, K, R, st, pad)
+            ref_s = ops.conv2d_fwd(z2, wk, None, K, R, R, (st, st), (pad, pad), bn_stats=True)
+            pr = ops.take_pending_stats(ref_s)
+            got_s = ops.conv2d_fwd_xf(yh, xf, True, wk, K, R, R, (st, st), (pad, pad), bn_stats=True)
+            pg = ops.take_pending_stats(got_s)
+            assert torch.equal(got_s.cpu(), ref_s.cpu()) and torch.equal(pg.partial.cpu(), pr.partial.cpu())
+        finally:
+            L.cn_set_option(b'igemm_variant', 0)
