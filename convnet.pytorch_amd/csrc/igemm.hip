@@ -695,7 +695,7 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
   // EPI: epilogue with global-side operands (residual-branch addend, fused BN-backward reduction)
 #define IG_GO2(WC, WP, TI, TJ, EP)                                                                              \
   do {                                                                                                         \
-    cn_set_last_kernel("igemm_kernel<%s, %d, %d, %d, %d, %d, %s, %s, false, %s>", tname, WC, WP, TI, TJ,      \
+    cn_set_last_kernel("igemm_kernel<%s, %d, %d, %d, %d, %d, %s, %s, false, %s, false>", tname, WC, WP, TI, TJ, \
                        variant == 1 ? 1 : 2, OUTF32 ? "true" : "false", variant >= 3 ? "true" : "false",      \
                        EP ? "true" : "false");                                                                 \
     if (variant == 1) CN_LAUNCH((igemm_kernel<T, WC, WP, TI, TJ, 1, OUTF32, false, false, EP>), grid, dim3(256), stream, p); \
@@ -726,7 +726,7 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
       p.n_mtiles = (p.M + 255) / 256;
       dim3 g2((unsigned)(p.n_ntiles * p.n_mtiles));
       const bool fragdb = variant != 11;
-      cn_set_last_kernel("igemm_kernel<%s, 4, 2, 2, 4, 2, false, true, %s, false>", tname, fragdb ? "true" : "false");
+      cn_set_last_kernel("igemm_kernel<%s, 4, 2, 2, 4, 2, false, true, %s, false, false>", tname, fragdb ? "true" : "false");
       if (fragdb) CN_LAUNCH((igemm_kernel<T, 4, 2, 2, 4, 2, false, true, true, false>), g2, dim3(512), stream, p);
       else CN_LAUNCH((igemm_kernel<T, 4, 2, 2, 4, 2, false, true, false, false>), g2, dim3(512), stream, p);
       return cn_check_launch("igemm");
