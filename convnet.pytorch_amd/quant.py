@@ -447,6 +447,11 @@ class RangeBN(cnn.BatchNorm2d):
                                N * H * W, C, int(relu), 0, dtype_code(y.dtype), None, 0, stream_of(y)), 'cn_rangebn_fwd')
         return z
 
+    def reset_running_stats(self):
+        # Trainer.calibrate_bn (trainer.py:277-285) calls this on every `nn.BatchNorm2d`; the reference's RangeBN has
+        # no such method (AttributeError there) and no cumulative-average mode: say so instead of mis-calibrating
+        raise NotImplementedError('calibrate_bn is not defined for RangeBN (the reference raises AttributeError here)')
+
     def extra_repr(self):
         return '{}, eps={}, momentum={}, num_chunks={}'.format(self.num_features, self.eps, self.momentum,
                                                                self.num_chunks)
