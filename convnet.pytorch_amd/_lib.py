@@ -35,6 +35,10 @@ _SIGNATURES = {
     'cn_last_kernel_name': (ctypes.c_char_p, []),
     'cn_is_emulator': (c_i, []),
     'cn_set_option': (c_i, [ctypes.c_char_p, c_i]),
+    'cn_stream_fork': (c_i, [c_p, c_p]),
+    'cn_stream_arm': (c_i, []),
+    'cn_stream_disarm': (c_i, []),
+    'cn_stream_wait_mark': (c_i, [c_i, c_p]),
     'cn_conv2d_fwd': (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 11 + [c_i, c_i, c_i, c_p]),
     'cn_conv2d_bnstats_rows': (c_i, [c_ll]),
     'cn_conv2d_fwd_bnstats': (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 11 + [c_i, c_i, c_p, c_i, c_p]),

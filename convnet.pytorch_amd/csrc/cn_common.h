@@ -52,8 +52,22 @@ void cn_set_last_kernel(const char* fmt, ...);
     cn_emul::launch((grid), (block), [=]() { kern(__VA_ARGS__); });                 \
   } while (0)
 #else
-#define CN_LAUNCH(kern, grid, block, stream, ...) \
-  hipLaunchKernelGGL(kern, (grid), (block), 0, (stream), __VA_ARGS__)
+// While a mark is armed (cn_stream_arm, runtime.hip) every launch of this thread carries the mark's event as the
+// kernel's own completion event (hipExtLaunchKernel's stopEvent): another stream can wait for that kernel without a
+// marker packet in this stream's queue.
+#include <hip/hip_ext.h>
+extern thread_local hipEvent_t cn_tl_stop_event;
+extern thread_local int cn_tl_stop_recorded;
+#define CN_LAUNCH(kern, grid, block, stream, ...)                                                              \
+  do {                                                                                                          \
+    if (cn_tl_stop_event != nullptr) {                                                                          \
+      hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, (stream), (hipEvent_t) nullptr, cn_tl_stop_event, \
+                            0, __VA_ARGS__);                                                                    \
+      cn_tl_stop_recorded = 1;                                                                                  \
+    } else {                                                                                                    \
+      hipLaunchKernelGGL(kern, (grid), (block), 0, (stream), __VA_ARGS__);                                      \
+    }                                                                                                           \
+  } while (0)
 #endif
 
 // ---------------------------------------------------------------- vector types

@@ -63,6 +63,83 @@ int cn_get_option(const char* name, int dflt) {
   return dflt;
 }
 
+// Cross-stream ordering without torch: `to` waits for everything queued on `from` so far.  Events come from a
+// ring created once (timing disabled; with the system-scope fence disabled too unless knob "fork_sysfence" = 1:
+// both streams are on this device, nothing here has to become visible to the host).
+#define CN_FORK_EVENTS 256
+extern "C" int cn_stream_fork(void* from_, void* to_) {
+#ifdef CN_EMULATE
+  (void)from_; (void)to_;
+  return CN_OK;
+#else
+  static thread_local hipEvent_t ring[2][CN_FORK_EVENTS];
+  static thread_local int made[2] = {0, 0}, next[2] = {0, 0};
+  const int kind = cn_get_option("fork_sysfence", 0) != 0 ? 1 : 0;
+  if (!made[kind]) {
+    const unsigned flags = hipEventDisableTiming | (kind ? 0u : (unsigned)hipEventDisableSystemFence);
+    for (int i = 0; i < CN_FORK_EVENTS; ++i)
+      if (hipEventCreateWithFlags(&ring[kind][i], flags) != hipSuccess) { cn_set_error("stream_fork: hipEventCreate failed"); return CN_EHIP; }
+    made[kind] = 1;
+  }
+  hipEvent_t e = ring[kind][next[kind]];
+  next[kind] = (next[kind] + 1) % CN_FORK_EVENTS;
+  if (hipEventRecord(e, (hipStream_t)from_) != hipSuccess || hipStreamWaitEvent((hipStream_t)to_, e, 0) != hipSuccess) {
+    cn_set_error("stream_fork: %s", hipGetErrorString(hipGetLastError()));
+    return CN_EHIP;
+  }
+  return CN_OK;
+#endif
+}
+
+// Marks: arm -> the kernels this thread launches until disarm carry a ring event as their completion event;
+// cn_stream_wait_mark makes another stream wait for the last of them.  disarm returns 1 when a kernel took the event.
+#ifndef CN_EMULATE
+thread_local hipEvent_t cn_tl_stop_event = nullptr;
+thread_local int cn_tl_stop_recorded = 0;
+static thread_local hipEvent_t g_marks[CN_FORK_EVENTS];
+static thread_local int g_marks_made = 0, g_mark_next = 0;
+#endif
+extern "C" int cn_stream_arm(void) {
+#ifdef CN_EMULATE
+  return 0;
+#else
+  if (!g_marks_made) {
+    for (int i = 0; i < CN_FORK_EVENTS; ++i)
+      if (hipEventCreateWithFlags(&g_marks[i], hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) {
+        cn_set_error("stream_arm: hipEventCreate failed");
+        return CN_EHIP;
+      }
+    g_marks_made = 1;
+  }
+  const int h = g_mark_next;
+  g_mark_next = (g_mark_next + 1) % CN_FORK_EVENTS;
+  cn_tl_stop_event = g_marks[h];
+  cn_tl_stop_recorded = 0;
+  return h;
+#endif
+}
+extern "C" int cn_stream_disarm(void) {
+#ifdef CN_EMULATE
+  return 0;
+#else
+  cn_tl_stop_event = nullptr;
+  return cn_tl_stop_recorded;
+#endif
+}
+extern "C" int cn_stream_wait_mark(int handle, void* to_stream) {
+#ifdef CN_EMULATE
+  (void)handle; (void)to_stream;
+  return CN_OK;
+#else
+  if (!g_marks_made || handle < 0 || handle >= CN_FORK_EVENTS) { cn_set_error("stream_wait_mark: bad handle %d", handle); return CN_EINVAL; }
+  if (hipStreamWaitEvent((hipStream_t)to_stream, g_marks[handle], 0) != hipSuccess) {
+    cn_set_error("stream_wait_mark: %s", hipGetErrorString(hipGetLastError()));
+    return CN_EHIP;
+  }
+  return CN_OK;
+#endif
+}
+
 extern "C" int cn_is_emulator(void) {
 #ifdef CN_EMULATE
   return 1;

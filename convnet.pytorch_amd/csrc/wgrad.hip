@@ -563,7 +563,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, fl
       s2 += (v[2] + v[6]) + (v[10] + v[14]);
       s3 += (v[3] + v[7]) + (v[11] + v[15]);
     }
-    for (; k < nsplit; ++k) s0 += src[(long long)k * stride_split];
+    if (k < nsplit) {   // < 16 slabs left: requested together (clamped index), added in slab order
+      float v[15];
+#pragma unroll
+      for (int u = 0; u < 15; ++u) {
+        const int kc = k + u < nsplit ? k + u : nsplit - 1;
+        const float x = src[(long long)kc * stride_split];
+        v[u] = k + u < nsplit ? x : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 15; ++u) s0 += v[u];
+    }
     float s = ((s0 + s1) + (s2 + s3)) * scale;
     dw[idx] = beta != 0.f ? beta * dw[idx] + s : s;
   }

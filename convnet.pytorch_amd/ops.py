@@ -7,6 +7,7 @@ NCHW / OIHW shapes at their boundary): activations are contiguous NHWC tensors i
 PyTorch is used here for allocation, stream handles and the autograd tape only; every arithmetic
 pass over tensor data is one of the `cn_*` kernels.
 """
+import contextlib
 import os
 import weakref
 
@@ -103,6 +104,10 @@ class SideStream(object):
         self._streams = {}
         self._rr = 0
         self.used = False
+        # CONVNET_AMD_MARKS=0: always hand off with an event record (A/B knob)
+        self.marks = os.environ.get('CONVNET_AMD_MARKS', '1') == '1'
+        self.capturing = False      # set by Trainer around HIP-graph capture (marks are an eager-mode mechanism)
+        self._mark = None
 
     def _all(self, device):
         ss = self._streams.get(device)
@@ -123,6 +128,39 @@ class SideStream(object):
         self._rr = (self._rr + 1) % len(ss)
         return ss[self._rr]
 
+    @contextlib.contextmanager
+    def mark(self, dy):
+        """Around the library call that produces the gradient tensor `dy`: its last kernel signals a mark event on
+        completion (cn_stream_arm), so the weight-gradient launch that consumes `dy` can wait for exactly that
+        kernel (hipExtLaunchKernel's stop event) instead of an event recorded behind it in the chain's queue."""
+        self._mark = None
+        if not (self.marks and self.enabled and dy.is_cuda and not PROFILER.enabled and not self.capturing):
+            yield
+            return
+        h = _L().cn_stream_arm()
+        try:
+            yield
+        finally:
+            if _L().cn_stream_disarm() == 1 and h >= 0:
+                self._mark = (dy.data_ptr(), h, dy)   # dy held: its memory cannot be recycled under the mark
+
+    def submit(self, device, launch, notify, dy=None):
+        """Run `launch()` (returns the tensors it reads / scratch it uses) on the side stream once `dy` - and
+        everything else queued on the current stream so far - is ready, then `notify()`."""
+        cur = torch.cuda.current_stream(device)
+        side = self.get(device)
+        mark, self._mark = self._mark, None
+        if mark is not None and dy is not None and dy.data_ptr() == mark[0]:
+            check(_L().cn_stream_wait_mark(mark[1], side.cuda_stream), 'cn_stream_wait_mark')   # dy's producer is done
+        else:
+            self.fork(cur, side)
+        with torch.cuda.stream(side):
+            held = launch()
+        for t in held:
+            t.record_stream(side)
+        self.used = True
+        notify()
+
     def gather(self, device):
         """Stream 0 after it has been made to wait for the other side streams: the one stream a collective
         (or a join) has to order itself behind."""
@@ -133,6 +171,10 @@ class SideStream(object):
 
     def active(self, t):
         return self.enabled and t.is_cuda and not PROFILER.enabled
+
+    def fork(self, cur, side):
+        """`side` waits for everything queued on `cur` so far (one device-scope event from the library's ring)."""
+        check(_L().cn_stream_fork(cur.cuda_stream, side.cuda_stream), 'cn_stream_fork')
 
     def join(self, device):
         """Make the current stream wait for everything queued on the side stream(s)."""
@@ -435,22 +477,18 @@ class Conv2dFunction(Function):
         if dy.dtype != x.dtype:  # fp32 logits gradient -> compute dtype
             dy = cast_from_f32(dy, x.dtype)
         R, S = mod.kernel_size
+        if ctx.has_bias:
+            colsum(dy.view(-1, mod.out_channels), mod.grad_view('bias'))
         if SIDE.active(x):
-            cur = torch.cuda.current_stream(x.device)
-            side = SIDE.get(x.device)
-            side.wait_stream(cur)                       # dy (and everything before it) is ready
-            with torch.cuda.stream(side):
+            def launch():
                 conv2d_wgrad(x, dy, mod.grad_view('weight'), mod.in_channels, mod.out_channels, R, S, mod.stride,
                              mod.padding, tag='side')
-            x.record_stream(side)
-            dy.record_stream(side)
-            SIDE.used = True
+                return (x, dy)
+            SIDE.submit(x.device, launch, mod._notify_grad_ready, dy)
         else:
             conv2d_wgrad(x, dy, mod.grad_view('weight'), mod.in_channels, mod.out_channels, R, S, mod.stride,
                          mod.padding)
-        if ctx.has_bias:
-            colsum(dy.view(-1, mod.out_channels), mod.grad_view('bias'))
-        mod._notify_grad_ready()
+            mod._notify_grad_ready()
         dx = None
         if ctx.needs_input_grad[0]:
             addend = None
@@ -539,17 +577,10 @@ class StemPairConvFunction(Function):
             return tmp
 
         if SIDE.active(x):
-            cur = torch.cuda.current_stream(x.device)
-            side = SIDE.get(x.device)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                tmp = run('side')
-            for t in (x, dy, tmp):
-                t.record_stream(side)
-            SIDE.used = True
+            SIDE.submit(x.device, lambda: (x, dy, run('side')), mod._notify_grad_ready, dy)
         else:
             run('main')
-        mod._notify_grad_ready()
+            mod._notify_grad_ready()
         return None, None, None
 
 
@@ -664,24 +695,26 @@ class BatchNormActFunction(Function):
             _, _, partial, rows = pp
             COUNTERS['bn_bwd_fused'] += 1
             dres = dz if want_res else None       # the residual branch's gradient is g itself
-            PROFILER.run('bn_bwd_finalize+bn_bwd_apply (reduce in dgrad epilogue)', 2 if rows <= 512 else 3, 0.0,
-                         nb * 3 + partial.numel() * 4,
-                         lambda: check(L.cn_bn_bwd_partials(ptr(dz), ptr(y), ptr(mod.weight), ptr(stats), ptr(dy),
-                                                            ptr(mod.grad_view('weight')), ptr(mod.grad_view('bias')),
-                                                            1.0, 1.0, ptr(coef), M, C, code, ptr(partial), rows,
-                                                            ptr(ws), ws.numel() * 4, stream_of(y)),
-                                       'cn_bn_bwd_partials'),
-                         y.device)
+            with SIDE.mark(dy):
+                PROFILER.run('bn_bwd_finalize+bn_bwd_apply (reduce in dgrad epilogue)', 2 if rows <= 512 else 3, 0.0,
+                             nb * 3 + partial.numel() * 4,
+                             lambda: check(L.cn_bn_bwd_partials(ptr(dz), ptr(y), ptr(mod.weight), ptr(stats), ptr(dy),
+                                                                ptr(mod.grad_view('weight')), ptr(mod.grad_view('bias')),
+                                                                1.0, 1.0, ptr(coef), M, C, code, ptr(partial), rows,
+                                                                ptr(ws), ws.numel() * 4, stream_of(y)),
+                                           'cn_bn_bwd_partials'),
+                             y.device)
         else:
             COUNTERS['bn_bwd_plain'] += 1
             dres = torch.empty_like(y) if want_res else None
-            PROFILER.run('bn_bwd_reduce+bn_bwd_finalize+bn_bwd_apply', 3, 0.0,
-                         nb * (5 + (1 if dres is not None else 0)) + (2 * zmask.numel() if zmask is not None else 0),
-                         lambda: check(L.cn_bn_bwd(ptr(dz), ptr(y), ptr(zmask), ptr(mod.weight), ptr(stats), ptr(dy),
-                                                   ptr(dres), ptr(mod.grad_view('weight')), ptr(mod.grad_view('bias')),
-                                                   1.0, 1.0, ptr(coef), M, C, int(ctx.relu), code, ptr(ws),
-                                                   ws.numel() * 4, stream_of(y)), 'cn_bn_bwd'),
-                         y.device)
+            with SIDE.mark(dy):
+                PROFILER.run('bn_bwd_reduce+bn_bwd_finalize+bn_bwd_apply', 3, 0.0,
+                             nb * (5 + (1 if dres is not None else 0)) + (2 * zmask.numel() if zmask is not None else 0),
+                             lambda: check(L.cn_bn_bwd(ptr(dz), ptr(y), ptr(zmask), ptr(mod.weight), ptr(stats), ptr(dy),
+                                                       ptr(dres), ptr(mod.grad_view('weight')), ptr(mod.grad_view('bias')),
+                                                       1.0, 1.0, ptr(coef), M, C, int(ctx.relu), code, ptr(ws),
+                                                       ws.numel() * 4, stream_of(y)), 'cn_bn_bwd'),
+                             y.device)
         mod._notify_grad_ready()
         holder = getattr(mod, '_res_holder', None)
         if holder is not None:
@@ -784,12 +817,13 @@ class BnReluMaxPoolFunction(Function):
         dy = torch.empty_like(y)
         coef = torch.empty(3 * C, dtype=torch.float32, device=y.device)
         COUNTERS['bn_bwd_plain'] += 1
-        PROFILER.run('bn_bwd_maxpool (stem)', 3, 0.0, y.numel() * _esize(y) * 3 + dpool.numel() * (_esize(dpool) + 1) * 2,
-                     lambda: check(L.cn_bn_bwd_maxpool(ptr(dpool), ptr(idx), ptr(y), ptr(mod.weight), ptr(stats), ptr(dy),
-                                                       ptr(mod.grad_view('weight')), ptr(mod.grad_view('bias')), 1.0, 1.0,
-                                                       ptr(coef), N, H, W, C, k, stride, pad, code, ptr(ws),
-                                                       ws.numel() * 4, stream_of(y)), 'cn_bn_bwd_maxpool'),
-                     y.device)
+        with SIDE.mark(dy):
+            PROFILER.run('bn_bwd_maxpool (stem)', 3, 0.0, y.numel() * _esize(y) * 3 + dpool.numel() * (_esize(dpool) + 1) * 2,
+                         lambda: check(L.cn_bn_bwd_maxpool(ptr(dpool), ptr(idx), ptr(y), ptr(mod.weight), ptr(stats), ptr(dy),
+                                                           ptr(mod.grad_view('weight')), ptr(mod.grad_view('bias')), 1.0, 1.0,
+                                                           ptr(coef), N, H, W, C, k, stride, pad, code, ptr(ws),
+                                                           ws.numel() * 4, stream_of(y)), 'cn_bn_bwd_maxpool'),
+                         y.device)
         mod._notify_grad_ready()
         return dy, None, None, None, None, None, None
 

@@ -288,8 +288,12 @@ class Trainer(object):
         t.copy_(target)
         steps_before = self.training_steps
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=cur, capture_error_mode='thread_local'):
-            out, loss, grad = self._body(x, t, True, chunk_batch)
+        ops.SIDE.capturing = True
+        try:
+            with torch.cuda.graph(g, stream=cur, capture_error_mode='thread_local'):
+                out, loss, grad = self._body(x, t, True, chunk_batch)
+        finally:
+            ops.SIDE.capturing = False
         self.training_steps = steps_before     # capture executes nothing: the replay is the step
         self._graph = {'key': key, 'graph': g, 'x': x, 't': t, 'out': out, 'loss': loss, 'grad': grad}
         logging.debug('captured the training step as one HIP graph (%s)', (key[0],))

@@ -44,6 +44,15 @@ const char* cn_last_kernel_name(void);
 int cn_is_emulator(void); /* 1 only in the TEST-ONLY CPU emulator build */
 /* kernel-variant tuning knobs for A/B measurement (e.g. "igemm_stages" = 1|2); results never change */
 int cn_set_option(const char* name, int value);
+/* stream plumbing: `to` waits for everything queued on `from` so far (one device-scope event from a ring; replaces
+ * torch's Stream.wait_stream between the backward chain and the weight-gradient side stream, trainer.py:151-159) */
+int cn_stream_fork(void* from_stream, void* to_stream);
+/* the same hand-off without a marker in the producer's queue: between cn_stream_arm() (returns a handle >= 0) and
+ * cn_stream_disarm() (returns 1 if a kernel was launched in between) every kernel this thread launches signals the
+ * handle's event on completion; cn_stream_wait_mark(handle, s) makes stream s wait for the last of them */
+int cn_stream_arm(void);
+int cn_stream_disarm(void);
+int cn_stream_wait_mark(int handle, void* to_stream);
 
 /* ---- nn.Conv2d / nn.Linear (models/resnet.py:75-78,126-132,178-179,226-227,242) ------------- */
 /* y[N,P,Q,K] = conv(x[N,H,W,C], w[K,R,S,C]) (+bias[K]) (ReLU optional); out_f32 writes fp32
