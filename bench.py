@@ -239,6 +239,22 @@ def main():
             if (args.depth, args.dtype) in MODEL_MB_PER_IMG and not args.quantize else None,
             'roofline': roof, 'cpu_baseline': cpu, 'kernels': kernels, 'conv_layers': layers,
         }
+        # measured HBM traffic of the whole step (all kernels, latest committed PMC passes: static, like
+        # roofline.traffic) over this run's step time: how close the step as a whole runs to the memory system
+        try:
+            cands = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('pmc_traffic.json'))
+            pm = json.load(open(os.path.join(ROOT, 'profiles', cands[-1])))
+            if 'hbm_bytes_per_step' in pm and args.depth == 50 and args.dtype == 'bf16' and B == 256 \
+                    and not args.quantize and world == 1:
+                rate = pm['hbm_bytes_per_step'] / (elapsed / args.steps) / 1e9
+                out['hbm_measured_whole_step'] = {
+                    'traffic_gb_per_step': round(pm['hbm_bytes_per_step'] / 1e9, 1), 'rate_gbs': round(rate, 0),
+                    'frac_of_peak': round(rate / PEAK_HBM_GBS, 4),
+                    'frac_of_streaming_rate': round(rate / 5100.0, 4),
+                    'note': 'traffic: static, %s (FETCH_SIZE / WRITE_SIZE over every kernel of the step); 5100 GB/s = '
+                            'the 2-read + 1-write streaming rate measured on this part (tools/bench_skew.py)' % cands[-1]}
+        except Exception:
+            pass
         print(json.dumps(out))
     if distributed:
         dist.destroy_process_group()

@@ -35,8 +35,12 @@ def main():
         wr = write.get(k, 0.0) * 1024.0
         res[k] = {'launches': n, 'read_bytes_per_launch': rd / n, 'write_bytes_per_launch': wr / n,
                   'hbm_bytes_per_launch': (rd + wr) / n}
+    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3    # tools/pmc_round.sh profiles bench.py --steps 2 --warmup 1
+    total = sum(v['hbm_bytes_per_launch'] * v['launches'] for v in res.values())
     json.dump({'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 (gfx950)',
-               'kernels': res}, open(out, 'w'), indent=1, sort_keys=True)
+               'kernels': res, 'profiled_steps': steps, 'hbm_bytes_per_step': total / steps,
+               'workload': 'bench.py defaults (ResNet-50 bf16 b=256, 1 GPU)'}, open(out, 'w'), indent=1, sort_keys=True)
+    print('all kernels: %.1f GB of HBM traffic per step (%d profiled steps)' % (total / steps / 1e9, steps))
     top = sorted(res.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches'])[:12]
     for k, v in top:
         print('%-90s n=%4d  %.1f MB/launch' % (k[:90], v['launches'], v['hbm_bytes_per_launch'] / 1e6))
