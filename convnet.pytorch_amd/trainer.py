@@ -268,14 +268,42 @@ class Trainer(object):
                 e1.synchronize()
                 dev_ms = e0.elapsed_time(e1)
                 self._graph_seen['use'] = host_ms > 0.75 * dev_ms
+                self._graph_seen['eager_ms'] = dev_ms
                 logging.debug('step: host %.2f ms, device %.2f ms -> %s', host_ms, dev_ms,
-                              'HIP graph' if self._graph_seen['use'] else 'eager launches')
+                              'try a HIP graph' if self._graph_seen['use'] else 'eager launches')
                 return res
             if not self._graph_seen.get('use', True):
                 return self._body(inputs, target, True, chunk_batch)
             st = self._capture(inputs, target, chunk_batch, key)
         st['x'].copy_(inputs, non_blocking=True)
         st['t'].copy_(target, non_blocking=True)
+        if self._graph_mode == 'auto' and 'graph_ms' not in self._graph_seen and 'eager_ms' in self._graph_seen:
+            # the prediction above is checked once: a nearly host-bound eager step can still beat the replay
+            # (ResNet-50 b=128: 12.2 ms eager vs 13.3 ms replayed), so the second replay is timed and the graph
+            # dropped if it is not faster than the eager step it was meant to replace
+            n = self._graph_seen.get('replays', 0)
+            self._graph_seen['replays'] = n + 1
+            if n == 1:
+                torch.cuda.synchronize(self.device)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                st['graph'].replay()
+                e1.record()
+                e1.synchronize()
+                self._graph_seen['graph_ms'] = e0.elapsed_time(e1)
+                if self._graph_seen['graph_ms'] > 0.98 * self._graph_seen['eager_ms']:
+                    self._graph_seen['use'] = False
+                    logging.debug('replayed step %.2f ms vs eager %.2f ms -> eager launches from now on',
+                                  self._graph_seen['graph_ms'], self._graph_seen['eager_ms'])
+                out, loss, grad = st['out'], st['loss'], st['grad']
+                self.arena.bump_version()
+                self.training_steps += 1
+                if not self._graph_seen['use']:
+                    out = out.clone()
+                    loss = loss.clone()
+                    grad = grad.clone() if grad is not None else None
+                    self._graph = None
+                return out, loss, grad
         st['graph'].replay()
         self.arena.bump_version()      # what optimizer.step() does on the host: master weights moved
         self.training_steps += 1

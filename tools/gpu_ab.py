@@ -4,7 +4,8 @@ out = os.path.join('gpurun_out', sys.argv[1])
 os.makedirs(out, exist_ok=True)
 rounds = int(sys.argv[2])
 specs = [s.split() for s in sys.argv[3:]]
-cmd = [sys.executable, 'bench.py', '--steps', '30', '--warmup', '5', '--no-cpu-baseline', '--no-kernel-profile']
+cmd = [sys.executable, 'bench.py', '--steps', os.environ.get('AB_STEPS', '30'), '--warmup', '5', '--no-cpu-baseline', '--no-kernel-profile'] + \
+    os.environ.get('AB_ARGS', '').split()
 res = {}
 for r in range(rounds):
     for spec in specs:
