@@ -66,6 +66,33 @@ static int bn_row_blocks(long long M, const BnMap& m, int target_blocks) {
   return (int)nb;
 }
 
+// Column sums of a 256-thread workgroup laid out as row slices of `tpr` chunk columns (thread tid owns column
+// tid & (tpr-1) of row slice tid >> tpr_log2): the row slices that live in one wave are folded with wavefront
+// shuffles (an xor butterfly over the lane bits above log2(tpr)), LDS then carries one value set per wave instead of
+// one per thread, and the owner (row slice 0) adds the <= 4 of them in a fixed order.  Deterministic.
+template <int N>
+__device__ __forceinline__ void bn_block_colsum(float (&a)[N], float (&b)[N], float* red /*[256][2N]*/, int tpr_log2,
+                                                int tid) {
+  const int tpr = 1 << tpr_log2;
+  for (int m = 32; m >= tpr; m >>= 1) {   // wave-uniform trip count (0 when a row slice fills a wave or more)
+#pragma unroll
+    for (int e = 0; e < N; ++e) { a[e] += cn_shfl_xor(a[e], m); b[e] += cn_shfl_xor(b[e], m); }
+  }
+#pragma unroll
+  for (int e = 0; e < N; ++e) { red[tid * 2 * N + e] = a[e]; red[tid * 2 * N + N + e] = b[e]; }
+  __syncthreads();
+  if ((tid >> tpr_log2) == 0) {
+    const int stride = tpr > 64 ? tpr : 64;   // one representative per wave (or per row slice when slices span waves)
+#pragma unroll
+    for (int e = 0; e < N; ++e) { a[e] = 0.f; b[e] = 0.f; }
+    for (int t = tid; t < 256; t += stride) {
+      const float* o = red + t * 2 * N;
+#pragma unroll
+      for (int e = 0; e < N; ++e) { a[e] += o[e]; b[e] += o[N + e]; }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const char* y, float* partial, int M, int C,
@@ -104,15 +131,8 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const char* y, float* par
       for (int e = 0; e < CH; ++e) { s[e] += f[e]; q[e] = fmaf(f[e], f[e], q[e]); }
     }
   }
-#pragma unroll
-  for (int e = 0; e < CH; ++e) { red[tid * 2 * CH + e] = s[e]; red[tid * 2 * CH + CH + e] = q[e]; }
-  __syncthreads();
+  bn_block_colsum<CH>(s, q, red, tpr_log2, tid);
   if (rsub == 0 && col < cpr) {
-    for (int r = 1; r < rpp; ++r) {
-      const float* o = red + (r * tpr + tcol) * 2 * CH;
-#pragma unroll
-      for (int e = 0; e < CH; ++e) { s[e] += o[e]; q[e] += o[CH + e]; }
-    }
     float* dst = partial + (size_t)blockIdx.x * 2 * C + col * CH;
 #pragma unroll
     for (int e = 0; e < CH; ++e) { dst[e] = s[e]; dst[C + e] = q[e]; }
@@ -381,15 +401,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const char* dz, cons
       accum(bn_ld<NT, 5>(dz + (size_t)row * rb + cb), bn_ld<NT, 6>(y + (size_t)row * rb + cb), bits);
     }
   }
-#pragma unroll
-  for (int e = 0; e < CH; ++e) { red[tid * 2 * CH + e] = s1[e]; red[tid * 2 * CH + CH + e] = s2[e]; }
-  __syncthreads();
+  bn_block_colsum<CH>(s1, s2, red, tpr_log2, tid);
   if (rsub == 0 && col < cpr) {
-    for (int r = 1; r < rpp; ++r) {
-      const float* o = red + (r * tpr + tcol) * 2 * CH;
-#pragma unroll
-      for (int e = 0; e < CH; ++e) { s1[e] += o[e]; s2[e] += o[CH + e]; }
-    }
     float* dst = partial + (size_t)blockIdx.x * 2 * C + col * CH;
 #pragma unroll
     for (int e = 0; e < CH; ++e) { dst[e] = s1[e]; dst[C + e] = s2[e]; }
@@ -581,15 +594,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(BnPoolGeom geo,
       accum(g, v);
     }
   }
-#pragma unroll
-  for (int e = 0; e < CH; ++e) { red[tid * 2 * CH + e] = s1[e]; red[tid * 2 * CH + CH + e] = s2[e]; }
-  __syncthreads();
+  bn_block_colsum<CH>(s1, s2, red, tpr_log2, tid);
   if (rsub == 0 && col < cpr) {
-    for (int r = 1; r < rpp; ++r) {
-      const float* o = red + (r * tpr + tcol) * 2 * CH;
-#pragma unroll
-      for (int e = 0; e < CH; ++e) { s1[e] += o[e]; s2[e] += o[CH + e]; }
-    }
     float* dst = partial + (size_t)blockIdx.x * 2 * C + col * CH;
 #pragma unroll
     for (int e = 0; e < CH; ++e) { dst[e] = s1[e]; dst[C + e] = s2[e]; }
