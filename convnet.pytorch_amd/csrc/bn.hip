@@ -814,11 +814,13 @@ extern "C" int cn_bn_bwd(const void* dz, const void* y, const unsigned char* rel
   dim3 grid((unsigned)nrb, (unsigned)m.gy);
   const int revopt = cn_get_option("bn_reverse", BN_REVERSE_DEFAULT);
   const int rev_r = (revopt >> 1) & 1, rev_a = ((revopt >> 2) & 1);
+  CnMarkLast last;   // an armed completion mark goes on the apply kernel only
   BN_DISPATCH(bn_bwd_reduce_kernel, dtype, (cn_get_option("bn_reduce_nt", 0) != 0), grid, stream, (const char*)dz, (const char*)y, relu_mask, mean, invstd, scale, shift, partial, M, C, relu, m.tpr_log2, rev_r);
   CN_LAUNCH(bn_bwd_finalize_kernel, dim3((unsigned)((C + BN_FC - 1) / BN_FC)), dim3(256), stream, (const float*)partial,
             nrb, M, C, gamma, mean, invstd, dgamma, dbeta, beta_acc, gscale, coef_scratch);
   int nab = bn_row_blocks(M, m, cn_get_option("bn_apply_blocks", BN_APPLY_BLOCKS));
   dim3 agrid((unsigned)nab, (unsigned)m.gy);
+  last.release();
   BN_DISPATCH(bn_bwd_apply_kernel, dtype, bn_nt_flag(M, C, dtype), agrid, stream, (const char*)dz, (const char*)y, relu_mask, scale, shift, (const float*)coef_scratch, (char*)dy, (char*)dres, M, C, relu, m.tpr_log2, rev_a);
   return cn_check_launch("bn_bwd");
 }
@@ -836,6 +838,7 @@ extern "C" int cn_bn_bwd_partials(const void* g, const void* y, const float* gam
   hipStream_t stream = (hipStream_t)stream_;
   const int CH = cn_dtype_chunk(dtype);
   BnMap m = bn_map(C / CH);
+  CnMarkLast last;   // an armed completion mark goes on the apply kernel only
   if (nrb > BN_TARGET_BLOCKS) {
     const int G = (nrb + BN_TARGET_BLOCKS - 1) / BN_TARGET_BLOCKS;
     const int nr2 = (nrb + G - 1) / G;
@@ -857,6 +860,7 @@ extern "C" int cn_bn_bwd_partials(const void* g, const void* y, const float* gam
   int nab = bn_row_blocks(M, m, cn_get_option("bn_apply_blocks", BN_APPLY_BLOCKS));
   dim3 agrid((unsigned)nab, (unsigned)m.gy);
   const int rev_a = ((cn_get_option("bn_reverse", BN_REVERSE_DEFAULT) >> 2) & 1);
+  last.release();
   BN_DISPATCH(bn_bwd_apply_kernel, dtype, bn_nt_flag(M, C, dtype), agrid, stream, (const char*)g, (const char*)y, (const unsigned char*)nullptr, scale, shift, (const float*)coef_scratch, (char*)dy, (char*)nullptr, M, C, 0, m.tpr_log2, rev_a);
   return cn_check_launch("bn_bwd_partials");
 }
@@ -1077,12 +1081,14 @@ extern "C" int cn_bn_bwd_maxpool(const void* dpool, const unsigned char* idx, co
   const float* scale = stats + 2 * C;
   const float* shift = stats + 3 * C;
   dim3 grid((unsigned)nrb, (unsigned)m.gy);
+  CnMarkLast last;   // an armed completion mark goes on the apply kernel only
   CN_DISPATCH_T(dtype, CN_LAUNCH(bn_bwd_reduce_pool_kernel<TT>, grid, dim3(256), stream, geo, (const char*)y, mean, invstd, scale,
               shift, partial, M, C, m.tpr_log2));
   CN_LAUNCH(bn_bwd_finalize_kernel, dim3((unsigned)((C + BN_FC - 1) / BN_FC)), dim3(256), stream, (const float*)partial,
             nrb, M, C, gamma, mean, invstd, dgamma, dbeta, beta_acc, gscale, coef_scratch);
   int nab = bn_row_blocks(M, m, cn_get_option("bn_apply_blocks", BN_APPLY_BLOCKS));
   dim3 agrid((unsigned)nab, (unsigned)m.gy);
+  last.release();
   CN_DISPATCH_T(dtype, CN_LAUNCH(bn_bwd_apply_pool_kernel<TT>, agrid, dim3(256), stream, geo, (const char*)y, scale, shift,
               (const float*)coef_scratch, (char*)dy, M, C, m.tpr_log2));
   return cn_check_launch("bn_bwd_maxpool");

@@ -46,6 +46,7 @@ void cn_set_last_kernel(const char* fmt, ...);
 
 // ---------------------------------------------------------------- launch macro
 #ifdef CN_EMULATE
+struct CnMarkLast { void release() {} };
 #define CN_LAUNCH(kern, grid, block, stream, ...)                                   \
   do {                                                                              \
     (void)(stream);                                                                 \
@@ -58,9 +59,16 @@ void cn_set_last_kernel(const char* fmt, ...);
 #include <hip/hip_ext.h>
 extern thread_local hipEvent_t cn_tl_stop_event;
 extern thread_local int cn_tl_stop_recorded;
+extern thread_local int cn_tl_stop_hold;   // > 0: launches stay plain (CnMarkLast: only a call's last kernel takes the event)
+struct CnMarkLast {   // scope guard of a multi-kernel entry point: release() right before its final launch
+  CnMarkLast() { ++cn_tl_stop_hold; }
+  ~CnMarkLast() { release(); }
+  void release() { if (held) { --cn_tl_stop_hold; held = false; } }
+  bool held = true;
+};
 #define CN_LAUNCH(kern, grid, block, stream, ...)                                                              \
   do {                                                                                                          \
-    if (cn_tl_stop_event != nullptr) {                                                                          \
+    if (cn_tl_stop_event != nullptr && cn_tl_stop_hold == 0) {                                                  \
       hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, (stream), (hipEvent_t) nullptr, cn_tl_stop_event, \
                             0, __VA_ARGS__);                                                                    \
       cn_tl_stop_recorded = 1;                                                                                  \

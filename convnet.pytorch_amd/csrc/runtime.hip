@@ -96,6 +96,7 @@ extern "C" int cn_stream_fork(void* from_, void* to_) {
 #ifndef CN_EMULATE
 thread_local hipEvent_t cn_tl_stop_event = nullptr;
 thread_local int cn_tl_stop_recorded = 0;
+thread_local int cn_tl_stop_hold = 0;
 static thread_local hipEvent_t g_marks[CN_FORK_EVENTS];
 static thread_local int g_marks_made = 0, g_mark_next = 0;
 #endif
