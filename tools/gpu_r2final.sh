@@ -19,8 +19,8 @@ echo "== world-1 RCCL"; BENCH_FORCE_DIST=1 timeout 300 python bench.py --steps 2
 echo "== ResNet-18 fp32"; timeout 600 python bench.py --depth 18 --dtype f32 --steps 5 --warmup 2 --no-cpu-baseline 2>&1 | grep '"metric"' | tee $OUT/bench_r18_f32.txt | cut -c80-200
 echo "== ResNet-101 bf16"; timeout 600 python bench.py --depth 101 --steps 5 --warmup 2 $B 2>&1 | grep '"metric"' | tee $OUT/bench_r101.txt | cut -c80-200
 echo "== layers"; timeout 600 python tools/bench_layers.py --variants 0,1,3 2>&1 | tail -26 | tee $OUT/layers.txt | tail -2
-echo "== rocprof"
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o r50 -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-profile > $OUT/rocprof.log 2>&1
+echo "== rocprof"   # eager launches forced: under the tracer the trainer's auto mode would replay the step as a HIP graph
+CONVNET_AMD_GRAPH=0 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o r50 -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-profile > $OUT/rocprof.log 2>&1
 STATS=$(find $OUT/prof -name "*kernel_stats.csv" | head -1)
 [ -n "$STATS" ] && head -12 "$STATS" | cut -c1-160
 TR=$(find $OUT/prof -name "*kernel_trace.csv" | head -1)
