@@ -85,3 +85,34 @@ def test_mfma_i8_lane_map(mode):
     D = torch.zeros(32, 32, dtype=torch.int32, device=dev)
     ca._lib.check(ca._lib.load().cn_probe_mfma_i8(Ad.data_ptr(), Bd.data_ptr(), D.data_ptr(), stream))
     assert torch.equal(D.cpu(), A @ B)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('how', ['fork', 'mark'])
+def test_cross_stream_hand_off_orders_the_consumer(how):
+    """cn_stream_fork (event ring) and cn_stream_arm / cn_stream_wait_mark (the producer kernel's own completion
+    event): a kernel on the second stream that is handed a tensor must see what the long producer kernel on the
+    first stream wrote, every time (stale reads would show the previous round's value)."""
+    ca, dev, _ = _setup('gpu')
+    L, lib = ca._lib.load(), ca._lib
+    s1, s2 = torch.cuda.Stream(dev, priority=-1), torch.cuda.Stream(dev)
+    n = 1 << 27                                   # 512 MB: the producer runs for ~100 us
+    a = torch.zeros(n, dtype=torch.float32, device=dev)
+    out = torch.zeros(n, dtype=torch.float32, device=dev)
+    zero = torch.zeros(n, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    for it in range(1, 13):
+        if how == 'mark':
+            h = L.cn_stream_arm()
+            lib.check(L.cn_fill_f32(a.data_ptr(), n, float(it), s1.cuda_stream), 'fill')
+            assert L.cn_stream_disarm() == 1 and h >= 0
+            lib.check(L.cn_stream_wait_mark(h, s2.cuda_stream), 'wait_mark')
+        else:
+            lib.check(L.cn_fill_f32(a.data_ptr(), n, float(it), s1.cuda_stream), 'fill')
+            lib.check(L.cn_stream_fork(s1.cuda_stream, s2.cuda_stream), 'fork')
+        # out = relu(a + 0) on the second stream (cn_eltwise op 4)
+        lib.check(L.cn_eltwise(4, out.data_ptr(), a.data_ptr(), zero.data_ptr(), n, lib.F32, s2.cuda_stream), 'eltwise')
+        lib.check(L.cn_stream_fork(s2.cuda_stream, s1.cuda_stream), 'join')   # the next fill must not overtake the read
+        s2.synchronize()
+        assert float(out.min()) == float(it) and float(out.max()) == float(it), (how, it)
+    torch.cuda.synchronize()
