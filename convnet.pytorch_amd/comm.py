@@ -92,7 +92,24 @@ def create_default(device, process_group=None):
     global _DEFAULT
     if _DEFAULT is not None:
         _DEFAULT.destroy()
-    _DEFAULT = RcclCommunicator(process_group, device)
+    comm, err = None, None
+    try:
+        comm = RcclCommunicator(process_group, device)
+    except Exception as e:      # e.g. librccl missing / ncclCommInitRank refused on this node
+        err = e
+    if dist.get_world_size(process_group) > 1:
+        # every rank must take the same transport: agree through the process group that is already up
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=torch.device(device))
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=process_group)
+        if int(ok.item()) == 0 and comm is not None:
+            comm.destroy()
+            comm = None
+    if comm is None:
+        import logging
+        logging.warning('direct RCCL communicator unavailable (%s): the gradient exchange goes through '
+                        'torch.distributed (%s) instead', err if err is not None else 'another rank failed',
+                        dist.get_backend(process_group))
+    _DEFAULT = comm
     return _DEFAULT
 
 
