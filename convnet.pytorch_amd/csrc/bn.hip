@@ -96,7 +96,7 @@ __device__ __forceinline__ void bn_block_colsum(float (&a)[N], float (&b)[N], fl
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const char* y, float* partial, int M, int C,
-                                                      int tpr_log2) {
+                                                      int tpr_log2, const float* pivot) {
   constexpr int CH = ElemTraits<T>::kChunk;
   constexpr int EB = ElemTraits<T>::kBytes;
   __shared__ float red[256 * 2 * CH];
@@ -105,10 +105,14 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const char* y, float* par
   const int cpr = C / CH;
   const int tcol = tid & (tpr - 1), rsub = tid >> tpr_log2;
   const int col = blockIdx.y * tpr + tcol;
-  float s[CH], q[CH];
+  float s[CH], q[CH], pv[CH];   // centred sums: sum (y - pivot), sum (y - pivot)^2 (pivot = 0 without one)
 #pragma unroll
-  for (int e = 0; e < CH; ++e) { s[e] = 0.f; q[e] = 0.f; }
+  for (int e = 0; e < CH; ++e) { s[e] = 0.f; q[e] = 0.f; pv[e] = 0.f; }
   if (col < cpr) {
+    if (pivot != nullptr) {
+#pragma unroll
+      for (int e = 0; e < CH; ++e) pv[e] = pivot[col * CH + e];
+    }
     const int step = gridDim.x * rpp;
     const size_t cb = (size_t)col * CH * EB, rb = (size_t)C * EB;
     int row = blockIdx.x * rpp + rsub;
@@ -121,14 +125,14 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const char* y, float* par
         float f[CH];
         Chunk<T>::unpack(v[u], f);
 #pragma unroll
-        for (int e = 0; e < CH; ++e) { s[e] += f[e]; q[e] = fmaf(f[e], f[e], q[e]); }
+        for (int e = 0; e < CH; ++e) { const float d = f[e] - pv[e]; s[e] += d; q[e] = fmaf(d, d, q[e]); }
       }
     }
     for (; row < M; row += step) {
       float f[CH];
       Chunk<T>::unpack(cn_ld16(y + (size_t)row * rb + cb), f);
 #pragma unroll
-      for (int e = 0; e < CH; ++e) { s[e] += f[e]; q[e] = fmaf(f[e], f[e], q[e]); }
+      for (int e = 0; e < CH; ++e) { const float d = f[e] - pv[e]; s[e] += d; q[e] = fmaf(d, d, q[e]); }
     }
   }
   bn_block_colsum<CH>(s, q, red, tpr_log2, tid);
@@ -239,7 +243,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* partial, 
                                                          float* running_mean, float* running_var,
                                                          long long* num_batches_tracked, float momentum,
                                                          float eps, float* save_mean, float* save_invstd,
-                                                         float* scale, float* shift) {
+                                                         float* scale, float* shift, int centered) {
   __shared__ double red[512];
   const int c = blockIdx.x * BN_FC + (threadIdx.x % BN_FC);
   const int part = threadIdx.x / BN_FC;
@@ -254,8 +258,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* partial, 
   double s, q;
   bn_sum_partials(partial, nrb, C, c, part, red, s, q);
   if (c >= C || part != 0) return;
-  const double mean = s / (double)M;
-  double var = q / (double)M - mean * mean;
+  // centred partials (sums of y - running_mean as it was before this update): the variance no longer comes out of
+  // the difference of two numbers of size mean^2
+  const double dmean = s / (double)M;
+  const double mean = centered ? (double)rm_pre + dmean : dmean;
+  double var = q / (double)M - dmean * dmean;
   if (var < 0.0) var = 0.0;
   const float invstd = (float)(1.0 / sqrt(var + (double)eps));
   save_mean[c] = (float)mean;
@@ -705,10 +712,11 @@ static int bn_check(const char* who, int M, int C, int dtype) {
 static int bn_fwd_tail(const float* partial, int nrb, const void* y, const void* residual, void* z,
                        unsigned char* relu_mask, const float* gamma, const float* beta, float* running_mean,
                        float* running_var, long long* num_batches_tracked, float momentum, float eps,
-                       float* stats_out, int M, int C, int relu, int dtype, const BnMap& m, hipStream_t stream) {
+                       float* stats_out, int M, int C, int relu, int dtype, const BnMap& m, hipStream_t stream,
+                       int centered) {
   CN_LAUNCH(bn_finalize_kernel, dim3((unsigned)((C + BN_FC - 1) / BN_FC)), dim3(256), stream, partial, nrb,
             M, C, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, stats_out,
-            stats_out + C, stats_out + 2 * C, stats_out + 3 * C);
+            stats_out + C, stats_out + 2 * C, stats_out + 3 * C, centered);
   if (z == nullptr) return cn_check_launch("bn_fwd_train");   // statistics only (the consumer applies them itself)
   int nab = bn_row_blocks(M, m, cn_get_option("bn_apply_blocks", BN_APPLY_BLOCKS));
   dim3 agrid((unsigned)nab, (unsigned)m.gy);
@@ -736,21 +744,24 @@ extern "C" int cn_bn_fwd_train(const void* y, const void* residual, void* z, uns
   }
   float* partial = (float*)workspace;
   dim3 grid((unsigned)nrb, (unsigned)m.gy);
-  CN_DISPATCH_T(dtype, CN_LAUNCH(bn_stats_kernel<TT>, grid, dim3(256), stream, (const char*)y, partial, M, C, m.tpr_log2));
+  // statistics centred on the running mean whenever there is one (see bn_finalize_kernel)
+  const float* pivot = running_mean;
+  CN_DISPATCH_T(dtype, CN_LAUNCH(bn_stats_kernel<TT>, grid, dim3(256), stream, (const char*)y, partial, M, C, m.tpr_log2, pivot));
   return bn_fwd_tail(partial, nrb, y, residual, z, relu_mask, gamma, beta, running_mean, running_var,
-                     num_batches_tracked, momentum, eps, stats_out, M, C, relu, dtype, m, stream);
+                     num_batches_tracked, momentum, eps, stats_out, M, C, relu, dtype, m, stream, pivot != nullptr);
 }
 
 // Training forward from statistics partials a producer already reduced (cn_conv2d_fwd_bnstats):
 // partial = [nrb][2*C] floats (sum | sum of squares per row).  Skips the statistics read of y.
-extern "C" int cn_bn_fwd_train_partials(const void* y, const void* residual, void* z, unsigned char* relu_mask,
+static int bn_fwd_train_partials_impl(const void* y, const void* residual, void* z, unsigned char* relu_mask,
                                         const float* gamma, const float* beta, float* running_mean,
                                         float* running_var, long long* num_batches_tracked, float momentum,
                                         float eps, float* stats_out, int M, int C, int relu, int dtype,
                                         const float* partial, int nrb, void* workspace, size_t ws_bytes,
-                                        void* stream_) {
+                                        void* stream_, int centered) {
   int rc = bn_check("bn_fwd_train_partials", M, C, dtype);
   if (rc) return rc;
+  if (centered && running_mean == nullptr) { cn_set_error("bn_fwd_train_partials_centered: the pivot is running_mean"); return CN_EINVAL; }
   if (partial == nullptr || nrb <= 0) { cn_set_error("bn_fwd_train_partials: no partials"); return CN_EINVAL; }
   hipStream_t stream = (hipStream_t)stream_;
   const int CH = cn_dtype_chunk(dtype);
@@ -768,7 +779,32 @@ extern "C" int cn_bn_fwd_train_partials(const void* y, const void* residual, voi
     nrb = nr2;
   }
   return bn_fwd_tail(partial, nrb, y, residual, z, relu_mask, gamma, beta, running_mean, running_var,
-                     num_batches_tracked, momentum, eps, stats_out, M, C, relu, dtype, m, stream);
+                     num_batches_tracked, momentum, eps, stats_out, M, C, relu, dtype, m, stream, centered);
+}
+
+extern "C" int cn_bn_fwd_train_partials(const void* y, const void* residual, void* z, unsigned char* relu_mask,
+                                        const float* gamma, const float* beta, float* running_mean,
+                                        float* running_var, long long* num_batches_tracked, float momentum,
+                                        float eps, float* stats_out, int M, int C, int relu, int dtype,
+                                        const float* partial, int nrb, void* workspace, size_t ws_bytes,
+                                        void* stream_) {
+  return bn_fwd_train_partials_impl(y, residual, z, relu_mask, gamma, beta, running_mean, running_var,
+                                    num_batches_tracked, momentum, eps, stats_out, M, C, relu, dtype, partial, nrb,
+                                    workspace, ws_bytes, stream_, 0);
+}
+
+// Partials that cn_conv2d_fwd_bnstats_centered emitted with pivot = running_mean (as it is now, before this call
+// updates it): sum (y - running_mean) | sum (y - running_mean)^2 per row.
+extern "C" int cn_bn_fwd_train_partials_centered(const void* y, const void* residual, void* z,
+                                                 unsigned char* relu_mask, const float* gamma, const float* beta,
+                                                 float* running_mean, float* running_var,
+                                                 long long* num_batches_tracked, float momentum, float eps,
+                                                 float* stats_out, int M, int C, int relu, int dtype,
+                                                 const float* partial, int nrb, void* workspace, size_t ws_bytes,
+                                                 void* stream_) {
+  return bn_fwd_train_partials_impl(y, residual, z, relu_mask, gamma, beta, running_mean, running_var,
+                                    num_batches_tracked, momentum, eps, stats_out, M, C, relu, dtype, partial, nrb,
+                                    workspace, ws_bytes, stream_, 1);
 }
 
 // Inference forward from running statistics.  coeffs = scratch of 2*C floats.
@@ -961,7 +997,7 @@ extern "C" int cn_bn_local_sums(const void* y, int M, int C, int dtype, const fl
       return CN_EWORKSPACE;
     }
     dim3 grid((unsigned)nrb, (unsigned)m.gy);
-    CN_DISPATCH_T(dtype, CN_LAUNCH(bn_stats_kernel<TT>, grid, dim3(256), stream, (const char*)y, (float*)workspace, M, C, m.tpr_log2));
+    CN_DISPATCH_T(dtype, CN_LAUNCH(bn_stats_kernel<TT>, grid, dim3(256), stream, (const char*)y, (float*)workspace, M, C, m.tpr_log2, (const float*)nullptr));
     partial = (const float*)workspace;
   }
   CN_LAUNCH(bn_partials_total_kernel, dim3((unsigned)((2 * C + 31) / 32)), dim3(256), stream, partial, nrb, 2 * C, sums);

@@ -30,6 +30,7 @@ struct IgemmParams {
   const char* addend;   // optional tensor added to the output (same layout / dtype as y)
   const float* bias;
   float* stats;         // optional [n_mtiles][2*Co]: per pixel-tile sum / sum of squares of the stored outputs
+  const float* stats_pivot;   // optional [Co]: the sums are taken of (output - pivot[c]) (centred statistics)
   // optional fused BatchNorm-backward reduction (dgrad): the output is the gradient w.r.t. z = act(BN(bn_y));
   // the epilogue applies the ReLU mask, stores g = dz*mask and emits per-tile sum(g), sum(g*xhat)
   const char* bn_y;              // BN input, same layout / dtype as the output
@@ -488,15 +489,25 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
     int nrows = p.M - m0;
     if (nrows > BM) nrows = BM;
     const char* src = lds + col * 4 + g * RPG * pitch;
+    // centred sums: with a per-channel pivot near the mean (the consumer BatchNorm's running mean) the fp32
+    // sum of squares no longer cancels against mean^2 when |mean| >> sigma
+    float pv0 = 0.f, pv1 = 0.f;
+    if (p.stats_pivot != nullptr) {
+      const int c = n0 + (OEBc == 4 ? col : 2 * col);
+      if (c < p.Co) pv0 = p.stats_pivot[c];
+      if (OEBc != 4 && c + 1 < p.Co) pv1 = p.stats_pivot[c + 1];
+    }
     auto acc_row = [&](int r) {
       const unsigned int v = *(const unsigned int*)(src + r * pitch);
       if (OEBc == 4) {
-        const float f = __builtin_bit_cast(float, v);
+        const float f = __builtin_bit_cast(float, v) - pv0;
         st[0] += f;
         st[2] = fmaf(f, f, st[2]);
       } else {
         float lo, hi;
         cn_unpack2<T>(v, lo, hi);
+        lo -= pv0;
+        hi -= pv1;
         st[0] += lo;
         st[1] += hi;
         st[2] = fmaf(lo, lo, st[2]);
@@ -804,7 +815,8 @@ static int ig_is_simple(const IgemmParams& p, const int* dhdw, int ntaps) {
 
 static int ig_conv_fwd(const void* x, const void* w_krsc, void* y, const float* bias, float* stats, int N, int H,
                        int W, int C, int K, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w,
-                       int dtype, int out_f32, int relu, void* stream, const float* xf = nullptr, int xf_relu = 0) {
+                       int dtype, int out_f32, int relu, void* stream, const float* xf = nullptr, int xf_relu = 0,
+                       const float* stats_pivot = nullptr) {
   const int P = (H + 2 * pad_h - R) / stride_h + 1;
   const int Q = (W + 2 * pad_w - S) / stride_w + 1;
   if (P <= 0 || Q <= 0 || N <= 0) { cn_set_error("conv2d_fwd: empty output"); return CN_ESHAPE; }
@@ -812,6 +824,7 @@ static int ig_conv_fwd(const void* x, const void* w_krsc, void* y, const float* 
   memset(&p, 0, sizeof(p));
   p.x = (const char*)x; p.w = (const char*)w_krsc; p.y = (char*)y; p.bias = bias; p.stats = stats;
   p.xf = xf; p.xf_relu = xf_relu;
+  p.stats_pivot = stats_pivot;
   p.stats_rows = (int)(((long long)N * P * Q + 127) / 128);
   p.N = N; p.Hi = H; p.Wi = W; p.Ci = C;
   p.Hg = P; p.Wg = Q; p.a_h = stride_h; p.a_w = stride_w;
@@ -856,6 +869,21 @@ extern "C" int cn_conv2d_fwd_bnstats(const void* x, const void* w_krsc, void* y,
   }
   return ig_conv_fwd(x, w_krsc, y, bias, partial, N, H, W, C, K, R, S, stride_h, stride_w, pad_h, pad_w, dtype,
                      0, relu, stream);
+}
+
+// The same with centred statistics: partial rows hold sum (y - pivot[c]) | sum (y - pivot[c])^2 (pivot: K floats,
+// normally the running mean of the BatchNorm that consumes y; cn_bn_fwd_train_partials_centered un-centres them).
+extern "C" int cn_conv2d_fwd_bnstats_centered(const void* x, const void* w_krsc, void* y, const float* bias, int N,
+                                              int H, int W, int C, int K, int R, int S, int stride_h, int stride_w,
+                                              int pad_h, int pad_w, int dtype, int relu, float* partial,
+                                              int partial_rows, const float* pivot, void* stream) {
+  const long long P = (H + 2 * pad_h - R) / stride_h + 1, Q = (W + 2 * pad_w - S) / stride_w + 1;
+  if (partial == nullptr || pivot == nullptr || partial_rows < cn_conv2d_bnstats_rows((long long)N * P * Q)) {
+    cn_set_error("conv2d_fwd_bnstats_centered: needs a pivot and a partial buffer of enough rows (%d given)", partial_rows);
+    return CN_EWORKSPACE;
+  }
+  return ig_conv_fwd(x, w_krsc, y, bias, partial, N, H, W, C, K, R, S, stride_h, stride_w, pad_h, pad_w, dtype,
+                     0, relu, stream, nullptr, 0, pivot);
 }
 
 // Convolution forward whose input is a BatchNorm *input*: x_op = act(x*scale[c] + shift[c]) (xf = [scale | shift],

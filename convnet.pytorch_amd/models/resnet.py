@@ -69,6 +69,7 @@ class ResidualBlock(tnn.Module):
             setattr(self, 'bn%d' % i, Norm(cout))
             if not self.quantized:
                 getattr(self, 'conv%d' % i).feeds_batchnorm = True   # BN statistics come out of the conv epilogue
+                getattr(self, 'conv%d' % i).__dict__['stats_bn'] = getattr(self, 'bn%d' % i)   # ... centred on its running mean
             if i > 1 and not self.quantized:   # this conv reads relu(bn_{i-1}(.)): its dgrad epilogue does that BN's backward reduction
                 # (instance dict, not setattr: the BN must not become a registered sub-module of the conv)
                 getattr(self, 'conv%d' % i).__dict__['input_bn'] = getattr(self, 'bn%d' % (i - 1))
@@ -95,6 +96,7 @@ class ResidualBlock(tnn.Module):
         else:
             downsample[0]._res_holder = self._holder      # downsample conv dgrad + conv1 dgrad
             downsample[0].feeds_batchnorm = True
+            downsample[0].__dict__['stats_bn'] = downsample[1]
 
     def last_bn(self):
         return getattr(self, 'bn%d' % self.n_convs)
@@ -161,6 +163,8 @@ class ResNetImagenet(tnn.Module):
         self.conv1.needs_dgrad = False  # network input needs no gradient
         self.conv1.feeds_batchnorm = not quantize
         self.bn1 = Norm(inplanes)
+        if not quantize:
+            self.conv1.__dict__['stats_bn'] = self.bn1   # the stem's statistics partials are centred on bn1.running_mean
         self.relu = cnn.ReLU(inplace=True)
         self.maxpool = cnn.MaxPool2d(kernel_size=3, stride=2, padding=1)
         for i, nblocks in enumerate(layers):

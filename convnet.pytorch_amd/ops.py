@@ -87,6 +87,9 @@ class KernelProfiler(object):
 
 
 PROFILER = KernelProfiler()
+# CONVNET_AMD_CENTERED_STATS=0: plain sum / sum-of-squares statistics partials (A/B knob)
+_cs = os.environ.get('CONVNET_AMD_CENTERED_STATS', '1')   # 0 = never, 1 = fp32 models, all = every dtype
+CENTERED_STATS = 'all' if _cs == 'all' else (_cs == '1')
 
 
 class SideStream(object):
@@ -235,15 +238,16 @@ COUNTERS = {'bn_fwd_fused': 0, 'bn_fwd_plain': 0, 'bn_bwd_fused': 0, 'bn_bwd_pla
 class _PendingStats(object):
     """BatchNorm statistics partials a convolution emitted for its output tensor, waiting for the
     BatchNorm that consumes that very tensor object (checked by identity through a weak reference)."""
-    __slots__ = ('ref', 'partial', 'rows')
+    __slots__ = ('ref', 'partial', 'rows', 'pivot')   # pivot: data_ptr of the running mean the sums are centred on (or None)
 
 
 _PENDING = {}   # id(y) -> _PendingStats; a handful of entries at most
 
 
-def _park_stats(y, partial, rows):
+def _park_stats(y, partial, rows, pivot=None):
     ps = _PendingStats()
     ps.ref, ps.partial, ps.rows = weakref.ref(y), partial, rows
+    ps.pivot = pivot.data_ptr() if pivot is not None else None
     if len(_PENDING) >= 4:     # entries nobody consumed (their BatchNorm ran in eval mode / the tensor died):
         for k in [k for k, v in _PENDING.items() if v.ref() is None]:   # dead tensors first,
             del _PENDING[k]
@@ -260,7 +264,21 @@ def take_pending_stats(y):
     return None
 
 
-def conv2d_fwd(x, w_krsc, bias, K, R, S, stride, pad, out_f32=False, relu=False, bn_stats=False):
+def stats_pivot(conv_mod):
+    """The running mean of the BatchNorm that consumes this convolution's output (wired by the model as
+    conv.stats_bn): the pivot of the centred statistics the epilogue emits.  None: plain sums."""
+    bn = getattr(conv_mod, 'stats_bn', None)
+    if bn is None or not CENTERED_STATS or not getattr(bn, 'track_running_stats', False) \
+            or getattr(bn, 'running_mean', None) is None or _sync_group(bn) is not None:
+        return None
+    # fp32 storage only: with 16-bit storage y itself carries 2^-8 (2^-11) of relative rounding, so once |mean| >> sigma
+    # the information is gone before any sum is taken, and the epilogue's pivot loads cost the bf16 step 0.3 %
+    if getattr(conv_mod, 'compute_dtype', None) != torch.float32 and CENTERED_STATS != 'all':
+        return None
+    return bn.running_mean
+
+
+def conv2d_fwd(x, w_krsc, bias, K, R, S, stride, pad, out_f32=False, relu=False, bn_stats=False, pivot=None):
     N, H, W, C = x.shape
     P, Q = conv_out_hw(H, W, R, S, stride, pad)
     y = torch.empty((N, P, Q, K), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
@@ -271,12 +289,17 @@ def conv2d_fwd(x, w_krsc, bias, K, R, S, stride, pad, out_f32=False, relu=False,
         PROFILER.run(_last_kernel(),
                      1, 2.0 * N * P * Q * K * C * R * S,
                      x.numel() * _esize(x) + y.numel() * _esize(y) + K * R * S * C * _esize(x) + partial.numel() * 4,
-                     lambda: check(L.cn_conv2d_fwd_bnstats(ptr(x), ptr(w_krsc), ptr(y), ptr(bias), N, H, W, C, K, R, S,
-                                                           stride[0], stride[1], pad[0], pad[1], dtype_code(x.dtype),
-                                                           int(relu), ptr(partial), rows, stream_of(x)),
-                                   'cn_conv2d_fwd_bnstats'),
+                     (lambda: check(L.cn_conv2d_fwd_bnstats(ptr(x), ptr(w_krsc), ptr(y), ptr(bias), N, H, W, C, K, R, S,
+                                                            stride[0], stride[1], pad[0], pad[1], dtype_code(x.dtype),
+                                                            int(relu), ptr(partial), rows, stream_of(x)),
+                                    'cn_conv2d_fwd_bnstats')) if pivot is None else
+                     (lambda: check(L.cn_conv2d_fwd_bnstats_centered(ptr(x), ptr(w_krsc), ptr(y), ptr(bias), N, H, W, C,
+                                                                     K, R, S, stride[0], stride[1], pad[0], pad[1],
+                                                                     dtype_code(x.dtype), int(relu), ptr(partial), rows,
+                                                                     ptr(pivot), stream_of(x)),
+                                    'cn_conv2d_fwd_bnstats_centered')),
                      x.device, detail=_conv_detail('fwd', C, H, K, R, stride))
-        _park_stats(y, partial, rows)
+        _park_stats(y, partial, rows, pivot)
         return y
     PROFILER.run(_last_kernel(),
                  1, 2.0 * N * P * Q * K * C * R * S,
@@ -465,7 +488,8 @@ class Conv2dFunction(Function):
         mod.ensure_prepared()
         y = conv2d_fwd(x, mod.w_krsc, bias, mod.out_channels, mod.kernel_size[0], mod.kernel_size[1],
                        mod.stride, mod.padding, out_f32=mod.out_f32,
-                       bn_stats=FUSE_BN_STATS and mod.training and getattr(mod, 'feeds_batchnorm', False))
+                       bn_stats=FUSE_BN_STATS and mod.training and getattr(mod, 'feeds_batchnorm', False),
+                       pivot=stats_pivot(mod))
         ctx.mod = mod
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x)
@@ -557,7 +581,8 @@ class StemPairConvFunction(Function):
         check(L.cn_weight_prep_pairs(ptr(mod.master_view('weight')), ptr(wp), K, R, S, mod.in_channels,
                                      stream_of(x_pairs)), 'cn_weight_prep_pairs')
         y = conv2d_fwd(x_pairs, wp, None, K, R, S2, (mod.stride[0], 1), (0, 0),
-                       bn_stats=FUSE_BN_STATS and mod.training and getattr(mod, 'feeds_batchnorm', False))
+                       bn_stats=FUSE_BN_STATS and mod.training and getattr(mod, 'feeds_batchnorm', False),
+                       pivot=stats_pivot(mod))
         ctx.mod = mod
         ctx.save_for_backward(x_pairs)
         return y
@@ -605,6 +630,8 @@ class BatchNormActFunction(Function):
         track = mod.track_running_stats
         nb = y.numel() * _esize(y)
         ps = take_pending_stats(y)
+        if ps is not None and ps.pivot is not None and not (track and ps.pivot == mod.running_mean.data_ptr()):
+            ps = None     # sums centred on something that is not this BatchNorm's running mean: take the statistics pass
         COUNTERS['bn_fwd_fused' if ps is not None else 'bn_fwd_plain'] += 1
         sync = _sync_group(mod)
         ctx.sync = sync
@@ -628,7 +655,8 @@ class BatchNormActFunction(Function):
             PROFILER.run('bn_finalize+bn_apply (stats from conv epilogue)', 2 if ps.rows <= 512 else 3, 0.0,
                          nb * (3 if residual is not None else 2) + (mask.numel() if mask is not None else 0)
                          + ps.partial.numel() * 4,
-                         lambda: check(L.cn_bn_fwd_train_partials(
+                         lambda: check((L.cn_bn_fwd_train_partials if ps.pivot is None
+                                        else L.cn_bn_fwd_train_partials_centered)(
                              ptr(y), ptr(residual), ptr(z), ptr(mask), ptr(gamma), ptr(beta),
                              ptr(mod.running_mean) if track else None, ptr(mod.running_var) if track else None,
                              ptr(mod.num_batches_tracked) if track else None, momentum, mod.eps, ptr(stats), M, C,
@@ -784,6 +812,8 @@ class BnReluMaxPoolFunction(Function):
         rv = ptr(mod.running_var) if track else None
         nbt = ptr(mod.num_batches_tracked) if track else None
         ps = take_pending_stats(y)
+        if ps is not None and ps.pivot is not None and not (track and ps.pivot == mod.running_mean.data_ptr()):
+            ps = None
         COUNTERS['bn_fwd_fused' if ps is not None else 'bn_fwd_plain'] += 1
         P, Q = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
         out = torch.empty((N, P, Q, C), dtype=y.dtype, device=y.device)
@@ -791,9 +821,10 @@ class BnReluMaxPoolFunction(Function):
 
         def run():
             if ps is not None:
-                check(L.cn_bn_fwd_train_partials(ptr(y), None, None, None, ptr(gamma), ptr(beta), rm, rv, nbt, momentum,
-                                                 mod.eps, ptr(stats), M, C, 1, code, ptr(ps.partial), ps.rows, ptr(ws),
-                                                 ws.numel() * 4, stream_of(y)), 'cn_bn_fwd_train_partials')
+                fn = L.cn_bn_fwd_train_partials if ps.pivot is None else L.cn_bn_fwd_train_partials_centered
+                check(fn(ptr(y), None, None, None, ptr(gamma), ptr(beta), rm, rv, nbt, momentum,
+                         mod.eps, ptr(stats), M, C, 1, code, ptr(ps.partial), ps.rows, ptr(ws),
+                         ws.numel() * 4, stream_of(y)), 'cn_bn_fwd_train_partials')
             else:
                 check(L.cn_bn_fwd_train(ptr(y), None, None, None, ptr(gamma), ptr(beta), rm, rv, nbt, momentum, mod.eps,
                                         ptr(stats), M, C, 1, code, ptr(ws), ws.numel() * 4, stream_of(y)),

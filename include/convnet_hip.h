@@ -68,6 +68,14 @@ int cn_conv2d_bnstats_rows(long long M);
 int cn_conv2d_fwd_bnstats(const void* x, const void* w_krsc, void* y, const float* bias, int N, int H, int W,
                           int C, int K, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w,
                           int dtype, int relu, float* partial, int partial_rows, void* stream);
+/* centred form of the two calls above / below: the partial rows hold sum (y - pivot[k]) | sum (y - pivot[k])^2 with
+ * pivot = the consumer BatchNorm's running_mean (K floats), so that the variance is not the difference of two numbers of
+ * size mean^2 (ATen's batch_norm_stats uses Welford for the same reason, nn.BatchNorm2d of models/resnet.py:128-133);
+ * cn_bn_fwd_train_partials_centered takes exactly such rows and the same running_mean before it updates it */
+int cn_conv2d_fwd_bnstats_centered(const void* x, const void* w_krsc, void* y, const float* bias, int N, int H, int W,
+                                   int C, int K, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w,
+                                   int dtype, int relu, float* partial, int partial_rows, const float* pivot,
+                                   void* stream);
 /* dx[N,H,W,C] from dy[N,P,Q,K] and the transposed filter w_crsk[C][R][S][K]
  * (written by cn_weight_prep).  Strided convs run one launch per output-parity class. */
 /* conv forward on a BatchNorm INPUT: the operand is act(x*scale[c] + shift[c]) (xf = [scale | shift], 2*C floats =
@@ -113,6 +121,11 @@ int cn_bn_fwd_train(const void* y, const void* residual, void* z, unsigned char*
 /* cn_bn_fwd_train with the statistics partials supplied by the producer of y (cn_conv2d_fwd_bnstats):
  * partial = [nrb][2*C] floats. */
 int cn_bn_fwd_train_partials(const void* y, const void* residual, void* z, unsigned char* relu_mask,
+                             const float* gamma, const float* beta, float* running_mean, float* running_var,
+                             long long* num_batches_tracked, float momentum, float eps, float* stats_out,
+                             int M, int C, int relu, int dtype, const float* partial, int nrb, void* workspace,
+                             size_t ws_bytes, void* stream);
+int cn_bn_fwd_train_partials_centered(const void* y, const void* residual, void* z, unsigned char* relu_mask,
                              const float* gamma, const float* beta, float* running_mean, float* running_var,
                              long long* num_batches_tracked, float momentum, float eps, float* stats_out,
                              int M, int C, int relu, int dtype, const float* partial, int nrb, void* workspace,

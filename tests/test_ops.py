@@ -404,6 +404,53 @@ def test_stem_bn_relu_maxpool_fused_equals_chain(mode, dtype):
 
 
 @pytest.mark.parametrize('mode', MODES)
+def test_batchnorm_statistics_are_centred_on_the_running_mean(mode):
+    """|mean| = 1000 sigma: E[x^2] - E[x]^2 in fp32 partials loses the variance; with the sums taken of
+    (y - running_mean) - standalone statistics pass and convolution epilogue alike - mean and invstd come out to
+    fp32 accuracy once the running mean is near the batch mean (bn.hip variance)."""
+    dev = _dev(mode)
+    import convnet_amd as ca
+    lib, L, ops = ca._lib, ca._lib.load(), ca.ops
+    code = lib.F32
+    N, H, W, C = (2, 12, 12, 16) if mode == 'emul' else (8, 56, 56, 64)
+    M = N * H * W
+    g = torch.Generator().manual_seed(3)
+    mu = (torch.rand(C, generator=g) + 0.5) * 1000.0 * torch.where(torch.rand(C, generator=g) > 0.5, 1.0, -1.0)
+    x = (mu.view(1, 1, 1, C) + torch.randn(N, H, W, C, generator=g)).to(dev)
+    xd = x.double().cpu().reshape(M, C)
+    mean_ref, var_ref = xd.mean(0), xd.var(0, unbiased=False)
+    invstd_ref = 1.0 / torch.sqrt(var_ref + 1e-5)
+    gamma, beta = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    ws = ops.workspace(L.cn_bn_workspace(M, C, code), dev)
+    w_eye = torch.eye(C, device=dev).view(C, 1, 1, C).contiguous()            # 1x1 identity convolution: y == x
+    for fused in (False, True):
+        rm = (mu * 0.999).to(dev).contiguous()      # a running mean that has converged to within 0.1 % (= 1 sigma)
+        rv = torch.ones(C, device=dev)
+        st = torch.empty(4 * C, device=dev)
+        z = torch.empty_like(x)
+        if fused:
+            y = ops.conv2d_fwd(x, w_eye, None, C, 1, 1, (1, 1), (0, 0), bn_stats=True, pivot=rm)
+            assert torch.equal(y, x)
+            ps = ops.take_pending_stats(y)
+            assert ps is not None and ps.pivot == rm.data_ptr()
+            lib.check(L.cn_bn_fwd_train_partials_centered(lib.ptr(y), None, lib.ptr(z), None, lib.ptr(gamma), lib.ptr(beta),
+                                                          lib.ptr(rm), lib.ptr(rv), None, 0.1, 1e-5, lib.ptr(st), M, C, 0,
+                                                          code, lib.ptr(ps.partial), ps.rows, lib.ptr(ws), ws.numel() * 4,
+                                                          lib.stream_of(y)))
+        else:
+            lib.check(L.cn_bn_fwd_train(lib.ptr(x), None, lib.ptr(z), None, lib.ptr(gamma), lib.ptr(beta), lib.ptr(rm),
+                                        lib.ptr(rv), None, 0.1, 1e-5, lib.ptr(st), M, C, 0, code, lib.ptr(ws),
+                                        ws.numel() * 4, lib.stream_of(x)))
+        mean, invstd = st[:C].double().cpu(), st[C:2 * C].double().cpu()
+        assert float(((mean - mean_ref).abs() / mean_ref.abs()).max()) < 1e-6, fused
+        assert float(((invstd - invstd_ref).abs() / invstd_ref).max()) < 1e-3, fused      # plain sums: off by 10-100 %
+        zr = ((xd - mean_ref) * invstd_ref).float()
+        assert float((z.cpu().reshape(M, C) - zr).abs().max()) < 2e-2, fused    # x itself carries 6e-5 of rounding at |x| = 1000
+        # running statistics moved from the pivot towards the batch statistics
+        assert rel_l2(rm.cpu(), (0.9 * mu * 0.999 + 0.1 * mean_ref.float())) < 1e-6
+
+
+@pytest.mark.parametrize('mode', MODES)
 def test_batchnorm_from_many_partial_rows(mode):
     """cn_bn_fwd_train_partials / cn_bn_bwd_partials with more than 512 partial rows (the 1024-thread
     finalize that replaces a separate row-compression launch) against the standalone passes."""
