@@ -116,6 +116,7 @@ class Trainer(object):
         self._use_graph = self._graph_mode != '0'
         self._graph_dp = os.environ.get('CONVNET_AMD_GRAPH_DP', '0') == '1'   # capture RCCL buckets too (opt-in)
         self._graph, self._graph_seen = None, {}
+        self._graph_eager_for = None
         from . import nn as cnn
         # a captured step replays the SAME kernels: host-drawn Dropout masks (models/mnist.py) rule it out
         self._graph_model_ok = not any((isinstance(m, cnn.Dropout) and m.p > 0) or getattr(m, 'no_graph', False)
@@ -153,7 +154,10 @@ class Trainer(object):
             # host side of trainer.py:111-112 (the regime moves lr / momentum; nothing here touches the device
             # except a tiny H2D copy when the schedule changes)
             self.optimizer.update(self.epoch, self.training_steps)
-            if self._graph_ok(inputs_batch, target_batch):
+            # (shape, chunking) for which auto mode already settled on eager launches: straight to the eager body (the
+            # bookkeeping of _graph_step costs a nearly host-bound step 1 %)
+            if self._graph_eager_for != (inputs_batch.shape, target_batch.shape, chunk_batch) \
+                    and self._graph_ok(inputs_batch, target_batch):
                 return self._graph_step(inputs_batch, target_batch, chunk_batch)
         return self._body(inputs_batch, target_batch, training, chunk_batch)
 
@@ -250,11 +254,13 @@ class Trainer(object):
             if self._graph_seen.get('key') != key:
                 self._graph_seen = {'key': key, 'n': 0}
                 self._graph = None
-            if self._graph_seen['n'] < 2:          # eager warm-up (lazy workspace growth, allocator warm)
+            warm = 4 if self._graph_mode == 'auto' else 2
+            if self._graph_seen['n'] < warm:       # eager warm-up (lazy workspace growth, allocator warm)
                 self._graph_seen['n'] += 1
-                if self._graph_seen['n'] < 2 or self._graph_mode != 'auto':
+                if self._graph_seen['n'] < warm or self._graph_mode != 'auto':
                     return self._body(inputs, target, True, chunk_batch)
-                # second warm-up step, mode 'auto': is the eager step bound by the host (launch time ~ device
+                # last warm-up step, mode 'auto' (the fourth: the first ones still grow workspaces and the allocator's
+                # pools): is the eager step bound by the host (launch time ~ device
                 # time) or by the device?  A replayed graph removes the host cost but measured 5 % SLOWER than the
                 # eager two-stream schedule when the device is the limit (ResNet-50 b=256: 22.1 vs 21.0 ms), and
                 # 1.55x faster when the host is (b=8: 5.5 vs 8.6 ms) - profiles/README.md.
@@ -269,6 +275,8 @@ class Trainer(object):
                 dev_ms = e0.elapsed_time(e1)
                 self._graph_seen['use'] = host_ms > 0.75 * dev_ms
                 self._graph_seen['eager_ms'] = dev_ms
+                if not self._graph_seen['use']:
+                    self._graph_eager_for = (inputs.shape, target.shape, chunk_batch)
                 logging.debug('step: host %.2f ms, device %.2f ms -> %s', host_ms, dev_ms,
                               'try a HIP graph' if self._graph_seen['use'] else 'eager launches')
                 return res
@@ -293,6 +301,7 @@ class Trainer(object):
                 self._graph_seen['graph_ms'] = e0.elapsed_time(e1)
                 if self._graph_seen['graph_ms'] > 0.98 * self._graph_seen['eager_ms']:
                     self._graph_seen['use'] = False
+                    self._graph_eager_for = (inputs.shape, target.shape, chunk_batch)
                     logging.debug('replayed step %.2f ms vs eager %.2f ms -> eager launches from now on',
                                   self._graph_seen['graph_ms'], self._graph_seen['eager_ms'])
                 out, loss, grad = st['out'], st['loss'], st['grad']
