@@ -16,6 +16,9 @@ Rank 0 prints ONE JSON line.  Extra objects:
                  conv/fc fwd+dgrad+wgrad) or bytes per launch / measured launch time vs the
                  gfx950 peak (MI355X_MICROARCH.md: 2.5 PFLOP/s dense bf16 MFMA, 8 TB/s HBM3E).
   kernels      : the same figures for every kernel family of the step (time share per step).
+  conv_layers  : per conv layer shape and direction: us, TFLOP/s, GB/s, which roof binds, fraction of it.
+  hbm_measured_whole_step : HBM traffic of ALL kernels of a step (committed rocprofv3 PMC passes, static) over this
+                 run's step time: the step as a whole against the memory system.
   cpu_baseline : the CPU oracle (oracle/convnet_oracle.py, kind "port") timed on this host's
                  cores on a bounded sample (ResNet-50 fp32, batch 32, 1 warm-up + 2 steps).
 """
