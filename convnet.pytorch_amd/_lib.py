@@ -64,6 +64,8 @@ _SIGNATURES = {
     'cn_maxpool_bwd': (c_i, [c_p, c_p, c_p] + [c_i] * 8 + [c_p]),
     'cn_maxpool_fwd_bnrelu': (c_i, [c_p, c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_p]),
     'cn_bn_bwd_maxpool': (c_i, [c_p] * 8 + [c_f, c_f, c_p] + [c_i] * 8 + [c_p, c_sz, c_p]),
+    'cn_maxpool_fwd_bnrelu_xmax': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_p]),
+    'cn_bn_bwd_maxpool_xmax': (c_i, [c_p] * 9 + [c_f, c_f, c_p] + [c_i] * 8 + [c_p, c_sz, c_p]),
     'cn_avgpool_fwd': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     'cn_avgpool_bwd': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     'cn_nchw_to_nhwc': (c_i, [c_p, c_p] + [c_i] * 6 + [c_p]),

@@ -1082,10 +1082,10 @@ extern "C" int cn_bn_bwd_sums(const void* dz, const void* y, const unsigned char
 // Backward of bn -> relu -> maxpool(k, stride, pad) given the gradient of the pooled map: the pool's
 // gather backward is folded into both BatchNorm-backward passes (no dense dz tensor).
 // y = BN input [N,H,W,C]; dpool / idx = [N,P,Q,C]; stats = the 4*C floats of the forward.
-extern "C" int cn_bn_bwd_maxpool(const void* dpool, const unsigned char* idx, const void* y, const float* gamma,
-                                 const float* stats, void* dy, float* dgamma, float* dbeta, float beta_acc,
-                                 float gscale, float* coef_scratch, int N, int H, int W, int C, int k, int stride,
-                                 int pad, int dtype, void* workspace, size_t ws_bytes, void* stream_) {
+static int bn_bwd_maxpool_impl(const void* dpool, const unsigned char* idx, const void* y, const void* xmax,
+                               const float* gamma, const float* stats, void* dy, float* dgamma, float* dbeta,
+                               float beta_acc, float gscale, float* coef_scratch, int N, int H, int W, int C, int k,
+                               int stride, int pad, int dtype, void* workspace, size_t ws_bytes, void* stream_) {
   const long long Ml = (long long)N * H * W;
   if (Ml >= (1ll << 31)) { cn_set_error("bn_bwd_maxpool: too many rows"); return CN_ESHAPE; }
   const int M = (int)Ml;
@@ -1118,8 +1118,17 @@ extern "C" int cn_bn_bwd_maxpool(const void* dpool, const unsigned char* idx, co
   const float* shift = stats + 3 * C;
   dim3 grid((unsigned)nrb, (unsigned)m.gy);
   CnMarkLast last;   // an armed completion mark goes on the apply kernel only
-  CN_DISPATCH_T(dtype, CN_LAUNCH(bn_bwd_reduce_pool_kernel<TT>, grid, dim3(256), stream, geo, (const char*)y, mean, invstd, scale,
-              shift, partial, M, C, m.tpr_log2));
+  if (xmax != nullptr) {
+    // sums over the pooled map: every pooled element sends its gradient to exactly one input pixel, whose
+    // pre-BatchNorm value the forward kept (xmax), so sum g and sum g*xhat need neither the gather nor the big map
+    const long long Mp = (long long)N * geo.P * geo.Q;
+    nrb = bn_row_blocks((int)Mp, m, cn_get_option("bn_reduce_blocks", BN_TARGET_BLOCKS));
+    dim3 pgrid((unsigned)nrb, (unsigned)m.gy);
+    BN_DISPATCH(bn_bwd_reduce_kernel, dtype, false, pgrid, stream, (const char*)dpool, (const char*)xmax, (const unsigned char*)nullptr, mean, invstd, scale, shift, partial, (int)Mp, C, 1, m.tpr_log2, 0);
+  } else {
+    CN_DISPATCH_T(dtype, CN_LAUNCH(bn_bwd_reduce_pool_kernel<TT>, grid, dim3(256), stream, geo, (const char*)y, mean, invstd, scale,
+                shift, partial, M, C, m.tpr_log2));
+  }
   CN_LAUNCH(bn_bwd_finalize_kernel, dim3((unsigned)((C + BN_FC - 1) / BN_FC)), dim3(256), stream, (const float*)partial,
             nrb, M, C, gamma, mean, invstd, dgamma, dbeta, beta_acc, gscale, coef_scratch);
   int nab = bn_row_blocks(M, m, cn_get_option("bn_apply_blocks", BN_APPLY_BLOCKS));
@@ -1128,4 +1137,23 @@ extern "C" int cn_bn_bwd_maxpool(const void* dpool, const unsigned char* idx, co
   CN_DISPATCH_T(dtype, CN_LAUNCH(bn_bwd_apply_pool_kernel<TT>, agrid, dim3(256), stream, geo, (const char*)y, scale, shift,
               (const float*)coef_scratch, (char*)dy, M, C, m.tpr_log2));
   return cn_check_launch("bn_bwd_maxpool");
+}
+
+extern "C" int cn_bn_bwd_maxpool(const void* dpool, const unsigned char* idx, const void* y, const float* gamma,
+                                 const float* stats, void* dy, float* dgamma, float* dbeta, float beta_acc,
+                                 float gscale, float* coef_scratch, int N, int H, int W, int C, int k, int stride,
+                                 int pad, int dtype, void* workspace, size_t ws_bytes, void* stream_) {
+  return bn_bwd_maxpool_impl(dpool, idx, y, nullptr, gamma, stats, dy, dgamma, dbeta, beta_acc, gscale, coef_scratch, N,
+                             H, W, C, k, stride, pad, dtype, workspace, ws_bytes, stream_);
+}
+
+// With the winning taps' pre-BatchNorm values (cn_maxpool_fwd_bnrelu_xmax): the reduction reads dpool and xmax only.
+extern "C" int cn_bn_bwd_maxpool_xmax(const void* dpool, const unsigned char* idx, const void* y, const void* xmax,
+                                      const float* gamma, const float* stats, void* dy, float* dgamma, float* dbeta,
+                                      float beta_acc, float gscale, float* coef_scratch, int N, int H, int W, int C,
+                                      int k, int stride, int pad, int dtype, void* workspace, size_t ws_bytes,
+                                      void* stream_) {
+  if (xmax == nullptr) { cn_set_error("bn_bwd_maxpool_xmax: no xmax tensor"); return CN_EINVAL; }
+  return bn_bwd_maxpool_impl(dpool, idx, y, xmax, gamma, stats, dy, dgamma, dbeta, beta_acc, gscale, coef_scratch, N, H,
+                             W, C, k, stride, pad, dtype, workspace, ws_bytes, stream_);
 }

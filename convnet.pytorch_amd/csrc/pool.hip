@@ -20,7 +20,7 @@ template <typename T, bool AFF, int KS>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const char* x, char* y, unsigned char* idx, int N,
                                                          int H, int W, int C, int P, int Q, int k, int st,
                                                          int pad, FastDiv div_cpr, const float* scale,
-                                                         const float* shift) {
+                                                         const float* shift, char* xmax) {
   constexpr int CH = ElemTraits<T>::kChunk;
   constexpr int EB = ElemTraits<T>::kBytes;
   const int cpr = C / CH;
@@ -34,15 +34,17 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const char* x, char* y
   for (int e = 0; e < CH; ++e) { sc[e] = AFF ? scale[col * CH + e] : 1.f; sh[e] = AFF ? shift[col * CH + e] : 0.f; }
   for (int row = blockIdx.y; row < N * P; row += gridDim.y) {
     const int n = row / P, pp = row - n * P;
-    float best[CH];
+    float best[CH], braw[CH];   // braw (AFF): the pre-BatchNorm value at the winning tap, for the backward sums
     int bi[CH];
 #pragma unroll
-    for (int e = 0; e < CH; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+    for (int e = 0; e < CH; ++e) { best[e] = -INFINITY; bi[e] = 0; braw[e] = 0.f; }
     bool first = true;
     auto take = [&](const u32x4& raw, int t) {
-      float f[CH];
+      float f[CH], r0[CH];
       Chunk<T>::unpack(raw, f);
       if (AFF) {
+#pragma unroll
+        for (int e = 0; e < CH; ++e) r0[e] = f[e];
 #pragma unroll
         for (int e = 0; e < CH; ++e) {
           const float v = fmaf(f[e], sc[e], sh[e]);
@@ -52,7 +54,11 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const char* x, char* y
       }
 #pragma unroll
       for (int e = 0; e < CH; ++e)
-        if (first || f[e] > best[e]) { best[e] = f[e]; bi[e] = t; }
+        if (first || f[e] > best[e]) {
+          best[e] = f[e];
+          bi[e] = t;
+          if (AFF) braw[e] = r0[e];
+        }
       first = false;
     };
     if (KS > 0) {   // compile-time window: all KS*KS taps are requested before the first comparison
@@ -85,6 +91,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const char* x, char* y
     }
     const size_t o = ((size_t)row * Q + q) * C + (size_t)col * CH;
     cn_st16(y + o * EB, Chunk<T>::pack(best));
+    if (AFF && xmax != nullptr) cn_st16(xmax + o * EB, Chunk<T>::pack(braw));   // exact: the values were stored as T
     if (CH == 8) {   // one 8-byte store of the chunk's winning taps
       unsigned long long pk = 0;
 #pragma unroll
@@ -318,9 +325,10 @@ extern "C" int cn_maxpool_fwd(const void* x, void* y, unsigned char* idx, int N,
   const long long rows_f = (long long)N * P;
   dim3 grid((unsigned)((Q * (C / CH) + 255) / 256), (unsigned)(rows_f < 65535 ? rows_f : 65535));
   const FastDiv div_cpr = cn_make_fastdiv((unsigned)(C / CH));
+  void* xmax_ = nullptr;
 #define MP_GO(T, AFF, KS, SC, SH)                                                                               \
   CN_LAUNCH((maxpool_fwd_kernel<T, AFF, KS>), grid, dim3(256), (hipStream_t)stream, (const char*)x, (char*)y, idx, N, H, \
-            W, C, P, Q, k, stride, pad, div_cpr, SC, SH)
+            W, C, P, Q, k, stride, pad, div_cpr, SC, SH, (char*)xmax_)
   const float* none = nullptr;
   if (dtype == CN_BF16) { if (k == 3) MP_GO(bf16_t, false, 3, none, none); else MP_GO(bf16_t, false, 0, none, none); }
   else if (dtype == CN_F16) { if (k == 3) MP_GO(f16_t, false, 3, none, none); else MP_GO(f16_t, false, 0, none, none); }
@@ -331,9 +339,9 @@ extern "C" int cn_maxpool_fwd(const void* x, void* y, unsigned char* idx, int N,
 // y = maxpool(relu(x*scale + shift)): x is the pre-BatchNorm tensor, scale/shift the per-channel
 // coefficients cn_bn_fwd_train* wrote (stats_out + 2C / + 3C).  The pooled values are rounded to the
 // compute dtype exactly like the unfused chain rounds z before pooling it.
-extern "C" int cn_maxpool_fwd_bnrelu(const void* x, const float* scale, const float* shift, void* y,
-                                     unsigned char* idx, int N, int H, int W, int C, int k, int stride, int pad,
-                                     int dtype, void* stream) {
+static int maxpool_fwd_bnrelu_impl(const void* x, const float* scale, const float* shift, void* y,
+                                   unsigned char* idx, void* xmax_, int N, int H, int W, int C, int k, int stride,
+                                   int pad, int dtype, void* stream) {
   int rc = pool_check("maxpool_fwd_bnrelu", C, dtype);
   if (rc) return rc;
   if (k * k > 255 || pad * 2 > k || scale == nullptr || shift == nullptr) {
@@ -350,6 +358,22 @@ extern "C" int cn_maxpool_fwd_bnrelu(const void* x, const float* scale, const fl
   else { if (k == 3) MP_GO(float, true, 3, scale, shift); else MP_GO(float, true, 0, scale, shift); }
 #undef MP_GO
   return cn_check_launch("maxpool_fwd_bnrelu");
+}
+
+extern "C" int cn_maxpool_fwd_bnrelu(const void* x, const float* scale, const float* shift, void* y,
+                                     unsigned char* idx, int N, int H, int W, int C, int k, int stride, int pad,
+                                     int dtype, void* stream) {
+  return maxpool_fwd_bnrelu_impl(x, scale, shift, y, idx, nullptr, N, H, W, C, k, stride, pad, dtype, stream);
+}
+
+// The same pass, additionally storing the pre-BatchNorm value of every winning tap (xmax, shaped like y): with it the
+// BatchNorm-backward sums of the fused stem are taken over the pooled map (cn_bn_bwd_maxpool_xmax) instead of the
+// 4x larger input map with the pool's gather per pixel.
+extern "C" int cn_maxpool_fwd_bnrelu_xmax(const void* x, const float* scale, const float* shift, void* y,
+                                          unsigned char* idx, void* xmax, int N, int H, int W, int C, int k,
+                                          int stride, int pad, int dtype, void* stream) {
+  if (xmax == nullptr) { cn_set_error("maxpool_fwd_bnrelu_xmax: no xmax buffer"); return CN_EINVAL; }
+  return maxpool_fwd_bnrelu_impl(x, scale, shift, y, idx, xmax, N, H, W, C, k, stride, pad, dtype, stream);
 }
 
 extern "C" int cn_maxpool_bwd(const void* dy, const unsigned char* idx, void* dx, int N, int H, int W, int C,

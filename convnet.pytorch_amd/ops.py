@@ -87,6 +87,8 @@ class KernelProfiler(object):
 
 
 PROFILER = KernelProfiler()
+# CONVNET_AMD_STEM_XMAX=0: the fused stem's BatchNorm-backward sums over the input map with the pool gather (A/B knob)
+STEM_XMAX = os.environ.get('CONVNET_AMD_STEM_XMAX', '1') == '1'
 # CONVNET_AMD_CENTERED_STATS=0: plain sum / sum-of-squares statistics partials (A/B knob)
 _cs = os.environ.get('CONVNET_AMD_CENTERED_STATS', '1')   # 0 = never, 1 = fp32 models, all = every dtype
 CENTERED_STATS = 'all' if _cs == 'all' else (_cs == '1')
@@ -818,6 +820,8 @@ class BnReluMaxPoolFunction(Function):
         P, Q = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
         out = torch.empty((N, P, Q, C), dtype=y.dtype, device=y.device)
         idx = torch.empty((N, P, Q, C), dtype=torch.uint8, device=y.device)
+        # the pre-BatchNorm value of every winning tap: the backward sums then run over the pooled map
+        xmax = torch.empty_like(out) if (STEM_XMAX and ctx.needs_input_grad[0]) else None
 
         def run():
             if ps is not None:
@@ -829,18 +833,29 @@ class BnReluMaxPoolFunction(Function):
                 check(L.cn_bn_fwd_train(ptr(y), None, None, None, ptr(gamma), ptr(beta), rm, rv, nbt, momentum, mod.eps,
                                         ptr(stats), M, C, 1, code, ptr(ws), ws.numel() * 4, stream_of(y)),
                       'cn_bn_fwd_train')
-            check(L.cn_maxpool_fwd_bnrelu(ptr(y), ptr(stats[2 * C:3 * C]), ptr(stats[3 * C:]), ptr(out), ptr(idx), N, H, W,
-                                          C, k, stride, pad, code, stream_of(y)), 'cn_maxpool_fwd_bnrelu')
+            if xmax is not None:
+                check(L.cn_maxpool_fwd_bnrelu_xmax(ptr(y), ptr(stats[2 * C:3 * C]), ptr(stats[3 * C:]), ptr(out), ptr(idx),
+                                                   ptr(xmax), N, H, W, C, k, stride, pad, code, stream_of(y)),
+                      'cn_maxpool_fwd_bnrelu_xmax')
+            else:
+                check(L.cn_maxpool_fwd_bnrelu(ptr(y), ptr(stats[2 * C:3 * C]), ptr(stats[3 * C:]), ptr(out), ptr(idx), N, H,
+                                              W, C, k, stride, pad, code, stream_of(y)), 'cn_maxpool_fwd_bnrelu')
         PROFILER.run('bn_finalize+maxpool_fwd_bnrelu (stem)', 3, 0.0,
-                     y.numel() * _esize(y) * (1 if ps is not None else 2) + out.numel() * (_esize(out) + 1), run, y.device)
+                     y.numel() * _esize(y) * (1 if ps is not None else 2)
+                     + out.numel() * (_esize(out) * (2 if xmax is not None else 1) + 1), run, y.device)
         ctx.mod = mod
         ctx.cfg = (N, H, W, C, k, stride, pad)
-        ctx.save_for_backward(y, stats, idx)
+        ctx.has_xmax = xmax is not None
+        if xmax is not None:
+            ctx.save_for_backward(y, stats, idx, xmax)
+        else:
+            ctx.save_for_backward(y, stats, idx)
         return out
 
     @staticmethod
     def backward(ctx, dpool):
-        y, stats, idx = ctx.saved_tensors
+        y, stats, idx = ctx.saved_tensors[:3]
+        xmax = ctx.saved_tensors[3] if ctx.has_xmax else None
         mod = ctx.mod
         N, H, W, C, k, stride, pad = ctx.cfg
         L = _L()
@@ -851,11 +866,19 @@ class BnReluMaxPoolFunction(Function):
         coef = torch.empty(3 * C, dtype=torch.float32, device=y.device)
         COUNTERS['bn_bwd_plain'] += 1
         with SIDE.mark(dy):
-            PROFILER.run('bn_bwd_maxpool (stem)', 3, 0.0, y.numel() * _esize(y) * 3 + dpool.numel() * (_esize(dpool) + 1) * 2,
-                         lambda: check(L.cn_bn_bwd_maxpool(ptr(dpool), ptr(idx), ptr(y), ptr(mod.weight), ptr(stats), ptr(dy),
-                                                           ptr(mod.grad_view('weight')), ptr(mod.grad_view('bias')), 1.0, 1.0,
-                                                           ptr(coef), N, H, W, C, k, stride, pad, code, ptr(ws),
-                                                           ws.numel() * 4, stream_of(y)), 'cn_bn_bwd_maxpool'),
+            PROFILER.run('bn_bwd_maxpool (stem)', 3, 0.0,
+                         (y.numel() * _esize(y) * 3 + dpool.numel() * (_esize(dpool) + 1) * 2) if xmax is None else
+                         (y.numel() * _esize(y) * 2 + dpool.numel() * (3 * _esize(dpool) + 1)),
+                         (lambda: check(L.cn_bn_bwd_maxpool(ptr(dpool), ptr(idx), ptr(y), ptr(mod.weight), ptr(stats), ptr(dy),
+                                                            ptr(mod.grad_view('weight')), ptr(mod.grad_view('bias')), 1.0, 1.0,
+                                                            ptr(coef), N, H, W, C, k, stride, pad, code, ptr(ws),
+                                                            ws.numel() * 4, stream_of(y)), 'cn_bn_bwd_maxpool'))
+                         if xmax is None else
+                         (lambda: check(L.cn_bn_bwd_maxpool_xmax(ptr(dpool), ptr(idx), ptr(y), ptr(xmax), ptr(mod.weight),
+                                                                 ptr(stats), ptr(dy), ptr(mod.grad_view('weight')),
+                                                                 ptr(mod.grad_view('bias')), 1.0, 1.0, ptr(coef), N, H, W, C,
+                                                                 k, stride, pad, code, ptr(ws), ws.numel() * 4,
+                                                                 stream_of(y)), 'cn_bn_bwd_maxpool_xmax')),
                          y.device)
         mod._notify_grad_ready()
         return dy, None, None, None, None, None, None

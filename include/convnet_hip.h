@@ -180,6 +180,16 @@ int cn_bn_bwd_maxpool(const void* dpool, const unsigned char* idx, const void* y
                       const float* stats, void* dy, float* dgamma, float* dbeta, float beta_acc, float gscale,
                       float* coef_scratch /*3C*/, int N, int H, int W, int C, int k, int stride, int pad, int dtype,
                       void* workspace, size_t ws_bytes, void* stream);
+/* the same pair with the pre-BatchNorm value of every winning tap kept by the forward (xmax, shaped like the pooled
+ * map): the backward sums sum g and sum g*xhat are then taken over the pooled map (dpool, xmax) instead of the 4x larger
+ * input map with a 2x2-window gather per pixel; dy is computed as before */
+int cn_maxpool_fwd_bnrelu_xmax(const void* x_prebn, const float* scale, const float* shift, void* y, unsigned char* idx,
+                               void* xmax, int N, int H, int W, int C, int k, int stride, int pad, int dtype,
+                               void* stream);
+int cn_bn_bwd_maxpool_xmax(const void* dpool, const unsigned char* idx, const void* y_prebn, const void* xmax,
+                           const float* gamma, const float* stats, void* dy, float* dgamma, float* dbeta,
+                           float beta_acc, float gscale, float* coef_scratch, int N, int H, int W, int C, int k,
+                           int stride, int pad, int dtype, void* workspace, size_t ws_bytes, void* stream);
 int cn_avgpool_fwd(const void* x, void* y, int N, int HW, int C, int dtype, void* stream);
 int cn_avgpool_bwd(const void* dy, void* dx, int N, int HW, int C, int dtype, void* stream);
 

@@ -399,7 +399,11 @@ def test_stem_bn_relu_maxpool_fused_equals_chain(mode, dtype):
         assert torch.equal(f[0], u[0])
         tol = 1e-5 if dtype == torch.float32 else 4e-3
         assert rel_l2(f[1], u[1]) < tol
-        assert rel_l2(f[2], u[2]) < 1e-4 and rel_l2(f[3], u[3]) < 1e-4
+        # dgamma / dbeta: the fused form sums the pooled gradients unrounded (over the pooled map, ops.STEM_XMAX); the
+        # chain rounds the max-pool backward's output to the storage type first - one storage epsilon on a few dozen
+        # terms per channel at these sizes
+        ptol = 1e-4 if dtype == torch.float32 else 4e-3
+        assert rel_l2(f[2], u[2]) < ptol and rel_l2(f[3], u[3]) < ptol
         assert torch.equal(f[4], u[4]) and torch.equal(f[5], u[5])
 
 
