@@ -47,6 +47,8 @@ _SIGNATURES = {
     'cn_conv2d_dgrad': (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 11 + [c_i, c_i, c_p]),
     'cn_conv2d_dgrad_bnbwd_rows': (c_i, [c_i] * 6),
     'cn_conv2d_dgrad_bnbwd': (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 11 + [c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_p]),
+    'cn_conv2d_dgrad_sa': (c_i, [c_p, c_p, c_p, c_p, c_i] + [c_i] * 11 + [c_i, c_i, c_p]),
+    'cn_conv2d_dgrad_bnbwd_sa': (c_i, [c_p, c_p, c_p, c_p, c_i] + [c_i] * 11 + [c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_p]),
     'cn_conv2d_wgrad_workspace': (c_sz, [c_i] * 12),
     'cn_conv2d_wgrad': (c_i, [c_p, c_p, c_p, c_i] + [c_i] * 11 + [c_i, c_f, c_f, c_p, c_sz, c_p]),
     'cn_bn_workspace': (c_sz, [c_i, c_i, c_i]),

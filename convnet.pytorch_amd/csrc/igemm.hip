@@ -28,6 +28,7 @@ struct IgemmParams {
   const char* w;
   char* y;
   const char* addend;   // optional tensor added to the output (same layout / dtype as y)
+  int addend_sub, add_H, add_W;   // addend_sub = 2: the addend holds the even (h, w) pixels only, [N][add_H][add_W][Co] (the rest is zero)
   const float* bias;
   float* stats;         // optional [n_mtiles][2*Co]: per pixel-tile sum / sum of squares of the stored outputs
   const float* stats_pivot;   // optional [Co]: the sums are taken of (output - pivot[c]) (centred statistics)
@@ -119,11 +120,12 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
   constexpr int STAGE = (BM + BN) * 128;
   constexpr int OUT_MAX = BM * (BN * (OUTF32 ? 4 : EB) + 16);
   constexpr int MAIN = (STAGES * STAGE > OUT_MAX) ? STAGES * STAGE : OUT_MAX;
-  constexpr int LDS_BYTES = MAIN + IG_MAX_TAPS * 16 + BM * 4 + (XF ? IG_XF_MAX * 8 : 0);
+  constexpr int LDS_BYTES = MAIN + IG_MAX_TAPS * 16 + BM * 4 + (XF ? IG_XF_MAX * 8 : 0) + (EPI ? BM * 4 : 0);
   __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
   int* s_taps = (int*)(lds + MAIN);                       // per tap: {dhdw, woff bytes, x delta bytes, 0}
   int* s_outpix = (int*)(lds + MAIN + IG_MAX_TAPS * 16);
   float* s_xf = (float*)(lds + MAIN + IG_MAX_TAPS * 16 + BM * 4);   // XF: [scale | shift] of the Ci input channels
+  int* s_addpix = (int*)(lds + MAIN + IG_MAX_TAPS * 16 + BM * 4);   // EPI (never together with XF): pixel index into a subsampled addend
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -151,15 +153,18 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
   }
   if (tid < BM) {
     int m = m0 + tid;
-    int pix = -1;
+    int pix = -1, apix = -1;
     if (m < p.M) {
       int n = (int)cn_fastdiv((unsigned)m, p.div_hw);
       int rem = m - n * HgWg;
       int hg = (int)cn_fastdiv((unsigned)rem, p.div_w);
       int wg = rem - hg * p.Wg;
-      pix = (n * p.Ho + hg * p.oh_mul + p.oh_off) * p.Wo + wg * p.ow_mul + p.ow_off;
+      const int ho = hg * p.oh_mul + p.oh_off, wo = wg * p.ow_mul + p.ow_off;
+      pix = (n * p.Ho + ho) * p.Wo + wo;
+      if (EPI && p.addend_sub == 2 && ((ho | wo) & 1) == 0) apix = (n * p.add_H + (ho >> 1)) * p.add_W + (wo >> 1);
     }
     s_outpix[tid] = pix;
+    if (EPI) s_addpix[tid] = apix;
   }
   if (XF) {
     for (int c = tid; c < 2 * p.Ci; c += NT) s_xf[c] = p.xf[c];
@@ -241,7 +246,10 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
       const int pix = s_outpix[erow0 + (k0 + kk) * (NT / CPR)];
       const size_t goff = ((size_t)(pix < 0 ? 0 : pix) * (size_t)p.Co + (size_t)c_first) * OEBc;
       const u32x4 zero = {0u, 0u, 0u, 0u};
-      adv[kk] = (pix >= 0 && p.addend != nullptr) ? cn_ld16(p.addend + goff) : zero;
+      // a subsampled addend (the gradient of a stride-2 1x1 projection: zero off the even pixels) is read where it exists
+      const int apx = p.addend_sub == 2 ? s_addpix[erow0 + (k0 + kk) * (NT / CPR)] : pix;
+      const size_t aoff = ((size_t)(apx < 0 ? 0 : apx) * (size_t)p.Co + (size_t)c_first) * OEBc;
+      adv[kk] = (pix >= 0 && apx >= 0 && p.addend != nullptr) ? cn_ld16(p.addend + aoff) : zero;
       bitv[kk] = (pix >= 0 && bnb && p.bn_mask != nullptr) ? (unsigned int)p.bn_mask[goff >> 4] : 0u;
     }
   };
@@ -546,6 +554,8 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
         const char* src = lds + row * pitch + ecol * 16;
         const size_t goff = ((size_t)pix * (size_t)p.Co + (size_t)c_first) * OEB;
         char* dst = p.y + goff;
+        const int apx = (EPI && p.addend_sub == 2) ? s_addpix[row] : pix;   // element-wise tail below
+        const size_t aoff = ((size_t)(apx < 0 ? 0 : apx) * (size_t)p.Co + (size_t)c_first) * OEB;
         if (vec_ok) {
           u32x4 v = cn_ld16(src);
           if (pre) {
@@ -585,11 +595,11 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
           for (int e = 0; e < epc && c_first + e < p.Co; ++e) {
             if (OEB == 4) {
               float f = ((const float*)src)[e];
-              if (p.addend != nullptr) f += ((const float*)(p.addend + goff))[e];
+              if (p.addend != nullptr && apx >= 0) f += ((const float*)(p.addend + aoff))[e];
               ((float*)dst)[e] = f;
             } else {
               float f = cn_load_elem<T>((const T*)src + e);
-              if (p.addend != nullptr) f += cn_load_elem<T>((const T*)(p.addend + goff) + e);
+              if (p.addend != nullptr && apx >= 0) f += cn_load_elem<T>((const T*)(p.addend + aoff) + e);
               cn_store_elem<T>((T*)dst + e, f);
             }
           }
@@ -912,7 +922,8 @@ struct IgBnBwd {
 
 static int ig_conv_dgrad(const void* dy, const void* w_crsk, void* dx, const void* addend, int N, int H,
                          int W, int C, int K, int R, int S, int stride_h, int stride_w, int pad_h,
-                         int pad_w, int dtype, int out_f32, const IgBnBwd* bn, void* stream) {
+                         int pad_w, int dtype, int out_f32, const IgBnBwd* bn, void* stream, int addend_sub = 1) {
+  if (addend_sub != 1 && addend_sub != 2) { cn_set_error("conv2d_dgrad: addend subsampling %d (1 or 2)", addend_sub); return CN_EINVAL; }
   int bn_row = 0;
   const int P = (H + 2 * pad_h - R) / stride_h + 1;
   const int Q = (W + 2 * pad_w - S) / stride_w + 1;
@@ -925,6 +936,7 @@ static int ig_conv_dgrad(const void* dy, const void* w_crsk, void* dx, const voi
       memset(&p, 0, sizeof(p));
       p.x = (const char*)dy; p.w = (const char*)w_crsk; p.y = (char*)dx; p.bias = nullptr;
       p.addend = (const char*)addend;
+      p.addend_sub = addend != nullptr ? addend_sub : 1; p.add_H = (H + 1) / 2; p.add_W = (W + 1) / 2;
       p.N = N; p.Hi = P; p.Wi = Q; p.Ci = K;
       p.Hg = (H - ph + stride_h - 1) / stride_h;
       p.Wg = (W - pw + stride_w - 1) / stride_w;
@@ -977,6 +989,16 @@ extern "C" int cn_conv2d_dgrad(const void* dy, const void* w_crsk, void* dx, con
                        out_f32, nullptr, stream);
 }
 
+// The same with a SUBSAMPLED addend: `addend` is [N][(H+1)/2][(W+1)/2][C], the values at the even (h, w) pixels of a
+// tensor that is zero everywhere else - the input gradient of a stride-2 1x1 projection (models/resnet.py:176-181),
+// which is what meets this gradient at the block input.  Saves writing and re-reading the three quarters of zeros.
+extern "C" int cn_conv2d_dgrad_sa(const void* dy, const void* w_crsk, void* dx, const void* addend, int addend_sub, int N,
+                                  int H, int W, int C, int K, int R, int S, int stride_h, int stride_w, int pad_h,
+                                  int pad_w, int dtype, int out_f32, void* stream) {
+  return ig_conv_dgrad(dy, w_crsk, dx, addend, N, H, W, C, K, R, S, stride_h, stride_w, pad_h, pad_w, dtype,
+                       out_f32, nullptr, stream, addend_sub);
+}
+
 // Partial rows cn_conv2d_dgrad_bnbwd writes: one per pixel tile (128, or 64 with "igemm_epi_bm64") of every
 // output-parity class.
 extern "C" int cn_conv2d_dgrad_bnbwd_rows(int N, int H, int W, int C, int stride_h, int stride_w) {
@@ -997,11 +1019,10 @@ extern "C" int cn_conv2d_dgrad_bnbwd_rows(int N, int H, int W, int C, int stride
 // writes partial[row] = [sum g | sum g*(bn_y-mean)*invstd] per 128-pixel tile
 // (cn_conv2d_dgrad_bnbwd_rows rows of 2*C floats) for cn_bn_bwd_partials.  bn_coef = the 4*C floats
 // [mean | invstd | scale | shift] cn_bn_fwd_train wrote.
-extern "C" int cn_conv2d_dgrad_bnbwd(const void* dy, const void* w_crsk, void* g, const void* addend, int N, int H,
-                                     int W, int C, int K, int R, int S, int stride_h, int stride_w, int pad_h,
-                                     int pad_w, int dtype, const void* bn_y, const unsigned char* bn_mask,
-                                     const float* bn_coef, int bn_relu, float* partial, int partial_rows,
-                                     void* stream) {
+static int dgrad_bnbwd_impl(const void* dy, const void* w_crsk, void* g, const void* addend, int addend_sub, int N,
+                            int H, int W, int C, int K, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w,
+                            int dtype, const void* bn_y, const unsigned char* bn_mask, const float* bn_coef,
+                            int bn_relu, float* partial, int partial_rows, void* stream) {
   const int CH = cn_dtype_chunk(dtype);
   if (bn_y == nullptr || bn_coef == nullptr || partial == nullptr || C % CH != 0) {
     cn_set_error("conv2d_dgrad_bnbwd: needs bn_y, bn_coef, partial and C (%d) a multiple of %d", C, CH);
@@ -1011,5 +1032,24 @@ extern "C" int cn_conv2d_dgrad_bnbwd(const void* dy, const void* w_crsk, void* g
   bn.y = bn_y; bn.mask = bn_mask; bn.coef = bn_coef; bn.partial = partial; bn.relu = bn_relu;
   bn.rows_cap = partial_rows;
   return ig_conv_dgrad(dy, w_crsk, g, addend, N, H, W, C, K, R, S, stride_h, stride_w, pad_h, pad_w, dtype, 0, &bn,
-                       stream);
+                       stream, addend_sub);
+}
+
+extern "C" int cn_conv2d_dgrad_bnbwd(const void* dy, const void* w_crsk, void* g, const void* addend, int N, int H,
+                                     int W, int C, int K, int R, int S, int stride_h, int stride_w, int pad_h,
+                                     int pad_w, int dtype, const void* bn_y, const unsigned char* bn_mask,
+                                     const float* bn_coef, int bn_relu, float* partial, int partial_rows,
+                                     void* stream) {
+  return dgrad_bnbwd_impl(dy, w_crsk, g, addend, 1, N, H, W, C, K, R, S, stride_h, stride_w, pad_h, pad_w, dtype, bn_y,
+                          bn_mask, bn_coef, bn_relu, partial, partial_rows, stream);
+}
+
+// ... with a subsampled addend (see cn_conv2d_dgrad_sa)
+extern "C" int cn_conv2d_dgrad_bnbwd_sa(const void* dy, const void* w_crsk, void* g, const void* addend, int addend_sub,
+                                        int N, int H, int W, int C, int K, int R, int S, int stride_h, int stride_w,
+                                        int pad_h, int pad_w, int dtype, const void* bn_y,
+                                        const unsigned char* bn_mask, const float* bn_coef, int bn_relu,
+                                        float* partial, int partial_rows, void* stream) {
+  return dgrad_bnbwd_impl(dy, w_crsk, g, addend, addend_sub, N, H, W, C, K, R, S, stride_h, stride_w, pad_h, pad_w, dtype,
+                          bn_y, bn_mask, bn_coef, bn_relu, partial, partial_rows, stream);
 }

@@ -87,6 +87,8 @@ class KernelProfiler(object):
 
 
 PROFILER = KernelProfiler()
+# CONVNET_AMD_SUBSAMPLED_SHORTCUT_GRAD=0: the stride-2 projection shortcut's input gradient as a dense tensor (A/B knob)
+SUBSAMPLED_SHORTCUT_GRAD = os.environ.get('CONVNET_AMD_SUBSAMPLED_SHORTCUT_GRAD', '1') == '1'
 # CONVNET_AMD_STEM_XMAX=0: the fused stem's BatchNorm-backward sums over the input map with the pool gather (A/B knob)
 STEM_XMAX = os.environ.get('CONVNET_AMD_STEM_XMAX', '1') == '1'
 # CONVNET_AMD_CENTERED_STATS=0: plain sum / sum-of-squares statistics partials (A/B knob)
@@ -335,21 +337,24 @@ def conv2d_fwd_xf(x, xf, xf_relu, w_krsc, K, R, S, stride, pad, bn_stats=False):
     return y
 
 
-def conv2d_dgrad(dy, w_crsk, x_shape, K, R, S, stride, pad, addend=None, bn=None):
+def conv2d_dgrad(dy, w_crsk, x_shape, K, R, S, stride, pad, addend=None, bn=None, addend_sub=1):
     """dx (NHWC).  With bn = (bn_y, bn_mask_or_None, bn_stats[4C], relu) the epilogue also does the
-    reduction half of that BatchNorm's backward: returns (g = dx*relu_mask, partial, rows)."""
+    reduction half of that BatchNorm's backward: returns (g = dx*relu_mask, partial, rows).
+    addend_sub = 2: `addend` holds only the even (h, w) pixels of a gradient that is zero elsewhere."""
     N, H, W, C = x_shape
     dx = torch.empty((N, H, W, C), dtype=dy.dtype, device=dy.device)
     name = _last_kernel()
     detail = _conv_detail('dgrad', C, H, K, R, stride)
     flops = 2.0 * dy.numel() * C * R * S
-    nbytes = dy.numel() * _esize(dy) + dx.numel() * _esize(dx) * (2 if addend is not None else 1) \
-        + K * R * S * C * _esize(dy)
+    nbytes = dy.numel() * _esize(dy) + dx.numel() * _esize(dx) + K * R * S * C * _esize(dy) \
+        + (addend.numel() * _esize(addend) if addend is not None else 0)
+    if addend is not None and addend_sub == 2:
+        assert tuple(addend.shape) == (N, (H + 1) // 2, (W + 1) // 2, C), 'subsampled addend shape'
     if bn is None:
         PROFILER.run(name, stride[0] * stride[1], flops, nbytes,
-                     lambda: check(_L().cn_conv2d_dgrad(ptr(dy), ptr(w_crsk), ptr(dx), ptr(addend), N, H, W, C, K, R, S,
-                                                        stride[0], stride[1], pad[0], pad[1], dtype_code(dy.dtype), 0,
-                                                        stream_of(dy)), 'cn_conv2d_dgrad'),
+                     lambda: check(_L().cn_conv2d_dgrad_sa(ptr(dy), ptr(w_crsk), ptr(dx), ptr(addend), int(addend_sub), N, H,
+                                                           W, C, K, R, S, stride[0], stride[1], pad[0], pad[1],
+                                                           dtype_code(dy.dtype), 0, stream_of(dy)), 'cn_conv2d_dgrad'),
                      dy.device, detail=detail)
         return dx
     bn_y, bn_mask, bn_stats, bn_relu = bn
@@ -357,10 +362,11 @@ def conv2d_dgrad(dy, w_crsk, x_shape, K, R, S, stride, pad, addend=None, bn=None
     rows = L.cn_conv2d_dgrad_bnbwd_rows(N, H, W, C, stride[0], stride[1])
     partial = torch.empty((rows, 2 * C), dtype=torch.float32, device=dy.device)
     PROFILER.run(name, stride[0] * stride[1], flops, nbytes + dx.numel() * _esize(dx) + partial.numel() * 4,
-                 lambda: check(L.cn_conv2d_dgrad_bnbwd(ptr(dy), ptr(w_crsk), ptr(dx), ptr(addend), N, H, W, C, K, R, S,
-                                                       stride[0], stride[1], pad[0], pad[1], dtype_code(dy.dtype),
-                                                       ptr(bn_y), ptr(bn_mask), ptr(bn_stats), int(bn_relu),
-                                                       ptr(partial), rows, stream_of(dy)), 'cn_conv2d_dgrad_bnbwd'),
+                 lambda: check(L.cn_conv2d_dgrad_bnbwd_sa(ptr(dy), ptr(w_crsk), ptr(dx), ptr(addend), int(addend_sub), N, H,
+                                                          W, C, K, R, S, stride[0], stride[1], pad[0], pad[1],
+                                                          dtype_code(dy.dtype), ptr(bn_y), ptr(bn_mask), ptr(bn_stats),
+                                                          int(bn_relu), ptr(partial), rows, stream_of(dy)),
+                               'cn_conv2d_dgrad_bnbwd'),
                  dy.device, detail=detail)
     return dx, partial, rows
 
@@ -484,6 +490,19 @@ def _input_bn_state(conv_mod, x):
     return bn_mod, y, mask, stats, bctx.relu
 
 
+_ZEROS = {}
+
+
+def _zero_like_placeholder(x):
+    """A storage-free all-zero tensor of x's shape (one cached zero element, expanded): what autograd is handed when the
+    real gradient travels through a ResGradHolder."""
+    key = (x.device, x.dtype)
+    z = _ZEROS.get(key)
+    if z is None:
+        z = _ZEROS[key] = torch.zeros(1, dtype=x.dtype, device=x.device)
+    return z.expand(x.shape)
+
+
 class Conv2dFunction(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, mod):
@@ -519,12 +538,23 @@ class Conv2dFunction(Function):
             mod._notify_grad_ready()
         dx = None
         if ctx.needs_input_grad[0]:
-            addend = None
+            addend, addend_sub = None, 1
             holder = getattr(mod, '_res_holder', None)
-            if holder is not None and holder.dres is not None and holder.dres.shape == x.shape \
-                    and holder.dres.dtype == dy.dtype:
-                addend = holder.dres          # the other branch's gradient, folded into this dgrad epilogue
+            if holder is not None and holder.dres is not None and holder.dres.dtype == dy.dtype \
+                    and (holder.dres.shape == x.shape if holder.sub == 1 else
+                         tuple(holder.dres.shape) == (x.shape[0], (x.shape[1] + 1) // 2, (x.shape[2] + 1) // 2, x.shape[3])):
+                addend, addend_sub = holder.dres, holder.sub   # the other branch's gradient, folded into this dgrad epilogue
                 holder.fused = True
+            elif holder is not None and holder.dres is None and SUBSAMPLED_SHORTCUT_GRAD \
+                    and (R, S) == (1, 1) and mod.stride == (2, 2) and mod.padding == (0, 0):
+                # stride-2 1x1 projection shortcut, first of the two gradients that meet at the block input: its input
+                # gradient is zero off the even pixels - compute those on the coarse grid (a stride-1 dgrad), park
+                # them, and hand autograd a storage-free placeholder (ForkFunction returns the other branch's sum)
+                N_, H_, W_, C_ = x.shape
+                compact = conv2d_dgrad(dy, mod.w_crsk, (N_, (H_ + 1) // 2, (W_ + 1) // 2, C_), mod.out_channels, 1, 1,
+                                       (1, 1), (0, 0))
+                holder.dres, holder.sub, holder.fused = compact, 2, False
+                return _zero_like_placeholder(x), None, None, None
             # this dgrad is the last contribution to the gradient of x when x has no other consumer
             # (inner convs) or when the other branch's gradient is being added right here
             final = holder is None or addend is not None
@@ -536,13 +566,14 @@ class Conv2dFunction(Function):
             if bn_args is not None:
                 bn_mod, bn_y, bn_mask, bn_stats, bn_relu = bn_args
                 dx, partial, rows = conv2d_dgrad(dy, mod.w_crsk, x.shape, mod.out_channels, R, S, mod.stride,
-                                                 mod.padding, addend=addend, bn=(bn_y, bn_mask, bn_stats, bn_relu))
+                                                 mod.padding, addend=addend, bn=(bn_y, bn_mask, bn_stats, bn_relu),
+                                                 addend_sub=addend_sub)
                 bn_mod._bwd_partials = (dx.data_ptr(), tuple(dx.shape), partial, rows)
             else:
                 dx = conv2d_dgrad(dy, mod.w_crsk, x.shape, mod.out_channels, R, S, mod.stride, mod.padding,
-                                  addend=addend)
+                                  addend=addend, addend_sub=addend_sub)
             if holder is not None and addend is None:
-                holder.dres = dx              # first producer of the fork gradient: park it for the other
+                holder.dres, holder.sub = dx, 1   # first producer of the fork gradient: park it for the other
                 holder.fused = False
         return dx, None, None, None
 
@@ -750,7 +781,7 @@ class BatchNormActFunction(Function):
         mod._notify_grad_ready()
         holder = getattr(mod, '_res_holder', None)
         if holder is not None:
-            holder.dres = dres
+            holder.dres, holder.sub = dres, 1
             holder.fused = False
         return dy, None, None, dres, None, None
 
@@ -991,8 +1022,16 @@ class ForkFunction(Function):
         holder = ctx.holder
         fused = holder is not None and holder.fused
         first = holder.dres if holder is not None else None
+        sub = holder.sub if holder is not None else 1
         if holder is not None:
-            holder.dres, holder.fused = None, False
+            holder.dres, holder.fused, holder.sub = None, False, 1
+        if sub == 2 and not fused and first is not None:
+            # a subsampled projection-shortcut gradient that no dgrad epilogue picked up (not the case in the ResNet
+            # blocks: conv1 always does): scatter it into a dense tensor here (data movement only) and add
+            dense = torch.zeros((first.shape[0], gb.shape[1], gb.shape[2], first.shape[3]), dtype=first.dtype,
+                                device=first.device)
+            dense[:, ::2, ::2, :] = first
+            return (add_(ga.contiguous(), dense) if ga is not None else dense), None
         if ga is None:
             return gb, None
         if gb is None:
@@ -1008,10 +1047,10 @@ class ResGradHolder(object):
     finishes first (the last BN's `dres` in identity blocks, one of the two convs in downsample
     blocks) parks its gradient here; the other branch's conv dgrad adds it in its epilogue (one pass
     instead of a separate add kernel), independent of autograd's execution order."""
-    __slots__ = ('dres', 'fused')
+    __slots__ = ('dres', 'fused', 'sub')   # sub = 2: dres holds only the even (h, w) pixels (stride-2 1x1 projection)
 
     def __init__(self):
-        self.dres, self.fused = None, False
+        self.dres, self.fused, self.sub = None, False, 1
 
 
 class SoftmaxCrossEntropyFunction(Function):

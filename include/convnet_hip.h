@@ -99,6 +99,17 @@ int cn_conv2d_dgrad_bnbwd(const void* dy, const void* w_crsk, void* g, const voi
                           int C, int K, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w, int dtype,
                           const void* bn_y, const unsigned char* bn_mask, const float* bn_coef, int bn_relu,
                           float* partial, int partial_rows, void* stream);
+/* cn_conv2d_dgrad / cn_conv2d_dgrad_bnbwd with a SUBSAMPLED addend (addend_sub = 2): `addend` is
+ * [N][(H+1)/2][(W+1)/2][C], the values at the even (h, w) pixels of a gradient that is zero everywhere else - the
+ * input gradient of the stride-2 1x1 projection shortcut (models/resnet.py:176-181), computed as a stride-1 dgrad on
+ * the coarse grid; the three quarters of zeros are neither written nor re-read */
+int cn_conv2d_dgrad_sa(const void* dy, const void* w_crsk, void* dx, const void* addend, int addend_sub, int N, int H,
+                       int W, int C, int K, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w, int dtype,
+                       int out_f32, void* stream);
+int cn_conv2d_dgrad_bnbwd_sa(const void* dy, const void* w_crsk, void* g, const void* addend, int addend_sub, int N,
+                             int H, int W, int C, int K, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w,
+                             int dtype, const void* bn_y, const unsigned char* bn_mask, const float* bn_coef,
+                             int bn_relu, float* partial, int partial_rows, void* stream);
 /* dw[K,R,S,C_real] (fp32) = beta*dw + scale * sum_pixels dy (x) x ; split reduction through
  * `workspace` (cn_conv2d_wgrad_workspace bytes), fixed summation order. */
 size_t cn_conv2d_wgrad_workspace(int N, int H, int W, int C, int K, int R, int S, int stride_h, int stride_w,

@@ -168,6 +168,43 @@ BNBWD_GPU = [(8, 56, 56, 64, 64, 3, 1, 1, False, False), (16, 56, 56, 256, 64, 1
 
 
 @pytest.mark.parametrize('mode', MODES)
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_dgrad_with_subsampled_addend_equals_dense_addend(mode, dtype):
+    """addend_sub = 2 (cn_conv2d_dgrad_sa / cn_conv2d_dgrad_bnbwd_sa): the addend holds only the even (h, w) pixels of
+    a gradient that is zero elsewhere (the stride-2 1x1 projection shortcut's input gradient); same bits as adding the
+    dense tensor, for a 1x1 stride-1 dgrad (Bottleneck conv1) and a 3x3 stride-2 one (BasicBlock conv1), odd sizes too."""
+    dev = _dev(mode)
+    import convnet_amd as ca
+    ops = ca.ops
+    ch = ca._lib.chunk_elems(dtype)
+    cases = [(2, 9, 7, 16, 24, 1, 1, 0), (1, 10, 12, 16, 16, 3, 2, 1)] if mode == 'emul' else \
+        [(8, 56, 56, 256, 128, 1, 1, 0), (4, 56, 56, 64, 128, 3, 2, 1), (3, 17, 13, 64, 72, 1, 1, 0)]
+    for (N, H, W, C, K, R, st, pad) in cases:
+        if C % ch:
+            continue
+        g_ = torch.Generator().manual_seed(H + C)
+        P, Q = ops.conv_out_hw(H, W, R, R, (st, st), (pad, pad))
+        dyh = _nhwc(torch.randn(N, K, P, Q, generator=g_), dtype, dev)
+        wc = (torch.randn(C, R, R, K, generator=g_) * 0.1).to(dtype).to(dev)
+        compact = _nhwc(torch.randn(N, C, (H + 1) // 2, (W + 1) // 2, generator=g_), dtype, dev)
+        dense = torch.zeros(N, H, W, C, dtype=dtype, device=dev)
+        dense[:, ::2, ::2, :] = compact
+        a = ops.conv2d_dgrad(dyh, wc, (N, H, W, C), K, R, R, (st, st), (pad, pad), addend=dense)
+        b = ops.conv2d_dgrad(dyh, wc, (N, H, W, C), K, R, R, (st, st), (pad, pad), addend=compact, addend_sub=2)
+        assert torch.equal(a.cpu(), b.cpu()), (N, H, W, C, K, R, st)
+        # ... and with the fused BatchNorm-backward reduction
+        bn_y = _nhwc(torch.randn(N, C, H, W, generator=g_), dtype, dev)
+        yf = bn_y.float().reshape(-1, C)
+        mean, invstd = yf.mean(0), 1.0 / torch.sqrt(yf.var(0, unbiased=False) + 1e-5)
+        stats = torch.cat([mean, invstd, invstd, -mean * invstd]).contiguous()
+        ga, pa, ra = ops.conv2d_dgrad(dyh, wc, (N, H, W, C), K, R, R, (st, st), (pad, pad), addend=dense,
+                                      bn=(bn_y, None, stats, True))
+        gb, pb, rb = ops.conv2d_dgrad(dyh, wc, (N, H, W, C), K, R, R, (st, st), (pad, pad), addend=compact,
+                                      bn=(bn_y, None, stats, True), addend_sub=2)
+        assert torch.equal(ga.cpu(), gb.cpu()) and ra == rb and torch.equal(pa.cpu(), pb.cpu())
+
+
+@pytest.mark.parametrize('mode', MODES)
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_dgrad_epilogue_bn_backward_reduction(mode, dtype):
     """cn_conv2d_dgrad_bnbwd + cn_bn_bwd_partials == cn_conv2d_dgrad followed by cn_bn_bwd: the masked
