@@ -368,6 +368,73 @@ __global__ __launch_bounds__(Q_NT) void rangebn_finalize_kernel(const RbnPartial
   }
 }
 
+// The same result from a workgroup of RF_C channels x RF_T threads per channel (chunks <= RF_T / 2): the one-thread-
+// per-channel walk above is chunks * sub (400 on the 56x56 layers) dependent L2 round trips, ~0.2 ms per launch.
+// Thread t of a channel merges half h = t / chunks of the slices of chunk j = t % chunks, eight partials requested
+// at a time; the halves are merged in order (ties keep the first, i.e. smaller, index), the chunk maxima / minima
+// are then summed in chunk order exactly as above.
+#define RF_C 8
+#define RF_T 32
+__global__ __launch_bounds__(RF_C * RF_T) void rangebn_finalize_par_kernel(const RbnPartial* part, int M, int C, int chunks,
+                                                                          int sub, float scale_fix, float eps,
+                                                                          float momentum, float* running_mean,
+                                                                          float* running_var, float* stats, int* arg) {
+  __shared__ float h_mx[RF_C][RF_T], h_mn[RF_C][RF_T];
+  __shared__ int h_imx[RF_C][RF_T], h_imn[RF_C][RF_T];
+  __shared__ double h_sum[RF_C][RF_T];
+  const int lc = threadIdx.x % RF_C, t = threadIdx.x / RF_C;
+  const int c = blockIdx.x * RF_C + lc;
+  const int j = t % chunks, h = t / chunks;          // t < 2 * chunks <= RF_T does work
+  const int half = (sub + 1) / 2;
+  float bmx = -INFINITY, bmn = INFINITY;
+  int bimx = 0, bimn = 0;
+  double tot = 0.0;
+  if (c < C && t < 2 * chunks) {
+    const int s0 = h * half, s1 = (s0 + half < sub) ? s0 + half : sub;
+    for (int s = s0; s < s1; s += 8) {
+      RbnPartial o[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int su = s + u < s1 ? s + u : s1 - 1;      // clamped: a repeated partial changes neither max nor min
+        o[u] = part[(size_t)(j * sub + su) * C + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (s + u >= s1) break;
+        if (o[u].mx > bmx) { bmx = o[u].mx; bimx = o[u].imx; }
+        if (o[u].mn < bmn) { bmn = o[u].mn; bimn = o[u].imn; }
+        tot += (double)o[u].sum;
+      }
+    }
+  }
+  h_mx[lc][t] = bmx; h_mn[lc][t] = bmn; h_imx[lc][t] = bimx; h_imn[lc][t] = bimn; h_sum[lc][t] = tot;
+  __syncthreads();
+  if (c < C && t < chunks) {          // second half of chunk t merged behind the first (strict compares: ties keep the first)
+    const int u = t + chunks;
+    if (h_mx[lc][u] > bmx) { bmx = h_mx[lc][u]; bimx = h_imx[lc][u]; }
+    if (h_mn[lc][u] < bmn) { bmn = h_mn[lc][u]; bimn = h_imn[lc][u]; }
+    arg[(size_t)c * 2 * chunks + t] = bimx;
+    arg[(size_t)c * 2 * chunks + chunks + t] = bimn;
+  }
+  __syncthreads();
+  if (c < C && t < chunks) { h_mx[lc][t] = bmx; h_mn[lc][t] = bmn; }
+  __syncthreads();
+  if (c >= C || t != 0) return;
+  double total = 0.0;
+  float smx = 0.f, smn = 0.f;
+  for (int k = 0; k < chunks; ++k) { smx += h_mx[lc][k]; smn += h_mn[lc][k]; }
+  for (int k = 0; k < 2 * chunks; ++k) total += h_sum[lc][k];
+  const float mean = (float)(total / (double)M);
+  const float scale = (smx / (float)chunks - smn / (float)chunks) * scale_fix;
+  stats[c] = mean;
+  stats[C + c] = scale + eps;
+  if (running_mean != nullptr) {
+    const float keep = 1.f - momentum;
+    running_mean[c] = running_mean[c] * momentum + mean * keep;
+    running_var[c] = running_var[c] * momentum + scale * keep;
+  }
+}
+
 // inference statistics: stats = {running_mean, running_var + eps}
 __global__ __launch_bounds__(Q_NT) void rangebn_infer_stats_kernel(const float* running_mean, const float* running_var,
                                                                   float eps, int C, float* stats) {
@@ -404,15 +471,14 @@ __global__ __launch_bounds__(Q_NT) void rangebn_apply_kernel(const T* x, const T
 
 extern "C" size_t cn_rangebn_workspace(int M, int C, int chunks) {
   if (M <= 0 || C <= 0 || chunks <= 0) return 0;
-  int sub = (M / chunks + 2047) / 2048;   // >= 2 Ki pixels per slice
-  if (sub < 1) sub = 1;
-  if (sub > 64) sub = 64;
+  int sub = 64;   // upper bound over the tunable slice lengths (rbn_sub)
   const size_t stats = (size_t)chunks * sub * C * sizeof(RbnPartial);
-  const size_t bwd = ((size_t)((M + 1023) / 1024) * 2 * C + 3 * (size_t)C) * sizeof(float);
+  const size_t bwd = ((size_t)((M + 255) / 256) * 2 * C + 3 * (size_t)C) * sizeof(float);   // >= 256 pixels per partial row
   return stats > bwd ? stats : bwd;
 }
 static int rbn_sub(int M, int chunks) {
-  int sub = (M / chunks + 2047) / 2048;
+  const int px = cn_get_option("rbn_slice_px", 512);   // pixels per slice of a chunk (knob)
+  int sub = (M / chunks + px - 1) / px;
   if (sub < 1) sub = 1;
   if (sub > 64) sub = 64;
   return sub;
@@ -447,7 +513,11 @@ extern "C" int cn_rangebn_fwd(const void* x, const void* residual, void* z, cons
       CN_LAUNCH(rangebn_stats_kernel<bf16_t>, grid, dim3(Q_NT), stream, (const bf16_t*)x, M, C, chunks, sub, cols, (RbnPartial*)ws);
     else
       CN_LAUNCH(rangebn_stats_kernel<float>, grid, dim3(Q_NT), stream, (const float*)x, M, C, chunks, sub, cols, (RbnPartial*)ws);
-    CN_LAUNCH(rangebn_finalize_kernel, dim3((unsigned)((C + Q_NT - 1) / Q_NT)), dim3(Q_NT), stream, (const RbnPartial*)ws, M,
+    if (2 * chunks <= RF_T)
+      CN_LAUNCH(rangebn_finalize_par_kernel, dim3((unsigned)((C + RF_C - 1) / RF_C)), dim3(RF_C * RF_T), stream, (const RbnPartial*)ws, M,
+              C, chunks, sub, scale_fix, eps, momentum, running_mean, running_var, stats, arg);
+    else
+      CN_LAUNCH(rangebn_finalize_kernel, dim3((unsigned)((C + Q_NT - 1) / Q_NT)), dim3(Q_NT), stream, (const RbnPartial*)ws, M,
               C, chunks, sub, scale_fix, eps, momentum, running_mean, running_var, stats, arg);
   } else {
     if (running_mean == nullptr || running_var == nullptr) { cn_set_error("rangebn_fwd: inference needs the running statistics"); return CN_EINVAL; }
@@ -518,13 +588,37 @@ __global__ __launch_bounds__(Q_NT) void rangebn_bwd_reduce_kernel(const T* g, co
 }
 
 // coef[c] = w r, coef[C + c] = -(w r) S1 / M, coef[2C + c] = -w r^2 S2 * fix / chunks; parameter gradients accumulated.
-__global__ __launch_bounds__(Q_NT) void rangebn_bwd_finalize_kernel(const float* partial, int rows, int M, int C,
-                                                                   const float* weight, const float* stats, float route,
-                                                                   float* dweight, float* dbias, float* coef) {
-  const int c = blockIdx.x * Q_NT + threadIdx.x;
-  if (c >= C) return;
+// RF_C channels x RF_T row slices per workgroup, sixteen partial rows requested at a time, fixed-order combine (a single
+// thread per channel walked all M / 1024 rows - 784 on the 56x56 layers - one dependent round trip after the other).
+__global__ __launch_bounds__(RF_C * RF_T) void rangebn_bwd_finalize_kernel(const float* partial, int rows, int M, int C,
+                                                                          const float* weight, const float* stats, float route,
+                                                                          float* dweight, float* dbias, float* coef) {
+  __shared__ double r1[RF_T][RF_C], r2[RF_T][RF_C];
+  const int lc = threadIdx.x % RF_C, t = threadIdx.x / RF_C;
+  const int c = blockIdx.x * RF_C + lc;
   double S1 = 0.0, S2 = 0.0;
-  for (int r = 0; r < rows; ++r) { S1 += (double)partial[(size_t)r * 2 * C + c]; S2 += (double)partial[(size_t)r * 2 * C + C + c]; }
+  if (c < C) {
+    for (int r = t; r < rows; r += 16 * RF_T) {
+      float a[16], b[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int ru = r + u * RF_T;
+        const int rc = ru < rows ? ru : rows - 1;
+        const float av = partial[(size_t)rc * 2 * C + c], bv = partial[(size_t)rc * 2 * C + C + c];
+        a[u] = ru < rows ? av : 0.f;
+        b[u] = ru < rows ? bv : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { S1 += (double)a[u]; S2 += (double)b[u]; }
+    }
+  }
+  r1[t][lc] = S1;
+  r2[t][lc] = S2;
+  __syncthreads();
+  if (c >= C || t != 0) return;
+  S1 = 0.0;
+  S2 = 0.0;
+  for (int k = 0; k < RF_T; ++k) { S1 += r1[k][lc]; S2 += r2[k][lc]; }
   const float r = 1.f / stats[C + c];
   const float w = weight[c];
   const float s1 = (float)S1, s2 = (float)S2;
@@ -549,17 +643,24 @@ __global__ __launch_bounds__(Q_NT) void rangebn_bwd_apply_kernel(const T* g, T* 
   }
 }
 
-// one thread per channel walks its 2 * chunks routed positions (distinct channels never share an element)
+// one thread per (channel, chunk): the chunk's first maximum gets +d, its first minimum -d (distinct chunks and
+// distinct channels never share an element; maximum == minimum only in a constant chunk, where the two cancel)
 template <typename T>
 __global__ __launch_bounds__(Q_NT) void rangebn_bwd_route_kernel(T* dx, const float* coef, const int* arg, int C, int chunks) {
-  const int c = blockIdx.x * Q_NT + threadIdx.x;
-  if (c >= C) return;
+  const int id = blockIdx.x * Q_NT + threadIdx.x;
+  if (id >= C * chunks) return;
+  const int c = id / chunks, j = id - c * chunks;
   const float d = coef[2 * C + c];
-  for (int j = 0; j < chunks; ++j) {
-    T* pm = dx + (size_t)arg[(size_t)c * 2 * chunks + j] * C + c;
-    cn_store_elem<T>(pm, cn_load_elem<T>(pm) + d);
-    T* pn = dx + (size_t)arg[(size_t)c * 2 * chunks + chunks + j] * C + c;
-    cn_store_elem<T>(pn, cn_load_elem<T>(pn) - d);
+  const int imx = arg[(size_t)c * 2 * chunks + j], imn = arg[(size_t)c * 2 * chunks + chunks + j];
+  T* pm = dx + (size_t)imx * C + c;
+  T* pn = dx + (size_t)imn * C + c;
+  const float vm = cn_load_elem<T>(pm), vn = cn_load_elem<T>(pn);
+  if (imx == imn) {     // +d then -d on one element, each rounded to T like the two separate updates
+    cn_store_elem<T>(pm, vm + d);
+    cn_store_elem<T>(pm, cn_load_elem<T>(pm) - d);
+  } else {
+    cn_store_elem<T>(pm, vm + d);
+    cn_store_elem<T>(pn, vn - d);
   }
 }
 
@@ -574,22 +675,24 @@ extern "C" int cn_rangebn_bwd(const void* g, const void* x, const float* weight,
       dweight == nullptr || dbias == nullptr) { cn_set_error("rangebn_bwd: null operand"); return CN_EINVAL; }
   if (ws == nullptr || ws_bytes < cn_rangebn_workspace(M, C, chunks)) { cn_set_error("rangebn_bwd: workspace too small"); return CN_EWORKSPACE; }
   const int CC = C / CH, cols = rbn_cols(CC);
-  const int rows = (M + 1023) / 1024;
+  int rpr = cn_get_option("rbn_bwd_row_px", 512);   // pixels per partial row of the backward reduction (knob)
+  if (rpr < 256) rpr = 256;
+  const int rows = (M + rpr - 1) / rpr;
   float* partial = ws;
   float* coef = ws + (size_t)rows * 2 * C;
   dim3 grid((unsigned)((CC + cols - 1) / cols), (unsigned)rows);
   const long long nch = (long long)M * CC;
   const float route = scale_fix / (float)chunks;
   if (dtype == CN_BF16) {
-    CN_LAUNCH(rangebn_bwd_reduce_kernel<bf16_t>, grid, dim3(Q_NT), stream, (const bf16_t*)g, (const bf16_t*)x, stats, M, C, 1024, cols, partial);
-    CN_LAUNCH(rangebn_bwd_finalize_kernel, dim3((unsigned)((C + Q_NT - 1) / Q_NT)), dim3(Q_NT), stream, (const float*)partial, rows, M, C, weight, stats, route, dweight, dbias, coef);
+    CN_LAUNCH(rangebn_bwd_reduce_kernel<bf16_t>, grid, dim3(Q_NT), stream, (const bf16_t*)g, (const bf16_t*)x, stats, M, C, rpr, cols, partial);
+    CN_LAUNCH(rangebn_bwd_finalize_kernel, dim3((unsigned)((C + RF_C - 1) / RF_C)), dim3(RF_C * RF_T), stream, (const float*)partial, rows, M, C, weight, stats, route, dweight, dbias, coef);
     CN_LAUNCH(rangebn_bwd_apply_kernel<bf16_t>, dim3(q_grid(nch)), dim3(Q_NT), stream, (const bf16_t*)g, (bf16_t*)dx, (const float*)coef, nch, C);
-    CN_LAUNCH(rangebn_bwd_route_kernel<bf16_t>, dim3((unsigned)((C + Q_NT - 1) / Q_NT)), dim3(Q_NT), stream, (bf16_t*)dx, (const float*)coef, arg, C, chunks);
+    CN_LAUNCH(rangebn_bwd_route_kernel<bf16_t>, dim3((unsigned)((C * chunks + Q_NT - 1) / Q_NT)), dim3(Q_NT), stream, (bf16_t*)dx, (const float*)coef, arg, C, chunks);
   } else {
-    CN_LAUNCH(rangebn_bwd_reduce_kernel<float>, grid, dim3(Q_NT), stream, (const float*)g, (const float*)x, stats, M, C, 1024, cols, partial);
-    CN_LAUNCH(rangebn_bwd_finalize_kernel, dim3((unsigned)((C + Q_NT - 1) / Q_NT)), dim3(Q_NT), stream, (const float*)partial, rows, M, C, weight, stats, route, dweight, dbias, coef);
+    CN_LAUNCH(rangebn_bwd_reduce_kernel<float>, grid, dim3(Q_NT), stream, (const float*)g, (const float*)x, stats, M, C, rpr, cols, partial);
+    CN_LAUNCH(rangebn_bwd_finalize_kernel, dim3((unsigned)((C + RF_C - 1) / RF_C)), dim3(RF_C * RF_T), stream, (const float*)partial, rows, M, C, weight, stats, route, dweight, dbias, coef);
     CN_LAUNCH(rangebn_bwd_apply_kernel<float>, dim3(q_grid(nch)), dim3(Q_NT), stream, (const float*)g, (float*)dx, (const float*)coef, nch, C);
-    CN_LAUNCH(rangebn_bwd_route_kernel<float>, dim3((unsigned)((C + Q_NT - 1) / Q_NT)), dim3(Q_NT), stream, (float*)dx, (const float*)coef, arg, C, chunks);
+    CN_LAUNCH(rangebn_bwd_route_kernel<float>, dim3((unsigned)((C * chunks + Q_NT - 1) / Q_NT)), dim3(Q_NT), stream, (float*)dx, (const float*)coef, arg, C, chunks);
   }
   return cn_check_launch("rangebn_bwd");
 }

@@ -18,6 +18,7 @@ echo "== host inputs (PCIe-inclusive)"; timeout 300 python bench.py --host-input
 echo "== world-1 RCCL"; BENCH_FORCE_DIST=1 timeout 300 python bench.py --steps 20 --warmup 5 $B 2>&1 | grep '"metric"' | tee $OUT/bench_dist1.txt | cut -c80-200
 echo "== ResNet-18 fp32"; timeout 600 python bench.py --depth 18 --dtype f32 --steps 5 --warmup 2 --no-cpu-baseline 2>&1 | grep '"metric"' | tee $OUT/bench_r18_f32.txt | cut -c80-200
 echo "== ResNet-101 bf16"; timeout 600 python bench.py --depth 101 --steps 5 --warmup 2 $B 2>&1 | grep '"metric"' | tee $OUT/bench_r101.txt | cut -c80-200
+echo "== config 5 (quantize=True)"; timeout 600 python bench.py --quantize --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | grep '"metric"' | tee $OUT/bench_quantize.txt | cut -c80-220
 echo "== layers"; timeout 600 python tools/bench_layers.py --variants 0,1,3 2>&1 | tail -26 | tee $OUT/layers.txt | tail -2
 echo "== rocprof"   # eager launches forced: under the tracer the trainer's auto mode would replay the step as a HIP graph
 CONVNET_AMD_GRAPH=0 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o r50 -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-profile > $OUT/rocprof.log 2>&1
