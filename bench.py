@@ -50,6 +50,40 @@ def roof_fraction(records, dtype):
     return round(ideal / meas, 4) if meas > 0 else None
 
 
+def run_pmc_passes(args):
+    """roofline.traffic measured by THIS command: two rocprofv3 counter passes (FETCH_SIZE, then WRITE_SIZE - they do
+    not fit one pass; kernel trace only, never combined with other trace domains) over a 1 warm-up + 2 step run of
+    the same workload on eager launches, corrected as MI355X_MICROARCH.md prescribes (KiB units, FETCH_SIZE x2 on
+    gfx950): tools/pmc_traffic.py.  Returns the per-kernel dict or None when rocprofv3 is not usable here."""
+    import shutil
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import pmc_traffic
+    if shutil.which('rocprofv3') is None:
+        return None
+    tmp = tempfile.mkdtemp(prefix='bench_pmc_', dir='/tmp')
+    env = dict(os.environ, TMPDIR='/tmp', CONVNET_AMD_GRAPH='0')
+    cmd = [sys.executable, os.path.abspath(__file__), '--steps', '2', '--warmup', '1', '--no-cpu-baseline',
+           '--no-kernel-profile', '--batch', str(args.batch), '--depth', str(args.depth), '--dtype', args.dtype] + \
+        (['--quantize'] if args.quantize else [])
+    for name, ctr in (('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE')):
+        r = subprocess.run(['rocprofv3', '--pmc', ctr, '--kernel-trace', '--output-format', 'csv', '-d',
+                            os.path.join(tmp, name), '-o', name, '--'] + cmd, env=env, cwd='/tmp',
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1200)
+        if r.returncode != 0:
+            sys.stderr.write('bench.py --pmc: %s pass failed:\n%s\n' % (ctr, r.stdout[-1500:]))
+            return None
+    res = pmc_traffic.collect(tmp, steps=3)
+    res['workload'] = 'bench.py --batch %d --depth %d --dtype %s%s' % (args.batch, args.depth, args.dtype,
+                                                                      ' --quantize' if args.quantize else '')
+    if args.pmc_out:
+        with open(args.pmc_out, 'w') as f:
+            json.dump(res, f, indent=1, sort_keys=True)
+    shutil.rmtree(tmp, ignore_errors=True)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -66,6 +100,11 @@ def main():
                          "configuration, not the contract workload)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
+    ap.add_argument('--pmc', action='store_true',
+                    help='also measure roofline.traffic LIVE: two extra rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; '
+                         'kernel trace only) of a 3-step run of this same workload, ~2-4 min (N=1 only)')
+    ap.add_argument('--pmc-out', default=None, help='where --pmc writes the per-kernel traffic JSON (for profiles/)')
+    ap.add_argument('--cpu-steps', type=int, default=5, help='timed steps of the CPU baseline (batch 32, 1 warm-up)')
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -145,45 +184,71 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- live per-kernel timing (separate profiled pass, HIP events on the launch stream) ----
-    kernels, layers, roof = {}, {}, None
+    # ---- live per-kernel timing: two profiled passes after the timed region, HIP events on the launch stream ----
+    #  (1) overlapped: the step keeps its two-stream schedule; the events sit on the stream each call is launched on.
+    #      These are the durations rocprofv3 reports for the timed region; the dominant kernel is chosen and priced here.
+    #  (2) alone: the weight-gradient side stream folded into the main stream, every kernel runs by itself: the
+    #      per-kernel / per-layer tables (how far each launch is from ITS roof without a neighbour sharing the chip).
+    kernels, layers, roof, kernels_ovl = {}, {}, None, {}
     nprof = 2
+    agg = agg_ovl = None
     if not args.no_kernel_profile:
         # every rank runs the profiled steps (they contain the gradient all-reduce: a rank-0-only pass would
         # wait for collectives the other ranks never enter); only rank 0 reports
-        ca.ops.PROFILER.records = []
-        ca.ops.PROFILER.enabled = True
+        P = ca.ops.PROFILER
+        P.records, P.enabled, P.fold_streams = [], True, False
         tr.train(loader(nprof))
-        ca.ops.PROFILER.enabled = False
+        P.enabled = False
+        fence()
+        agg_ovl = P.summary() if rank == 0 else None
+        P.records, P.enabled, P.fold_streams = [], True, True
+        tr.train(loader(nprof))
+        P.enabled = False
         fence()
     if rank == 0 and not args.no_kernel_profile:
         agg = ca.ops.PROFILER.summary()
-        total_ms = sum(a['ms'] for a in agg.values())
-        for name, a in sorted(agg.items(), key=lambda kv: -kv[1]['ms']):
-            sec = a['ms'] * 1e-3
-            kernels[name] = {
-                'ms_per_step': round(a['ms'] / nprof, 3),
-                'share': round(a['ms'] / total_ms, 4),
-                'launches_per_step': a['launches'] // nprof,
-                'avg_us_per_launch': round(a['ms'] * 1e3 / max(a['launches'], 1), 2),
-                'tflops': round(a['flops'] / sec / 1e12, 2) if a['flops'] else None,
-                'gbs': round(a['bytes'] / sec / 1e9, 1),
-                # launches priced one by one against the roof that binds each (HBM-bound 1x1 and MFMA-bound 3x3
-                # layers share kernel names): sum of max(bytes/8 TB/s, flops/peak) over the measured time
-                'roof_frac': roof_fraction(a['records'], args.dtype),
-            }
+
+        def table(ag):
+            out, total_ms = {}, sum(a['ms'] for a in ag.values())
+            for name, a in sorted(ag.items(), key=lambda kv: -kv[1]['ms']):
+                sec = a['ms'] * 1e-3
+                out[name] = {
+                    'ms_per_step': round(a['ms'] / nprof, 3),
+                    'share': round(a['ms'] / total_ms, 4),
+                    'launches_per_step': a['launches'] // nprof,
+                    'avg_us_per_launch': round(a['ms'] * 1e3 / max(a['launches'], 1), 2),
+                    'tflops': round(a['flops'] / sec / 1e12, 2) if a['flops'] else None,
+                    'gbs': round(a['bytes'] / sec / 1e9, 1),
+                    # launches priced one by one against the roof that binds each (HBM-bound 1x1 and MFMA-bound 3x3
+                    # layers share kernel names): sum of max(bytes/8 TB/s, flops/peak) over the measured time
+                    'roof_frac': roof_fraction(a['records'], args.dtype),
+                }
+            return out
+        kernels = table(agg)
+        kernels_ovl = {k: {f: v[f] for f in ('ms_per_step', 'launches_per_step', 'avg_us_per_launch', 'gbs', 'tflops',
+                                             'roof_frac')} for k, v in table(agg_ovl).items()}
         # the same per convolution layer shape (fwd / dgrad / wgrad): which roof binds it and how close it runs
-        for det, a in sorted(ca.ops.PROFILER.summary(by_detail=True).items(), key=lambda kv: -kv[1]['ms']):
+        # (a weight gradient's fixed-order split reduction, timed separately, is folded back into its layer's row)
+        det = ca.ops.PROFILER.summary(by_detail=True)
+        for d in [d for d in det if d.endswith(' [reduce]')]:
+            parent = det.get(d[:-len(' [reduce]')])
+            if parent is not None:
+                parent['ms'] += det[d]['ms']
+                parent['bytes'] += det[d]['bytes']
+            del det[d]
+        for d, a in sorted(det.items(), key=lambda kv: -kv[1]['ms']):
             sec = a['ms'] * 1e-3
             t_hbm = a['bytes'] / (PEAK_HBM_GBS * 1e9)
             t_mfma = a['flops'] / (PEAK_TFLOPS[args.dtype] * 1e12)
-            layers[det] = {'n': a['calls'] // nprof, 'us': round(a['ms'] * 1e3 / a['calls'], 1),
-                           'tflops': round(a['flops'] / sec / 1e12, 1), 'gbs': round(a['bytes'] / sec / 1e9, 1),
-                           'bound': 'mfma' if t_mfma >= t_hbm else 'hbm',
-                           'roof_frac': round(max(t_hbm, t_mfma) / sec, 3)}
-        # the dominant single HIP kernel ('+' names are multi-kernel C-ABI calls, reported in `kernels`)
-        dom = next(k for k in kernels if '+' not in k)
-        k = kernels[dom]
+            layers[d] = {'n': a['calls'] // nprof, 'us': round(a['ms'] * 1e3 / a['calls'], 1),
+                         'tflops': round(a['flops'] / sec / 1e12, 1), 'gbs': round(a['bytes'] / sec / 1e9, 1),
+                         'bound': 'mfma' if t_mfma >= t_hbm else 'hbm',
+                         'roof_frac': round(max(t_hbm, t_mfma) / sec, 3)}
+        # the dominant single HIP kernel of the OVERLAPPED step (' + ' labels are calls that launched several different
+        # kernels: reported in the tables, never chosen as "the" kernel)
+        dom = next(k for k in kernels_ovl if ' + ' not in k)
+        k = kernels_ovl[dom]
+        ka = kernels.get(dom, {})
         if k['tflops'] and k['tflops'] / PEAK_TFLOPS[args.dtype] >= k['gbs'] / PEAK_HBM_GBS:
             roof = {'kernel': dom, 'bound': 'mfma', 'achieved': k['tflops'], 'peak': PEAK_TFLOPS[args.dtype],
                     'unit': 'TFLOP/s', 'frac': round(k['tflops'] / PEAK_TFLOPS[args.dtype], 4), 'traffic': None}
@@ -193,31 +258,40 @@ def main():
         roof['avg_us_per_launch'] = k['avg_us_per_launch']
         roof['launches_per_step'] = k['launches_per_step']
         roof['frac_per_launch_roof'] = k['roof_frac']   # each launch against max(HBM, MFMA) time instead of one blended bound
-        roof['timing'] = ('HIP events around every launch of a separate pass with the wgrad side stream folded into '
-                          'the main stream (kernels run alone); rocprofv3 of the overlapped step: profiles/')
-        # HBM traffic per launch: NOT measured in this run (PMC counters need rocprofv3 passes of their own);
-        # the latest committed PMC result (profiles/*_pmc_traffic.json) is quoted and tagged as static
-        try:
-            cands = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('pmc_traffic.json'))
-            pm = json.load(open(os.path.join(ROOT, 'profiles', cands[-1])))
+        roof['alone'] = {f: ka.get(f) for f in ('avg_us_per_launch', 'gbs', 'tflops', 'roof_frac')}
+        roof['algorithmic_bytes_per_launch'] = round(agg_ovl[dom]['bytes'] / max(agg_ovl[dom]['launches'], 1))
+        roof['timing'] = ('HIP events on the launching stream around every launch of a profiled pass that keeps the '
+                          'two-stream schedule of the timed region (kernel chosen by its total time there; `alone` = the '
+                          'same launches with the side stream folded in); rocprofv3 of the same command: profiles/')
+        pm, pm_file, live = None, None, False
+        if args.pmc and world == 1:
+            pm = run_pmc_passes(args)
+            live = pm is not None
+        if pm is None:
+            # HBM traffic per launch NOT measured in this run (PMC counters need rocprofv3 passes of their own:
+            # `--pmc`): the latest committed PMC result (profiles/*_pmc_traffic.json) is quoted and tagged static
+            try:
+                cands = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('pmc_traffic.json'))
+                pm_file = cands[-1]
+                pm = json.load(open(os.path.join(ROOT, 'profiles', pm_file)))
+            except Exception:
+                pm = None
+        if pm is not None:
             for kn, kv in pm['kernels'].items():
                 if kn.replace('void ', '').startswith(dom.split(' (')[0]):
                     roof['traffic'] = round(kv['hbm_bytes_per_launch'])
-                    roof['traffic_unit'] = 'bytes/launch (avg), ' + pm['source'] + ', ' + cands[-1]
-                    roof['traffic_source'] = 'static: committed rocprofv3 --pmc passes (%s), not this run' % cands[-1]
-                    roof['algorithmic_bytes_per_launch'] = round(
-                        agg[dom]['bytes'] / max(agg[dom]['launches'], 1))
+                    roof['traffic_unit'] = 'bytes/launch (avg), ' + pm['source']
+                    roof['traffic_source'] = 'live: rocprofv3 --pmc passes run by this command' if live else \
+                        'static: committed rocprofv3 --pmc passes (%s), not this run' % pm_file
                     break
-        except Exception:
-            pass
-
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import convnet_oracle as O
-        r = O.time_cpu_baseline(depth=args.depth, batch=32, steps=2, warmup=1, size=224)
+        r = O.time_cpu_baseline(depth=args.depth, batch=32, steps=args.cpu_steps, warmup=1, size=224)
         cpu = {'value': round(r['img_per_s'], 2), 'unit': 'images/sec', 'cores': r['cores'], 'kind': 'port',
-               'sample': 'oracle ResNet-%d fp32 CPU training, batch 32, 1 warm-up + 2 timed steps '
-                         '(%.2f s/step)' % (args.depth, r['s_per_step'])}
+               'sample': 'oracle/convnet_oracle.py (CPU restatement of the reference Trainer step; the reference tree '
+                         'itself is not on the GPU box) ResNet-%d fp32 training, batch 32, 1 warm-up + %d timed steps '
+                         '(%.2f s/step)' % (args.depth, args.cpu_steps, r['s_per_step'])}
 
     if rank == 0:
         img_s = B * world * args.steps / elapsed
@@ -240,7 +314,8 @@ def main():
             'hbm_frac_whole_step': round(MODEL_MB_PER_IMG[(args.depth, args.dtype)] * 1e6 * B / (elapsed / args.steps)
                                          / (PEAK_HBM_GBS * 1e9), 4)
             if (args.depth, args.dtype) in MODEL_MB_PER_IMG and not args.quantize else None,
-            'roofline': roof, 'cpu_baseline': cpu, 'kernels': kernels, 'conv_layers': layers,
+            'roofline': roof, 'cpu_baseline': cpu, 'kernels': kernels, 'kernels_overlapped': kernels_ovl,
+            'conv_layers': layers,
         }
         # measured HBM traffic of the whole step (all kernels, latest committed PMC passes: static, like
         # roofline.traffic) over this run's step time: how close the step as a whole runs to the memory system

@@ -33,6 +33,7 @@ _SIGNATURES = {
     'cn_last_error': (ctypes.c_char_p, []),
     'cn_build_info': (ctypes.c_char_p, []),
     'cn_last_kernel_name': (ctypes.c_char_p, []),
+    'cn_kernel_log': (ctypes.c_char_p, [c_i]),
     'cn_is_emulator': (c_i, []),
     'cn_set_option': (c_i, [ctypes.c_char_p, c_i]),
     'cn_stream_fork': (c_i, [c_p, c_p]),
@@ -99,6 +100,7 @@ _SIGNATURES = {
     'cn_i8_prepare_activation': (c_i, [c_p] * 5 + [c_i] * 11 + [c_p, c_p, c_p, c_p, c_i, c_p]),
     'cn_i8_prepare_weight': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     'cn_conv2d_fwd_i8': (c_i, [c_p] * 10 + [c_i, c_p] + [c_i] * 12 + [c_p]),
+    'cn_comm_load': (c_i, []),
     'cn_comm_unique_id': (c_i, [c_p]),
     'cn_comm_init': (c_i, [c_p, c_p, c_i, c_i]),
     'cn_comm_info': (c_i, [c_p, c_p, c_p, c_p]),
@@ -174,6 +176,11 @@ def _apply_env_options(lib):
 def is_emulated():
     load()
     return _emulated
+
+
+def last_error():
+    msg = load().cn_last_error()
+    return msg.decode() if msg else ''
 
 
 def check(rc, what=''):

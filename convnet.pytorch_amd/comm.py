@@ -8,7 +8,9 @@ ships rank 0's 128-byte RCCL unique id), exactly the part the reference delegate
 
 On a host without devices (the gloo CPU tests) or with a non-RCCL process group there is no
 communicator and the callers use ``torch.distributed`` collectives instead - stated, not silent:
-``describe()`` names the transport and bench.py prints it.
+``describe()`` names the transport and bench.py prints it.  With RCCL ranks there is no second transport to
+fall back to: if the direct communicator cannot be built the job stops (``CONVNET_AMD_COMM=torch`` selects
+the torch.distributed collectives explicitly, for A/B).
 """
 import ctypes
 import os
@@ -22,23 +24,52 @@ from ._lib import check
 _DEFAULT = None     # the communicator of the default data-parallel group (set by Trainer)
 
 
+def _agree(ok, what, err, process_group, device):
+    """One MIN all-reduce over a status flag through the process group that is already up: every rank learns
+    whether ALL ranks passed the phase, and every rank raises if one did not - nobody is left blocked in the next
+    phase's collective (a rank that failed early used to meet its peers in mismatched collectives)."""
+    if dist.get_world_size(process_group) > 1:
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=process_group)
+        all_ok = int(flag.item()) == 1
+    else:
+        all_ok = ok
+    if not all_ok:
+        raise _lib.ConvNetHipError('direct-RCCL set-up failed in phase "%s" on %s: %s' % (
+            what, 'this rank' if not ok else 'another rank', err if err is not None else 'see that rank'))
+
+
 class RcclCommunicator(object):
+    """Set-up in three phases, each closed by an agreement step (`_agree`), so that an asymmetric failure raises
+    on every rank instead of hanging the job:
+      1. every rank resolves librccl (cn_comm_load: no communicator, no collective);
+      2. rank 0 draws the unique id and ALWAYS broadcasts - a 128-byte sentinel on failure;
+      3. every rank enters ncclCommInitRank (cn_comm_init)."""
+
     def __init__(self, process_group=None, device=None):
         L = _lib.load()
         self.pg = process_group
         self.rank = dist.get_rank(process_group)
         self.world = dist.get_world_size(process_group)
         self.device = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+        self._h = ctypes.c_void_p()
+        # phase 1
+        rc = L.cn_comm_load()
+        _agree(rc == 0, 'load librccl', _lib.last_error() if rc != 0 else None, process_group, self.device)
+        # phase 2
         buf = ctypes.create_string_buffer(128)
-        if self.rank == 0:
-            check(L.cn_comm_unique_id(buf), 'cn_comm_unique_id')
-        box = [buf.raw if self.rank == 0 else None]
+        err = None
+        if self.rank == 0 and L.cn_comm_unique_id(buf) != 0:
+            err = _lib.last_error()
+        box = [(buf.raw if err is None else b'') if self.rank == 0 else None]
         if self.world > 1:
             src = dist.get_global_rank(process_group, 0) if process_group is not None else 0
             dist.broadcast_object_list(box, src=src, group=process_group)
-        self._h = ctypes.c_void_p()
+        _agree(len(box[0]) == 128, 'unique id', err, process_group, self.device)
+        # phase 3
         with torch.cuda.device(self.device):
-            check(L.cn_comm_init(ctypes.byref(self._h), box[0], self.rank, self.world), 'cn_comm_init')
+            rc = L.cn_comm_init(ctypes.byref(self._h), box[0], self.rank, self.world)
+        _agree(rc == 0, 'ncclCommInitRank', _lib.last_error() if rc != 0 else None, process_group, self.device)
         ver = ctypes.c_int(0)
         check(L.cn_comm_info(self._h, None, None, ctypes.byref(ver)), 'cn_comm_info')
         self.rccl_version = ver.value
@@ -89,27 +120,15 @@ def wanted(device, process_group=None):
 
 
 def create_default(device, process_group=None):
+    """The communicator of the default data-parallel group.  There is ONE transport per configuration and no
+    fallback: with RCCL ranks (`wanted`) the direct communicator is built or the job stops with the reason on
+    every rank; the torch.distributed collectives are used only where there is no RCCL to talk to (gloo CPU /
+    emulator tests) or on explicit request (CONVNET_AMD_COMM=torch, an A/B switch)."""
     global _DEFAULT
     if _DEFAULT is not None:
         _DEFAULT.destroy()
-    comm, err = None, None
-    try:
-        comm = RcclCommunicator(process_group, device)
-    except Exception as e:      # e.g. librccl missing / ncclCommInitRank refused on this node
-        err = e
-    if dist.get_world_size(process_group) > 1:
-        # every rank must take the same transport: agree through the process group that is already up
-        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=torch.device(device))
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=process_group)
-        if int(ok.item()) == 0 and comm is not None:
-            comm.destroy()
-            comm = None
-    if comm is None:
-        import logging
-        logging.warning('direct RCCL communicator unavailable (%s): the gradient exchange goes through '
-                        'torch.distributed (%s) instead', err if err is not None else 'another rank failed',
-                        dist.get_backend(process_group))
-    _DEFAULT = comm
+        _DEFAULT = None
+    _DEFAULT = RcclCommunicator(process_group, device)
     return _DEFAULT
 
 

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const char* y, float* par
   if (col < cpr) {
     if (pivot != nullptr) {
 #pragma unroll
-      for (int e = 0; e < CH; ++e) pv[e] = pivot[col * CH + e];
+      for (int e = 0; e < CH; ++e) pv[e] = cn_pivot(pivot[col * CH + e]);
     }
     const int step = gridDim.x * rpp;
     const size_t cb = (size_t)col * CH * EB, rb = (size_t)C * EB;
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* partial, 
   // centred partials (sums of y - running_mean as it was before this update): the variance no longer comes out of
   // the difference of two numbers of size mean^2
   const double dmean = s / (double)M;
-  const double mean = centered ? (double)rm_pre + dmean : dmean;
+  const double mean = centered ? (double)cn_pivot(rm_pre) + dmean : dmean;
   double var = q / (double)M - dmean * dmean;
   if (var < 0.0) var = 0.0;
   const float invstd = (float)(1.0 / sqrt(var + (double)eps));

@@ -234,6 +234,13 @@ template <> __host__ __device__ __forceinline__ void cn_store_elem<bf16_t>(bf16_
 #endif
 }
 
+// Pivot of the centred BatchNorm statistics (the running mean): any finite value gives the same batch statistics up
+// to rounding, so a non-finite one (a diverged step, a bad checkpoint) is replaced by 0 in every kernel that reads it
+// - the batch statistics must not depend on the running buffers (they do not in the reference).
+__host__ __device__ __forceinline__ float cn_pivot(float v) {
+  return (v == v && v < 3.0e38f && v > -3.0e38f) ? v : 0.f;
+}
+
 // ---------------------------------------------------------------- fast division (host-precomputed)
 // q = n / d for 0 <= n < 2^31 using one mulhi + shift.
 struct FastDiv {

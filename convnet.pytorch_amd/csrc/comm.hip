@@ -25,6 +25,7 @@
 
 #ifdef CN_EMULATE
 // The TEST-ONLY CPU emulator has no devices and no RCCL: the host tests run the data-parallel path over gloo.
+extern "C" int cn_comm_load(void) { cn_set_error("cn_comm: not available in the emulator build"); return CN_ERCCL; }
 extern "C" int cn_comm_unique_id(char*) { cn_set_error("cn_comm: not available in the emulator build"); return CN_ERCCL; }
 extern "C" int cn_comm_init(void**, const char*, int, int) { cn_set_error("cn_comm: not available in the emulator build"); return CN_ERCCL; }
 extern "C" int cn_comm_info(void*, int*, int*, int*) { return CN_ERCCL; }
@@ -55,8 +56,15 @@ RcclApi g_api;   // function table only (no communicator state)
 const RcclApi* rccl() {
   if (g_api.so != nullptr) return &g_api;
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-  void* so = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);   // the copy the process already loaded (torch's)
-  for (int i = 0; so == nullptr && i < 3; ++i) so = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+  void* so = nullptr;
+  const char* forced = getenv("CN_RCCL_LIB");   // explicit path: that file or nothing (also how the tests provoke a failed set-up)
+  if (forced != nullptr && forced[0] != 0) {
+    so = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+    if (so == nullptr) { cn_set_error("cn_comm: cannot load CN_RCCL_LIB=%s: %s", forced, dlerror()); return nullptr; }
+  } else {
+    so = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);   // the copy the process already loaded (torch's)
+    for (int i = 0; so == nullptr && i < 3; ++i) so = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+  }
   if (so == nullptr) { cn_set_error("cn_comm: cannot load librccl.so.1: %s", dlerror()); return nullptr; }
   RcclApi a;
   a.so = so;
@@ -80,7 +88,7 @@ struct Comm {
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1, device = 0;
   hipStream_t stream = nullptr;      // bucket all-reduces
-  hipEvent_t ev[CN_NEVENTS];
+  hipEvent_t ev[CN_NEVENTS] = {};   // zero-initialised: the clean-up path destroys only what was created
   int next_ev = 0;
   long long buckets = 0;
 };
@@ -102,7 +110,24 @@ hipEvent_t next_event(Comm* c) {
   return e;
 }
 
+// Releases whatever a (possibly partly initialised) communicator owns.
+void comm_free(Comm* c) {
+  if (c == nullptr) return;
+  const RcclApi* api = rccl();
+  if (c->stream != nullptr) (void)hipStreamSynchronize(c->stream);
+  if (api != nullptr && c->comm != nullptr) (void)api->CommDestroy(c->comm);
+  for (int i = 0; i < CN_NEVENTS; ++i)
+    if (c->ev[i] != nullptr) (void)hipEventDestroy(c->ev[i]);
+  if (c->stream != nullptr) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
 }  // namespace
+
+// Resolves librccl and its entry points, nothing else (no communicator, no device work): phase 1 of the
+// multi-rank set-up, so that a rank whose RCCL cannot be loaded is found out BEFORE any rank enters a
+// collective (ncclCommInitRank blocks until every rank has arrived).
+extern "C" int cn_comm_load(void) { return rccl() != nullptr ? CN_OK : CN_ERCCL; }
 
 // Rank 0 calls this and ships the 128 bytes to every other rank.
 extern "C" int cn_comm_unique_id(char* id128) {
@@ -126,15 +151,18 @@ extern "C" int cn_comm_init(void** handle, const char* id128, int rank, int worl
   Comm* c = new Comm();
   c->rank = rank;
   c->world = world;
-  CN_HIP(hipGetDevice(&c->device));
+  // every failure below leaves through comm_free(): no leaked ncclComm_t / stream / events
+#define CN_HIP_C(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { comm_free(c); return hip_fail(#call, e_); } } while (0)
+  CN_HIP_C(hipGetDevice(&c->device));
   ncclUniqueId id;
   memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
   ncclResult_t r = api->CommInitRank(&c->comm, world, id, rank);
-  if (r != ncclSuccess) { delete c; return rccl_fail(api, "ncclCommInitRank", r); }
+  if (r != ncclSuccess) { c->comm = nullptr; comm_free(c); return rccl_fail(api, "ncclCommInitRank", r); }
   int lo = 0, hi = 0;
-  CN_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-  CN_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));   // `hi` = numerically lowest = highest priority
-  for (int i = 0; i < CN_NEVENTS; ++i) CN_HIP(hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming));
+  CN_HIP_C(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  CN_HIP_C(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));   // `hi` = numerically lowest = highest priority
+  for (int i = 0; i < CN_NEVENTS; ++i) CN_HIP_C(hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming));
+#undef CN_HIP_C
   *handle = c;
   return CN_OK;
 }
@@ -208,14 +236,7 @@ extern "C" int cn_comm_broadcast(void* handle, void* buf, long long nbytes, int 
 }
 
 extern "C" int cn_comm_destroy(void* handle) {
-  Comm* c = (Comm*)handle;
-  if (c == nullptr) return CN_OK;
-  const RcclApi* api = rccl();
-  if (c->stream != nullptr) (void)hipStreamSynchronize(c->stream);
-  if (api != nullptr && c->comm != nullptr) (void)api->CommDestroy(c->comm);
-  for (int i = 0; i < CN_NEVENTS; ++i) (void)hipEventDestroy(c->ev[i]);
-  if (c->stream != nullptr) (void)hipStreamDestroy(c->stream);
-  delete c;
+  comm_free((Comm*)handle);
   return CN_OK;
 }
 #endif

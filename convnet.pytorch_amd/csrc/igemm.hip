@@ -502,8 +502,8 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
     float pv0 = 0.f, pv1 = 0.f;
     if (p.stats_pivot != nullptr) {
       const int c = n0 + (OEBc == 4 ? col : 2 * col);
-      if (c < p.Co) pv0 = p.stats_pivot[c];
-      if (OEBc != 4 && c + 1 < p.Co) pv1 = p.stats_pivot[c + 1];
+      if (c < p.Co) pv0 = cn_pivot(p.stats_pivot[c]);
+      if (OEBc != 4 && c + 1 < p.Co) pv1 = cn_pivot(p.stats_pivot[c + 1]);
     }
     auto acc_row = [&](int r) {
       const unsigned int v = *(const unsigned int*)(src + r * pitch);

@@ -5,6 +5,7 @@
 #include "cn_api_internal.h"
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
 
 static thread_local char g_err[512] = "";
 
@@ -35,13 +36,29 @@ extern "C" const char* cn_last_error(void) { return g_err; }
 // cn_conv2d_* / cn_conv2d_wgrad call of this thread launched: the dispatchers choose an instantiation per
 // shape, and measurement code labels its timings with this instead of mirroring the heuristics.
 static thread_local char g_kernel[160] = "";
+// ... and the names of ALL GEMM-class launches since the log was last cleared, ';'-separated, in launch order: one
+// entry point can launch several instantiations (a strided dgrad runs one launch per output-parity class, each
+// dispatched on its own reduction length), and measurement code must count launches per kernel the way rocprofv3 does.
+static thread_local char g_klog[1024] = "";
+static thread_local int g_klog_len = 0;
 void cn_set_last_kernel(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
   va_end(ap);
+  const int n = (int)strlen(g_kernel);
+  if (g_klog_len + n + 2 < (int)sizeof(g_klog)) {
+    if (g_klog_len > 0) g_klog[g_klog_len++] = ';';
+    memcpy(g_klog + g_klog_len, g_kernel, (size_t)n + 1);
+    g_klog_len += n;
+  }
 }
 extern "C" const char* cn_last_kernel_name(void) { return g_kernel; }
+// clear != 0: empty the log and return ""; clear == 0: the names logged since the last clear
+extern "C" const char* cn_kernel_log(int clear) {
+  if (clear) { g_klog[0] = 0; g_klog_len = 0; }
+  return g_klog;
+}
 
 // Tuning knobs (kernel variant selection for A/B measurements; never change results).
 #include <string.h>

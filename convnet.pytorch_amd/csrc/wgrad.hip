@@ -722,11 +722,17 @@ extern "C" int cn_conv2d_wgrad(const void* x, const void* dy, float* dw_krsc, in
   p.div_w = cn_make_fastdiv((unsigned)Q);
   for (int r = 0; r < R; ++r)
     for (int s = 0; s < S; ++s) p.tap_dhdw[r * S + s] = ((r - pad_h) & 0xffff) | ((s - pad_w) << 16);
-  if (dtype == CN_BF16) wg_launch<bf16_t>(p, pl, (hipStream_t)stream);
-  else if (dtype == CN_F16) wg_launch<f16_t>(p, pl, (hipStream_t)stream);
-  else wg_launch<float>(p, pl, (hipStream_t)stream);
-  int rc = cn_check_launch("wgrad");
-  if (rc) return rc;
+  // measurement only (knob "wgrad_phase"): 1 = the partial-product launch alone, 2 = the reduction launch alone (on the
+  // partials a phase-1 call left in the workspace), so that a profiler can time the two kernels of this call separately
+  const int phase = cn_get_option("wgrad_phase", 0);
+  if (phase != 2) {
+    if (dtype == CN_BF16) wg_launch<bf16_t>(p, pl, (hipStream_t)stream);
+    else if (dtype == CN_F16) wg_launch<f16_t>(p, pl, (hipStream_t)stream);
+    else wg_launch<float>(p, pl, (hipStream_t)stream);
+    int rc = cn_check_launch("wgrad");
+    if (rc) return rc;
+  }
+  if (phase == 1) return CN_OK;
   long long total = (long long)K * R * S * C_real;
   unsigned nb = (unsigned)((total + 255) / 256);
   if (nb > 8192) nb = 8192;

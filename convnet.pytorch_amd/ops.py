@@ -52,14 +52,23 @@ class KernelProfiler(object):
     def __init__(self):
         self.enabled = False
         self.records = []
+        # True: the weight-gradient side stream is folded into the main stream while recording, so every kernel
+        # runs ALONE (per-kernel / per-layer tables).  False: the step keeps its two-stream schedule and the events
+        # sit on whichever stream the call is launched on: durations of the OVERLAPPED step, i.e. what rocprofv3
+        # reports for the timed region (used to choose and price the dominant kernel).
+        self.fold_streams = True
 
     def run(self, name, launches, flops, nbytes, fn, device, detail=None):
-        """name: label, or a callable evaluated AFTER fn() (the library reports which kernel instantiation its
-        dispatcher picked: cn_last_kernel_name); detail: optional per-shape label (conv layers)."""
+        """name: label, or a callable evaluated AFTER fn() (the library reports which kernel instantiation(s) its
+        dispatcher picked: cn_kernel_log); detail: optional per-shape label (conv layers).  A call that launched
+        several DIFFERENT GEMM instantiations (a strided dgrad: one launch per parity class) is recorded under the
+        joined label 'a + b' with its true launch count - never under the last launch's name."""
         if not self.enabled or device.type != 'cuda':
             return fn()
         s = torch.cuda.Event(enable_timing=True)
         e = torch.cuda.Event(enable_timing=True)
+        if callable(name):
+            _L().cn_kernel_log(1)
         s.record()
         out = fn()
         e.record()
@@ -179,7 +188,7 @@ class SideStream(object):
     def active(self, t):
         # not while a HIP graph is being captured: a replayed graph runs faster as one chain (b=8 +4 %, b=32 +3 %,
         # b=64 +2 %, b=128 +1 %; the runtime's graph queues put the chain behind a weight gradient every few layers)
-        return self.enabled and t.is_cuda and not PROFILER.enabled and not self.capturing
+        return self.enabled and t.is_cuda and not (PROFILER.enabled and PROFILER.fold_streams) and not self.capturing
 
     def fork(self, cur, side):
         """`side` waits for everything queued on `cur` so far (one device-scope event from the library's ring)."""
@@ -200,8 +209,18 @@ def _esize(t):
 
 
 def _last_kernel(suffix=''):
-    """Label of the kernel the library's dispatcher just launched (cn_last_kernel_name)."""
-    return lambda: _L().cn_last_kernel_name().decode() + suffix
+    """Label of the GEMM-class kernel(s) the library's dispatcher launched in the call just made (cn_kernel_log):
+    one name, or the distinct names joined with ' + ' when the call's launches used different instantiations."""
+    def label():
+        names = [n for n in _L().cn_kernel_log(0).decode().split(';') if n]
+        if not names:
+            names = [_L().cn_last_kernel_name().decode()]
+        uniq = []
+        for n in names:
+            if n not in uniq:
+                uniq.append(n)
+        return ' + '.join(uniq) + suffix
+    return label
 
 
 def _conv_detail(kind, C, H, K, R, stride):
@@ -240,32 +259,26 @@ COUNTERS = {'bn_fwd_fused': 0, 'bn_fwd_plain': 0, 'bn_bwd_fused': 0, 'bn_bwd_pla
 
 
 class _PendingStats(object):
-    """BatchNorm statistics partials a convolution emitted for its output tensor, waiting for the
-    BatchNorm that consumes that very tensor object (checked by identity through a weak reference)."""
-    __slots__ = ('ref', 'partial', 'rows', 'pivot')   # pivot: data_ptr of the running mean the sums are centred on (or None)
-
-
-_PENDING = {}   # id(y) -> _PendingStats; a handful of entries at most
+    """BatchNorm statistics partials a convolution emitted for its output tensor.  They travel ON that tensor
+    object (attribute `_cn_stats`, set by the producing convolution): the BatchNorm that consumes the very same
+    object takes them, a copy / view / re-materialised tensor has none and falls back to the statistics pass, and
+    the partial buffer dies with the tensor.  No module-level table, nothing keyed by id()."""
+    __slots__ = ('partial', 'rows', 'pivot')   # pivot: data_ptr of the running mean the sums are centred on (or None)
 
 
 def _park_stats(y, partial, rows, pivot=None):
     ps = _PendingStats()
-    ps.ref, ps.partial, ps.rows = weakref.ref(y), partial, rows
+    ps.partial, ps.rows = partial, rows
     ps.pivot = pivot.data_ptr() if pivot is not None else None
-    if len(_PENDING) >= 4:     # entries nobody consumed (their BatchNorm ran in eval mode / the tensor died):
-        for k in [k for k, v in _PENDING.items() if v.ref() is None]:   # dead tensors first,
-            del _PENDING[k]
-        while len(_PENDING) >= 4:                                       # then the oldest (dicts keep insertion order)
-            _PENDING.pop(next(iter(_PENDING)))
-    _PENDING[id(y)] = ps
+    y._cn_stats = ps
 
 
 def take_pending_stats(y):
-    """The partials emitted for exactly this tensor object, else None."""
-    ps = _PENDING.pop(id(y), None)
-    if ps is not None and ps.ref() is y:
-        return ps
-    return None
+    """The partials emitted for exactly this tensor object (taken: a second call returns None), else None."""
+    ps = getattr(y, '_cn_stats', None)
+    if ps is not None:
+        del y._cn_stats
+    return ps
 
 
 def stats_pivot(conv_mod):
@@ -378,13 +391,26 @@ def conv2d_wgrad(x, dy, dw_krsc, c_real, K, R, S, stride, pad, beta=1.0, scale=1
     L = _L()
     need = L.cn_conv2d_wgrad_workspace(N, H, W, C, K, R, S, stride[0], stride[1], pad[0], pad[1], code)
     ws = workspace(need, x.device, tag)
-    PROFILER.run(_last_kernel(' (+wgrad_reduce)'),
-                 2, 2.0 * dy.numel() * C * R * S,
-                 x.numel() * _esize(x) + dy.numel() * _esize(dy) + K * R * S * C * 4,
-                 lambda: check(L.cn_conv2d_wgrad(ptr(x), ptr(dy), ptr(dw_krsc), c_real, N, H, W, C, K, R, S,
-                                                 stride[0], stride[1], pad[0], pad[1], code, beta, scale, ptr(ws),
-                                                 ws.numel() * 4, stream_of(x)), 'cn_conv2d_wgrad'),
-                 x.device, detail=_conv_detail('wgrad', C, H, K, R, stride))
+    def call():
+        check(L.cn_conv2d_wgrad(ptr(x), ptr(dy), ptr(dw_krsc), c_real, N, H, W, C, K, R, S, stride[0], stride[1],
+                                pad[0], pad[1], code, beta, scale, ptr(ws), ws.numel() * 4, stream_of(x)),
+              'cn_conv2d_wgrad')
+    if not (PROFILER.enabled and x.is_cuda):
+        return call()
+    # profiled: the call's two launches (partial products, then the fixed-order reduction of the splits) are timed
+    # separately - measurement-only knob "wgrad_phase" - so each is reported under its own kernel name
+    flops = 2.0 * dy.numel() * C * R * S
+    part_bytes = float(need)
+    detail = _conv_detail('wgrad', C, H, K, R, stride)
+    L.cn_set_option(b'wgrad_phase', 1)
+    try:
+        PROFILER.run(_last_kernel(), 1, flops, x.numel() * _esize(x) + dy.numel() * _esize(dy) + part_bytes, call,
+                     x.device, detail=detail)
+        L.cn_set_option(b'wgrad_phase', 2)
+        PROFILER.run('wgrad_reduce_kernel', 1, 0.0, part_bytes + K * R * S * c_real * 4, call, x.device,
+                     detail=detail + ' [reduce]')
+    finally:
+        L.cn_set_option(b'wgrad_phase', 0)
 
 
 def weight_prep(w_master_krsc, w_krsc, w_crsk, Co, taps, c_real, c_pad):
@@ -787,7 +813,7 @@ class BatchNormActFunction(Function):
 
 
 def batch_norm_infer(y, residual, mod, relu):
-    _PENDING.pop(id(y), None)
+    take_pending_stats(y)     # eval mode: the partials (if any) are not needed
     N, H, W, C = y.shape
     z = torch.empty_like(y)
     coeffs = torch.empty(2 * C, dtype=torch.float32, device=y.device)

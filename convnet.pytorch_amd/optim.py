@@ -222,6 +222,9 @@ class OptimRegime(Regime):
         return self.get_value('lr')
 
     # -- checkpoint -----------------------------------------------------------------------
+    def _import_torch_sgd_state(self, st):
+        return _torch_sgd_state_as_named_buffers(self.model, st)
+
     def state_dict(self):
         self._bind()
         bufs = {}
@@ -241,15 +244,22 @@ class OptimRegime(Regime):
         position is deliberately NOT restored: `setting` is cumulative over all phases passed so far
         (e.g. the WeightDecay regulariser only appears in phase 0 of the ResNet regime,
         models/resnet.py:250-256), so the first `update(epoch, steps)` after a resume replays the
-        regime from the start exactly as a fresh OptimRegime at that epoch would.  Only this
-        implementation's own format is understood: a foreign optimizer state (e.g. the reference's
-        torch.optim state) is refused loudly instead of silently starting from zero momentum."""
+        regime from the start exactly as a fresh OptimRegime at that epoch would.
+        Two formats are understood: this engine's own ({'momentum_buffer': {name: tensor}, ...}) and the
+        reference's, i.e. what its OptimRegime.state_dict() hands to torch.save (utils.pytorch optim.py: the
+        torch.optim.SGD state_dict, bare or under 'optimizer_state'): {'state': {i: {'momentum_buffer': t}},
+        'param_groups': [{'params': [i...]}]} with i enumerating model.parameters() - so a checkpoint written by
+        the reference resumes WITH its momentum.  Anything else is refused loudly (never a silent restart from
+        zero momentum)."""
         self._bind()
         bufs = state.get('momentum_buffer') if isinstance(state, dict) else None
+        if bufs is None and isinstance(state, dict):
+            bufs = self._import_torch_sgd_state(state.get('optimizer_state', state))
         if bufs is None:
             raise _lib.ConvNetHipError(
-                "OptimRegime.load_state_dict: no 'momentum_buffer' entry - not a checkpoint of this engine "
-                "(only the model state_dict is interchangeable with the reference)")
+                "OptimRegime.load_state_dict: neither this engine's format ('momentum_buffer') nor a "
+                "torch.optim.SGD state_dict ('state' + 'param_groups'): refusing to resume from zero momentum "
+                "(main.py --drop-optim-state skips the optimizer state on purpose)")
         missing = [s.name for s in self.arena.slots if s.name not in bufs]
         if missing:
             raise _lib.ConvNetHipError('OptimRegime.load_state_dict: momentum buffers missing for %s%s'
@@ -266,6 +276,24 @@ class OptimRegime(Regime):
         self.hyper.update(state.get('hyper', {}))
         self.reset()          # current_regime_phase = None, setting = defaults: next update() replays the regime
         self._runs = None
+
+
+def _torch_sgd_state_as_named_buffers(model, st):
+    """torch.optim.SGD state_dict -> {parameter name: momentum buffer (reference OIHW shape)} or None."""
+    if not (isinstance(st, dict) and 'state' in st and 'param_groups' in st):
+        return None
+    order = [i for grp in st['param_groups'] for i in grp['params']]
+    names = [n for n, _ in model.named_parameters()]
+    if len(order) != len(names):
+        raise _lib.ConvNetHipError('OptimRegime.load_state_dict: optimizer state covers %d parameters, the model '
+                                   'has %d' % (len(order), len(names)))
+    bufs = {}
+    for name, idx in zip(names, order):
+        ent = st['state'].get(idx, st['state'].get(str(idx)))
+        mb = ent.get('momentum_buffer') if isinstance(ent, dict) else None
+        # a parameter that never received a gradient has no entry yet: zero momentum is exactly its state
+        bufs[name] = mb if mb is not None else torch.zeros_like(dict(model.named_parameters())[name], device='cpu')
+    return bufs
 
 
 def deepcopy_regularizer(reg):

@@ -115,8 +115,8 @@ class Trainer(object):
         self._graph_mode = os.environ.get('CONVNET_AMD_GRAPH', 'auto')
         self._use_graph = self._graph_mode != '0'
         self._graph_dp = os.environ.get('CONVNET_AMD_GRAPH_DP', '0') == '1'   # capture RCCL buckets too (opt-in)
-        self._graph, self._graph_seen = None, {}
-        self._graph_eager_for = None
+        self._gstates = {}               # per (shapes, step options) key: {'seen': warm-up / timing bookkeeping, 'graph': capture}
+        self._graph_eager_for = set()    # (shapes, chunking) for which auto mode settled on eager launches
         from . import nn as cnn
         # a captured step replays the SAME kernels: host-drawn Dropout masks (models/mnist.py) rule it out
         self._graph_model_ok = not any((isinstance(m, cnn.Dropout) and m.p > 0) or getattr(m, 'no_graph', False)
@@ -156,7 +156,7 @@ class Trainer(object):
             self.optimizer.update(self.epoch, self.training_steps)
             # (shape, chunking) for which auto mode already settled on eager launches: straight to the eager body (the
             # bookkeeping of _graph_step costs a nearly host-bound step 1 %)
-            if self._graph_eager_for != (inputs_batch.shape, target_batch.shape, chunk_batch) \
+            if (inputs_batch.shape, target_batch.shape, chunk_batch) not in self._graph_eager_for \
                     and self._graph_ok(inputs_batch, target_batch):
                 return self._graph_step(inputs_batch, target_batch, chunk_batch)
         return self._body(inputs_batch, target_batch, training, chunk_batch)
@@ -245,19 +245,28 @@ class Trainer(object):
         return True
 
     def _graph_step(self, inputs, target, chunk_batch):
+        """State is kept PER KEY (batch shapes + step options): the odd-shaped last batch of an epoch warms up /
+        runs eagerly under its own key and leaves the captured full-batch graph alone (a single slot
+        used to be discarded and rebuilt every epoch).  NOTE: the (output, loss, grad-norm) a replay returns are
+        the graph's STATIC buffers - the next replay of the same graph overwrites them; Trainer.forward folds them
+        into the device meters right away, other callers must clone what they keep."""
         opt = self.optimizer
         opt.push_hyper()
         key = (tuple(inputs.shape), tuple(target.shape), chunk_batch, float(self.grad_clip), self.loss_scale,
                self.grad_scale, opt.runs_signature(), self.criterion.smooth_eps, self.world_size)
-        st = self._graph
-        if st is None or st['key'] != key:
-            if self._graph_seen.get('key') != key:
-                self._graph_seen = {'key': key, 'n': 0}
-                self._graph = None
+        gs = self._gstates.get(key)
+        if gs is None:
+            if len(self._gstates) >= 4:      # bounded: drop the oldest key (dicts keep insertion order)
+                self._gstates.pop(next(iter(self._gstates)))
+            gs = self._gstates[key] = {'seen': {'n': 0}, 'graph': None}
+        seen = gs['seen']
+        st = gs['graph']
+        eager_key = (inputs.shape, target.shape, chunk_batch)
+        if st is None:
             warm = 4 if self._graph_mode == 'auto' else 2
-            if self._graph_seen['n'] < warm:       # eager warm-up (lazy workspace growth, allocator warm)
-                self._graph_seen['n'] += 1
-                if self._graph_seen['n'] < warm or self._graph_mode != 'auto':
+            if seen['n'] < warm:       # eager warm-up (lazy workspace growth, allocator warm)
+                seen['n'] += 1
+                if seen['n'] < warm or self._graph_mode != 'auto':
                     return self._body(inputs, target, True, chunk_batch)
                 # last warm-up step, mode 'auto' (the fourth: the first ones still grow workspaces and the allocator's
                 # pools): is the eager step bound by the host (launch time ~ device
@@ -273,24 +282,24 @@ class Trainer(object):
                 host_ms = (time.perf_counter() - t0) * 1e3
                 e1.synchronize()
                 dev_ms = e0.elapsed_time(e1)
-                self._graph_seen['use'] = host_ms > 0.75 * dev_ms
-                self._graph_seen['eager_ms'] = dev_ms
-                if not self._graph_seen['use']:
-                    self._graph_eager_for = (inputs.shape, target.shape, chunk_batch)
+                seen['use'] = host_ms > 0.75 * dev_ms
+                seen['eager_ms'] = dev_ms
+                if not seen['use']:
+                    self._graph_eager_for.add(eager_key)
                 logging.debug('step: host %.2f ms, device %.2f ms -> %s', host_ms, dev_ms,
-                              'try a HIP graph' if self._graph_seen['use'] else 'eager launches')
+                              'try a HIP graph' if seen['use'] else 'eager launches')
                 return res
-            if not self._graph_seen.get('use', True):
+            if not seen.get('use', True):
                 return self._body(inputs, target, True, chunk_batch)
-            st = self._capture(inputs, target, chunk_batch, key)
+            st = gs['graph'] = self._capture(inputs, target, chunk_batch, key)
         st['x'].copy_(inputs, non_blocking=True)
         st['t'].copy_(target, non_blocking=True)
-        if self._graph_mode == 'auto' and 'graph_ms' not in self._graph_seen and 'eager_ms' in self._graph_seen:
+        if self._graph_mode == 'auto' and 'graph_ms' not in seen and 'eager_ms' in seen:
             # the prediction above is checked once: a nearly host-bound eager step can still beat the replay
             # (ResNet-50 b=128: 12.2 ms eager vs 13.3 ms replayed), so the second replay is timed and the graph
             # dropped if it is not faster than the eager step it was meant to replace
-            n = self._graph_seen.get('replays', 0)
-            self._graph_seen['replays'] = n + 1
+            n = seen.get('replays', 0)
+            seen['replays'] = n + 1
             if n == 1:
                 torch.cuda.synchronize(self.device)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -298,20 +307,20 @@ class Trainer(object):
                 st['graph'].replay()
                 e1.record()
                 e1.synchronize()
-                self._graph_seen['graph_ms'] = e0.elapsed_time(e1)
-                if self._graph_seen['graph_ms'] > 0.98 * self._graph_seen['eager_ms']:
-                    self._graph_seen['use'] = False
-                    self._graph_eager_for = (inputs.shape, target.shape, chunk_batch)
+                seen['graph_ms'] = e0.elapsed_time(e1)
+                if seen['graph_ms'] > 0.98 * seen['eager_ms']:
+                    seen['use'] = False
+                    self._graph_eager_for.add(eager_key)
                     logging.debug('replayed step %.2f ms vs eager %.2f ms -> eager launches from now on',
-                                  self._graph_seen['graph_ms'], self._graph_seen['eager_ms'])
+                                  seen['graph_ms'], seen['eager_ms'])
                 out, loss, grad = st['out'], st['loss'], st['grad']
                 self.arena.bump_version()
                 self.training_steps += 1
-                if not self._graph_seen['use']:
+                if not seen['use']:
                     out = out.clone()
                     loss = loss.clone()
                     grad = grad.clone() if grad is not None else None
-                    self._graph = None
+                    gs['graph'] = None
                 return out, loss, grad
         st['graph'].replay()
         self.arena.bump_version()      # what optimizer.step() does on the host: master weights moved
@@ -332,9 +341,8 @@ class Trainer(object):
         finally:
             ops.SIDE.capturing = False
         self.training_steps = steps_before     # capture executes nothing: the replay is the step
-        self._graph = {'key': key, 'graph': g, 'x': x, 't': t, 'out': out, 'loss': loss, 'grad': grad}
         logging.debug('captured the training step as one HIP graph (%s)', (key[0],))
-        return self._graph
+        return {'key': key, 'graph': g, 'x': x, 't': t, 'out': out, 'loss': loss, 'grad': grad}
 
     # ------------------------------------------------------------------------------------
     def forward(self, data_loader, num_steps=None, training=False, average_output=False, chunk_batch=1):

@@ -9,7 +9,14 @@
  * Conventions
  *   - Plain pointers and sizes only; every pointer is a DEVICE pointer unless stated otherwise.
  *   - The caller owns every buffer including workspaces; the library never allocates or frees
- *     device memory, keeps no global state, and never synchronises the device.
+ *     device memory and never synchronises the device.  State it does keep, all of it process-side: (i) the table
+ *     of tuning knobs behind cn_set_option (global, read at launch time: kernel-variant A/B only, results are the
+ *     same for every value); (ii) the per-thread completion-event arming of cn_stream_arm / cn_stream_disarm, which
+ *     changes HOW every launch of that thread is issued until disarmed (the last kernel of each entry point carries
+ *     the armed event); (iii) one communicator handle per cn_comm_init, owned by the caller.
+ *   - Size limit: gather sources and filters are addressed through 32-bit buffer descriptors, so a single conv /
+ *     linear operand (N*H*W*C*elemsize, Co*R*S*Ci*elemsize) must be < 2 GiB; larger operands are refused with
+ *     CN_ESHAPE (ResNet-50 b=256: the largest is 822 MB).
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); calls are
  *     asynchronous and re-entrant.
  *   - Every function returns 0 (CN_OK) or a negative CN_E* code; cn_last_error() returns the
@@ -41,6 +48,10 @@ const char* cn_build_info(void);
 /* name of the GEMM-class kernel instantiation the last cn_conv2d_* call of this thread launched (as rocprofv3
  * prints it, minus "void " and the parameter list); measurement code labels its timings with it */
 const char* cn_last_kernel_name(void);
+/* the names of ALL GEMM-class launches of this thread since the log was cleared, ';'-separated in launch order (one
+ * entry point may launch several instantiations: a strided dgrad dispatches each output-parity class on its own
+ * reduction length).  clear != 0 empties the log.  Lets measurement code count launches per kernel as rocprofv3 does. */
+const char* cn_kernel_log(int clear);
 int cn_is_emulator(void); /* 1 only in the TEST-ONLY CPU emulator build */
 /* kernel-variant tuning knobs for A/B measurement (e.g. "igemm_stages" = 1|2); results never change */
 int cn_set_option(const char* name, int value);
@@ -159,8 +170,8 @@ int cn_bn_bwd_partials(const void* g, const void* y, const float* gamma, const f
                        void* stream);
 
 /* ---- nn.SyncBatchNorm (main.py:190-191, --sync-bn) ----------------------------------------------
- * The library holds no communicator.  Each rank reduces its own statistics to 2*C doubles, the caller
- * all-reduces that buffer (torch.distributed over RCCL) and passes the global sums and the global row
+ * Each rank reduces its own statistics to 2*C doubles, the caller all-reduces that buffer in-stream
+ * (cn_comm_allreduce, dtype 2, on the rank's communicator handle) and passes the global sums and the global row
  * count back; dgamma/dbeta stay per-rank sums (averaged by the data-parallel gradient all-reduce). */
 int cn_bn_local_sums(const void* y, int M, int C, int dtype, const float* partial /*optional conv-epilogue rows*/,
                      int nrb, double* sums /*[sum y | sum y^2]*/, void* workspace, size_t ws_bytes, void* stream);
@@ -331,7 +342,11 @@ int cn_conv2d_fwd_i8(const signed char* xq, const signed char* wq, void* y, cons
  * caller: an ncclComm_t, one high-priority HIP stream for the gradient buckets and a ring of events.
  * Rendezvous is the caller's job: rank 0 calls cn_comm_unique_id and ships the 128 bytes to the other ranks
  * (torch.distributed's store, MPI, a file ...), then every rank calls cn_comm_init with its HIP device current.
- * RCCL is bound at run time (the process's librccl.so.1). */
+ * RCCL is bound at run time (the process's librccl.so.1).
+ * Multi-rank set-up is done in phases that the caller separates with its own agreement step, so that a rank which
+ * cannot proceed is found out before any rank blocks in a collective: (1) every rank: cn_comm_load (resolves the
+ * library, nothing else); (2) rank 0: cn_comm_unique_id, shipped to all; (3) every rank: cn_comm_init. */
+int cn_comm_load(void);
 int cn_comm_unique_id(char* id128 /* HOST, 128 bytes */);
 int cn_comm_init(void** handle /* HOST */, const char* id128 /* HOST */, int rank, int world);
 int cn_comm_info(void* handle, int* rank, int* world, int* rccl_version /* HOST, any may be NULL */);

@@ -153,9 +153,121 @@ def big():
     trajectory('r50_b256', dict(depth=50), B=256, size=224, classes=1000, steps=2, seed=24)
 
 
+# ---------------------------------------------------------------------------------------------------------
+# Warm-start goldens.  `init_model` zeroes the last BatchNorm gamma of every block
+# (/root/reference/models/resnet.py:24-28), so in a cold-start trajectory every inner convolution's weight /
+# data gradient is exactly zero at step 0 and ~1e-4 of its natural size at step 1: the cold goldens cannot
+# see a wrong inner wgrad / dgrad.  Here every BatchNorm of the REFERENCE model gets seeded non-trivial
+# gamma / beta / running statistics before training, and the per-tensor gradients after step 0 are recorded.
+WARM_SEED = 977
+WARM_SAMPLE = 2048
+
+
+def warm_bn_state(model, seed=WARM_SEED):
+    """Overwrite gamma / beta / running_mean / running_var of every BatchNorm (module order) from one seeded
+    generator.  tests/helpers.py applies the same recipe to our model (same module names and order)."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, m in model.named_modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                C = m.num_features
+                m.weight.copy_(torch.rand(C, generator=g) + 0.5)           # gamma in [0.5, 1.5)
+                m.bias.copy_(torch.randn(C, generator=g) * 0.1)
+                m.running_mean.copy_(torch.randn(C, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+
+
+def warm_tensor_names(depth):
+    names = ['conv1.weight', 'bn1.weight', 'bn1.bias', 'fc.weight']
+    third = depth >= 50
+    for s in (1, 2, 3, 4):
+        for blk in (0, 1):
+            b = 'layer%d.%d.' % (s, blk)
+            names += [b + 'conv1.weight', b + 'conv2.weight', b + 'bn1.weight', b + 'bn2.weight', b + 'bn2.bias']
+            if third:
+                names += [b + 'conv3.weight', b + 'bn3.weight', b + 'bn3.bias']
+        if s > 1 or third:
+            names += ['layer%d.0.downsample.0.weight' % s, 'layer%d.0.downsample.1.weight' % s]
+    return names
+
+
+def sample_index(name, n):
+    """Up to WARM_SAMPLE seeded flat positions of a logical (reference-shape, row-major) tensor; the position set
+    depends on the tensor's name and size only (tests/helpers.py draws the same set)."""
+    if n <= WARM_SAMPLE:
+        return torch.arange(n)
+    gi = torch.Generator().manual_seed(sum(map(ord, name)) + n)
+    return torch.randperm(n, generator=gi)[:WARM_SAMPLE].sort().values
+
+
+def sample_tensor(v, name):
+    """norm / sum of the full tensor + its elements at sample_index()."""
+    v = v.detach().float().contiguous().flatten()
+    n = v.numel()
+    idx = sample_index(name, n)
+    return {'norm': float(v.double().norm()), 'sum': float(v.double().sum()), 'numel': n, 'val': v[idx].clone()}
+
+
+def warm_trajectory(tag, model_kw, B, size, classes, steps, seed, dtype=torch.float):
+    """dtype=torch.double: the reference itself run in float64.  On the small fixture (batch 8, 32x32 inputs: the
+    last stages normalise over 8..32 values per channel) the fp32 reference is only good to ~4e-2 on the inner
+    gradients - its own float64 run says so - while a perturbation in float64 shows the function is well
+    conditioned (1e-6 in -> 5e-10 out): the fp32 error is cancellation inside BatchNorm.  A double-precision
+    golden measures the engine against the truth instead of against another rounding pattern."""
+    torch.manual_seed(123)
+    model = ref_models.resnet(dataset='imagenet', **model_kw)
+    warm_bn_state(model)
+    model.to(dtype)
+    start_sums = tensor_sums({k: v for k, v in model.state_dict().items() if v.dtype.is_floating_point})
+    opt = OptimRegime(model, model.regime)
+    tr = RefTrainer(model, CrossEntropyLoss(), opt, device_ids=None, device='cpu', dtype=dtype,
+                    distributed=False, grad_clip=1e9, print_freq=10 ** 9)
+    data = batches(steps, B, size, classes, seed)
+    names = warm_tensor_names(model_kw['depth'])
+    params = dict(model.named_parameters())
+    recs, grads0 = [], None
+    for i, (x, t) in enumerate(data):
+        r = tr.train([(x, t)])
+        recs.append({k: float(r[k]) for k in ('loss', 'prec1', 'prec5', 'grad')})
+        if i == 0:   # Trainer._step zeroes the gradients at the START of a step: these are step 0's
+            grads0 = {k: sample_tensor(params[k].grad, k) for k in names}
+    val = tr.validate(data[:2])
+    sd = model.state_dict()
+    out = {'tag': tag, 'model_kw': model_kw, 'B': B, 'size': size, 'classes': classes, 'steps': steps,
+           'seed': seed, 'loss_scale': 1.0, 'grad_clip': 1e9, 'chunk_batch': 1, 'smooth_eps': 0.0,
+           'warm_seed': WARM_SEED, 'reference_dtype': str(dtype).replace('torch.', ''), 'records': recs,
+           'validate': {k: float(val[k]) for k in ('loss', 'prec1', 'prec5')},
+           'input_sums': [[float(x.double().sum()), float(t.sum())] for x, t in data],
+           'start_sums': start_sums,
+           'final_sums': tensor_sums({k: v for k, v in sd.items() if v.dtype.is_floating_point}),
+           'grad0_norms': {k: v['norm'] for k, v in grads0.items()},
+           'num_batches_tracked': int(sd['bn1.num_batches_tracked'])}
+    with open(os.path.join(OUT, 'traj_%s.json' % tag), 'w') as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    final = {k: sample_tensor(sd[k], k) for k in names}
+    for k in ('bn1.running_mean', 'bn1.running_var', 'layer3.1.bn2.running_mean', 'layer3.1.bn2.running_var'):
+        final[k] = sample_tensor(sd[k], k)
+    torch.save({'grad0': grads0, 'final': final}, os.path.join(OUT, 'traj_%s_tensors.pt' % tag))
+    print(tag, recs, 'val', out['validate'])
+    print('  smallest / largest recorded step-0 gradient norms:',
+          sorted(out['grad0_norms'].items(), key=lambda kv: kv[1])[:3],
+          sorted(out['grad0_norms'].items(), key=lambda kv: kv[1])[-3:])
+
+
+def warm(which=('small', 'r18', 'r50')):
+    if 'small' in which:
+        warm_trajectory('r50s_warm', dict(depth=50, **SMALL), B=8, size=32, classes=16, steps=3, seed=41,
+                        dtype=torch.double)
+    if 'r18' in which:
+        warm_trajectory('r18_b256_warm', dict(depth=18), B=256, size=224, classes=1000, steps=3, seed=43,
+                        dtype=torch.double)
+    if 'r50' in which:   # float64 at this size would need ~50 GB; at 12544..802816 values per channel fp32 is well conditioned
+        warm_trajectory('r50_b256_warm', dict(depth=50), B=256, size=224, classes=1000, steps=3, seed=42)
+
+
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and sys.argv[1] == 'big':
-        big()
+    if len(sys.argv) > 1 and sys.argv[1] in ('big', 'warm'):
+        big() if sys.argv[1] == 'big' else warm(tuple(sys.argv[2:]) or ('small', 'r18', 'r50'))
         assert not os.path.exists(os.path.join(REF, '__pycache__')), 'bytecode leaked into the reference tree'
         sys.exit(0)
     structure()
@@ -168,4 +280,5 @@ if __name__ == '__main__':
     mnist_eval()
     mnist_trajectory()
     big()
+    warm()
     assert not os.path.exists(os.path.join(REF, '__pycache__')), 'bytecode leaked into the reference tree'

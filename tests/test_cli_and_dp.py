@@ -15,7 +15,7 @@ import pytest
 import torch
 
 from conftest import HAS_GPU
-from helpers import ROOT, rel_l2
+from helpers import ROOT, rel_l2, check_dp_against_oracle, check_syncbn_against_oracle, DP_WORKER
 
 MODES = [pytest.param('emul'), pytest.param('gpu', marks=pytest.mark.gpu)]
 
@@ -62,31 +62,6 @@ def test_cli_train_checkpoint_resume(mode, tmp_path):
     assert ck2['epoch'] == 2
 
 
-DP_WORKER = r'''
-import os, sys, json, torch, torch.distributed as dist
-sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, 'tests'))
-import convnet_amd as ca
-DEV = %(dev)r
-if DEV != 'cpu':
-    torch.cuda.set_device(0)
-    assert not ca._lib.is_emulated()
-rank = int(os.environ['RANK'])
-dist.init_process_group('gloo', init_method='env://')
-torch.manual_seed(123 + 7 * rank)          # different initial weights per rank: the broadcast must fix that
-model = ca.models.resnet(depth=18, width=(8, 16, 32, 64), inplanes=8, num_classes=16)
-tr = ca.Trainer(model, ca.CrossEntropyLoss(), ca.OptimRegime(model, model.regime), device=DEV,
-                dtype=torch.float32, distributed=True, local_rank=rank, grad_clip=1e9, print_freq=10**9,
-                bucket_mb=0.05)
-g = torch.Generator().manual_seed(77)
-data = [(torch.randn(8, 3, 32, 32, generator=g), torch.randint(0, 16, (8,), generator=g)) for _ in range(2)]
-recs = []
-for x, t in data:
-    r = tr.train([(x[rank * 4:(rank + 1) * 4], t[rank * 4:(rank + 1) * 4])])
-    recs.append({k: float(r[k]) for k in ('loss', 'grad')})
-sd = {k: v.float().cpu() for k, v in model.state_dict().items() if v.dtype.is_floating_point}
-torch.save({'recs': recs, 'sd': sd, 'nbuckets': len(tr.arena.buckets)}, %(out)r %% rank)
-dist.destroy_process_group()
-'''
 
 
 def _worker_env(dev, port):
@@ -100,7 +75,7 @@ def test_data_parallel_two_ranks_gloo(mode, tmp_path):
     dev = _mode(mode)
     script = tmp_path / 'dp_worker.py'
     out_pat = str(tmp_path / 'rank%d.pt')
-    script.write_text(DP_WORKER % {'root': ROOT, 'out': out_pat, 'dev': dev if dev == 'cpu' else 'cuda:0'})
+    script.write_text(DP_WORKER % {'root': ROOT, 'out': out_pat, 'dev': dev if dev == 'cpu' else 'cuda:0', 'backend': 'gloo'})
     env = _worker_env(dev, 29531)
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)))
              for r in range(2)]
@@ -113,36 +88,7 @@ def test_data_parallel_two_ranks_gloo(mode, tmp_path):
         if 'running' in k or 'num_batches' in k:
             continue
         assert torch.equal(outs[0]['sd'][k], outs[1]['sd'][k]), k
-    # oracle-side DDP semantics: rank-0 initial weights everywhere, per-rank BN statistics,
-    # gradients averaged over the 2 ranks, one SGD step per iteration
-    from oracle import convnet_oracle as O
-    torch.manual_seed(123)
-    replicas = [O.OracleResNet(18, 16, 8, (8, 16, 32, 64)) for _ in range(2)]
-    replicas[1].load_state_dict(replicas[0].state_dict())
-    opts = [O.OracleSGD(m) for m in replicas]
-    g = torch.Generator().manual_seed(77)
-    data = [(torch.randn(8, 3, 32, 32, generator=g), torch.randint(0, 16, (8,), generator=g)) for _ in range(2)]
-    for step, (x, t) in enumerate(data):
-        losses = []
-        for r, m in enumerate(replicas):
-            m.train()
-            opts[r].zero_grad()
-            loss = O.oracle_cross_entropy(m(x[r * 4:(r + 1) * 4]), t[r * 4:(r + 1) * 4])
-            loss.backward()
-            losses.append(float(loss))
-        for p0, p1 in zip(replicas[0].parameters(), replicas[1].parameters()):
-            avg = (p0.grad + p1.grad) / 2
-            p0.grad.copy_(avg)
-            p1.grad.copy_(avg)
-        gnorm = torch.norm(torch.stack([p.grad.norm(2) for p in replicas[0].parameters()]), 2).item()
-        for o in opts:
-            o.step()
-        for r in range(2):
-            assert outs[r]['recs'][step]['loss'] == pytest.approx(losses[r], abs=1e-4)
-            assert outs[r]['recs'][step]['grad'] == pytest.approx(gnorm, rel=1e-3)
-    ref_sd = replicas[0].state_dict()
-    for k in ('conv1.weight', 'layer2.0.downsample.0.weight', 'fc.weight', 'layer4.1.bn2.bias'):
-        assert rel_l2(outs[0]['sd'][k], ref_sd[k]) < 1e-4, k
+    check_dp_against_oracle(outs)
 
 
 @pytest.mark.parametrize('mode', MODES)
@@ -156,7 +102,7 @@ def test_sync_batchnorm_two_ranks_equals_global_batch(mode, tmp_path):
     out_pat = str(tmp_path / 'sync_rank%d.pt')
     worker = DP_WORKER.replace("tr = ca.Trainer(", "ca.nn.convert_sync_batchnorm(model)\ntr = ca.Trainer(", 1)
     assert worker != DP_WORKER
-    script.write_text(worker % {'root': ROOT, 'out': out_pat, 'dev': dev if dev == 'cpu' else 'cuda:0'})
+    script.write_text(worker % {'root': ROOT, 'out': out_pat, 'dev': dev if dev == 'cpu' else 'cuda:0', 'backend': 'gloo'})
     env = _worker_env(dev, 29533)
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)))
              for r in range(2)]
@@ -167,23 +113,4 @@ def test_sync_batchnorm_two_ranks_equals_global_batch(mode, tmp_path):
         if 'num_batches' in k:
             continue
         assert torch.equal(outs[0]['sd'][k], outs[1]['sd'][k]), k
-    from oracle import convnet_oracle as O
-    torch.manual_seed(123)
-    model = O.OracleResNet(18, 16, 8, (8, 16, 32, 64))
-    opt = O.OracleSGD(model)
-    g = torch.Generator().manual_seed(77)
-    data = [(torch.randn(8, 3, 32, 32, generator=g), torch.randint(0, 16, (8,), generator=g)) for _ in range(2)]
-    for step, (x, t) in enumerate(data):
-        model.train()
-        opt.zero_grad()
-        loss = O.oracle_cross_entropy(model(x), t)
-        loss.backward()
-        gnorm = torch.norm(torch.stack([p.grad.norm(2) for p in model.parameters()]), 2).item()
-        opt.step()
-        rank_mean = 0.5 * (outs[0]['recs'][step]['loss'] + outs[1]['recs'][step]['loss'])
-        assert rank_mean == pytest.approx(float(loss), abs=1e-4)
-        assert outs[0]['recs'][step]['grad'] == pytest.approx(gnorm, rel=1e-3)
-    ref_sd = model.state_dict()
-    for k in ('conv1.weight', 'layer2.0.downsample.0.weight', 'fc.weight', 'layer4.1.bn2.bias',
-              'bn1.running_mean', 'layer3.0.bn1.running_var', 'layer1.1.bn2.weight'):
-        assert rel_l2(outs[0]['sd'][k], ref_sd[k]) < 1e-4, k
+    check_syncbn_against_oracle(outs)

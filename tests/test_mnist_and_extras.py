@@ -151,3 +151,64 @@ def test_optimizer_resume_past_a_regime_boundary_keeps_weight_decay(device):
     # a foreign optimizer state (e.g. the reference's torch.optim dict) is refused, not silently ignored
     with pytest.raises(ca._lib.ConvNetHipError):
         opt2.load_state_dict({'state': {}, 'param_groups': []})
+
+
+def test_nonfinite_running_mean_does_not_poison_the_batch_statistics(device):
+    """with centred statistics the conv epilogue and the statistics pass use the BatchNorm's running mean
+    as the pivot of their sums.  In the reference the batch statistics do not depend on the running buffers, so a
+    non-finite running mean (bad checkpoint, diverged step) must not reach them: the kernels replace such a pivot
+    by 0 (cn_pivot).  Training output / loss / gradients of a model whose running means hold inf and NaN equal the
+    clean model's."""
+    import convnet_amd as ca
+    kw = dict(depth=18, width=(8, 16, 32, 64), inplanes=8, num_classes=16)
+    g = torch.Generator().manual_seed(3)
+    x, t = torch.randn(4, 3, 32, 32, generator=g), torch.randint(0, 16, (4,), generator=g)
+    res = []
+    for poison in (False, True):
+        torch.manual_seed(123)
+        model = ca.models.resnet(**kw)
+        tr = ca.Trainer(model, ca.CrossEntropyLoss(), ca.OptimRegime(model, model.regime), device=str(device),
+                        dtype=torch.float32, grad_clip=1e9, print_freq=10 ** 9)
+        tr._use_graph = False
+        if poison:
+            with torch.no_grad():
+                model.bn1.running_mean[0] = float('inf')
+                model.bn1.running_mean[1] = float('nan')
+                model.layer2[0].bn1.running_mean.fill_(float('-inf'))
+                model.layer3[1].bn2.running_mean[3] = float('nan')
+        r = tr.train([(x, t)])
+        res.append((float(r['loss']), float(r['grad']), model.fc.weight.detach().float().cpu().clone()))
+    (l0, g0, w0), (l1, g1, w1) = res
+    assert l1 == l1 and g1 == g1 and torch.isfinite(w1).all()
+    assert l1 == pytest.approx(l0, rel=1e-5) and g1 == pytest.approx(g0, rel=1e-4)
+    assert torch.allclose(w0, w1, rtol=1e-4, atol=1e-6)
+
+
+def test_reference_optimizer_state_resumes_with_its_momentum(device):
+    """a checkpoint written by the REFERENCE carries torch.optim.SGD's state_dict as `optim_state_dict`
+    (bare, or under 'optimizer_state').  OptimRegime.load_state_dict imports its momentum buffers (index i of
+    param_groups[*]['params'] = i-th model parameter) instead of refusing the file or restarting from zero; a state
+    that is neither format is still refused loudly."""
+    import convnet_amd as ca
+    from oracle import convnet_oracle as O
+    kw = dict(depth=18, width=(8, 16, 32, 64), inplanes=8, num_classes=16)
+    torch.manual_seed(123)
+    ref = O.OracleResNet(18, 16, 8, (8, 16, 32, 64))
+    sgd = torch.optim.SGD(ref.parameters(), lr=0.1, momentum=0.9)
+    g = torch.Generator().manual_seed(9)
+    x, t = torch.randn(4, 3, 32, 32, generator=g), torch.randint(0, 16, (4,), generator=g)
+    O.oracle_cross_entropy(ref(x), t).backward()
+    sgd.step()
+    ref_state = sgd.state_dict()
+    names = [n for n, _ in ref.named_parameters()]
+    for wrap in (lambda s: s, lambda s: {'optimizer_state': s, 'regime': []}):
+        torch.manual_seed(123)
+        model = ca.models.resnet(**kw)
+        opt = ca.OptimRegime(model, model.regime)
+        ca.Trainer(model, ca.CrossEntropyLoss(), opt, device=str(device), dtype=torch.float32, print_freq=10 ** 9)
+        opt.load_state_dict(wrap(ref_state))
+        mine = opt.state_dict()['momentum_buffer']
+        for i, n in enumerate(names):
+            assert torch.equal(mine[n].float().cpu(), ref_state['state'][i]['momentum_buffer']), n
+    with pytest.raises(ca._lib.ConvNetHipError):
+        opt.load_state_dict({'something': 'else'})

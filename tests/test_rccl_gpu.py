@@ -8,6 +8,13 @@
 * cn_comm_allreduce (fp64, in-stream) and cn_comm_broadcast on the 1-rank communicator.
 * `bench.py --gpus 2` with no launcher env starts its own ranks (here both on the one device of the
   test box, BENCH_SHARE_GPU=1 -> gloo) and reports n_gpus = 2.
+* With >= 2 devices visible (`skipif` otherwise: the 1-GPU test boxes; the driver's 8-GPU node runs them):
+  the SAME 2-rank bodies as tests/test_cli_and_dp.py, but one GPU per rank on the direct-RCCL transport -
+  training vs the oracle's restatement of DistributedDataParallel semantics, SyncBatchNorm over
+  cn_comm_allreduce vs the oracle on the global batch, and `bench.py --gpus 2` reporting
+  "direct RCCL ... 2 ranks".  These make the first multi-rank execution of cn_comm_allreduce_bucket a test,
+  not the scaling bench.
+* A failing set-up stops the job: there is no silent second transport (CONVNET_AMD_COMM=torch is explicit).
 """
 import json
 import os
@@ -17,7 +24,7 @@ import sys
 import pytest
 import torch
 
-from helpers import ROOT
+from helpers import ROOT, DP_WORKER, check_dp_against_oracle, check_syncbn_against_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -107,3 +114,90 @@ def test_bench_self_launches_its_ranks(tmp_path):
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--steps', '1'],
                         env=dict(env, WORLD_SIZE='1', RANK='0'), capture_output=True, text=True, timeout=300)
     assert r2.returncode != 0 and 'WORLD_SIZE' in (r2.stdout + r2.stderr)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# >= 2 devices: the direct-RCCL transport with more than one rank
+NDEV = torch.cuda.device_count() if torch.cuda.is_available() else 0
+two_gpus = pytest.mark.skipif(NDEV < 2, reason='needs >= 2 HIP devices (RCCL refuses two ranks on one device)')
+
+
+def _run_two_ranks(tmp_path, worker, port, name):
+    script = tmp_path / (name + '.py')
+    out_pat = str(tmp_path / (name + '_rank%d.pt'))
+    script.write_text(worker % {'root': ROOT, 'out': out_pat, 'dev': 'cuda:%d', 'backend': 'nccl'})
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE='2', OMP_NUM_THREADS='2',
+               CONVNET_AMD_EMULATE='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('CONVNET_AMD_COMM', None)
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)))
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=900) == 0
+    return [torch.load(out_pat % r) for r in range(2)]
+
+
+@two_gpus
+def test_two_ranks_direct_rccl_training_matches_oracle_ddp(tmp_path):
+    outs = _run_two_ranks(tmp_path, DP_WORKER, 29551, 'dp_rccl')
+    for o in outs:
+        assert 'direct RCCL' in o['transport'] and '2 ranks' in o['transport'], o['transport']
+    assert outs[0]['nbuckets'] > 1, 'the tiny bucket size must exercise multi-bucket overlap'
+    for k in outs[0]['sd']:   # replicas stay bit-identical (same broadcast weights, same reduced gradients)
+        if 'running' in k or 'num_batches' in k:
+            continue
+        assert torch.equal(outs[0]['sd'][k], outs[1]['sd'][k]), k
+    check_dp_against_oracle(outs)
+
+
+@two_gpus
+def test_two_ranks_sync_batchnorm_over_cn_comm_allreduce(tmp_path):
+    worker = DP_WORKER.replace("tr = ca.Trainer(", "ca.nn.convert_sync_batchnorm(model)\ntr = ca.Trainer(", 1)
+    assert worker != DP_WORKER
+    outs = _run_two_ranks(tmp_path, worker, 29553, 'sync_rccl')
+    for o in outs:
+        assert 'direct RCCL' in o['transport'], o['transport']
+    for k in outs[0]['sd']:
+        if 'num_batches' in k:
+            continue
+        assert torch.equal(outs[0]['sd'][k], outs[1]['sd'][k]), k
+    check_syncbn_against_oracle(outs)
+
+
+@two_gpus
+def test_bench_two_gpus_runs_on_direct_rccl(tmp_path):
+    env = dict(os.environ, CONVNET_AMD_EMULATE='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'BENCH_SHARE_GPU', 'CONVNET_AMD_COMM'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--batch', '32', '--steps', '3',
+                        '--warmup', '2', '--no-cpu-baseline', '--no-kernel-profile'], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    rec = json.loads([l for l in r.stdout.split('\n') if l.startswith('{"metric"')][0])
+    assert rec['n_gpus'] == 2 and rec['config']['global_batch'] == 64 and rec['config']['parallelism'] == 'dp2'
+    assert 'direct RCCL' in rec['config']['transport'] and '2 ranks' in rec['config']['transport'], rec['config']
+
+
+def test_failed_rccl_setup_raises_instead_of_falling_back(tmp_path):
+    """No silent second transport: with the RCCL library unresolvable the communicator set-up raises on the rank
+    (and, through the agreement step, on every rank).  CN_RCCL_LIB points the loader at a file that is not there."""
+    code = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+import convnet_amd as ca
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', init_method='env://', world_size=1, rank=0)
+try:
+    ca.comm.create_default(torch.device('cuda', 0))
+except ca._lib.ConvNetHipError as e:
+    print('RAISED', e)
+else:
+    print('NO ERROR')
+dist.destroy_process_group()
+""" % ROOT
+    script = tmp_path / 'fail_worker.py'
+    script.write_text(code)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29557', CONVNET_AMD_EMULATE='0',
+               CN_RCCL_LIB=str(tmp_path / 'no_such_librccl.so'))
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert 'RAISED' in r.stdout and 'load librccl' in r.stdout, r.stdout[-2000:]

@@ -24,8 +24,9 @@ def load(d, counter):
     return agg, {k: len(v) for k, v in calls.items()}
 
 
-def main():
-    root, out = sys.argv[1], sys.argv[2]
+def collect(root, steps=3):
+    """{source, kernels: {name: per-launch bytes}, profiled_steps, hbm_bytes_per_step} from <root>/fetch and
+    <root>/write (one rocprofv3 --pmc pass each)."""
     fetch, fc = load(os.path.join(root, 'fetch'), 'FETCH_SIZE')
     write, wc = load(os.path.join(root, 'write'), 'WRITE_SIZE')
     res = {}
@@ -35,11 +36,18 @@ def main():
         wr = write.get(k, 0.0) * 1024.0
         res[k] = {'launches': n, 'read_bytes_per_launch': rd / n, 'write_bytes_per_launch': wr / n,
                   'hbm_bytes_per_launch': (rd + wr) / n}
-    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3    # tools/pmc_round.sh profiles bench.py --steps 2 --warmup 1
     total = sum(v['hbm_bytes_per_launch'] * v['launches'] for v in res.values())
-    json.dump({'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 (gfx950)',
-               'kernels': res, 'profiled_steps': steps, 'hbm_bytes_per_step': total / steps,
-               'workload': 'bench.py defaults (ResNet-50 bf16 b=256, 1 GPU)'}, open(out, 'w'), indent=1, sort_keys=True)
+    return {'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 (gfx950)',
+            'kernels': res, 'profiled_steps': steps, 'hbm_bytes_per_step': total / steps,
+            'workload': 'bench.py defaults (ResNet-50 bf16 b=256, 1 GPU)'}
+
+
+def main():
+    root, out = sys.argv[1], sys.argv[2]
+    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3    # tools/pmc_round.sh profiles bench.py --steps 2 --warmup 1
+    doc = collect(root, steps)
+    res, total = doc['kernels'], doc['hbm_bytes_per_step'] * steps
+    json.dump(doc, open(out, 'w'), indent=1, sort_keys=True)
     print('all kernels: %.1f GB of HBM traffic per step (%d profiled steps)' % (total / steps / 1e9, steps))
     top = sorted(res.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches'])[:12]
     for k, v in top:
