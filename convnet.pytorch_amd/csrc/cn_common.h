@@ -448,6 +448,15 @@ __device__ __forceinline__ void cn_raw_barrier() { __builtin_amdgcn_s_barrier();
 static inline void cn_raw_barrier() { cn_emul::sync_threads(); }
 #endif
 
+// A value the program knows to be the same in every lane of the wave (e.g. threadIdx.x >> 6): tells the compiler so
+// (v_readfirstlane -> SGPR), which keeps wave-uniform bases (the M0 operand of an LDS-DMA) out of VGPRs and avoids the
+// waterfall loops hipcc otherwise builds around them.
+#ifndef CN_EMULATE
+__device__ __forceinline__ int cn_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+#else
+static inline int cn_uniform(int v) { return v; }
+#endif
+
 // Scheduling fence: nothing is moved across it by hipcc's machine scheduler (used to keep the
 // fragment reads of the NEXT k-step ahead of the MFMAs of the current one).
 #ifndef CN_EMULATE

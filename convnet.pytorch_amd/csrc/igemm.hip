@@ -105,9 +105,15 @@ __device__ __forceinline__ int ig_slot(int row, int chunk) {
 //     only), so the inner BatchNorm's apply pass - one read and one write of the activation - disappears.  Padded taps
 //     stay zero (they are zeros of z, not of y).
 #define IG_XF_MAX 512
-template <typename T, int WC, int WP, int TI, int TJ, int STAGES, bool OUTF32, bool GLDS, bool FRAGDB, bool EPI, bool XF = false>
+// ILV (round 3, LDS-DMA double buffer only): the DMA instructions of K tile kt+1 are issued BETWEEN the MFMAs of tile kt
+//     (one after each of the first NPR+NWR MFMAs, pinned by scheduling fences) instead of in a block ahead of them.  In
+//     the block form every wave of the workgroup issues its 8 DMA instructions (~100 cycles of issue each while the
+//     texture path is busy) right after the barrier, i.e. with the matrix pipe of all four SIMDs idle; interleaved,
+//     each one is issued while the MFMA before it executes.  Same instructions, same results (bit-identical).
+template <typename T, int WC, int WP, int TI, int TJ, int STAGES, bool OUTF32, bool GLDS, bool FRAGDB, bool EPI, bool XF = false, bool ILV = false>
 __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
   static_assert(!XF || (!GLDS && !EPI), "operand transform needs the register-staged path");
+  static_assert(!ILV || (GLDS && STAGES == 2), "interleaved DMA issue: LDS-DMA double buffer");
   static_assert(!GLDS || STAGES == 2 || STAGES == 4, "LDS-DMA needs the double-buffered tile or the 4-deep ring");
   constexpr int BN = WC * TI * 32;  // output channels per block
   constexpr int BM = WP * TJ * 32;  // pixels per block
@@ -129,7 +135,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = cn_uniform(tid >> 6);   // wave-uniform by construction: lets LDS-DMA bases live in SGPRs (no waterfall)
   const unsigned int tile = cn_xcd_remap(blockIdx.x, gridDim.x);
   const int nt = p.mt_fastest ? (int)(tile / p.n_mtiles) : (int)(tile % p.n_ntiles);
   const int mt = p.mt_fastest ? (int)(tile % p.n_mtiles) : (int)(tile / p.n_ntiles);
@@ -272,10 +278,11 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
 
   unsigned int xf_ok = 0;   // XF: which of this thread's staged pixel rows hold real data (bit i), and their channel chunk
   int xf_chunk = 0;
-  auto load_tile = [&](int kt, int buf) {
+  // per-K-tile addressing state of this thread (set by tile_addr, consumed by issue_p / issue_w)
+  unsigned int t_kb = 0, t_wofs = 0, t_xofs = 0;
+  int t_dh = 0, t_dw = 0;
+  auto tile_addr = [&](int kt) {
     const int kc = kt * 8 + cg;
-    char* dw_ = lds + buf * STAGE + (8 * wave) * 128;             // this wave's KiB of filter rows
-    char* dp_ = lds + buf * STAGE + BN * 128 + (8 * wave) * 128;  // ... and of pixel rows
     const bool kvalid = kc < p.nchunks;
     int tap = 0, cchunk = kc;
     if (p.ntaps > 1) {
@@ -283,37 +290,40 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
       cchunk = kc - tap * p.cpt;
     }
     const int dhdw = s_taps[4 * tap];
-    const unsigned int kb = kvalid ? (unsigned int)(cchunk * 16) : CN_OOB;   // 16 bytes per chunk
-    const unsigned int wofs = (unsigned int)s_taps[4 * tap + 1] + kb;
-    const unsigned int xofs = (unsigned int)s_taps[4 * tap + 2] + kb;
+    t_kb = kvalid ? (unsigned int)(cchunk * 16) : CN_OOB;   // 16 bytes per chunk
+    t_wofs = (unsigned int)s_taps[4 * tap + 1] + t_kb;
+    t_xofs = (unsigned int)s_taps[4 * tap + 2] + t_kb;
+    t_dh = (int)(short)(dhdw & 0xffff);
+    t_dw = dhdw >> 16;
     if (XF) { xf_ok = 0; xf_chunk = cchunk; }
-    if (simple) {
-#pragma unroll
-      for (int i = 0; i < NPR; ++i) {
-        const unsigned int o = (prow[i] | kb) >= CN_OOB ? CN_OOB : prow[i] + xofs;
-        if (XF) xf_ok |= (o < CN_OOB ? 1u : 0u) << i;
-        if (GLDS) cn_buf_ld16_lds(xbuf, o, dp_ + i * RS * 128);
-        else preg[i] = p.x_nt ? cn_buf_ld16_nt(xbuf, o) : cn_buf_ld16(xbuf, o);
-      }
+  };
+  auto issue_p = [&](int i, int buf) {   // pixel row r0 + RS*i of the tile
+    char* dp_ = lds + buf * STAGE + BN * 128 + (8 * wave) * 128;  // this wave's KiB of pixel rows
+    unsigned int o;
+    if (!ILV && simple) {   // (the interleaved form keeps ONE straight-line body: no branch between its MFMAs)
+      o = (prow[i] | t_kb) >= CN_OOB ? CN_OOB : prow[i] + t_xofs;
     } else {
-      const int dh = (int)(short)(dhdw & 0xffff);
-      const int dw = dhdw >> 16;
-#pragma unroll
-      for (int i = 0; i < NPR; ++i) {
-        const bool ok = (unsigned)(phin[i] + dh) < (unsigned)p.Hi && (unsigned)(pwin[i] + dw) < (unsigned)p.Wi &&
-                        kb < CN_OOB;
-        const unsigned int o = ok ? prow[i] + xofs : CN_OOB;
-        if (XF) xf_ok |= (ok ? 1u : 0u) << i;
-        if (GLDS) cn_buf_ld16_lds(xbuf, o, dp_ + i * RS * 128);
-        else preg[i] = cn_buf_ld16(xbuf, o);
-      }
+      // (bitwise &: one straight-line predicate, no short-circuit branches between the MFMAs of the interleaved form)
+      const bool ok = ((unsigned)(phin[i] + t_dh) < (unsigned)p.Hi) & ((unsigned)(pwin[i] + t_dw) < (unsigned)p.Wi) &
+                      (t_kb < CN_OOB);
+      o = ok ? prow[i] + t_xofs : CN_OOB;
     }
+    if (XF) xf_ok |= (o < CN_OOB ? 1u : 0u) << i;
+    if (GLDS) cn_buf_ld16_lds(xbuf, o, dp_ + i * RS * 128);
+    else preg[i] = (!ILV && simple && p.x_nt) ? cn_buf_ld16_nt(xbuf, o) : cn_buf_ld16(xbuf, o);
+  };
+  auto issue_w = [&](int i, int buf) {   // filter row r0 + RS*i of the tile
+    char* dw_ = lds + buf * STAGE + (8 * wave) * 128;             // this wave's KiB of filter rows
+    const unsigned int o = (wrow[i] | t_kb) >= CN_OOB ? CN_OOB : wrow[i] + t_wofs;
+    if (GLDS) cn_buf_ld16_lds(wbuf, o, dw_ + i * RS * 128);
+    else wreg[i] = cn_buf_ld16(wbuf, o);
+  };
+  auto load_tile = [&](int kt, int buf) {
+    tile_addr(kt);
 #pragma unroll
-    for (int i = 0; i < NWR; ++i) {
-      const unsigned int o = (wrow[i] | kb) >= CN_OOB ? CN_OOB : wrow[i] + wofs;
-      if (GLDS) cn_buf_ld16_lds(wbuf, o, dw_ + i * RS * 128);
-      else wreg[i] = cn_buf_ld16(wbuf, o);
-    }
+    for (int i = 0; i < NPR; ++i) issue_p(i, buf);
+#pragma unroll
+    for (int i = 0; i < NWR; ++i) issue_w(i, buf);
   };
   auto store_tile = [&](int buf) {
     char* base = lds + buf * STAGE;
@@ -382,6 +392,55 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
     }
   };
 
+  // ILV: compute(buf) with the DMA instructions of the next K tile (addresses set by tile_addr) issued one after every
+  // IEVERY-th MFMA, from the first MFMA on: all NPR+NWR of them are out by the middle of the tile, so they have half
+  // a tile of MFMA time to land before the barrier, and none is issued while the matrix pipe idles.
+  auto compute_ilv = [&](int buf, int nbuf) {
+    constexpr int IEVERY = (TI * TJ >= 8) ? 2 : 1;
+    static_assert(!ILV || (NPR + NWR) * IEVERY <= 2 * TI * TJ, "the DMA instructions must all be issued in the first two k-steps");
+    const char* wt = lds + buf * STAGE + rd_w;
+    const char* pt = lds + buf * STAGE + rd_p;
+    constexpr int NFB = FRAGDB ? 2 : 1;   // fragment buffers: double (reads of k-step kk+1 ahead of the MFMAs of kk) or single
+    u32x4 af[NFB][TI], bfr[NFB][TJ];
+    if (FRAGDB) {
+#pragma unroll
+      for (int a = 0; a < TI; ++a) af[0][a] = cn_ld16(wt + koff[0] + a * 32 * 128);
+#pragma unroll
+      for (int b = 0; b < TJ; ++b) bfr[0][b] = cn_ld16(pt + koff[0] + b * 32 * 128);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int cur = FRAGDB ? (kk & 1) : 0, nxt = FRAGDB ? (cur ^ 1) : 0;
+      if (FRAGDB) {
+        if (kk < 3) {
+#pragma unroll
+          for (int a = 0; a < TI; ++a) af[nxt][a] = cn_ld16(wt + koff[kk + 1] + a * 32 * 128);
+#pragma unroll
+          for (int b = 0; b < TJ; ++b) bfr[nxt][b] = cn_ld16(pt + koff[kk + 1] + b * 32 * 128);
+        }
+        cn_sched_fence();
+      } else {
+#pragma unroll
+        for (int a = 0; a < TI; ++a) af[0][a] = cn_ld16(wt + koff[kk] + a * 32 * 128);
+#pragma unroll
+        for (int b = 0; b < TJ; ++b) bfr[0][b] = cn_ld16(pt + koff[kk] + b * 32 * 128);
+      }
+#pragma unroll
+      for (int a = 0; a < TI; ++a)
+#pragma unroll
+        for (int b = 0; b < TJ; ++b) {
+          ig_mma<T>(af[cur][a], bfr[cur][b], acc[a][b]);
+          const int m = kk * TI * TJ + a * TJ + b;      // compile-time after unrolling
+          if (m % IEVERY == 0 && m / IEVERY < NPR + NWR) {
+            const int slot = m / IEVERY;
+            if (slot < NPR) issue_p(slot, nbuf);
+            else issue_w(slot - NPR, nbuf);
+            cn_sched_fence();
+          }
+        }
+    }
+  };
+
   if (nkt > 0 && !(p.dbg & 1)) {
     load_tile(0, 0);
     if (!GLDS) store_tile(0);
@@ -410,7 +469,16 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
       __syncthreads();
     } else
     for (int kt = 0; kt < nkt; ++kt) {
-      if (GLDS) {
+      if (GLDS && ILV) {
+        // ONE loop body for every tile (a second, DMA-free body for the last tile made the register allocator keep two
+        // accumulator sets and copy between them): past the end tile_addr() yields out-of-range offsets, so the last
+        // tile's DMA instructions fetch nothing and write zeros into the buffer nobody reads again; they have landed
+        // before the barrier below, i.e. before the epilogue reuses the LDS.
+        const int buf = kt & 1;
+        tile_addr(kt + 1);
+        compute_ilv(buf, buf ^ 1);                      // DMA issue interleaved with this tile's MFMAs
+        __syncthreads();
+      } else if (GLDS) {
         const int buf = kt & 1;
         if (kt + 1 < nkt) load_tile(kt + 1, buf ^ 1);   // DMA into the other buffer while we compute
         compute(buf);
@@ -689,7 +757,7 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
   // short reductions: register-staged single buffer (more workgroups per CU); from "igemm_dma_min_nkt" K tiles
   // on: LDS-DMA double buffer (measured per layer, profiles/r01_conv_layers_b256_bf16.txt)
   if (variant < 1 || variant > 12)
-    variant = cn_get_option("igemm_default_variant", nkt < cn_get_option("igemm_dma_min_nkt", 24) ? 1 : 3);
+    variant = cn_get_option("igemm_default_variant", nkt < cn_get_option("igemm_dma_min_nkt", 16) ? 1 : 3);
   if ((p.stats != nullptr || p.bn_y != nullptr || p.addend != nullptr) && variant == 6) variant = 3;   // 128-pixel tiles   // statistics rows are defined per 128-pixel tile
   const bool epi = p.addend != nullptr || p.bn_y != nullptr;
   // EPI launches on wide outputs can run on 64-pixel tiles (32 accumulator registers, half the prefetch
@@ -747,13 +815,16 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
       p.n_mtiles = (p.M + 255) / 256;
       dim3 g2((unsigned)(p.n_ntiles * p.n_mtiles));
       const bool fragdb = variant != 11;
-      cn_set_last_kernel("igemm_kernel<%s, 4, 2, 2, 4, 2, false, true, %s, false, false>", tname, fragdb ? "true" : "false");
-      if (fragdb) CN_LAUNCH((igemm_kernel<T, 4, 2, 2, 4, 2, false, true, true, false>), g2, dim3(512), stream, p);
+      const bool ilv = fragdb && cn_get_option("igemm_ilv", 2) != 0;   // interleaved DMA issue (A/B knob; bit-identical)
+      cn_set_last_kernel("igemm_kernel<%s, 4, 2, 2, 4, 2, false, true, %s, false, false, %s>", tname, (fragdb && !ilv) ? "true" : "false",
+                         ilv ? "true" : "false");
+      if (ilv) CN_LAUNCH((igemm_kernel<T, 4, 2, 2, 4, 2, false, true, false, false, false, true>), g2, dim3(512), stream, p);
+      else if (fragdb) CN_LAUNCH((igemm_kernel<T, 4, 2, 2, 4, 2, false, true, true, false>), g2, dim3(512), stream, p);
       else CN_LAUNCH((igemm_kernel<T, 4, 2, 2, 4, 2, false, true, false, false>), g2, dim3(512), stream, p);
       return cn_check_launch("igemm");
     }
   }
-  if (variant >= 7) variant = cn_get_option("igemm_default_variant", nkt < cn_get_option("igemm_dma_min_nkt", 24) ? 1 : 3);
+  if (variant >= 7) variant = cn_get_option("igemm_default_variant", nkt < cn_get_option("igemm_dma_min_nkt", 16) ? 1 : 3);
   if (variant >= 4 && p.Co > 64 && !epi) {
     // 4 / 5: experimental 4-deep DMA rings (4 or 8 waves), measured slower than variant 3, kept for A/B;
     // 6: 256-pixel x 128-channel tile, 8 waves, LDS-DMA double buffer with register-double-buffered
@@ -765,6 +836,14 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
     return cn_check_launch("igemm");
   }
   if (variant >= 4) variant = 3;
+  if constexpr (sizeof(T) == 2 && !OUTF32) {
+    // 128 x 128 LDS-DMA double buffer with interleaved DMA issue (see ILV): knob "igemm_ilv" >= 2 (A/B; bit-identical)
+    if (variant == 3 && !epi && !bm64 && p.Co > 64 && cn_get_option("igemm_ilv", 2) >= 2) {
+      cn_set_last_kernel("igemm_kernel<%s, 2, 2, 2, 2, 2, false, true, true, false, false, true>", tname);
+      CN_LAUNCH((igemm_kernel<T, 2, 2, 2, 2, 2, false, true, true, false, false, true>), grid, dim3(256), stream, p);
+      return cn_check_launch("igemm");
+    }
+  }
   if (p.Co <= 64) IG_GO(1, 4, 2, 1);
   else if (bm64 && epi) IG_GO2(2, 2, 2, 1, true);
   else if (bm64) IG_GO2(2, 2, 2, 1, false);

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = cn_uniform(tid >> 6);
   const int wi = wave & 1, wj = wave >> 1;
 
   unsigned int tile = cn_xcd_remap(blockIdx.x, gridDim.x);
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(WgradParams p) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = cn_uniform(tid >> 6);
   const int wi = wave & 1, wj = wave >> 1;
 
   unsigned int tile = cn_xcd_remap(blockIdx.x, gridDim.x);
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(512) void wgrad_dma256_kernel(WgradParams p) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;          // 0..7
+  const int wave = cn_uniform(tid >> 6);   // 0..7 (wave-uniform: LDS-DMA bases stay in SGPRs)
   const int wi = wave & 1, wj = wave >> 1;
 
   unsigned int tile = cn_xcd_remap(blockIdx.x, gridDim.x);
@@ -580,6 +580,245 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, fl
 }
 
 // ------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 weight gradient with the activation staged ONCE per band of image rows (round 3).
+//
+// The tile kernels above treat every tap as its own block of GEMM columns: each (co, tap*ci) tile re-gathers its
+// window of x and re-reads its dy rows, so a 3x3 layer moves 9 x (|x| + |dy|) through L2 -> LDS (0.9 - 1.8 GB per launch
+// at B = 256) and runs at that rate (105 - 133 us whatever the layer: 430 - 560 TFLOP/s, 0.19 - 0.27 of its roof).
+// Here a workgroup owns BI output channels x 32 input channels x ALL NINE taps (9 accumulators of 32 x 32 per wave):
+//   * the pixel reduction walks "bands" of whole image rows (<= 112 pixels = 7 MFMA k-steps of 16);
+//   * per band the 32-channel slice of x is written to LDS once, as a zero-padded 2-D image: buffer rows = the
+//     band's image rows plus one row above / below (the zero row between two images where the band crosses an image
+//     boundary), W + 2 positions of 64 bytes per row with zero border columns.  A tap is then a UNIFORM shift of
+//     dh*(W+2) + dw positions: no bounds tests, no per-tap gather - one v_add per transpose read;
+//   * 64-byte positions put four consecutive pixels on four distinct 64-byte bank quarters, so the
+//     ds_read_b64_tr_b16 fragment reads are conflict free without a swizzle;
+//   * dy (the band's pixels x BI channels, contiguous rows) arrives by LDS-DMA, double buffered.
+// L2 -> LDS traffic per launch: (Ci/32) x |dy| + (Co/BI) x (1 + 2/rows per band) x |x|.
+// BI = 128: four waves = four 32-channel blocks of co.  BI = 64 (64-channel layers): two co blocks x two waves
+// that split the k-steps of a band (alternating parity per band), summed through LDS at the end.
+// Partial sums go to the same [split][Co][9*Ci] workspace as the tile kernels (wgrad_reduce_kernel).
+#define WG3_NPX 112
+#define WG3_XBYTES 20480
+struct Wg3Params {
+  const char* x;
+  const char* dy;
+  float* part;
+  int N, H, W, Ci, Co;
+  int NR;               // image rows per band (NR * W <= WG3_NPX)
+  int rows_per_split;   // global rows (n*H + h) per workgroup: a multiple of NR
+  int total_rows;       // N * H
+  int n_itiles, n_jtiles;
+  unsigned int x_bytes, dy_bytes;
+  FastDiv div_hp1, div_w, div_wp2, div_h;
+};
+
+template <typename T, int BI>
+__global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(Wg3Params p) {
+  constexpr int NPX = WG3_NPX, KK = NPX / 16;
+  constexpr int RBI = BI * 2;              // dy row bytes in LDS
+  constexpr int DYSZ = NPX * RBI;          // one dy band tile
+  constexpr int NBLK = DYSZ / 1024;        // KiB blocks of a dy tile (28 / 14)
+  constexpr int NDI = (NBLK + 3) / 4;      // DMA instructions per wave and band
+  constexpr int CPR = RBI / 16;            // 16-byte chunks per dy row
+  constexpr int RPB = 1024 / RBI;          // dy rows per KiB block
+  constexpr int NSLOT = WG3_XBYTES / 16 / 256;   // 16-byte x slots per thread and band (5)
+  constexpr bool KSPLIT = (BI == 64);
+  constexpr int NW = BI / 32;              // co blocks
+  __shared__ __attribute__((aligned(1024))) char lds[2 * DYSZ + WG3_XBYTES + NPX * 4];
+  char* xb = lds + 2 * DYSZ;
+  int* s_pos = (int*)(lds + 2 * DYSZ + WG3_XBYTES);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = cn_uniform(tid >> 6);
+  const int wi = KSPLIT ? (wave & 1) : wave;     // co block of this wave
+  const int wk = KSPLIT ? (wave >> 1) : 0;       // k-step parity of this wave (BI = 64)
+
+  unsigned int tile = cn_xcd_remap(blockIdx.x, gridDim.x);
+  const int jt = tile % p.n_jtiles;
+  tile /= p.n_jtiles;
+  const int it = tile % p.n_itiles;
+  const int split = tile / p.n_itiles;
+  const int i0 = it * BI, j0 = jt * 32;
+  const int g_lo = split * p.rows_per_split;
+  int g_hi = g_lo + p.rows_per_split;
+  if (g_hi > p.total_rows) g_hi = p.total_rows;
+  const int W = p.W, H = p.H, WP = W + 2;
+
+  const cn_buf_t xbuf = cn_make_buf(p.x, p.x_bytes);
+  const cn_buf_t dybuf = cn_make_buf(p.dy, p.dy_bytes);
+  const unsigned int dy_pitch = (unsigned int)(p.Co * 2), x_pitch = (unsigned int)(p.Ci * 2);
+
+  // dy DMA coordinates (as wgrad_dma_kernel: instruction i of wave w fills KiB block i*4 + w; XOR swizzle of the
+  // 64-byte granule applied on the source side)
+  const int rI = lane / CPR, sI = lane % CPR;
+  const int cI = BI == 128 ? (sI ^ ((rI & 3) << 2)) : (sI ^ (((rI >> 1) & 1) << 2));
+  const unsigned int colI_b = (unsigned int)((i0 + cI * 8) * 2);
+  auto load_dy = [&](int gb, int buf) {   // the band that starts at global row gb
+    char* base = lds + buf * DYSZ;
+    int nrow = g_hi - gb;
+    if (nrow > p.NR) nrow = p.NR;
+    const int npx = nrow > 0 ? nrow * W : 0;
+    const unsigned int m0 = (unsigned int)gb * (unsigned int)W;
+#pragma unroll
+    for (int i = 0; i < NDI; ++i) {
+      const int blk = i * 4 + wave;
+      if (NBLK % 4 != 0 && blk >= NBLK) break;
+      const int r = blk * RPB + rI;               // pixel index inside the band
+      const unsigned int o = r < npx ? (m0 + (unsigned int)r) * dy_pitch + colI_b : CN_OOB;
+      cn_buf_ld16_lds(dybuf, o, base + blk * 1024);
+    }
+  };
+
+  // x band image: slot = (buffer row, position, 16-byte chunk); thread t owns slots t, t + 256, ...
+  u32x4 xr[NSLOT];
+  int nbr_cur = 0;     // buffer rows of the band held in xr
+  auto band_rows = [&](int gb, int& prb0) {   // padded-row range [prb0, prb0 + nbr) of the band starting at gb
+    int ge = gb + p.NR;
+    if (ge > g_hi) ge = g_hi;
+    // padded row of global row g = g + g / H + 1 (one zero row ahead of image 0, one after every image)
+    prb0 = gb + (int)cn_fastdiv((unsigned)gb, p.div_h);                     // pr(gb) - 1
+    const int pre = (ge - 1) + (int)cn_fastdiv((unsigned)(ge - 1), p.div_h) + 2;   // pr(ge - 1) + 1
+    return pre - prb0 + 1;
+  };
+  auto load_x = [&](int gb) {
+    int prb0;
+    const int nbr = band_rows(gb, prb0);
+    nbr_cur = nbr;
+    const int nslots = nbr * WP * 4;
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) {
+      const int s = tid + i * 256;
+      const int q = s >> 2, chunk = s & 3;                    // position index, chunk
+      const int br = (int)cn_fastdiv((unsigned)q, p.div_wp2);
+      const int c = q - br * WP;
+      const int t = prb0 + br - 1;                            // (padded row - 1) = n * (H + 1) + h
+      const int n = t >= 0 ? (int)cn_fastdiv((unsigned)t, p.div_hp1) : 0;
+      const int h = t - n * (H + 1);
+      const bool ok = (s < nslots) & (t >= 0) & (h < H) & (n < p.N) & (c >= 1) & (c <= W);
+      const unsigned int o = ok ? (unsigned int)((n * H + h) * W + (c - 1)) * x_pitch + (unsigned int)((j0 + chunk * 8) * 2)
+                                : CN_OOB;
+      xr[i] = cn_buf_ld16(xbuf, o);
+    }
+  };
+  auto store_x = [&]() {
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) {
+      const int s = tid + i * 256;
+      if (s < nbr_cur * WP * 4) cn_st16(xb + s * 16, xr[i]);
+    }
+  };
+  // position (in 64-byte units) of band pixel p inside the x band image; pixels past the band's end point at the
+  // image's first interior position (every tap of it lies in rows 0..2, which every band writes): their dy rows are
+  // zeros, and 0 x (written, finite data) stays 0 - never 0 x (uninitialised LDS bits)
+  auto fill_pos = [&](int gb) {
+    if (tid < NPX) {
+      int nrow = g_hi - gb;
+      if (nrow > p.NR) nrow = p.NR;
+      int pos = WP + 1;
+      if (tid < nrow * W) {
+        const int r = (int)cn_fastdiv((unsigned)tid, p.div_w);
+        const int w = tid - r * W;
+        const int g = gb + r;
+        const int prb0 = gb + (int)cn_fastdiv((unsigned)gb, p.div_h);
+        const int br = g + (int)cn_fastdiv((unsigned)g, p.div_h) + 1 - prb0;
+        pos = br * WP + w + 1;
+      }
+      s_pos[tid] = pos;
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // fragment addressing (cn_lds_read_tr16_b64): lane (L, g1, hh) supplies pixel rows kk*16 + hh*8 + (L>>2) (+4)
+  const int L = lane & 15, g1 = (lane >> 4) & 1, hh = lane >> 5;
+  const int rlo = hh * 8 + (L >> 2);
+  const int inner = g1 * 32 + (L & 3) * 8;
+  const int gsw = BI == 128 ? (wi ^ (rlo & 3)) : (wi ^ ((rlo >> 1) & 1));
+  const int offA = rlo * RBI + (gsw << 6) + inner;      // + kk*16*RBI (+ 4*RBI): the swizzle bits do not change
+  int tapsh[9];                                           // byte shift of tap (dh, dw) in the x band image
+#pragma unroll
+  for (int t = 0; t < 9; ++t) tapsh[t] = ((t / 3 - 1) * WP + (t % 3 - 1)) * 64;
+
+  auto compute = [&](int buf, int parity) {
+    const char* tA = lds + buf * DYSZ + offA;
+    const char* tX = xb + inner;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      if (KSPLIT && ((kk + parity) & 1) != wk) continue;     // wave-uniform
+      const s16x4 alo = cn_lds_read_tr16_b64(tA + kk * 16 * RBI);
+      const s16x4 ahi = cn_lds_read_tr16_b64(tA + kk * 16 * RBI + 4 * RBI);
+      const s16x8 af = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
+      const int plo = s_pos[kk * 16 + rlo] * 64, phi = s_pos[kk * 16 + rlo + 4] * 64;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const s16x4 blo = cn_lds_read_tr16_b64(tX + plo + tapsh[t]);
+        const s16x4 bhi = cn_lds_read_tr16_b64(tX + phi + tapsh[t]);
+        const s16x8 bf = __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7);
+        if constexpr (std::is_same<T, f16_t>::value) acc[t] = cn_mfma_32x32x16_f16(af, bf, acc[t]);
+        else acc[t] = cn_mfma_32x32x16_bf16(af, bf, acc[t]);
+      }
+    }
+  };
+
+  if (g_lo < g_hi) {
+    load_dy(g_lo, 0);
+    load_x(g_lo);
+    int buf = 0, parity = 0;
+    for (int gb = g_lo; gb < g_hi; gb += p.NR, buf ^= 1, parity ^= 1) {
+      __syncthreads();            // every wave is done with the previous band's x image and position table
+      store_x();                  // x band image of THIS band (requested one band ago)
+      fill_pos(gb);
+      __syncthreads();            // image + table visible; dy tile `buf` has landed (requested one band ago)
+      if (gb + p.NR < g_hi) {     // next band: dy by DMA into the other buffer, x into registers
+        load_dy(gb + p.NR, buf ^ 1);
+        load_x(gb + p.NR);
+      }
+      compute(buf, parity);
+    }
+  }
+
+  if (KSPLIT) {   // sum the two k-parity waves of each co block through LDS (three accumulators at a time)
+    float* red = (float*)lds;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      __syncthreads();
+      if (wk == 1) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[((wi * 3 + t) * 16 + r) * 64 + lane] = acc[c * 3 + t][r];
+      }
+      __syncthreads();
+      if (wk == 0) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[c * 3 + t][r] += red[((wi * 3 + t) * 16 + r) * 64 + lane];
+      }
+    }
+    if (wk != 0) return;
+  }
+  // partial tile -> workspace [split][Co][9 * Ci]   (A rows = co, B columns = ci)
+  float* out = p.part + (size_t)split * (size_t)p.Co * (size_t)(9 * p.Ci);
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int col = t * p.Ci + j0 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = i0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      out[(size_t)co * (size_t)(9 * p.Ci) + col] = acc[t][r];
+    }
+  }
+  (void)NW;
+}
+
+// ------------------------------------------------------------------------------------------------
 struct WgradPlan {
   int BI, BJ, BKP, n_itiles, n_jtiles, nsplit, m_per_split, ncols;
 };
@@ -596,6 +835,40 @@ static bool wg_use_256(int M, int Co, int ncols, int dtype, bool simple) {
   if (knob <= 0 || dtype != CN_BF16 || Co < 256 || Co % 128 != 0 || ncols < 256) return false;
   if (knob == 1) return true;
   return !simple && M >= cn_get_option("wgrad_256sq_min_m", 32768);
+}
+
+// Plan of the band kernel (wgrad3x3_kernel); ok = false: the shape is served by the tile kernels
+struct Wg3Plan {
+  bool ok;
+  int BI, NR, rows_per_split, nsplit, n_itiles, n_jtiles;
+};
+static Wg3Plan wg3_plan(int N, int H, int W, int C, int K, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w,
+                        int dtype) {
+  Wg3Plan pl;
+  memset(&pl, 0, sizeof(pl));
+  if (cn_get_option("wgrad_3x3", 1) == 0) return pl;
+  if (!(R == 3 && S == 3 && stride_h == 1 && stride_w == 1 && pad_h == 1 && pad_w == 1)) return pl;
+  if (dtype == CN_F32 || K % 64 != 0 || C % 32 != 0 || W > WG3_NPX || H < 1) return pl;
+  int NR = WG3_NPX / W;
+  if (NR > 16) NR = 16;
+  // buffer rows of a band: NR + one above + one below + one zero row per image boundary inside the band
+  while (NR >= 1 && (NR + 3 + (NR - 1) / H) * (W + 2) * 64 > WG3_XBYTES) --NR;
+  if (NR < 1) return pl;
+  pl.BI = K % 128 == 0 ? 128 : 64;
+  pl.NR = NR;
+  pl.n_itiles = K / pl.BI;
+  pl.n_jtiles = C / 32;
+  const int tiles = pl.n_itiles * pl.n_jtiles;
+  const long long total_rows = (long long)N * H;
+  const long long bands = (total_rows + NR - 1) / NR;
+  int target = cn_get_option("wgrad_3x3_wgs", 512);      // two 256-thread workgroups per CU
+  long long want = (target + tiles - 1) / tiles;          // splits wanted
+  long long bps = (bands + want - 1) / want;              // bands per split
+  if (bps < 2) bps = bands < 2 ? 1 : 2;
+  pl.rows_per_split = (int)(bps * NR);
+  pl.nsplit = (int)((total_rows + pl.rows_per_split - 1) / pl.rows_per_split);
+  pl.ok = true;
+  return pl;
 }
 
 static WgradPlan wg_plan(int M, int Co, int ntaps, int Ci, int dtype, bool simple) {
@@ -648,7 +921,13 @@ extern "C" size_t cn_conv2d_wgrad_workspace(int N, int H, int W, int C, int K, i
   if (P <= 0 || Q <= 0 || N <= 0) return 0;
   const bool simple = R == 1 && S == 1 && stride_h == 1 && stride_w == 1 && pad_h == 0 && pad_w == 0;
   WgradPlan pl = wg_plan(N * P * Q, K, R * S, C, dtype, simple);
-  return (size_t)pl.nsplit * (size_t)K * (size_t)pl.ncols * sizeof(float);
+  size_t need = (size_t)pl.nsplit * (size_t)K * (size_t)pl.ncols * sizeof(float);
+  const Wg3Plan p3 = wg3_plan(N, H, W, C, K, R, S, stride_h, stride_w, pad_h, pad_w, dtype);
+  if (p3.ok) {   // (either kernel may serve the call, depending on the knobs at launch time)
+    const size_t n3 = (size_t)p3.nsplit * (size_t)K * (size_t)(9 * C) * sizeof(float);
+    if (n3 > need) need = n3;
+  }
+  return need;
 }
 
 template <typename T>
@@ -694,6 +973,52 @@ extern "C" int cn_conv2d_wgrad(const void* x, const void* dy, float* dw_krsc, in
   if (R * S > WG_MAX_TAPS) { cn_set_error("conv2d_wgrad: too many taps"); return CN_ESHAPE; }
   if (C_real <= 0 || C_real > C) { cn_set_error("conv2d_wgrad: bad C_real"); return CN_EINVAL; }
   const bool simple_gather = R == 1 && S == 1 && stride_h == 1 && stride_w == 1 && pad_h == 0 && pad_w == 0;
+  const Wg3Plan p3 = wg3_plan(N, H, W, C, K, R, S, stride_h, stride_w, pad_h, pad_w, dtype);
+  if (p3.ok) {
+    // 3x3 / stride 1 / pad 1: the band kernel (activation staged once per band of image rows, all nine taps per tile)
+    const size_t need3 = (size_t)p3.nsplit * (size_t)K * (size_t)(9 * C) * sizeof(float);
+    const long long xb3 = (long long)N * H * W * C * 2, dyb3 = (long long)N * H * W * K * 2;
+    if (ws_bytes < need3 || workspace == nullptr) {
+      cn_set_error("conv2d_wgrad: workspace %zu < %zu bytes", ws_bytes, need3);
+      return CN_EWORKSPACE;
+    }
+    if (xb3 >= (1ll << 31) || dyb3 >= (1ll << 31)) {
+      cn_set_error("conv2d_wgrad: operand exceeds the 2 GiB buffer-descriptor window");
+      return CN_ESHAPE;
+    }
+    const int phase3 = cn_get_option("wgrad_phase", 0);
+    if (phase3 != 2) {
+      Wg3Params q;
+      memset(&q, 0, sizeof(q));
+      q.x = (const char*)x; q.dy = (const char*)dy; q.part = (float*)workspace;
+      q.N = N; q.H = H; q.W = W; q.Ci = C; q.Co = K;
+      q.NR = p3.NR; q.rows_per_split = p3.rows_per_split; q.total_rows = N * H;
+      q.n_itiles = p3.n_itiles; q.n_jtiles = p3.n_jtiles;
+      q.x_bytes = (unsigned int)xb3; q.dy_bytes = (unsigned int)dyb3;
+      q.div_hp1 = cn_make_fastdiv((unsigned)(H + 1));
+      q.div_w = cn_make_fastdiv((unsigned)W);
+      q.div_wp2 = cn_make_fastdiv((unsigned)(W + 2));
+      q.div_h = cn_make_fastdiv((unsigned)H);
+      dim3 grid((unsigned)(p3.n_itiles * p3.n_jtiles * p3.nsplit));
+      cn_set_last_kernel("wgrad3x3_kernel<%s, %d>", dtype == CN_F16 ? "f16_t" : "bf16_t", p3.BI);
+      if (dtype == CN_F16) {
+        if (p3.BI == 128) CN_LAUNCH((wgrad3x3_kernel<f16_t, 128>), grid, dim3(256), (hipStream_t)stream, q);
+        else CN_LAUNCH((wgrad3x3_kernel<f16_t, 64>), grid, dim3(256), (hipStream_t)stream, q);
+      } else {
+        if (p3.BI == 128) CN_LAUNCH((wgrad3x3_kernel<bf16_t, 128>), grid, dim3(256), (hipStream_t)stream, q);
+        else CN_LAUNCH((wgrad3x3_kernel<bf16_t, 64>), grid, dim3(256), (hipStream_t)stream, q);
+      }
+      int rc3 = cn_check_launch("wgrad3x3");
+      if (rc3) return rc3;
+    }
+    if (phase3 == 1) return CN_OK;
+    long long total3 = (long long)K * 9 * C_real;
+    unsigned nb3 = (unsigned)((total3 + 255) / 256);
+    if (nb3 > 8192) nb3 = 8192;
+    CN_LAUNCH(wgrad_reduce_kernel, dim3(nb3), dim3(256), (hipStream_t)stream, (const float*)workspace, dw_krsc,
+              p3.nsplit, K, 9, C, C_real, beta, scale);
+    return cn_check_launch("wgrad_reduce");
+  }
   WgradPlan pl = wg_plan(N * P * Q, K, R * S, C, dtype, simple_gather);
   size_t need = (size_t)pl.nsplit * (size_t)K * (size_t)pl.ncols * sizeof(float);
   if (ws_bytes < need || workspace == nullptr) {

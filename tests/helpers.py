@@ -40,19 +40,24 @@ def rel_l2(a, b):
 WARM_SAMPLE = 2048     # == oracle/make_golden.py
 
 
-def warm_bn_state(model, seed, bn_type=None):
+def warm_bn_state(model, seed, bn_type=None, last_gamma=(0.03, 0.1)):
     """The recipe of oracle/make_golden.py:warm_bn_state applied to OUR model (same module names and order):
     seeded non-trivial gamma / beta / running statistics for every BatchNorm, so that the inner blocks' weight
-    and data gradients are non-zero from step 0 (init_model zeroes the last gamma of every block)."""
+    and data gradients are non-zero from step 0 (init_model zeroes the last gamma of every block).  The last
+    BatchNorm of every block draws gamma from `last_gamma` (conditioning: see the generator), the others from
+    [0.5, 1.5)."""
     if bn_type is None:
         import convnet_amd as ca
         bn_type = ca.nn.BatchNorm2d
     g = torch.Generator().manual_seed(seed)
+    names = set(n for n, _ in model.named_modules())
     with torch.no_grad():
         for name, m in model.named_modules():
             if isinstance(m, bn_type):
                 C = m.num_features
-                m.weight.copy_(torch.rand(C, generator=g) + 0.5)
+                last = name.endswith('.bn3') or (name.endswith('.bn2') and (name[:-4] + '.bn3') not in names)
+                lo, hi = last_gamma if last else (0.5, 1.5)
+                m.weight.copy_(torch.rand(C, generator=g) * (hi - lo) + lo)
                 m.bias.copy_(torch.randn(C, generator=g) * 0.1)
                 m.running_mean.copy_(torch.randn(C, generator=g) * 0.1)
                 m.running_var.copy_(torch.rand(C, generator=g) + 0.5)
@@ -87,7 +92,7 @@ def run_engine_trajectory(meta, dtype, device, steps=None, graph=True, grads_aft
     kw = dict(meta['model_kw'])
     model = ca.models.resnet(dataset='imagenet', **kw)
     if meta.get('warm_seed') is not None:
-        warm_bn_state(model, meta['warm_seed'])
+        warm_bn_state(model, meta['warm_seed'], last_gamma=tuple(meta['warm_last_gamma']))
     crit = ca.CrossEntropyLoss(smooth_eps=meta['smooth_eps']) if meta['smooth_eps'] else ca.CrossEntropyLoss()
     opt = ca.OptimRegime(model, model.regime)
     tr = ca.Trainer(model, crit, opt, device=str(device), dtype=dtype, loss_scale=meta['loss_scale'],

@@ -812,6 +812,52 @@ def test_igemm_256x256_tile_is_bit_identical_to_128x128(mode):
 
 
 @pytest.mark.parametrize('mode', MODES)
+def test_igemm_interleaved_dma_issue_is_bit_identical(mode):
+    """Round 3: the LDS-DMA instructions of K tile kt+1 are issued between the MFMAs of tile kt (ILV instantiations:
+    the 256x256 tile by default, the 128x128 LDS-DMA tile with knob igemm_ilv=2) instead of in a block ahead of them.
+    Same loads, same accumulation order: outputs identical to the block-issue kernels bit for bit (forward with the
+    statistics epilogue, and dgrad), including reductions that end in a partial K tile and a single-tile reduction
+    (where every interleaved DMA is an out-of-range no-op)."""
+    dev = _dev(mode)
+    import convnet_amd as ca
+    ops, L = ca.ops, ca._lib.load()
+    dtype = torch.bfloat16
+    # (N, H, W, C, K, R, stride, pad, knobs): igemm_256sq forces the big tile; igemm_variant=3 the 128x128 LDS-DMA tile
+    cfgs = [(2, 12, 12, 16, 256, 3, 1, 1, {'igemm_256sq': 1}), (1, 9, 10, 64, 384, 1, 1, 0, {'igemm_256sq': 1}),
+            (2, 8, 9, 24, 128, 3, 1, 1, {'igemm_variant': 3}), (1, 6, 6, 40, 192, 3, 2, 1, {'igemm_variant': 3})] \
+        if mode == 'emul' else \
+        [(8, 14, 14, 256, 256, 3, 1, 1, {'igemm_256sq': 1}), (6, 14, 14, 1024, 256, 1, 1, 0, {'igemm_256sq': 1}),
+         (4, 28, 28, 256, 256, 3, 2, 1, {'igemm_256sq': 1}), (5, 7, 7, 512, 512, 3, 1, 1, {'igemm_variant': 3}),
+         (4, 7, 7, 2048, 512, 1, 1, 0, {'igemm_variant': 3}), (3, 14, 15, 72, 384, 1, 1, 0, {'igemm_256sq': 1})]
+    for (N, H, W, C, K, R, st, pad, knobs) in cfgs:
+        g = torch.Generator().manual_seed(K + H)
+        xh = _nhwc(torch.randn(N, C, H, W, generator=g), dtype, dev)
+        wk = (torch.randn(K, R, R, C, generator=g) * (2.0 / (C * R * R)) ** 0.5).to(dtype).to(dev)
+        dy = _nhwc(torch.randn(N, C, H, W, generator=torch.Generator().manual_seed(5)), dtype, dev)
+        wt = (torch.randn(C, R, R, K, generator=torch.Generator().manual_seed(6)) * 0.05).to(dtype).to(dev)
+        Hin, Win = (H - 1) * st + R - 2 * pad, (W - 1) * st + R - 2 * pad
+        res = {}
+        try:
+            for k, v in knobs.items():
+                L.cn_set_option(k.encode(), v)
+            for ilv in (0, 2):
+                L.cn_set_option(b'igemm_ilv', ilv)
+                ys = ops.conv2d_fwd(xh, wk, None, K, R, R, (st, st), (pad, pad), bn_stats=True)
+                name = L.cn_last_kernel_name().decode()
+                assert name.endswith(', true>') == bool(ilv), name
+                ps = ops.take_pending_stats(ys)
+                dx = ops.conv2d_dgrad(dy, wt.permute(3, 1, 2, 0).contiguous(), (N, Hin, Win, K), C, R, R, (st, st),
+                                      (pad, pad))
+                res[ilv] = (ys.cpu(), ps.partial.cpu(), dx.cpu())
+        finally:
+            for k in knobs:
+                L.cn_set_option(k.encode(), -1 if k == 'igemm_256sq' else 0)
+            L.cn_set_option(b'igemm_ilv', 2)
+        assert torch.equal(res[0][0], res[2][0]) and torch.equal(res[0][1], res[2][1]), (C, K, R)
+        assert torch.equal(res[0][2], res[2][2]), (C, K, R)
+
+
+@pytest.mark.parametrize('mode', MODES)
 def test_wgrad_256x256_tile_matches_128_tile_and_cpu(mode):
     """wgrad_dma256_kernel (8 waves, 256 x 256 tile; forced with the wgrad_256sq knob) against the 128-wide
     kernels and the CPU weight gradient: identity gather (1x1), 3x3 with padding, a strided 3x3, ragged Co."""
@@ -823,6 +869,7 @@ def test_wgrad_256x256_tile_matches_128_tile_and_cpu(mode):
         [(8, 14, 14, 1024, 256, 1, 1, 0), (8, 14, 14, 256, 256, 3, 1, 1), (4, 28, 28, 256, 384, 3, 2, 1),
          (6, 7, 7, 512, 512, 3, 1, 1)]
     try:
+        L.cn_set_option(b'wgrad_3x3', 0)      # the tile kernels under test (3x3 / stride 1 normally takes the band kernel)
         for (N, H, W, C, K, R, st, pad) in cfgs:
             g = torch.Generator().manual_seed(K + H + R)
             P, Q = (H + 2 * pad - R) // st + 1, (W + 2 * pad - R) // st + 1
@@ -843,6 +890,57 @@ def test_wgrad_256x256_tile_matches_128_tile_and_cpu(mode):
             assert rel_l2(outs[1], outs[0]) < 1e-5
     finally:
         L.cn_set_option(b'wgrad_256sq', 0)
+        L.cn_set_option(b'wgrad_3x3', 1)
+
+
+@pytest.mark.parametrize('mode', MODES)
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_wgrad_3x3_band_kernel(mode, dtype):
+    """wgrad3x3_kernel (round 3): 3x3 / stride 1 / pad 1 weight gradients with the activation staged once per band of
+    image rows as a zero-padded 2-D LDS image (a tap = a uniform shift; all nine taps per tile).  Against the CPU
+    weight gradient and the tile kernels (knob wgrad_3x3=0) on: bands that cross image boundaries (H smaller than the
+    band), H != W, a last band / last split that is ragged, 64-channel outputs (two k-parity waves summed through
+    LDS) and 128-multiple outputs (four co waves), 32 / 64 / 96 input channels, accumulation (beta) and scaling."""
+    dev = _dev(mode)
+    import convnet_amd as ca
+    ops, L = ca.ops, ca._lib.load()
+    if mode == 'emul' and dtype == torch.float16:
+        cfgs = [(2, 5, 6, 32, 64)]
+    elif mode == 'emul':
+        cfgs = [(3, 5, 6, 32, 64), (2, 9, 7, 64, 128), (5, 3, 4, 96, 64), (1, 13, 11, 32, 128), (7, 2, 3, 32, 64)]
+    else:
+        cfgs = [(256, 56, 56, 64, 64), (64, 28, 28, 128, 128), (37, 14, 14, 256, 256), (61, 7, 7, 512, 512),
+                (5, 28, 20, 96, 192), (3, 9, 31, 32, 64), (16, 56, 56, 64, 128)]
+    for (N, H, W, C, K) in cfgs:
+        g = torch.Generator().manual_seed(K + H + C)
+        x = torch.randn(N, C, H, W, generator=g)
+        dy = torch.randn(N, K, H, W, generator=g)
+        xh, dyh = _nhwc(x, dtype, dev), _nhwc(dy, dtype, dev)
+        ref = None
+        if N * H * W <= 200000:
+            ref = torch.nn.grad.conv2d_weight(xh.float().cpu().permute(0, 3, 1, 2), (K, C, 3, 3),
+                                              dyh.float().cpu().permute(0, 3, 1, 2), 1, 1)
+        outs = {}
+        try:
+            for band in (1, 0):
+                L.cn_set_option(b'wgrad_3x3', band)
+                dw = torch.zeros(K, 3, 3, C, device=dev)
+                ops.conv2d_wgrad(xh, dyh, dw, C, K, 3, 3, (1, 1), (1, 1), beta=0.0)
+                name = L.cn_last_kernel_name().decode()
+                assert ('wgrad3x3_kernel' in name) == bool(band), name
+                if band:
+                    assert ('128>' in name) == (K % 128 == 0), name
+                outs[band] = dw.cpu().permute(0, 3, 1, 2)
+        finally:
+            L.cn_set_option(b'wgrad_3x3', 1)
+        # fp32 accumulation of bf16 products in a different (fixed) order: the two kernels agree to fp32 rounding
+        assert rel_l2(outs[1], outs[0]) < 2e-5, (N, H, W, C, K, rel_l2(outs[1], outs[0]))
+        if ref is not None:
+            assert rel_l2(outs[1], ref) < 2e-5, (N, H, W, C, K, rel_l2(outs[1], ref))
+        # accumulate + scale: dw = beta*dw + scale*wgrad
+        dw2 = torch.full((K, 3, 3, C), 0.5, device=dev)
+        ops.conv2d_wgrad(xh, dyh, dw2, C, K, 3, 3, (1, 1), (1, 1), beta=1.0, scale=0.25)
+        assert rel_l2(dw2.cpu().permute(0, 3, 1, 2), 0.5 + 0.25 * outs[1]) < 2e-5
 
 
 @pytest.mark.parametrize('mode', MODES)
