@@ -34,6 +34,8 @@ _SIGNATURES = {
     'cn_build_info': (ctypes.c_char_p, []),
     'cn_last_kernel_name': (ctypes.c_char_p, []),
     'cn_kernel_log': (ctypes.c_char_p, [c_i]),
+    'cn_stream_create_masked': (c_i, [c_i, c_i, c_p]),
+    'cn_stream_destroy': (c_i, [c_p]),
     'cn_is_emulator': (c_i, []),
     'cn_set_option': (c_i, [ctypes.c_char_p, c_i]),
     'cn_stream_fork': (c_i, [c_p, c_p]),
@@ -52,6 +54,8 @@ _SIGNATURES = {
     'cn_conv2d_dgrad_bnbwd_sa': (c_i, [c_p, c_p, c_p, c_p, c_i] + [c_i] * 11 + [c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_p]),
     'cn_conv2d_wgrad_workspace': (c_sz, [c_i] * 12),
     'cn_conv2d_wgrad': (c_i, [c_p, c_p, c_p, c_i] + [c_i] * 11 + [c_i, c_f, c_f, c_p, c_sz, c_p]),
+    'cn_conv2d_dgrad_lazy': (c_i, [c_p, c_p, c_p, c_p, c_p] + [c_i] * 11 + [c_i, c_p]),
+    'cn_conv2d_wgrad_lazy': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i] + [c_i] * 11 + [c_i, c_f, c_f, c_p, c_sz, c_p]),
     'cn_bn_workspace': (c_sz, [c_i, c_i, c_i]),
     'cn_bn_fwd_train': (c_i, [c_p] * 9 + [c_f, c_f, c_p, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
     'cn_bn_fwd_train_partials': (c_i, [c_p] * 9 + [c_f, c_f, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_sz, c_p]),

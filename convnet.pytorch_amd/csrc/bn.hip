@@ -852,8 +852,15 @@ extern "C" int cn_bn_bwd(const void* dz, const void* y, const unsigned char* rel
   const int rev_r = (revopt >> 1) & 1, rev_a = ((revopt >> 2) & 1);
   CnMarkLast last;   // an armed completion mark goes on the apply kernel only
   BN_DISPATCH(bn_bwd_reduce_kernel, dtype, (cn_get_option("bn_reduce_nt", 0) != 0), grid, stream, (const char*)dz, (const char*)y, relu_mask, mean, invstd, scale, shift, partial, M, C, relu, m.tpr_log2, rev_r);
+  if (dy == nullptr) {
+    // "lazy dy": reduce + finalize only, the consumers form c1*dz + c2*y + c3 themselves.  Only where dz needs no mask
+    // (no ReLU behind this BatchNorm) and no residual-branch copy is wanted.
+    if (relu != 0 || dres != nullptr) { cn_set_error("bn_bwd: dy = NULL needs relu = 0 and no dres"); return CN_EINVAL; }
+    last.release();
+  }
   CN_LAUNCH(bn_bwd_finalize_kernel, dim3((unsigned)((C + BN_FC - 1) / BN_FC)), dim3(256), stream, (const float*)partial,
             nrb, M, C, gamma, mean, invstd, dgamma, dbeta, beta_acc, gscale, coef_scratch);
+  if (dy == nullptr) return cn_check_launch("bn_bwd");
   int nab = bn_row_blocks(M, m, cn_get_option("bn_apply_blocks", BN_APPLY_BLOCKS));
   dim3 agrid((unsigned)nab, (unsigned)m.gy);
   last.release();
@@ -891,8 +898,12 @@ extern "C" int cn_bn_bwd_partials(const void* g, const void* y, const float* gam
   const float* invstd = stats + C;
   const float* scale = stats + 2 * C;
   const float* shift = stats + 3 * C;
+  if (dy == nullptr) last.release();   // finalize only: that kernel is the call's last
   CN_LAUNCH(bn_bwd_finalize_kernel, dim3((unsigned)((C + BN_FC - 1) / BN_FC)), dim3(256), stream, partial, nrb, M, C, gamma,
             mean, invstd, dgamma, dbeta, beta_acc, gscale, coef_scratch);
+  // dy == NULL ("lazy dy"): the consumers (cn_conv2d_dgrad_lazy / cn_conv2d_wgrad_lazy) form c1*g + c2*y + c3 on
+  // their operand loads from coef_scratch; no apply pass
+  if (dy == nullptr) return cn_check_launch("bn_bwd_partials");
   int nab = bn_row_blocks(M, m, cn_get_option("bn_apply_blocks", BN_APPLY_BLOCKS));
   dim3 agrid((unsigned)nab, (unsigned)m.gy);
   const int rev_a = ((cn_get_option("bn_reverse", BN_REVERSE_DEFAULT) >> 2) & 1);

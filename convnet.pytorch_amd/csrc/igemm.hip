@@ -55,6 +55,11 @@ struct IgemmParams {
   int x_nt;                        // 1: every gathered element is read by one workgroup only -> non-temporal loads
   const float* xf;                 // optional [scale(Ci) | shift(Ci)]: the gathered operand is act(x*scale+shift), applied on load (XF)
   int xf_relu;
+  // XF mode 2 ("lazy dy", round 3): the gathered operand is the BatchNorm-backward result c1[c]*x + c2[c]*x2 + c3[c]
+  // (x = masked upstream gradient g, x2 = BatchNorm input y, xf = [c1 | c2 | c3] of the Ci channels), rounded to T
+  // exactly as bn_bwd_apply_kernel stores it - so that apply pass (read g, read y, write dy) never runs
+  const char* x2;
+  int xf_mode;
   int dbg;                         // measurement only ("igemm_dbg"): 1 = skip the reduction loop, 2 = skip the global stores
   FastDiv div_hw, div_w, div_cpt;
   int tap_dhdw[IG_MAX_TAPS];
@@ -126,7 +131,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
   constexpr int STAGE = (BM + BN) * 128;
   constexpr int OUT_MAX = BM * (BN * (OUTF32 ? 4 : EB) + 16);
   constexpr int MAIN = (STAGES * STAGE > OUT_MAX) ? STAGES * STAGE : OUT_MAX;
-  constexpr int LDS_BYTES = MAIN + IG_MAX_TAPS * 16 + BM * 4 + (XF ? IG_XF_MAX * 8 : 0) + (EPI ? BM * 4 : 0);
+  constexpr int LDS_BYTES = MAIN + IG_MAX_TAPS * 16 + BM * 4 + (XF ? IG_XF_MAX * 12 : 0) + (EPI ? BM * 4 : 0);
   __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
   int* s_taps = (int*)(lds + MAIN);                       // per tap: {dhdw, woff bytes, x delta bytes, 0}
   int* s_outpix = (int*)(lds + MAIN + IG_MAX_TAPS * 16);
@@ -173,7 +178,8 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
     if (EPI) s_addpix[tid] = apix;
   }
   if (XF) {
-    for (int c = tid; c < 2 * p.Ci; c += NT) s_xf[c] = p.xf[c];
+    const int ntab = (p.xf_mode == 2 ? 3 : 2) * p.Ci;
+    for (int c = tid; c < ntab; c += NT) s_xf[c] = p.xf[c];
   }
 
   // per-thread staging coordinates (fixed for the whole reduction loop)
@@ -182,6 +188,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
   // LDS slot cc of row r0 holds chunk cc ^ swizzle(row): with DMA the lane must FETCH that chunk
   const int cg = GLDS ? (cc ^ ((r0 >> 1) & 7)) : cc;
   const cn_buf_t xbuf = cn_make_buf(p.x, p.x_bytes);
+  const cn_buf_t x2buf = cn_make_buf(XF ? p.x2 : p.x, p.x_bytes);   // XF mode 2: second source, same extent
   const cn_buf_t wbuf = cn_make_buf(p.w, p.w_bytes);
   int phin[NPR], pwin[NPR];
   unsigned int prow[NPR], wrow[NWR];   // byte offsets of the row starts (CN_OOB = row not valid)
@@ -273,6 +280,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   u32x4 preg[NPR], wreg[NWR];
+  u32x4 preg2[XF ? NPR : 1];   // XF mode 2: the second source's chunks
   const int nkt = (p.nchunks + 7) >> 3;
   const bool simple = p.simple != 0;   // every tap of every valid row is inside the image
 
@@ -311,6 +319,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
     if (XF) xf_ok |= (o < CN_OOB ? 1u : 0u) << i;
     if (GLDS) cn_buf_ld16_lds(xbuf, o, dp_ + i * RS * 128);
     else preg[i] = (!ILV && simple && p.x_nt) ? cn_buf_ld16_nt(xbuf, o) : cn_buf_ld16(xbuf, o);
+    if (XF) { if (p.xf_mode == 2) preg2[i] = cn_buf_ld16(x2buf, o); }
   };
   auto issue_w = [&](int i, int buf) {   // filter row r0 + RS*i of the tile
     char* dw_ = lds + buf * STAGE + (8 * wave) * 128;             // this wave's KiB of filter rows
@@ -331,20 +340,40 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
     for (int i = 0; i < NWR; ++i) cn_st16(base + st0 + i * RS * 128, wreg[i]);
     if (XF) {
       constexpr int CH = ElemTraits<T>::kChunk;
-      float sc[CH], sh[CH];
-#pragma unroll
-      for (int e = 0; e < CH; ++e) { sc[e] = s_xf[xf_chunk * CH + e]; sh[e] = s_xf[p.Ci + xf_chunk * CH + e]; }
-#pragma unroll
-      for (int i = 0; i < NPR; ++i) {
-        float f[CH];
-        Chunk<T>::unpack(preg[i], f);
+      if (p.xf_mode == 2) {   // dy = c1*g + c2*y + c3, the operation order of bn_bwd_apply_kernel (bit-identical operand)
+        float c1[CH], c2[CH], c3[CH];
 #pragma unroll
         for (int e = 0; e < CH; ++e) {
-          f[e] = fmaf(f[e], sc[e], sh[e]);
-          if (p.xf_relu) f[e] = f[e] > 0.f ? f[e] : 0.f;
+          c1[e] = s_xf[xf_chunk * CH + e];
+          c2[e] = s_xf[p.Ci + xf_chunk * CH + e];
+          c3[e] = s_xf[2 * p.Ci + xf_chunk * CH + e];
         }
-        const u32x4 v = Chunk<T>::pack(f);
-        preg[i] = ((xf_ok >> i) & 1u) ? v : cn_zero16();
+#pragma unroll
+        for (int i = 0; i < NPR; ++i) {
+          float g[CH], v[CH];
+          Chunk<T>::unpack(preg[i], g);
+          Chunk<T>::unpack(preg2[i], v);
+#pragma unroll
+          for (int e = 0; e < CH; ++e) g[e] = fmaf(c1[e], g[e], fmaf(c2[e], v[e], c3[e]));
+          const u32x4 o = Chunk<T>::pack(g);
+          preg[i] = ((xf_ok >> i) & 1u) ? o : cn_zero16();
+        }
+      } else {
+        float sc[CH], sh[CH];
+#pragma unroll
+        for (int e = 0; e < CH; ++e) { sc[e] = s_xf[xf_chunk * CH + e]; sh[e] = s_xf[p.Ci + xf_chunk * CH + e]; }
+#pragma unroll
+        for (int i = 0; i < NPR; ++i) {
+          float f[CH];
+          Chunk<T>::unpack(preg[i], f);
+#pragma unroll
+          for (int e = 0; e < CH; ++e) {
+            f[e] = fmaf(f[e], sc[e], sh[e]);
+            if (p.xf_relu) f[e] = f[e] > 0.f ? f[e] : 0.f;
+          }
+          const u32x4 v = Chunk<T>::pack(f);
+          preg[i] = ((xf_ok >> i) & 1u) ? v : cn_zero16();
+        }
       }
     }
 #pragma unroll
@@ -397,7 +426,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
   // a tile of MFMA time to land before the barrier, and none is issued while the matrix pipe idles.
   auto compute_ilv = [&](int buf, int nbuf) {
     constexpr int IEVERY = (TI * TJ >= 8) ? 2 : 1;
-    static_assert(!ILV || (NPR + NWR) * IEVERY <= 2 * TI * TJ, "the DMA instructions must all be issued in the first two k-steps");
+    static_assert(!ILV || (NPR + NWR) * IEVERY <= 3 * TI * TJ, "the DMA instructions must all be issued in the first three k-steps");
     const char* wt = lds + buf * STAGE + rd_w;
     const char* pt = lds + buf * STAGE + rd_p;
     constexpr int NFB = FRAGDB ? 2 : 1;   // fragment buffers: double (reads of k-step kk+1 ahead of the MFMAs of kk) or single
@@ -818,6 +847,7 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
       const bool ilv = fragdb && cn_get_option("igemm_ilv", 2) != 0;   // interleaved DMA issue (A/B knob; bit-identical)
       cn_set_last_kernel("igemm_kernel<%s, 4, 2, 2, 4, 2, false, true, %s, false, false, %s>", tname, (fragdb && !ilv) ? "true" : "false",
                          ilv ? "true" : "false");
+      // (interleaved issue WITH register-double-buffered fragments measured 1-2 % slower: profiles/r03_ab_ilv_with_fragdb_rejected.txt)
       if (ilv) CN_LAUNCH((igemm_kernel<T, 4, 2, 2, 4, 2, false, true, false, false, false, true>), g2, dim3(512), stream, p);
       else if (fragdb) CN_LAUNCH((igemm_kernel<T, 4, 2, 2, 4, 2, false, true, true, false>), g2, dim3(512), stream, p);
       else CN_LAUNCH((igemm_kernel<T, 4, 2, 2, 4, 2, false, true, false, false>), g2, dim3(512), stream, p);
@@ -844,6 +874,8 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
       return cn_check_launch("igemm");
     }
   }
+  // (a 64 x 256 tile for <= 64-channel layers - register-staged or LDS-DMA + interleaved issue - measured no faster /
+  //  slower than the 64 x 128 tile: profiles/r03_ab_c64_tile_rejected.txt)
   if (p.Co <= 64) IG_GO(1, 4, 2, 1);
   else if (bm64 && epi) IG_GO2(2, 2, 2, 1, true);
   else if (bm64) IG_GO2(2, 2, 2, 1, false);
@@ -1001,7 +1033,8 @@ struct IgBnBwd {
 
 static int ig_conv_dgrad(const void* dy, const void* w_crsk, void* dx, const void* addend, int N, int H,
                          int W, int C, int K, int R, int S, int stride_h, int stride_w, int pad_h,
-                         int pad_w, int dtype, int out_f32, const IgBnBwd* bn, void* stream, int addend_sub = 1) {
+                         int pad_w, int dtype, int out_f32, const IgBnBwd* bn, void* stream, int addend_sub = 1,
+                         const void* lazy_y = nullptr, const float* lazy_coef = nullptr) {
   if (addend_sub != 1 && addend_sub != 2) { cn_set_error("conv2d_dgrad: addend subsampling %d (1 or 2)", addend_sub); return CN_EINVAL; }
   int bn_row = 0;
   const int P = (H + 2 * pad_h - R) / stride_h + 1;
@@ -1014,6 +1047,7 @@ static int ig_conv_dgrad(const void* dy, const void* w_crsk, void* dx, const voi
       IgemmParams p;
       memset(&p, 0, sizeof(p));
       p.x = (const char*)dy; p.w = (const char*)w_crsk; p.y = (char*)dx; p.bias = nullptr;
+      if (lazy_y != nullptr) { p.x2 = (const char*)lazy_y; p.xf = lazy_coef; p.xf_mode = 2; }   // dy = c1*g + c2*y + c3 on load
       p.addend = (const char*)addend;
       p.addend_sub = addend != nullptr ? addend_sub : 1; p.add_H = (H + 1) / 2; p.add_W = (W + 1) / 2;
       p.N = N; p.Hi = P; p.Wi = Q; p.Ci = K;
@@ -1066,6 +1100,20 @@ extern "C" int cn_conv2d_dgrad(const void* dy, const void* w_crsk, void* dx, con
                                int pad_w, int dtype, int out_f32, void* stream) {
   return ig_conv_dgrad(dy, w_crsk, dx, addend, N, H, W, C, K, R, S, stride_h, stride_w, pad_h, pad_w, dtype,
                        out_f32, nullptr, stream);
+}
+
+// "Lazy dy" data gradient (round 3): the upstream gradient dy is the result of a training-mode BatchNorm backward,
+//     dy[m][k] = c1[k]*g[m][k] + c2[k]*y[m][k] + c3[k]      (cn_bn_bwd_partials with dy = NULL leaves coef = [c1 | c2 | c3]),
+// and is formed on the operand load from g (the masked gradient w.r.t. the BatchNorm output) and y (the BatchNorm
+// input), with the operation order and rounding of the apply kernel: the same bits as cn_bn_bwd_partials(dy) followed
+// by cn_conv2d_dgrad(dy), without writing / re-reading dy.  K <= 512 channels, no epilogue operands.
+extern "C" int cn_conv2d_dgrad_lazy(const void* g, const void* bn_y, const float* coef, const void* w_crsk, void* dx,
+                                    int N, int H, int W, int C, int K, int R, int S, int stride_h, int stride_w, int pad_h,
+                                    int pad_w, int dtype, void* stream) {
+  if (g == nullptr || bn_y == nullptr || coef == nullptr) { cn_set_error("conv2d_dgrad_lazy: needs g, y and the coefficients"); return CN_EINVAL; }
+  if (K > IG_XF_MAX) { cn_set_error("conv2d_dgrad_lazy: %d gradient channels > %d", K, IG_XF_MAX); return CN_ESHAPE; }
+  return ig_conv_dgrad(g, w_crsk, dx, nullptr, N, H, W, C, K, R, S, stride_h, stride_w, pad_h, pad_w, dtype, 0, nullptr,
+                       stream, 1, bn_y, coef);
 }
 
 // The same with a SUBSAMPLED addend: `addend` is [N][(H+1)/2][(W+1)/2][C], the values at the even (h, w) pixels of a

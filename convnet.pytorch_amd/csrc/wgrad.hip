@@ -31,11 +31,15 @@ struct WgradParams {
   unsigned int x_bytes, dy_bytes;
   int simple;   // 1x1, stride 1, no padding: the gather is the identity (row m of x)
   int nt;       // cache policy A/B knob "wgrad_nt": bit 0 = non-temporal x loads, bit 1 = non-temporal dy loads
+  // "lazy dy" (register-staged kernel only): dy[m][k] = c1[k]*dy[m][k] + c2[k]*dy2[m][k] + c3[k] formed on load
+  // (dy = masked gradient g, dy2 = BatchNorm input y, coef = [c1 | c2 | c3] of the Co channels), rounded to T
+  const char* dy2;
+  const float* coef;
   FastDiv div_hw, div_w, div_cpt;
   int tap_dhdw[WG_MAX_TAPS];
 };
 
-template <typename T, int BI, int BJ>
+template <typename T, int BI, int BJ, bool LAZY = false>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   constexpr int EB = ElemTraits<T>::kBytes;
   constexpr int CH = ElemTraits<T>::kChunk;
@@ -97,13 +101,32 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   u32x4 regI[NI], regJ[NJ];
+  u32x4 regI2[LAZY ? NI : 1];            // lazy dy: the BatchNorm input chunks (LAZY instantiations only: the plain
+  constexpr bool lazy = LAZY;            //  kernel keeps its register budget - 3 workgroups per CU)
+  const cn_buf_t dy2buf = cn_make_buf(lazy ? p.dy2 : p.dy, p.dy_bytes);
+  float lc1[CH], lc2[CH], lc3[CH];   // this thread's channel chunk is fixed: its coefficients live in registers
+#pragma unroll
+  for (int e = 0; e < CH; ++e) { lc1[e] = 1.f; lc2[e] = 0.f; lc3[e] = 0.f; }
+  if (lazy && validI) {
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+      const int c = i0 + colI * CH + e;
+      lc1[e] = p.coef[c];
+      lc2[e] = p.coef[p.Co + c];
+      lc3[e] = p.coef[2 * p.Co + c];
+    }
+  }
+  unsigned int okI = 0;
   auto load_stage = [&](int mb) {
+    okI = 0;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int m = mb + rowI0 + i * RI;
       const bool ok = m < m_end && colI_b < CN_OOB;
       const unsigned int oI = ok ? (unsigned int)m * rowI_pitch + colI_b : CN_OOB;
+      okI |= (ok ? 1u : 0u) << i;
       regI[i] = (p.nt & 2) ? cn_buf_ld16_nt(dybuf, oI) : cn_buf_ld16(dybuf, oI);
+      if (lazy) regI2[i] = cn_buf_ld16(dy2buf, oI);
     }
     if (p.simple) {
 #pragma unroll
@@ -131,6 +154,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     }
   };
   auto store_stage = [&]() {
+    if (lazy) {   // dy = c1*g + c2*y + c3 in bn_bwd_apply_kernel's operation order; rows past the split stay zero
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        float g[CH], v[CH];
+        Chunk<T>::unpack(regI[i], g);
+        Chunk<T>::unpack(regI2[i], v);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) g[e] = fmaf(lc1[e], g[e], fmaf(lc2[e], v[e], lc3[e]));
+        const u32x4 o = Chunk<T>::pack(g);
+        regI[i] = ((okI >> i) & 1u) ? o : cn_zero16();
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NI; ++i) cn_st16(tI + (rowI0 + i * RI) * PI + colI * 16, regI[i]);
 #pragma unroll
@@ -861,7 +896,7 @@ static Wg3Plan wg3_plan(int N, int H, int W, int C, int K, int R, int S, int str
   const int tiles = pl.n_itiles * pl.n_jtiles;
   const long long total_rows = (long long)N * H;
   const long long bands = (total_rows + NR - 1) / NR;
-  int target = cn_get_option("wgrad_3x3_wgs", 512);      // two 256-thread workgroups per CU
+  int target = cn_get_option("wgrad_3x3_wgs", 192);      // whole-step A/B (profiles/r03_ab_whole_step_knobs.txt): fewer, longer workgroups intrude less on the main stream
   long long want = (target + tiles - 1) / tiles;          // splits wanted
   long long bps = (bands + want - 1) / want;              // bands per split
   if (bps < 2) bps = bands < 2 ? 1 : 2;
@@ -937,7 +972,7 @@ static void wg_launch(const WgradParams& p, const WgradPlan& pl, hipStream_t str
   // (3x3, strided) the register-staged kernel at 3 workgroups/CU measured 20-30 % faster than the DMA one
   // at 2 (profiles/README.md).  Tuning knob "wgrad_variant": 0 = this heuristic, 1 = register-staged,
   // 2 = LDS-DMA everywhere.
-  const int wv = cn_get_option("wgrad_variant", 0);
+  const int wv = p.dy2 != nullptr ? 1 : cn_get_option("wgrad_variant", 0);   // lazy dy: register-staged only
   if (pl.BI == 256) {
     if constexpr (std::is_same<T, bf16_t>::value) {
       cn_set_last_kernel("wgrad_dma256_kernel");
@@ -951,16 +986,46 @@ static void wg_launch(const WgradParams& p, const WgradPlan& pl, hipStream_t str
     else CN_LAUNCH((wgrad_dma_kernel<128>), grid, dim3(256), stream, p);
     return;
   }
-  cn_set_last_kernel("wgrad_kernel<%s, %d, 128>",
-                     std::is_same<T, float>::value ? "float" : (std::is_same<T, f16_t>::value ? "f16_t" : "bf16_t"), pl.BI == 64 ? 64 : 128);
+  cn_set_last_kernel("wgrad_kernel<%s, %d, 128%s>",
+                     std::is_same<T, float>::value ? "float" : (std::is_same<T, f16_t>::value ? "f16_t" : "bf16_t"), pl.BI == 64 ? 64 : 128,
+                     p.dy2 != nullptr ? ", true" : "");
+  if (p.dy2 != nullptr) {
+    if (pl.BI == 64) CN_LAUNCH((wgrad_kernel<T, 64, 128, true>), grid, dim3(256), stream, p);
+    else CN_LAUNCH((wgrad_kernel<T, 128, 128, true>), grid, dim3(256), stream, p);
+    return;
+  }
   if (pl.BI == 64) CN_LAUNCH((wgrad_kernel<T, 64, 128>), grid, dim3(256), stream, p);
   else CN_LAUNCH((wgrad_kernel<T, 128, 128>), grid, dim3(256), stream, p);
 }
+
+static int wg_conv2d_wgrad(const void* x, const void* dy, float* dw_krsc, int C_real, int N, int H, int W,
+                           int C, int K, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w,
+                           int dtype, float beta, float scale, void* workspace, size_t ws_bytes,
+                           void* stream, const void* lazy_y, const float* lazy_coef);
 
 extern "C" int cn_conv2d_wgrad(const void* x, const void* dy, float* dw_krsc, int C_real, int N, int H, int W,
                                int C, int K, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w,
                                int dtype, float beta, float scale, void* workspace, size_t ws_bytes,
                                void* stream) {
+  return wg_conv2d_wgrad(x, dy, dw_krsc, C_real, N, H, W, C, K, R, S, stride_h, stride_w, pad_h, pad_w, dtype, beta,
+                         scale, workspace, ws_bytes, stream, nullptr, nullptr);
+}
+
+// "Lazy dy" weight gradient (see cn_conv2d_dgrad_lazy): dy = c1*g + c2*y + c3 is formed on the operand load of the
+// register-staged kernel; same bits as cn_bn_bwd_partials(dy) + cn_conv2d_wgrad(dy) for the kernels it replaces.
+extern "C" int cn_conv2d_wgrad_lazy(const void* x, const void* g, const void* bn_y, const float* coef, float* dw_krsc,
+                                    int C_real, int N, int H, int W, int C, int K, int R, int S, int stride_h,
+                                    int stride_w, int pad_h, int pad_w, int dtype, float beta, float scale,
+                                    void* workspace, size_t ws_bytes, void* stream) {
+  if (g == nullptr || bn_y == nullptr || coef == nullptr) { cn_set_error("conv2d_wgrad_lazy: needs g, y and the coefficients"); return CN_EINVAL; }
+  return wg_conv2d_wgrad(x, g, dw_krsc, C_real, N, H, W, C, K, R, S, stride_h, stride_w, pad_h, pad_w, dtype, beta, scale,
+                         workspace, ws_bytes, stream, bn_y, coef);
+}
+
+static int wg_conv2d_wgrad(const void* x, const void* dy, float* dw_krsc, int C_real, int N, int H, int W,
+                           int C, int K, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w,
+                           int dtype, float beta, float scale, void* workspace, size_t ws_bytes,
+                           void* stream, const void* lazy_y, const float* lazy_coef) {
   const int P = (H + 2 * pad_h - R) / stride_h + 1;
   const int Q = (W + 2 * pad_w - S) / stride_w + 1;
   if (P <= 0 || Q <= 0 || N <= 0) { cn_set_error("conv2d_wgrad: empty output"); return CN_ESHAPE; }
@@ -973,7 +1038,8 @@ extern "C" int cn_conv2d_wgrad(const void* x, const void* dy, float* dw_krsc, in
   if (R * S > WG_MAX_TAPS) { cn_set_error("conv2d_wgrad: too many taps"); return CN_ESHAPE; }
   if (C_real <= 0 || C_real > C) { cn_set_error("conv2d_wgrad: bad C_real"); return CN_EINVAL; }
   const bool simple_gather = R == 1 && S == 1 && stride_h == 1 && stride_w == 1 && pad_h == 0 && pad_w == 0;
-  const Wg3Plan p3 = wg3_plan(N, H, W, C, K, R, S, stride_h, stride_w, pad_h, pad_w, dtype);
+  Wg3Plan p3 = wg3_plan(N, H, W, C, K, R, S, stride_h, stride_w, pad_h, pad_w, dtype);
+  if (lazy_y != nullptr) p3.ok = false;   // (lazy dy feeds 1x1 layers; the register-staged tile kernel forms it)
   if (p3.ok) {
     // 3x3 / stride 1 / pad 1: the band kernel (activation staged once per band of image rows, all nine taps per tile)
     const size_t need3 = (size_t)p3.nsplit * (size_t)K * (size_t)(9 * C) * sizeof(float);
@@ -1020,6 +1086,7 @@ extern "C" int cn_conv2d_wgrad(const void* x, const void* dy, float* dw_krsc, in
     return cn_check_launch("wgrad_reduce");
   }
   WgradPlan pl = wg_plan(N * P * Q, K, R * S, C, dtype, simple_gather);
+  if (lazy_y != nullptr && pl.BI == 256) { cn_set_error("conv2d_wgrad_lazy: not with the 256 x 256 tile (knob wgrad_256sq)"); return CN_EINVAL; }
   size_t need = (size_t)pl.nsplit * (size_t)K * (size_t)pl.ncols * sizeof(float);
   if (ws_bytes < need || workspace == nullptr) {
     cn_set_error("conv2d_wgrad: workspace %zu < %zu bytes", ws_bytes, need);
@@ -1041,6 +1108,7 @@ extern "C" int cn_conv2d_wgrad(const void* x, const void* dy, float* dw_krsc, in
   p.x_bytes = (unsigned int)xb; p.dy_bytes = (unsigned int)dyb;
   p.simple = (R == 1 && S == 1 && stride_h == 1 && stride_w == 1 && pad_h == 0 && pad_w == 0) ? 1 : 0;
   p.nt = cn_get_option("wgrad_nt", 0);
+  p.dy2 = (const char*)lazy_y; p.coef = lazy_coef;
   p.M = N * P * Q; p.m_per_split = pl.m_per_split; p.nsplit = pl.nsplit;
   p.n_itiles = pl.n_itiles; p.n_jtiles = pl.n_jtiles;
   p.div_hw = cn_make_fastdiv((unsigned)(P * Q));

@@ -70,6 +70,7 @@ class ResidualBlock(tnn.Module):
             if not self.quantized:
                 getattr(self, 'conv%d' % i).feeds_batchnorm = True   # BN statistics come out of the conv epilogue
                 getattr(self, 'conv%d' % i).__dict__['stats_bn'] = getattr(self, 'bn%d' % i)   # ... centred on its running mean
+                getattr(self, 'bn%d' % i).__dict__['producer_conv'] = getattr(self, 'conv%d' % i)   # (lazy dy: ops.LAZY_DY)
             if i > 1 and not self.quantized:   # this conv reads relu(bn_{i-1}(.)): its dgrad epilogue does that BN's backward reduction
                 # (instance dict, not setattr: the BN must not become a registered sub-module of the conv)
                 getattr(self, 'conv%d' % i).__dict__['input_bn'] = getattr(self, 'bn%d' % (i - 1))
@@ -97,6 +98,7 @@ class ResidualBlock(tnn.Module):
             downsample[0]._res_holder = self._holder      # downsample conv dgrad + conv1 dgrad
             downsample[0].feeds_batchnorm = True
             downsample[0].__dict__['stats_bn'] = downsample[1]
+            downsample[1].__dict__['producer_conv'] = downsample[0]
 
     def last_bn(self):
         return getattr(self, 'bn%d' % self.n_convs)

@@ -131,8 +131,19 @@ class SideStream(object):
             # CONVNET_AMD_WGRAD_STREAM_PRIO: HIP stream priority of the side stream (A/B knob; default = the
             # runtime's default priority)
             prio = os.environ.get('CONVNET_AMD_WGRAD_STREAM_PRIO')
-            ss = [torch.cuda.Stream(device, priority=int(prio)) if prio is not None else torch.cuda.Stream(device)
-                  for _ in range(self.nstreams)]
+            # CONVNET_AMD_WGRAD_CUS = 1..7: the side stream owns that many eighths of the compute units (A/B knob)
+            share = int(os.environ.get('CONVNET_AMD_WGRAD_CUS', '8'))
+            if 1 <= share <= 7:
+                import ctypes
+                ss = []
+                for _ in range(self.nstreams):
+                    h = ctypes.c_void_p()
+                    with torch.cuda.device(device):
+                        check(_L().cn_stream_create_masked(share, 0, ctypes.byref(h)), 'cn_stream_create_masked')
+                    ss.append(torch.cuda.ExternalStream(h.value, device=device))
+            else:
+                ss = [torch.cuda.Stream(device, priority=int(prio)) if prio is not None else torch.cuda.Stream(device)
+                      for _ in range(self.nstreams)]
             self._streams[device] = ss
         return ss
 
@@ -250,12 +261,22 @@ FUSE_BN_BWD = os.environ.get('CONVNET_AMD_FUSE_BN_BWD', '1') != '0'
 # standalone reduction pass it removes on the 56x56 / 28x28 maps and is a wash on the small ones; whole-step
 # A/B: junctions only 21.34 ms vs everywhere 21.71 ms.  Threshold in MB of the BN input (0 = junctions only).
 FUSE_BN_BWD_INNER_MB = float(os.environ.get('CONVNET_AMD_FUSE_BN_BWD_INNER_MB', '0'))
+# A/B knob: 1 = the BNs inside a block whose upstream gradient comes out of a 1x1 dgrad (bn2 of a bottleneck, behind
+# conv3) take the fused reduction too (a bandwidth-bound producer: the epilogue's extra read replaces a two-tensor pass)
+FUSE_BN_BWD_INNER_1X1 = os.environ.get('CONVNET_AMD_FUSE_BN_BWD_INNER_1X1', '0') == '1'
+# "Lazy dy" (round 3): at a residual junction whose BatchNorm follows a 1x1 convolution (bn3(conv3(.)), the projection
+# shortcut's BatchNorm) the backward apply pass  dy = c1*g + c2*y + c3  is not run: the convolution's dgrad and wgrad
+# form dy on their operand loads (cn_conv2d_dgrad_lazy / cn_conv2d_wgrad_lazy) - one write and one read of the
+# largest tensors of the step less on the critical chain.  For BN inputs of at least LAZY_DY_MIN_MB (bandwidth-bound
+# layers; the small maps keep the LDS-DMA weight-gradient kernels).  CONVNET_AMD_LAZY_DY=0 disables it (A/B).
+LAZY_DY = os.environ.get('CONVNET_AMD_LAZY_DY', '1') == '1'
+LAZY_DY_MIN_MB = float(os.environ.get('CONVNET_AMD_LAZY_DY_MIN_MB', '150'))
 # junction fusion only for BN inputs of at least this many MB (A/B knob; 0 = every junction)
 FUSE_BN_BWD_JUNC_MIN_MB = float(os.environ.get('CONVNET_AMD_FUSE_BN_BWD_JUNC_MIN_MB', '0'))
 
 
 # how often each BatchNorm path ran (tests assert that the fused paths really are the ones in use)
-COUNTERS = {'bn_fwd_fused': 0, 'bn_fwd_plain': 0, 'bn_bwd_fused': 0, 'bn_bwd_plain': 0}
+COUNTERS = {'bn_fwd_fused': 0, 'bn_fwd_plain': 0, 'bn_bwd_fused': 0, 'bn_bwd_plain': 0, 'bn_bwd_lazy': 0}
 
 
 class _PendingStats(object):
@@ -413,6 +434,34 @@ def conv2d_wgrad(x, dy, dw_krsc, c_real, K, R, S, stride, pad, beta=1.0, scale=1
         L.cn_set_option(b'wgrad_phase', 0)
 
 
+def conv2d_dgrad_lazy(g, bn_y, coef, w_crsk, x_shape, K, R, S, stride, pad):
+    """dgrad whose upstream gradient dy = c1*g + c2*bn_y + c3 is formed on the operand load (cn_conv2d_dgrad_lazy)."""
+    N, H, W, C = x_shape
+    dx = torch.empty((N, H, W, C), dtype=g.dtype, device=g.device)
+    PROFILER.run(_last_kernel(' [lazy dy]'), stride[0] * stride[1], 2.0 * g.numel() * C * R * S,
+                 2 * g.numel() * _esize(g) + dx.numel() * _esize(dx) + K * R * S * C * _esize(g),
+                 lambda: check(_L().cn_conv2d_dgrad_lazy(ptr(g), ptr(bn_y), ptr(coef), ptr(w_crsk), ptr(dx), N, H, W, C, K,
+                                                         R, S, stride[0], stride[1], pad[0], pad[1], dtype_code(g.dtype),
+                                                         stream_of(g)), 'cn_conv2d_dgrad_lazy'),
+                 g.device, detail=_conv_detail('dgrad', C, H, K, R, stride))
+    return dx
+
+
+def conv2d_wgrad_lazy(x, g, bn_y, coef, dw_krsc, c_real, K, R, S, stride, pad, beta=1.0, scale=1.0, tag='main'):
+    """wgrad whose dy operand is formed on load from (g, bn_y, coef) (cn_conv2d_wgrad_lazy)."""
+    N, H, W, C = x.shape
+    code = dtype_code(x.dtype)
+    L = _L()
+    need = L.cn_conv2d_wgrad_workspace(N, H, W, C, K, R, S, stride[0], stride[1], pad[0], pad[1], code)
+    ws = workspace(need, x.device, tag)
+    PROFILER.run(_last_kernel(' [lazy dy] (+wgrad_reduce)'), 2, 2.0 * g.numel() * C * R * S,
+                 x.numel() * _esize(x) + 2 * g.numel() * _esize(g) + float(need),
+                 lambda: check(L.cn_conv2d_wgrad_lazy(ptr(x), ptr(g), ptr(bn_y), ptr(coef), ptr(dw_krsc), c_real, N, H, W, C,
+                                                      K, R, S, stride[0], stride[1], pad[0], pad[1], code, beta, scale,
+                                                      ptr(ws), ws.numel() * 4, stream_of(x)), 'cn_conv2d_wgrad_lazy'),
+                 x.device, detail=_conv_detail('wgrad', C, H, K, R, stride))
+
+
 def weight_prep(w_master_krsc, w_krsc, w_crsk, Co, taps, c_real, c_pad):
     PROFILER.run('weight_prep', 1, 0.0, Co * taps * c_real * 4 + Co * taps * c_pad * _esize(w_krsc) * (2 if w_crsk is not None else 1),
                  lambda: check(_L().cn_weight_prep(ptr(w_master_krsc), ptr(w_krsc), ptr(w_crsk), Co, taps, c_real,
@@ -546,10 +595,40 @@ class Conv2dFunction(Function):
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
         mod = ctx.mod
+        lazy = getattr(mod, '_lazy_dy', None)     # (g, bn_y, coef): the BatchNorm behind this conv left dy unformed
+        mod._lazy_dy = None
+        R, S = mod.kernel_size
+        if lazy is not None:
+            g, bn_y, coef = lazy
+            if SIDE.active(x):
+                def launch():
+                    conv2d_wgrad_lazy(x, g, bn_y, coef, mod.grad_view('weight'), mod.in_channels, mod.out_channels, R, S,
+                                      mod.stride, mod.padding, tag='side')
+                    return (x, g, bn_y, coef)
+                SIDE.submit(x.device, launch, mod._notify_grad_ready, coef)
+            else:
+                conv2d_wgrad_lazy(x, g, bn_y, coef, mod.grad_view('weight'), mod.in_channels, mod.out_channels, R, S,
+                                  mod.stride, mod.padding)
+                mod._notify_grad_ready()
+            if not ctx.needs_input_grad[0]:
+                return None, None, None, None
+            holder = getattr(mod, '_res_holder', None)
+            if holder is not None and holder.dres is not None:
+                raise _lib.ConvNetHipError('lazy dy met a fused-addend dgrad: the junction layout changed')
+            if holder is not None and SUBSAMPLED_SHORTCUT_GRAD and (R, S) == (1, 1) and mod.stride == (2, 2) \
+                    and mod.padding == (0, 0):
+                N_, H_, W_, C_ = x.shape
+                compact = conv2d_dgrad_lazy(g, bn_y, coef, mod.w_crsk, (N_, (H_ + 1) // 2, (W_ + 1) // 2, C_),
+                                            mod.out_channels, 1, 1, (1, 1), (0, 0))
+                holder.dres, holder.sub, holder.fused = compact, 2, False
+                return _zero_like_placeholder(x), None, None, None
+            dx = conv2d_dgrad_lazy(g, bn_y, coef, mod.w_crsk, x.shape, mod.out_channels, R, S, mod.stride, mod.padding)
+            if holder is not None:
+                holder.dres, holder.sub, holder.fused = dx, 1, False
+            return dx, None, None, None
         dy = dy.contiguous()
         if dy.dtype != x.dtype:  # fp32 logits gradient -> compute dtype
             dy = cast_from_f32(dy, x.dtype)
-        R, S = mod.kernel_size
         if ctx.has_bias:
             colsum(dy.view(-1, mod.out_channels), mod.grad_view('bias'))
         if SIDE.active(x):
@@ -585,7 +664,8 @@ class Conv2dFunction(Function):
             # (inner convs) or when the other branch's gradient is being added right here
             final = holder is None or addend is not None
             bn_args = _input_bn_state(mod, x) if (final and FUSE_BN_BWD) else None
-            if bn_args is not None and holder is None and x.numel() * _esize(x) > FUSE_BN_BWD_INNER_MB * 2 ** 20:
+            if bn_args is not None and holder is None and x.numel() * _esize(x) > FUSE_BN_BWD_INNER_MB * 2 ** 20 \
+                    and not (FUSE_BN_BWD_INNER_1X1 and (R, S) == (1, 1)):
                 bn_args = None
             if bn_args is not None and holder is not None and x.numel() * _esize(x) < FUSE_BN_BWD_JUNC_MIN_MB * 2 ** 20:
                 bn_args = None
@@ -668,6 +748,18 @@ class StemPairConvFunction(Function):
             run('main')
             mod._notify_grad_ready()
         return None, None, None
+
+
+def _lazy_dy_ok(bn_mod, y):
+    """This junction BatchNorm's backward apply can be left to the convolution that produced its input."""
+    conv = getattr(bn_mod, 'producer_conv', None)
+    if not LAZY_DY or conv is None or FUSE_BN_BWD_INNER_MB > 0 or FUSE_BN_BWD_INNER_1X1:
+        return False
+    if getattr(conv, 'kernel_size', None) != (1, 1) or getattr(conv, 'bias', None) is not None:
+        return False
+    if y.shape[-1] > 512 or y.dtype not in (torch.bfloat16, torch.float16, torch.float32):
+        return False
+    return y.numel() * _esize(y) >= LAZY_DY_MIN_MB * 2 ** 20
 
 
 class BatchNormActFunction(Function):
@@ -779,6 +871,23 @@ class BatchNormActFunction(Function):
                                    ptr(mod.grad_view('bias')), 1.0, 1.0, ptr(coef), M, C, int(ctx.relu),
                                    int(fused_in), code, ptr(local), ptr(glob), M * world, stream_of(y)),
                   'cn_bn_bwd_sums')
+        elif fused_in and _lazy_dy_ok(mod, y):
+            # ... and the apply pass is left to the consumers: finalize only, dy = c1*g + c2*y + c3 is formed on the
+            # operand loads of the producing convolution's dgrad / wgrad (see LAZY_DY)
+            _, _, partial, rows = pp
+            COUNTERS['bn_bwd_fused'] += 1
+            COUNTERS['bn_bwd_lazy'] = COUNTERS.get('bn_bwd_lazy', 0) + 1
+            dres = dz if want_res else None
+            with SIDE.mark(coef):
+                PROFILER.run('bn_bwd_finalize (lazy dy)', 1 if rows <= 512 else 2, 0.0, partial.numel() * 4,
+                             lambda: check(L.cn_bn_bwd_partials(ptr(dz), ptr(y), ptr(mod.weight), ptr(stats), None,
+                                                                ptr(mod.grad_view('weight')), ptr(mod.grad_view('bias')),
+                                                                1.0, 1.0, ptr(coef), M, C, code, ptr(partial), rows,
+                                                                ptr(ws), ws.numel() * 4, stream_of(y)),
+                                           'cn_bn_bwd_partials'),
+                             y.device)
+            mod.producer_conv._lazy_dy = (dz, y, coef)
+            dy = _zero_like_placeholder(y)
         elif fused_in:
             # dz arrived masked (g) with its reduction partials from the producing dgrad's epilogue
             _, _, partial, rows = pp
@@ -793,6 +902,21 @@ class BatchNormActFunction(Function):
                                                                 ptr(ws), ws.numel() * 4, stream_of(y)),
                                            'cn_bn_bwd_partials'),
                              y.device)
+        elif not ctx.relu and not want_res and zmask is None and _lazy_dy_ok(mod, y):
+            # a BatchNorm with no activation behind it (the projection shortcut's): reduce + finalize, apply left to the
+            # producing convolution's dgrad / wgrad (dz needs no mask)
+            COUNTERS['bn_bwd_plain'] += 1
+            COUNTERS['bn_bwd_lazy'] = COUNTERS.get('bn_bwd_lazy', 0) + 1
+            dres = None
+            with SIDE.mark(coef):
+                PROFILER.run('bn_bwd_reduce+bn_bwd_finalize (lazy dy)', 2, 0.0, nb * 2,
+                             lambda: check(L.cn_bn_bwd(ptr(dz), ptr(y), None, ptr(mod.weight), ptr(stats), None,
+                                                       None, ptr(mod.grad_view('weight')), ptr(mod.grad_view('bias')),
+                                                       1.0, 1.0, ptr(coef), M, C, 0, code, ptr(ws),
+                                                       ws.numel() * 4, stream_of(y)), 'cn_bn_bwd'),
+                             y.device)
+            mod.producer_conv._lazy_dy = (dz, y, coef)
+            dy = _zero_like_placeholder(y)
         else:
             COUNTERS['bn_bwd_plain'] += 1
             dres = torch.empty_like(y) if want_res else None

@@ -52,6 +52,10 @@ const char* cn_last_kernel_name(void);
  * entry point may launch several instantiations: a strided dgrad dispatches each output-parity class on its own
  * reduction length).  clear != 0 empties the log.  Lets measurement code count launches per kernel as rocprofv3 does. */
 const char* cn_kernel_log(int clear);
+/* a HIP stream restricted to `eighths`/8 of the compute units, spread evenly over the XCDs (hipExtStreamCreateWithCUMask);
+ * the caller owns it.  For the weight-gradient side stream of a bandwidth-bound step. */
+int cn_stream_create_masked(int eighths, int priority, void** stream /* HOST */);
+int cn_stream_destroy(void* stream);
 int cn_is_emulator(void); /* 1 only in the TEST-ONLY CPU emulator build */
 /* kernel-variant tuning knobs for A/B measurement (e.g. "igemm_stages" = 1|2); results never change */
 int cn_set_option(const char* name, int value);
@@ -128,6 +132,20 @@ size_t cn_conv2d_wgrad_workspace(int N, int H, int W, int C, int K, int R, int S
 int cn_conv2d_wgrad(const void* x, const void* dy, float* dw_krsc, int C_real, int N, int H, int W, int C,
                     int K, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w, int dtype,
                     float beta, float scale, void* workspace, size_t ws_bytes, void* stream);
+/* "Lazy dy" backward of a convolution that follows a training-mode BatchNorm in the backward direction (the last
+ * convolution of a residual branch: models/resnet.py:141-165, bn3(conv3(.))): the gradient w.r.t. the BatchNorm input,
+ *     dy[m][k] = c1[k]*g[m][k] + c2[k]*y[m][k] + c3[k],
+ * is NOT materialised.  cn_bn_bwd_partials(dy = NULL) runs the finalize only and leaves coef = [c1 | c2 | c3] (3*K
+ * floats); these two entry points form dy on their operand loads from g (masked gradient w.r.t. the BatchNorm output)
+ * and bn_y (BatchNorm input) with the apply kernel's operation order and rounding, so the results carry the same bits
+ * as cn_bn_bwd_partials(dy) + cn_conv2d_dgrad / cn_conv2d_wgrad on the register-staged kernels - minus one write and
+ * two reads of dy.  K <= 512 gradient channels; 16-bit or fp32 storage. */
+int cn_conv2d_dgrad_lazy(const void* g, const void* bn_y, const float* coef, const void* w_crsk, void* dx, int N, int H,
+                         int W, int C, int K, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w, int dtype,
+                         void* stream);
+int cn_conv2d_wgrad_lazy(const void* x, const void* g, const void* bn_y, const float* coef, float* dw_krsc, int C_real,
+                         int N, int H, int W, int C, int K, int R, int S, int stride_h, int stride_w, int pad_h,
+                         int pad_w, int dtype, float beta, float scale, void* workspace, size_t ws_bytes, void* stream);
 
 /* ---- nn.BatchNorm2d (+ fused residual add + ReLU) (models/resnet.py:128-134,141-165) -------- */
 size_t cn_bn_workspace(int M, int C, int dtype);

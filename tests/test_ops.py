@@ -994,3 +994,65 @@ def test_conv_with_batchnorm_apply_folded_into_the_operand_load(mode, dtype):
             assert torch.equal(got_s.cpu(), ref_s.cpu()) and torch.equal(pg.partial.cpu(), pr.partial.cpu())
         finally:
             L.cn_set_option(b'igemm_variant', 0)
+
+
+@pytest.mark.parametrize('mode', MODES)
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+def test_lazy_dy_dgrad_and_wgrad_are_bit_identical_to_apply_then_conv(mode, dtype):
+    """Round 3 ("lazy dy"): cn_bn_bwd_partials(dy = NULL) + cn_conv2d_dgrad_lazy / cn_conv2d_wgrad_lazy form
+    dy = c1*g + c2*y + c3 on the operand loads.  Same operation order and rounding as the apply kernel: the data
+    gradient carries the same bits as apply -> dgrad, the weight gradient the same bits as apply -> the register-staged
+    weight-gradient kernel (and agrees with the LDS-DMA kernel to fp32 rounding)."""
+    dev = _dev(mode)
+    import convnet_amd as ca
+    ops, L = ca.ops, ca._lib.load()
+    cfgs = [(3, 6, 5, 16, 64, 1), (2, 8, 8, 32, 136, 2)] if mode == 'emul' else \
+        [(32, 56, 56, 64, 256, 1), (16, 56, 56, 256, 512, 2), (8, 28, 28, 128, 512, 1)]
+    for (N, H, W, Cin, K, st) in cfgs:
+        g_ = torch.Generator().manual_seed(K + H)
+        P, Q = (H - 1) // st + 1, (W - 1) // st + 1
+        x = _nhwc(torch.randn(N, Cin, H, W, generator=g_), dtype, dev)
+        gz = _nhwc(torch.randn(N, K, P, Q, generator=g_), dtype, dev)           # masked gradient w.r.t. the BN output
+        y = _nhwc(torch.randn(N, K, P, Q, generator=g_) * 1.5 + 0.3, dtype, dev)  # BN input
+        w = (torch.randn(K, 1, 1, Cin, generator=g_) * 0.1).to(dtype).to(dev)
+        wt = w.permute(3, 1, 2, 0).contiguous()
+        M = N * P * Q
+        gamma = (torch.rand(K, generator=g_) + 0.5).to(dev)
+        mean, var = y.float().view(M, K).mean(0), y.float().view(M, K).var(0, unbiased=False)
+        invstd = (var + 1e-5).rsqrt()
+        stats = torch.cat([mean, invstd, gamma * invstd, -mean * gamma * invstd]).contiguous()
+        # partial rows as a dgrad epilogue would emit them: one row with the full sums
+        gf = gz.float().view(M, K)
+        xhat = (y.float().view(M, K) - mean) * invstd
+        partial = torch.cat([gf.sum(0), (gf * xhat).sum(0)]).view(1, 2 * K).contiguous()
+        code = ca._lib.dtype_code(dtype)
+        ws = torch.empty(L.cn_bn_workspace(M, K, code) // 4 + 16, dtype=torch.float32, device=dev)
+        dgam, dbet = torch.zeros(K, device=dev), torch.zeros(K, device=dev)
+        ptr, chk, so = ca._lib.ptr, ca._lib.check, ca._lib.stream_of
+        outs = {}
+        for lazy in (0, 1):
+            coef = torch.empty(3 * K, dtype=torch.float32, device=dev)
+            dy = torch.empty_like(y)
+            chk(L.cn_bn_bwd_partials(ptr(gz), ptr(y), ptr(gamma), ptr(stats), None if lazy else ptr(dy), ptr(dgam), ptr(dbet),
+                                     0.0, 1.0, ptr(coef), M, K, code, ptr(partial), 1, ptr(ws), ws.numel() * 4, so(y)),
+                'cn_bn_bwd_partials')
+            dw = torch.zeros(K, 1, 1, Cin, device=dev)
+            if lazy:
+                dx = ops.conv2d_dgrad_lazy(gz, y, coef, wt, x.shape, K, 1, 1, (st, st), (0, 0))
+                ops.conv2d_wgrad_lazy(x, gz, y, coef, dw, Cin, K, 1, 1, (st, st), (0, 0), beta=0.0)
+                assert 'wgrad_kernel' in L.cn_last_kernel_name().decode()
+            else:
+                dx = ops.conv2d_dgrad(dy, wt, x.shape, K, 1, 1, (st, st), (0, 0))
+                L.cn_set_option(b'wgrad_variant', 1)          # the register-staged kernel, as the lazy form uses
+                try:
+                    ops.conv2d_wgrad(x, dy, dw, Cin, K, 1, 1, (st, st), (0, 0), beta=0.0)
+                finally:
+                    L.cn_set_option(b'wgrad_variant', 0)
+                dw_dma = torch.zeros_like(dw)
+                ops.conv2d_wgrad(x, dy, dw_dma, Cin, K, 1, 1, (st, st), (0, 0), beta=0.0)
+                outs['dma'] = dw_dma.cpu()
+            outs[lazy] = (dx.cpu(), dw.cpu(), coef.cpu())
+        assert torch.equal(outs[0][2], outs[1][2])
+        assert torch.equal(outs[0][0], outs[1][0]), ('dgrad', N, H, Cin, K, st)
+        assert torch.equal(outs[0][1], outs[1][1]), ('wgrad', N, H, Cin, K, st)
+        assert rel_l2(outs[1][1], outs['dma']) < 2e-5
