@@ -17,10 +17,16 @@ Rank 0 prints ONE JSON line.  Extra objects:
                  gfx950 peak (MI355X_MICROARCH.md: 2.5 PFLOP/s dense bf16 MFMA, 8 TB/s HBM3E).
   kernels      : the same figures for every kernel family of the step (time share per step).
   conv_layers  : per conv layer shape and direction: us, TFLOP/s, GB/s, which roof binds, fraction of it.
-  hbm_measured_whole_step : HBM traffic of ALL kernels of a step (committed rocprofv3 PMC passes, static) over this
-                 run's step time: the step as a whole against the memory system.
-  cpu_baseline : the CPU oracle (oracle/convnet_oracle.py, kind "port") timed on this host's
-                 cores on a bounded sample (ResNet-50 fp32, batch 32, 1 warm-up + 2 steps).
+  kernels_overlapped : the same launches timed in a pass that keeps the step's two-stream schedule (events on the
+                 launching stream): the durations rocprofv3 reports for the timed region.  `roofline` names the kernel
+                 with the largest total there and prices it there (`roofline.alone`: the same launches by themselves).
+  roofline.traffic : HBM bytes per launch of that kernel from rocprofv3 PMC passes - measured by this command with
+                 `--pmc` (two extra passes of a short run, tagged live), else quoted from the latest committed passes
+                 (tagged static).
+  hbm_measured_whole_step : HBM traffic of ALL kernels of a step (the same PMC source) over this run's step time: the
+                 step as a whole against the memory system.
+  cpu_baseline : the CPU oracle (oracle/convnet_oracle.py, kind "port": the reference tree is not on the GPU box)
+                 timed on this host's cores on a bounded sample (ResNet-50 fp32, batch 32, 1 warm-up + 5 steps).
 """
 import argparse
 import json
@@ -40,6 +46,9 @@ PEAK_HBM_GBS = 8000.0
 TRAIN_GFLOP_PER_IMG = {50: 24.2991, 18: 10.6484}
 # compulsory HBM traffic per image of the SURVEY.md section 8(d) traffic model (MB): the whole-step HBM roofline
 MODEL_MB_PER_IMG = {(50, 'bf16'): 347.7, (18, 'f32'): 151.4}
+
+
+LIVE_PMC = {'pm': None}      # per-kernel traffic measured by this command (--pmc), shared by the two places that quote it
 
 
 def roof_fraction(records, dtype):
@@ -267,6 +276,7 @@ def main():
         if args.pmc and world == 1:
             pm = run_pmc_passes(args)
             live = pm is not None
+            LIVE_PMC['pm'] = pm
         if pm is None:
             # HBM traffic per launch NOT measured in this run (PMC counters need rocprofv3 passes of their own:
             # `--pmc`): the latest committed PMC result (profiles/*_pmc_traffic.json) is quoted and tagged static
@@ -278,7 +288,7 @@ def main():
                 pm = None
         if pm is not None:
             for kn, kv in pm['kernels'].items():
-                if kn.replace('void ', '').startswith(dom.split(' (')[0]):
+                if kn.replace('void ', '').startswith(dom.split(' (')[0].split(' [')[0]):
                     roof['traffic'] = round(kv['hbm_bytes_per_launch'])
                     roof['traffic_unit'] = 'bytes/launch (avg), ' + pm['source']
                     roof['traffic_source'] = 'live: rocprofv3 --pmc passes run by this command' if live else \
@@ -321,7 +331,11 @@ def main():
         # roofline.traffic) over this run's step time: how close the step as a whole runs to the memory system
         try:
             cands = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('pmc_traffic.json'))
-            pm = json.load(open(os.path.join(ROOT, 'profiles', cands[-1])))
+            if LIVE_PMC.get('pm') is not None:
+                pm, cands = LIVE_PMC['pm'], ['live: rocprofv3 --pmc passes run by this command']
+            else:
+                pm = json.load(open(os.path.join(ROOT, 'profiles', cands[-1])))
+                cands[-1] = 'static, ' + cands[-1]
             if 'hbm_bytes_per_step' in pm and args.depth == 50 and args.dtype == 'bf16' and B == 256 \
                     and not args.quantize and world == 1:
                 rate = pm['hbm_bytes_per_step'] / (elapsed / args.steps) / 1e9
@@ -329,7 +343,7 @@ def main():
                     'traffic_gb_per_step': round(pm['hbm_bytes_per_step'] / 1e9, 1), 'rate_gbs': round(rate, 0),
                     'frac_of_peak': round(rate / PEAK_HBM_GBS, 4),
                     'frac_of_streaming_rate': round(rate / 5100.0, 4),
-                    'note': 'traffic: static, %s (FETCH_SIZE / WRITE_SIZE over every kernel of the step); 5100 GB/s = '
+                    'note': 'traffic: %s (FETCH_SIZE / WRITE_SIZE over every kernel of the step); 5100 GB/s = '
                             'the 2-read + 1-write streaming rate measured on this part (tools/bench_skew.py)' % cands[-1]}
         except Exception:
             pass

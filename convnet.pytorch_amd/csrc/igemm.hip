@@ -813,7 +813,7 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
   // EPI: epilogue with global-side operands (residual-branch addend, fused BN-backward reduction)
 #define IG_GO2(WC, WP, TI, TJ, EP)                                                                              \
   do {                                                                                                         \
-    cn_set_last_kernel("igemm_kernel<%s, %d, %d, %d, %d, %d, %s, %s, false, %s, false>", tname, WC, WP, TI, TJ, \
+    cn_set_last_kernel("igemm_kernel<%s, %d, %d, %d, %d, %d, %s, %s, false, %s, false, false>", tname, WC, WP, TI, TJ, \
                        variant == 1 ? 1 : 2, OUTF32 ? "true" : "false", variant >= 3 ? "true" : "false",      \
                        EP ? "true" : "false");                                                                 \
     if (variant == 1) CN_LAUNCH((igemm_kernel<T, WC, WP, TI, TJ, 1, OUTF32, false, false, EP>), grid, dim3(256), stream, p); \
@@ -823,7 +823,7 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
 #define IG_GO(WC, WP, TI, TJ) do { if (epi) IG_GO2(WC, WP, TI, TJ, true); else IG_GO2(WC, WP, TI, TJ, false); } while (0)
   if (p.xf != nullptr) {   // operand transform: register-staged single buffer only
     if (epi || p.Ci > IG_XF_MAX) { cn_set_error("igemm: operand transform with an epilogue operand / more than %d channels", IG_XF_MAX); return CN_EINVAL; }
-    cn_set_last_kernel("igemm_kernel<%s, %s, 1, %s, false, false, false, true>", tname, p.Co <= 64 ? "1, 4, 2, 1" : "2, 2, 2, 2", OUTF32 ? "true" : "false");
+    cn_set_last_kernel("igemm_kernel<%s, %s, 1, %s, false, false, false, true, false>", tname, p.Co <= 64 ? "1, 4, 2, 1" : "2, 2, 2, 2", OUTF32 ? "true" : "false");
     if (p.Co <= 64) CN_LAUNCH((igemm_kernel<T, 1, 4, 2, 1, 1, OUTF32, false, false, false, true>), grid, dim3(256), stream, p);
     else CN_LAUNCH((igemm_kernel<T, 2, 2, 2, 2, 1, OUTF32, false, false, false, true>), grid, dim3(256), stream, p);
     return cn_check_launch("igemm");
@@ -876,6 +876,26 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
   }
   // (a 64 x 256 tile for <= 64-channel layers - register-staged or LDS-DMA + interleaved issue - measured no faster /
   //  slower than the 64 x 128 tile: profiles/r03_ab_c64_tile_rejected.txt)
+  if constexpr (sizeof(T) == 2 && !OUTF32) {
+    // junction dgrads (EPI: residual-branch addend + BatchNorm-backward reduction in the epilogue) are epilogue-bound
+    // streaming kernels with a short reduction: the same 128 x 128 tile on EIGHT waves (half the staging / epilogue
+    // registers per thread -> four waves per SIMD instead of two) hides the epilogue operands' latency better.
+    // Knob "igemm_epi_8w" (A/B; the stored outputs are identical - same tile, same accumulation order - the per-tile
+    // partial sums of the fused reduction are associated over 512 instead of 256 threads).  Whole step: -0.45 %
+    // (profiles/r03_ab_whole_step_knobs.txt).
+    if (epi && p.Co > 64 && !bm64 && variant == 1 && cn_get_option("igemm_epi_8w", 1) != 0) {
+      cn_set_last_kernel("igemm_kernel<%s, 2, 4, 2, 1, 1, false, false, false, true, false, false>", tname);
+      CN_LAUNCH((igemm_kernel<T, 2, 4, 2, 1, 1, false, false, false, true>), grid, dim3(512), stream, p);
+      return cn_check_launch("igemm");
+    }
+    // the same eight-wave form of the plain register-staged tile for short reductions (A/B knob "igemm_8w": number of
+    // K tiles up to which it is used; 0 = off)
+    if (!epi && p.Co > 64 && !bm64 && variant == 1 && nkt <= cn_get_option("igemm_8w", 16)) {
+      cn_set_last_kernel("igemm_kernel<%s, 2, 4, 2, 1, 1, false, false, false, false, false, false>", tname);
+      CN_LAUNCH((igemm_kernel<T, 2, 4, 2, 1, 1, false, false, false, false>), grid, dim3(512), stream, p);
+      return cn_check_launch("igemm");
+    }
+  }
   if (p.Co <= 64) IG_GO(1, 4, 2, 1);
   else if (bm64 && epi) IG_GO2(2, 2, 2, 1, true);
   else if (bm64) IG_GO2(2, 2, 2, 1, false);

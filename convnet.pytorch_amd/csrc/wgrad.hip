@@ -896,7 +896,7 @@ static Wg3Plan wg3_plan(int N, int H, int W, int C, int K, int R, int S, int str
   const int tiles = pl.n_itiles * pl.n_jtiles;
   const long long total_rows = (long long)N * H;
   const long long bands = (total_rows + NR - 1) / NR;
-  int target = cn_get_option("wgrad_3x3_wgs", 192);      // whole-step A/B (profiles/r03_ab_whole_step_knobs.txt): fewer, longer workgroups intrude less on the main stream
+  int target = cn_get_option("wgrad_3x3_wgs", 256);      // whole-step A/B (profiles/r03_ab_whole_step_knobs.txt): fewer, longer workgroups intrude less on the main stream
   long long want = (target + tiles - 1) / tiles;          // splits wanted
   long long bps = (bands + want - 1) / want;              // bands per split
   if (bps < 2) bps = bands < 2 ? 1 : 2;

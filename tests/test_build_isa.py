@@ -49,3 +49,16 @@ def test_gemm_kernels_are_mfma_lds_dma_and_transpose_reads(table):
     wg = _find(table, 'wgrad', 'kernel')
     assert any(c['tr_read'] > 0 and c['mfma'] > 0 for _, c in wg)
     assert any(c['lds_dma'] > 0 for _, c in wg)
+
+
+def test_round3_kernels_are_what_they_claim(table):
+    """The band weight-gradient kernel is MFMA + transpose reads + LDS-DMA (dy) with no scratch spill path visible as
+    plain 16-byte global stores only in its epilogue; the interleaved-issue GEMM instantiations carry their LDS-DMA
+    instructions; the lazy-dy weight-gradient instantiation exists next to the plain one."""
+    for name, c in _find(table, 'wgrad3x3_kernel', 'bf16_t'):
+        assert c['mfma'] >= 9 and c['tr_read'] >= 20 and c['lds_dma'] > 0, (name, c)
+    ilv = _find(table, 'igemm_kernel<bf16_t', ', true>(IgemmParams)')       # last template argument: ILV
+    assert all(c['lds_dma'] >= 8 and c['mfma'] >= 16 for _, c in ilv), ilv
+    lazy = _find(table, 'wgrad_kernel<bf16_t', ', true>(WgradParams)')
+    plain = _find(table, 'wgrad_kernel<bf16_t', ', false>(WgradParams)')
+    assert all(c['plain_load16'] > 0 for _, c in lazy) and all(c['plain_load16'] == 0 for _, c in plain)

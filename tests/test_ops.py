@@ -991,7 +991,10 @@ def test_conv_with_batchnorm_apply_folded_into_the_operand_load(mode, dtype):
             pr = ops.take_pending_stats(ref_s)
             got_s = ops.conv2d_fwd_xf(yh, xf, True, wk, K, R, R, (st, st), (pad, pad), bn_stats=True)
             pg = ops.take_pending_stats(got_s)
-            assert torch.equal(got_s.cpu(), ref_s.cpu()) and torch.equal(pg.partial.cpu(), pr.partial.cpu())
+            # the stored outputs are the same bits; the plain convolution may run the eight-wave form of the tile
+            # (igemm_8w), which associates the per-tile statistics over 512 instead of 256 threads
+            assert torch.equal(got_s.cpu(), ref_s.cpu())
+            assert torch.allclose(pg.partial.cpu(), pr.partial.cpu(), rtol=1e-5, atol=1e-4)
         finally:
             L.cn_set_option(b'igemm_variant', 0)
 

@@ -32,9 +32,11 @@ def _nchw(t):
     return t.float().cpu().permute(0, 3, 1, 2).contiguous()
 
 
-def test_bf16_b256_step_every_conv_shape_matches_fp32_formulas_on_its_own_tensors():
+def test_bf16_b256_step_every_conv_shape_matches_fp32_formulas_on_its_own_tensors(monkeypatch):
     import convnet_amd as ca
     dev = torch.device('cuda', 0)
+    # this pass materialises every dy (the hooks need it); the lazy-dy form of the same step is compared with it below
+    monkeypatch.setattr(ca.ops, 'LAZY_DY', False)
     meta, _ = load_warm('r50_b256_warm')
     torch.manual_seed(123)
     model = ca.models.resnet(dataset='imagenet', depth=50)
@@ -99,3 +101,30 @@ def test_bf16_b256_step_every_conv_shape_matches_fp32_formulas_on_its_own_tensor
         del xc, dyc, dw_ref
     print('\n'.join(report))
     print('worst wgrad %.2e, worst dgrad %.2e over %d layer shapes' % (worst_w, worst_d, len(rec)))
+
+    # ---- the same step with "lazy dy" (ops.LAZY_DY: the junction BatchNorms of layer1 / layer2 leave their backward
+    # apply to conv3's / the projection's dgrad and wgrad): every parameter gradient equals the materialised-dy run's -
+    # bit for bit where the same kernels ran, to fp32 rounding where the weight gradient moved from the LDS-DMA to the
+    # register-staged kernel
+    grads_ref = {n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters()}
+    del rec, tr, model
+    torch.cuda.empty_cache()
+    monkeypatch.setattr(ca.ops, 'LAZY_DY', True)
+    for k in ca.ops.COUNTERS:
+        ca.ops.COUNTERS[k] = 0
+    torch.manual_seed(123)
+    model2 = ca.models.resnet(dataset='imagenet', depth=50)
+    warm_bn_state(model2, meta['warm_seed'], last_gamma=tuple(meta['warm_last_gamma']))
+    tr2 = ca.Trainer(model2, ca.CrossEntropyLoss(), ca.OptimRegime(model2, model2.regime), device='cuda:0',
+                     dtype=torch.bfloat16, grad_clip=1e9, print_freq=10 ** 9)
+    tr2._use_graph = False
+    tr2.train([(x0, t0)])
+    torch.cuda.synchronize()
+    assert ca.ops.COUNTERS['bn_bwd_lazy'] >= 8, ca.ops.COUNTERS      # layer1 (3 + 1) and layer2 (4 + 1) junctions at b=256
+    worst = 0.0
+    for n, p in model2.named_parameters():
+        e = rel_l2(p.grad.detach().float().cpu(), grads_ref[n])
+        worst = max(worst, e)
+        assert e < 2e-5, (n, e)
+    print('lazy-dy step vs materialised-dy step: worst parameter-gradient rel-L2 %.1e (%d lazy junctions)' % (
+        worst, ca.ops.COUNTERS['bn_bwd_lazy']))
