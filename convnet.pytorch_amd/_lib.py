@@ -54,6 +54,7 @@ _SIGNATURES = {
     'cn_conv2d_dgrad_bnbwd_sa': (c_i, [c_p, c_p, c_p, c_p, c_i] + [c_i] * 11 + [c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_p]),
     'cn_conv2d_wgrad_workspace': (c_sz, [c_i] * 12),
     'cn_conv2d_wgrad': (c_i, [c_p, c_p, c_p, c_i] + [c_i] * 11 + [c_i, c_f, c_f, c_p, c_sz, c_p]),
+    'cn_conv2d_fwd_lazyz': (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p] + [c_i] * 6 + [c_p, c_i, c_p, c_p]),
     'cn_conv2d_dgrad_lazy': (c_i, [c_p, c_p, c_p, c_p, c_p] + [c_i] * 11 + [c_i, c_p]),
     'cn_conv2d_wgrad_lazy': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i] + [c_i] * 11 + [c_i, c_f, c_f, c_p, c_sz, c_p]),
     'cn_bn_workspace': (c_sz, [c_i, c_i, c_i]),
@@ -61,6 +62,7 @@ _SIGNATURES = {
     'cn_bn_fwd_train_partials': (c_i, [c_p] * 9 + [c_f, c_f, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_sz, c_p]),
     'cn_bn_fwd_train_partials_centered': (c_i, [c_p] * 9 + [c_f, c_f, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_sz, c_p]),
     'cn_bn_fwd_infer': (c_i, [c_p] * 7 + [c_f, c_p, c_i, c_i, c_i, c_i, c_p]),
+    'cn_bn_apply_dual': (c_i, [c_p] * 6 + [c_i, c_i, c_i, c_i, c_p]),
     'cn_bn_bwd': (c_i, [c_p] * 9 + [c_f, c_f, c_p, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
     'cn_bn_bwd_partials': (c_i, [c_p] * 7 + [c_f, c_f, c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_sz, c_p]),
     'cn_bn_local_sums': (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_sz, c_p]),

@@ -294,11 +294,15 @@ __global__ __launch_bounds__(256) void bn_infer_coeffs_kernel(int C, const float
 // z = act(y*scale[c] + shift[c] (+ residual)).  When `mask` is given (ReLU after a residual add) one
 // byte per 16-byte chunk records which outputs were positive, so backward reads M*C/CH bytes instead
 // of re-reading z (the mask cannot be recomputed from y alone once a residual was added).
-template <typename T, bool NT>
+// DUAL (the junction behind a projection shortcut): `res` is the shortcut BatchNorm's INPUT and that BatchNorm's apply,
+// r = round_T(res*rscale[c] + rshift[c]) - exactly what its own apply pass would have stored -, happens here, so the
+// normalised shortcut tensor is never written or re-read (one write + one read of the junction-sized tensor less).
+template <typename T, bool NT, bool DUAL = false>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const char* y, const char* res, char* z,
                                                       unsigned char* mask, const float* scale,
                                                       const float* shift, int M, int C, int relu,
-                                                      int tpr_log2, int rev) {
+                                                      int tpr_log2, int rev, const float* rscale,
+                                                      const float* rshift) {
   constexpr int CH = ElemTraits<T>::kChunk;
   constexpr int EB = ElemTraits<T>::kBytes;
   const int tid = threadIdx.x;
@@ -309,6 +313,11 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const char* y, const char
   float sc[CH], sh[CH];
 #pragma unroll
   for (int e = 0; e < CH; ++e) { sc[e] = scale[col * CH + e]; sh[e] = shift[col * CH + e]; }
+  float rs[DUAL ? CH : 1], rb[DUAL ? CH : 1];
+  if constexpr (DUAL) {
+#pragma unroll
+    for (int e = 0; e < CH; ++e) { rs[e] = rscale[col * CH + e]; rb[e] = rshift[col * CH + e]; }
+  }
   const int step = gridDim.x * rpp;
 #pragma unroll 4
   for (int it = blockIdx.x * rpp + rsub; it < M; it += step) {
@@ -321,6 +330,11 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const char* y, const char
     if (res != nullptr) {
       float r[CH];
       Chunk<T>::unpack(bn_ld<NT, 2>(res + off), r);
+      if constexpr (DUAL) {   // the shortcut BatchNorm's apply (no activation, no residual), rounded to T as stored
+#pragma unroll
+        for (int e = 0; e < CH; ++e) r[e] = fmaf(r[e], rs[e], rb[e]);
+        Chunk<T>::unpack(Chunk<T>::pack(r), r);
+      }
 #pragma unroll
       for (int e = 0; e < CH; ++e) f[e] += r[e];
     }
@@ -721,7 +735,7 @@ static int bn_fwd_tail(const float* partial, int nrb, const void* y, const void*
   int nab = bn_row_blocks(M, m, cn_get_option("bn_apply_blocks", BN_APPLY_BLOCKS));
   dim3 agrid((unsigned)nab, (unsigned)m.gy);
   const int rev = (cn_get_option("bn_reverse", BN_REVERSE_DEFAULT) & 1);
-  BN_DISPATCH(bn_apply_kernel, dtype, bn_nt_flag(M, C, dtype), agrid, stream, (const char*)y, (const char*)residual, (char*)z, relu_mask, (const float*)(stats_out + 2 * C), (const float*)(stats_out + 3 * C), M, C, relu, m.tpr_log2, rev);
+  BN_DISPATCH(bn_apply_kernel, dtype, bn_nt_flag(M, C, dtype), agrid, stream, (const char*)y, (const char*)residual, (char*)z, relu_mask, (const float*)(stats_out + 2 * C), (const float*)(stats_out + 3 * C), M, C, relu, m.tpr_log2, rev, (const float*)nullptr, (const float*)nullptr);
   return cn_check_launch("bn_fwd_train");
 }
 
@@ -821,8 +835,46 @@ extern "C" int cn_bn_fwd_infer(const void* y, const void* residual, void* z, con
   int nab = bn_row_blocks(M, m, cn_get_option("bn_apply_blocks", BN_APPLY_BLOCKS));
   dim3 agrid((unsigned)nab, (unsigned)m.gy);
   const int rev = (cn_get_option("bn_reverse", BN_REVERSE_DEFAULT) & 1);
-  BN_DISPATCH(bn_apply_kernel, dtype, bn_nt_flag(M, C, dtype), agrid, stream, (const char*)y, (const char*)residual, (char*)z, (unsigned char*)nullptr, (const float*)coeffs, (const float*)(coeffs + C), M, C, relu, m.tpr_log2, rev);
+  BN_DISPATCH(bn_apply_kernel, dtype, bn_nt_flag(M, C, dtype), agrid, stream, (const char*)y, (const char*)residual, (char*)z, (unsigned char*)nullptr, (const float*)coeffs, (const float*)(coeffs + C), M, C, relu, m.tpr_log2, rev, (const float*)nullptr, (const float*)nullptr);
   return cn_check_launch("bn_fwd_infer");
+}
+
+// The apply pass of a residual junction whose shortcut is a projection (conv + BatchNorm) with BOTH BatchNorms
+// already finalised (cn_bn_fwd_train* called with z = NULL: statistics, running statistics, scale / shift only):
+//   z = relu?( y*scale[c] + shift[c] + round_T(res_y*rscale[c] + rshift[c]) )
+// stats / res_stats = the 4*C floats [save_mean | save_invstd | scale | shift] of the junction / shortcut BatchNorm.
+// Bit-identical to the shortcut BatchNorm's own apply followed by the junction's (tests/test_ops.py), without the
+// write and the re-read of the normalised shortcut tensor.
+extern "C" int cn_bn_apply_dual(const void* y, const void* res_y, void* z, unsigned char* relu_mask,
+                                const float* stats, const float* res_stats, int M, int C, int relu, int dtype,
+                                void* stream_) {
+  int rc = bn_check("bn_apply_dual", M, C, dtype);
+  if (rc) return rc;
+  if (y == nullptr || res_y == nullptr || z == nullptr || stats == nullptr || res_stats == nullptr) {
+    cn_set_error("bn_apply_dual: null operand");
+    return CN_EINVAL;
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  const int CH = cn_dtype_chunk(dtype);
+  BnMap m = bn_map(C / CH);
+  int nab = bn_row_blocks(M, m, cn_get_option("bn_apply_blocks", BN_APPLY_BLOCKS));
+  dim3 agrid((unsigned)nab, (unsigned)m.gy);
+  const int rev = (cn_get_option("bn_reverse", BN_REVERSE_DEFAULT) & 1);
+  const int nt = bn_nt_flag(M, C, dtype);
+#define BN_DUAL_LAUNCH(TT)                                                                                             \
+  do {                                                                                                                 \
+    if (nt) CN_LAUNCH((bn_apply_kernel<TT, true, true>), agrid, dim3(256), stream, (const char*)y, (const char*)res_y,  \
+                      (char*)z, relu_mask, stats + 2 * C, stats + 3 * C, M, C, relu, m.tpr_log2, rev,                  \
+                      res_stats + 2 * C, res_stats + 3 * C);                                                           \
+    else CN_LAUNCH((bn_apply_kernel<TT, false, true>), agrid, dim3(256), stream, (const char*)y, (const char*)res_y,    \
+                   (char*)z, relu_mask, stats + 2 * C, stats + 3 * C, M, C, relu, m.tpr_log2, rev,                     \
+                   res_stats + 2 * C, res_stats + 3 * C);                                                              \
+  } while (0)
+  if (dtype == CN_BF16) BN_DUAL_LAUNCH(bf16_t);
+  else if (dtype == CN_F16) BN_DUAL_LAUNCH(f16_t);
+  else BN_DUAL_LAUNCH(float);
+#undef BN_DUAL_LAUNCH
+  return cn_check_launch("bn_apply_dual");
 }
 
 // Training backward.  stats = the 4*C floats written by cn_bn_fwd_train; coef_scratch = 3*C floats.
@@ -1032,7 +1084,7 @@ extern "C" int cn_bn_fwd_train_sums(const void* y, const void* residual, void* z
             stats_out + 2 * C, stats_out + 3 * C);
   int nab = bn_row_blocks(M, m, cn_get_option("bn_apply_blocks", BN_APPLY_BLOCKS));
   dim3 agrid((unsigned)nab, (unsigned)m.gy);
-  BN_DISPATCH(bn_apply_kernel, dtype, bn_nt_flag(M, C, dtype), agrid, stream, (const char*)y, (const char*)residual, (char*)z, relu_mask, (const float*)(stats_out + 2 * C), (const float*)(stats_out + 3 * C), M, C, relu, m.tpr_log2, 0);
+  BN_DISPATCH(bn_apply_kernel, dtype, bn_nt_flag(M, C, dtype), agrid, stream, (const char*)y, (const char*)residual, (char*)z, relu_mask, (const float*)(stats_out + 2 * C), (const float*)(stats_out + 3 * C), M, C, relu, m.tpr_log2, 0, (const float*)nullptr, (const float*)nullptr);
   return cn_check_launch("bn_fwd_train_sums");
 }
 

@@ -8,8 +8,21 @@ OUT=..
 if [ "$1" != "emul-only" ]; then
   # CN_EXTRA_FLAGS / CN_LIB_NAME: A/B builds (e.g. CN_EXTRA_FLAGS=-DCN_NT_STORES CN_LIB_NAME=libconvnet_hip_nt.so)
   LIB=${CN_LIB_NAME:-libconvnet_hip.so}
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-result $CN_EXTRA_FLAGS \
-      $SRCS -ldl -o $OUT/$LIB
+  # one object per source, compiled in parallel (igemm.hip alone is most of the serial build), unchanged objects reused
+  ODIR=${CN_OBJ_DIR:-/tmp/cn_hip_obj}${CN_EXTRA_FLAGS:+_ab}
+  mkdir -p $ODIR
+  pids=""
+  for s in $SRCS; do
+    o=$ODIR/${s%.hip}.o
+    if [ ! -f $o ] || [ $s -nt $o ] || [ -n "$(find . -maxdepth 1 -name '*.h' -newer $o)" ] || [ -n "$CN_EXTRA_FLAGS" ]; then
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result $CN_EXTRA_FLAGS -c $s -o $o &
+      pids="$pids $!"
+    fi
+  done
+  for p in $pids; do wait $p; done
+  OBJS=""
+  for s in $SRCS; do OBJS="$OBJS $ODIR/${s%.hip}.o"; done
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared $OBJS -ldl -o $OUT/$LIB
   echo "built $OUT/$LIB"
 fi
 if [ "$1" = "emul" ] || [ "$1" = "emul-only" ]; then

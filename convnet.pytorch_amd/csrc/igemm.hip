@@ -60,6 +60,17 @@ struct IgemmParams {
   // exactly as bn_bwd_apply_kernel stores it - so that apply pass (read g, read y, write dy) never runs
   const char* x2;
   int xf_mode;
+  // XF mode 3 ("lazy z", round 3; kernel instantiations XF = 3): the gathered operand is a residual JUNCTION's output
+  //   z = relu?( x*scale[c] + shift[c] + r ),  r = x2            (xf2 == NULL: x2 is the materialised shortcut tensor)
+  //                                            r = round_T(x2*rscale[c] + rshift[c])   (xf2 = [rscale | rshift]: x2 is
+  //                                                the projection shortcut's BatchNorm input, cf. cn_bn_apply_dual)
+  // formed between the global load and the LDS store with bn_apply_kernel's operation order and rounding, and ALSO
+  // stored to xz (+ the ReLU bits to xz_mask): the junction's apply pass never runs, z is written once by the 1x1
+  // convolution that consumes it and never re-read by it.  1x1 / stride 1 / one channel tile only (every element of x
+  // is visited exactly once).
+  const float* xf2;
+  char* xz;
+  unsigned char* xz_mask;
   int dbg;                         // measurement only ("igemm_dbg"): 1 = skip the reduction loop, 2 = skip the global stores
   FastDiv div_hw, div_w, div_cpt;
   int tap_dhdw[IG_MAX_TAPS];
@@ -110,12 +121,13 @@ __device__ __forceinline__ int ig_slot(int row, int chunk) {
 //     only), so the inner BatchNorm's apply pass - one read and one write of the activation - disappears.  Padded taps
 //     stay zero (they are zeros of z, not of y).
 #define IG_XF_MAX 512
+#define IG_XF_TAB_BYTES (IG_XF_MAX * 16)   /* up to four per-channel fp32 tables */
 // ILV (round 3, LDS-DMA double buffer only): the DMA instructions of K tile kt+1 are issued BETWEEN the MFMAs of tile kt
 //     (one after each of the first NPR+NWR MFMAs, pinned by scheduling fences) instead of in a block ahead of them.  In
 //     the block form every wave of the workgroup issues its 8 DMA instructions (~100 cycles of issue each while the
 //     texture path is busy) right after the barrier, i.e. with the matrix pipe of all four SIMDs idle; interleaved,
 //     each one is issued while the MFMA before it executes.  Same instructions, same results (bit-identical).
-template <typename T, int WC, int WP, int TI, int TJ, int STAGES, bool OUTF32, bool GLDS, bool FRAGDB, bool EPI, bool XF = false, bool ILV = false>
+template <typename T, int WC, int WP, int TI, int TJ, int STAGES, bool OUTF32, bool GLDS, bool FRAGDB, bool EPI, int XF = 0, bool ILV = false>
 __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
   static_assert(!XF || (!GLDS && !EPI), "operand transform needs the register-staged path");
   static_assert(!ILV || (GLDS && STAGES == 2), "interleaved DMA issue: LDS-DMA double buffer");
@@ -131,7 +143,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
   constexpr int STAGE = (BM + BN) * 128;
   constexpr int OUT_MAX = BM * (BN * (OUTF32 ? 4 : EB) + 16);
   constexpr int MAIN = (STAGES * STAGE > OUT_MAX) ? STAGES * STAGE : OUT_MAX;
-  constexpr int LDS_BYTES = MAIN + IG_MAX_TAPS * 16 + BM * 4 + (XF ? IG_XF_MAX * 12 : 0) + (EPI ? BM * 4 : 0);
+  constexpr int LDS_BYTES = MAIN + IG_MAX_TAPS * 16 + BM * 4 + (XF ? IG_XF_TAB_BYTES : 0) + (EPI ? BM * 4 : 0);
   __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
   int* s_taps = (int*)(lds + MAIN);                       // per tap: {dhdw, woff bytes, x delta bytes, 0}
   int* s_outpix = (int*)(lds + MAIN + IG_MAX_TAPS * 16);
@@ -180,6 +192,8 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
   if (XF) {
     const int ntab = (p.xf_mode == 2 ? 3 : 2) * p.Ci;
     for (int c = tid; c < ntab; c += NT) s_xf[c] = p.xf[c];
+    if (XF == 3 && p.xf2 != nullptr)
+      for (int c = tid; c < 2 * p.Ci; c += NT) s_xf[2 * p.Ci + c] = p.xf2[c];
   }
 
   // per-thread staging coordinates (fixed for the whole reduction loop)
@@ -319,7 +333,8 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
     if (XF) xf_ok |= (o < CN_OOB ? 1u : 0u) << i;
     if (GLDS) cn_buf_ld16_lds(xbuf, o, dp_ + i * RS * 128);
     else preg[i] = (!ILV && simple && p.x_nt) ? cn_buf_ld16_nt(xbuf, o) : cn_buf_ld16(xbuf, o);
-    if (XF) { if (p.xf_mode == 2) preg2[i] = cn_buf_ld16(x2buf, o); }
+    if (XF == 3) preg2[i] = cn_buf_ld16(x2buf, o);
+    else if (XF) { if (p.xf_mode == 2) preg2[i] = cn_buf_ld16(x2buf, o); }
   };
   auto issue_w = [&](int i, int buf) {   // filter row r0 + RS*i of the tile
     char* dw_ = lds + buf * STAGE + (8 * wave) * 128;             // this wave's KiB of filter rows
@@ -338,7 +353,49 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
     char* base = lds + buf * STAGE;
 #pragma unroll
     for (int i = 0; i < NWR; ++i) cn_st16(base + st0 + i * RS * 128, wreg[i]);
-    if (XF) {
+    if (XF == 3) {   // lazy z: the junction's apply (bn_apply_kernel's order and rounding), stored to xz as well
+      constexpr int CH = ElemTraits<T>::kChunk;
+      const bool dual = p.xf2 != nullptr;
+      float sc[CH], sh[CH], rs[CH], rb[CH];
+#pragma unroll
+      for (int e = 0; e < CH; ++e) {
+        sc[e] = s_xf[xf_chunk * CH + e];
+        sh[e] = s_xf[p.Ci + xf_chunk * CH + e];
+        rs[e] = dual ? s_xf[2 * p.Ci + xf_chunk * CH + e] : 1.f;
+        rb[e] = dual ? s_xf[3 * p.Ci + xf_chunk * CH + e] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < NPR; ++i) {
+        float f[CH], r[CH];
+        Chunk<T>::unpack(preg[i], f);
+        Chunk<T>::unpack(preg2[i], r);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) f[e] = fmaf(f[e], sc[e], sh[e]);
+        if (dual) {
+#pragma unroll
+          for (int e = 0; e < CH; ++e) r[e] = fmaf(r[e], rs[e], rb[e]);
+          Chunk<T>::unpack(Chunk<T>::pack(r), r);
+        }
+#pragma unroll
+        for (int e = 0; e < CH; ++e) f[e] += r[e];
+        unsigned int bits = 0;
+        if (p.xf_relu) {
+#pragma unroll
+          for (int e = 0; e < CH; ++e) {
+            bits |= (f[e] > 0.f ? 1u : 0u) << e;
+            f[e] = f[e] > 0.f ? f[e] : 0.f;
+          }
+        }
+        const u32x4 v = Chunk<T>::pack(f);
+        const bool ok = ((xf_ok >> i) & 1u) != 0;
+        if (ok) {   // (1x1, stride 1: the element's offset in z is its offset in x)
+          const unsigned int o = prow[i] + t_xofs;
+          cn_st16(p.xz + o, v);
+          if (p.xf_relu && p.xz_mask != nullptr) p.xz_mask[o >> 4] = (unsigned char)bits;
+        }
+        preg[i] = ok ? v : cn_zero16();
+      }
+    } else if (XF) {
       constexpr int CH = ElemTraits<T>::kChunk;
       if (p.xf_mode == 2) {   // dy = c1*g + c2*y + c3, the operation order of bn_bwd_apply_kernel (bit-identical operand)
         float c1[CH], c2[CH], c3[CH];
@@ -821,11 +878,29 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
     else CN_LAUNCH((igemm_kernel<T, WC, WP, TI, TJ, 2, OUTF32, true, false, EP>), grid, dim3(256), stream, p);        \
   } while (0)
 #define IG_GO(WC, WP, TI, TJ) do { if (epi) IG_GO2(WC, WP, TI, TJ, true); else IG_GO2(WC, WP, TI, TJ, false); } while (0)
+  if (p.xf != nullptr && p.xf_mode == 3) {   // lazy z: the junction apply on the operand load, z stored by this kernel
+    if (epi || p.Ci > IG_XF_MAX || !p.simple || p.ntaps != 1 || p.n_ntiles != 1 || p.xz == nullptr || p.x2 == nullptr) {
+      cn_set_error("igemm: lazy z needs a 1x1 / stride-1 gather, one channel tile (Co <= 128), <= %d input channels", IG_XF_MAX);
+      return CN_EINVAL;
+    }
+    // the tile shapes the plain convolution would run on (same statistics-partial association => same bits downstream):
+    // 64-channel tile, else the 128 x 128 tile on eight waves (16-bit storage, short reductions) or on four
+    bool w8 = false;
+    if constexpr (sizeof(T) == 2 && !OUTF32) w8 = p.Co > 64 && nkt <= cn_get_option("igemm_8w", 16);
+    cn_set_last_kernel("igemm_kernel<%s, %s, 1, %s, false, false, false, 3, false>", tname,
+                       p.Co <= 64 ? "1, 4, 2, 1" : (w8 ? "2, 4, 2, 1" : "2, 2, 2, 2"), OUTF32 ? "true" : "false");
+    if (p.Co <= 64) CN_LAUNCH((igemm_kernel<T, 1, 4, 2, 1, 1, OUTF32, false, false, false, 3>), grid, dim3(256), stream, p);
+    else if (w8) {
+      if constexpr (sizeof(T) == 2 && !OUTF32)
+        CN_LAUNCH((igemm_kernel<T, 2, 4, 2, 1, 1, false, false, false, false, 3>), grid, dim3(512), stream, p);
+    } else CN_LAUNCH((igemm_kernel<T, 2, 2, 2, 2, 1, OUTF32, false, false, false, 3>), grid, dim3(256), stream, p);
+    return cn_check_launch("igemm");
+  }
   if (p.xf != nullptr) {   // operand transform: register-staged single buffer only
     if (epi || p.Ci > IG_XF_MAX) { cn_set_error("igemm: operand transform with an epilogue operand / more than %d channels", IG_XF_MAX); return CN_EINVAL; }
     cn_set_last_kernel("igemm_kernel<%s, %s, 1, %s, false, false, false, true, false>", tname, p.Co <= 64 ? "1, 4, 2, 1" : "2, 2, 2, 2", OUTF32 ? "true" : "false");
-    if (p.Co <= 64) CN_LAUNCH((igemm_kernel<T, 1, 4, 2, 1, 1, OUTF32, false, false, false, true>), grid, dim3(256), stream, p);
-    else CN_LAUNCH((igemm_kernel<T, 2, 2, 2, 2, 1, OUTF32, false, false, false, true>), grid, dim3(256), stream, p);
+    if (p.Co <= 64) CN_LAUNCH((igemm_kernel<T, 1, 4, 2, 1, 1, OUTF32, false, false, false, 1>), grid, dim3(256), stream, p);
+    else CN_LAUNCH((igemm_kernel<T, 2, 2, 2, 2, 1, OUTF32, false, false, false, 1>), grid, dim3(256), stream, p);
     return cn_check_launch("igemm");
   }
   if constexpr (sizeof(T) == 2 && !OUTF32) {
@@ -954,10 +1029,17 @@ static int ig_is_simple(const IgemmParams& p, const int* dhdw, int ntaps) {
   return 1;
 }
 
+struct IgLazyZ {   // XF mode 3 operands (see IgemmParams::xf2)
+  const void* res;
+  const float* xf2;
+  void* z;
+  unsigned char* mask;
+};
+
 static int ig_conv_fwd(const void* x, const void* w_krsc, void* y, const float* bias, float* stats, int N, int H,
                        int W, int C, int K, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w,
                        int dtype, int out_f32, int relu, void* stream, const float* xf = nullptr, int xf_relu = 0,
-                       const float* stats_pivot = nullptr) {
+                       const float* stats_pivot = nullptr, const IgLazyZ* lz = nullptr) {
   const int P = (H + 2 * pad_h - R) / stride_h + 1;
   const int Q = (W + 2 * pad_w - S) / stride_w + 1;
   if (P <= 0 || Q <= 0 || N <= 0) { cn_set_error("conv2d_fwd: empty output"); return CN_ESHAPE; }
@@ -965,6 +1047,7 @@ static int ig_conv_fwd(const void* x, const void* w_krsc, void* y, const float* 
   memset(&p, 0, sizeof(p));
   p.x = (const char*)x; p.w = (const char*)w_krsc; p.y = (char*)y; p.bias = bias; p.stats = stats;
   p.xf = xf; p.xf_relu = xf_relu;
+  if (lz != nullptr) { p.xf_mode = 3; p.x2 = (const char*)lz->res; p.xf2 = lz->xf2; p.xz = (char*)lz->z; p.xz_mask = lz->mask; }
   p.stats_pivot = stats_pivot;
   p.stats_rows = (int)(((long long)N * P * Q + 127) / 128);
   p.N = N; p.Hi = H; p.Wi = W; p.Ci = C;
@@ -1041,6 +1124,30 @@ extern "C" int cn_conv2d_fwd_xf(const void* x, const float* xf, int xf_relu, con
   }
   return ig_conv_fwd(x, w_krsc, y, nullptr, partial, N, H, W, C, K, R, S, stride_h, stride_w, pad_h, pad_w, dtype, 0, 0,
                      stream, xf, xf_relu);
+}
+
+// "Lazy z" forward (round 3): the convolution's input is the output of a residual junction that has not been applied
+// yet,   z = relu?( bn_y*scale[c] + shift[c] + r ),   r = res   or   r = round_T(res*rscale[c] + rshift[c])  (res_stats
+// given: `res` is the projection shortcut's BatchNorm input, as in cn_bn_apply_dual).  The 1x1 / stride-1 convolution
+// with K <= 128 output channels forms z on its operand load - bn_apply_kernel's operation order and rounding -, stores
+// it to `z` (and the ReLU bits to z_mask, optional) and multiplies: the same bits as the junction's apply pass followed
+// by cn_conv2d_fwd_bnstats, without that pass (read y, read res, write z) and without this convolution's re-read of z.
+// stats / res_stats: the 4*C floats of cn_bn_fwd_train* (z = NULL).  partial (optional) as cn_conv2d_fwd_bnstats
+// (pivot optional: centred sums).
+extern "C" int cn_conv2d_fwd_lazyz(const void* bn_y, const void* res, const float* stats, const float* res_stats,
+                                   int relu, void* z, unsigned char* z_mask, const void* w_krsc, void* y, int N, int H,
+                                   int W, int C, int K, int dtype, float* partial, int partial_rows, const float* pivot,
+                                   void* stream) {
+  if (bn_y == nullptr || res == nullptr || stats == nullptr || z == nullptr) { cn_set_error("conv2d_fwd_lazyz: null operand"); return CN_EINVAL; }
+  if (K > 128) { cn_set_error("conv2d_fwd_lazyz: %d output channels > 128 (one channel tile)", K); return CN_ESHAPE; }
+  if (partial != nullptr && partial_rows < cn_conv2d_bnstats_rows((long long)N * H * W)) {
+    cn_set_error("conv2d_fwd_lazyz: partial buffer of %d rows is too small", partial_rows);
+    return CN_EWORKSPACE;
+  }
+  IgLazyZ lz;
+  lz.res = res; lz.xf2 = res_stats != nullptr ? res_stats + 2 * C : nullptr; lz.z = z; lz.mask = z_mask;
+  return ig_conv_fwd(bn_y, w_krsc, y, nullptr, partial, N, H, W, C, K, 1, 1, 1, 1, 0, 0, dtype, 0, 0, stream, stats + 2 * C,
+                     relu, pivot, &lz);
 }
 
 struct IgBnBwd {

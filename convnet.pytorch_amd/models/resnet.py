@@ -109,6 +109,7 @@ class ResidualBlock(tnn.Module):
         if self.quantized:
             return
         self.conv1.__dict__['input_bn'] = bn
+        bn.__dict__['consumer_conv'] = self.conv1   # (lazy z: conv1 can apply that junction on its operand load, ops.LAZY_Z)
         if self.downsample is not None:
             self.downsample[0].__dict__['input_bn'] = bn
 
@@ -127,7 +128,14 @@ class ResidualBlock(tnn.Module):
             from ..quant import add_relu
             return add_relu(out, residual)
         if self.downsample is not None:
-            residual = self.downsample[1](self.downsample[0](xb))
+            ds_conv, ds_bn = self.downsample[0], self.downsample[1]
+            from .. import ops
+            if ops.DUAL_BN and ds_bn.training and self.last_bn().training and isinstance(ds_bn, cnn.BatchNorm2d) \
+                    and ops._sync_group(ds_bn) is None and ops._sync_group(self.last_bn()) is None:
+                # the shortcut BatchNorm finalises its statistics only; the junction's apply pass applies both
+                residual = ds_bn(ds_conv(xb), defer_apply=True)
+                return self.last_bn()(out, residual=residual, relu=True, residual_bn=ds_bn)
+            residual = ds_bn(ds_conv(xb))
         return self.last_bn()(out, residual=residual, relu=True)
 
 
@@ -239,10 +247,15 @@ class ResNetImagenet(tnn.Module):
         else:
             x = self.conv1(x)
         x = cnn.bn_relu_maxpool(self.bn1, self.maxpool, x)
-        x = self.layer1(x)
-        x = self.layer2(x)
-        x = self.layer3(x)
-        x = self.layer4(x)
+        from .. import ops
+        ops.LAZY_Z_SCOPE[0] += 1    # block b's junction may be left to block b+1's conv1: it runs next, by construction
+        try:
+            x = self.layer1(x)
+            x = self.layer2(x)
+            x = self.layer3(x)
+            x = self.layer4(x)
+        finally:
+            ops.LAZY_Z_SCOPE[0] -= 1
         x = self.avgpool(x)
         return x.view(x.size(0), -1)
 

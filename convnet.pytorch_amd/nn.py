@@ -203,13 +203,18 @@ class BatchNorm2d(_ArenaModule):
             return 1.0 / float(self._host_batches)
         return float(self.momentum)
 
-    def forward(self, y, residual=None, relu=False):
+    def forward(self, y, residual=None, relu=False, defer_apply=False, residual_bn=None):
+        """defer_apply / residual_bn (ops.DUAL_BN): a projection shortcut's BatchNorm called with defer_apply=True only
+        finalises its batch statistics and returns its input; the junction BatchNorm, given that tensor as `residual`
+        and the shortcut BatchNorm as `residual_bn`, applies both in its one apply pass.  Ignored in eval mode."""
         self._require_prepared()
         if self.training or not self.track_running_stats:
             if torch.is_grad_enabled():
-                return ops.BatchNormActFunction.apply(y, self.weight, self.bias, residual, self, relu)
+                return ops.BatchNormActFunction.apply(y, self.weight, self.bias, residual, self, relu, defer_apply,
+                                                      residual_bn)
             with torch.no_grad():
-                return ops.BatchNormActFunction.apply(y, self.weight, self.bias, residual, self, relu)
+                return ops.BatchNormActFunction.apply(y, self.weight, self.bias, residual, self, relu, defer_apply,
+                                                      residual_bn)
         return ops.batch_norm_infer(y, residual, self, relu)
 
     def extra_repr(self):

@@ -271,6 +271,19 @@ FUSE_BN_BWD_INNER_1X1 = os.environ.get('CONVNET_AMD_FUSE_BN_BWD_INNER_1X1', '0')
 # layers; the small maps keep the LDS-DMA weight-gradient kernels).  CONVNET_AMD_LAZY_DY=0 disables it (A/B).
 LAZY_DY = os.environ.get('CONVNET_AMD_LAZY_DY', '1') == '1'
 LAZY_DY_MIN_MB = float(os.environ.get('CONVNET_AMD_LAZY_DY_MIN_MB', '150'))
+# Junction behind a projection shortcut (round 3): the shortcut BatchNorm only finalises its statistics; its apply runs
+# inside the junction BatchNorm's apply pass (cn_bn_apply_dual), so the normalised shortcut tensor is neither written nor
+# re-read.  Bit-identical; CONVNET_AMD_DUAL_BN=0 restores the two apply passes (A/B).
+DUAL_BN = os.environ.get('CONVNET_AMD_DUAL_BN', '1') == '1'
+# "Lazy z" (round 3): a residual junction whose output feeds a 1x1 / stride-1 convolution of at most 128 output channels
+# (the next bottleneck's conv1) is finalised but not applied; that convolution forms z = relu(bn(y) + residual) on its
+# operand load and stores it (cn_conv2d_fwd_lazyz): the junction's apply pass (read y, read residual, write z) and the
+# convolution's re-read of z become one read of y and the residual and one write of z.  Bit-identical.  Only inside a
+# model forward that guarantees the convolution runs next (LAZY_Z_SCOPE, set by ResNetImagenet.features) and for
+# junction tensors of at least LAZY_Z_MIN_MB (bandwidth-bound layers).  CONVNET_AMD_LAZY_Z=0 disables it (A/B).
+LAZY_Z = os.environ.get('CONVNET_AMD_LAZY_Z', '1') == '1'
+LAZY_Z_MIN_MB = float(os.environ.get('CONVNET_AMD_LAZY_Z_MIN_MB', '150'))
+LAZY_Z_SCOPE = [0]
 # junction fusion only for BN inputs of at least this many MB (A/B knob; 0 = every junction)
 FUSE_BN_BWD_JUNC_MIN_MB = float(os.environ.get('CONVNET_AMD_FUSE_BN_BWD_JUNC_MIN_MB', '0'))
 
@@ -369,6 +382,38 @@ def conv2d_fwd_xf(x, xf, xf_relu, w_krsc, K, R, S, stride, pad, bn_stats=False):
     if bn_stats:
         _park_stats(y, partial, rows)
     return y
+
+
+def conv2d_fwd_lazyz(lz, w_krsc, K, bn_stats=False, pivot=None):
+    """conv1x1(z) with z = relu(bn(y) + residual) formed on the operand load and stored by the kernel
+    (cn_conv2d_fwd_lazyz).  lz: the junction's parked state (BatchNormActFunction.forward)."""
+    y3, res, stats, res_stats, z, mask, relu = lz
+    N, H, W, C = y3.shape
+    out = torch.empty((N, H, W, K), dtype=y3.dtype, device=y3.device)
+    L = _L()
+    partial, rows = None, 0
+    if bn_stats:
+        rows = L.cn_conv2d_bnstats_rows(N * H * W)
+        partial = torch.empty((rows, 2 * K), dtype=torch.float32, device=y3.device)
+    nb = y3.numel() * _esize(y3)
+    PROFILER.run(_last_kernel(' [lazy z]'), 1, 2.0 * N * H * W * K * C,
+                 3 * nb + (mask.numel() if mask is not None else 0) + out.numel() * _esize(out) + K * C * _esize(y3)
+                 + (partial.numel() * 4 if partial is not None else 0),
+                 lambda: check(L.cn_conv2d_fwd_lazyz(ptr(y3), ptr(res), ptr(stats), ptr(res_stats), int(relu), ptr(z),
+                                                     ptr(mask), ptr(w_krsc), ptr(out), N, H, W, C, K, dtype_code(y3.dtype),
+                                                     ptr(partial), rows, ptr(pivot), stream_of(y3)), 'cn_conv2d_fwd_lazyz'),
+                 y3.device, detail=_conv_detail('fwd', C, H, K, 1, (1, 1)))
+    if bn_stats:
+        _park_stats(out, partial, rows, pivot)
+    return out
+
+
+def lazy_z_consumer_ok(conv):
+    """conv can take an unapplied junction as its input (cn_conv2d_fwd_lazyz's shape limits)."""
+    return (conv is not None and getattr(conv, 'kernel_size', None) == (1, 1) and getattr(conv, 'stride', None) == (1, 1)
+            and getattr(conv, 'padding', None) == (0, 0) and getattr(conv, 'bias', None) is None
+            and conv.out_channels <= 128 and conv.in_channels <= 512 and conv.training
+            and not getattr(conv, 'out_f32', False))
 
 
 def conv2d_dgrad(dy, w_crsk, x_shape, K, R, S, stride, pad, addend=None, bn=None, addend_sub=1):
@@ -582,10 +627,19 @@ class Conv2dFunction(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, mod):
         mod.ensure_prepared()
-        y = conv2d_fwd(x, mod.w_krsc, bias, mod.out_channels, mod.kernel_size[0], mod.kernel_size[1],
-                       mod.stride, mod.padding, out_f32=mod.out_f32,
-                       bn_stats=FUSE_BN_STATS and mod.training and getattr(mod, 'feeds_batchnorm', False),
-                       pivot=stats_pivot(mod))
+        lz = mod.__dict__.pop('_lazy_z', None)
+        if lz is not None:    # x is a junction output that exists only as (y, residual, statistics): this kernel writes it
+            if lz[0] != x.data_ptr() or bias is not None:
+                raise _lib.ConvNetHipError('lazy z: the parked junction is not this convolution\'s input')
+            y = conv2d_fwd_lazyz(lz[1:], mod.w_krsc, mod.out_channels,
+                                 bn_stats=FUSE_BN_STATS and mod.training and getattr(mod, 'feeds_batchnorm', False),
+                                 pivot=stats_pivot(mod))
+            COUNTERS['lazy_z'] = COUNTERS.get('lazy_z', 0) + 1
+        else:
+            y = conv2d_fwd(x, mod.w_krsc, bias, mod.out_channels, mod.kernel_size[0], mod.kernel_size[1],
+                           mod.stride, mod.padding, out_f32=mod.out_f32,
+                           bn_stats=FUSE_BN_STATS and mod.training and getattr(mod, 'feeds_batchnorm', False),
+                           pivot=stats_pivot(mod))
         ctx.mod = mod
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x)
@@ -766,13 +820,33 @@ class BatchNormActFunction(Function):
     """z = act(BN(y) + residual), training mode (batch statistics)."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, residual, mod, relu):
+    def forward(ctx, y, gamma, beta, residual, mod, relu, defer_apply=False, res_bn=None):
         N, H, W, C = y.shape
         M = N * H * W
         L = _L()
         code = dtype_code(y.dtype)
         ws = workspace(L.cn_bn_workspace(M, C, code), y.device)
-        z = torch.empty_like(y)
+        # defer_apply (a projection shortcut's BatchNorm, DUAL_BN): statistics only, the junction applies them; the
+        # "output" handed to autograd is the input itself (the junction reads it through this BatchNorm's stats)
+        defer = bool(defer_apply) and residual is None and not relu and _sync_group(mod) is None
+        # res_bn: `residual` is that BatchNorm's deferred input
+        dual = None
+        if res_bn is not None:
+            d = getattr(res_bn, '_deferred', None)
+            res_bn._deferred = None
+            if d is not None and residual is not None and d[0] == residual.data_ptr() and _sync_group(mod) is None \
+                    and tuple(residual.shape) == tuple(y.shape) and residual.dtype == y.dtype:
+                dual = d[1]
+            elif d is not None:
+                raise _lib.ConvNetHipError('deferred shortcut BatchNorm met a junction that cannot apply it')
+        z = None if defer else torch.empty_like(y)
+        # lazy z: the junction is finalised here and applied by the 1x1 convolution that consumes it (LAZY_Z)
+        cons = getattr(mod, 'consumer_conv', None)
+        lazyz = (LAZY_Z and LAZY_Z_SCOPE[0] > 0 and not defer and relu and residual is not None and C <= 512
+                 and _sync_group(mod) is None and y.numel() * _esize(y) >= LAZY_Z_MIN_MB * 2 ** 20
+                 and tuple(residual.shape) == tuple(y.shape) and residual.dtype == y.dtype and lazy_z_consumer_ok(cons)
+                 and cons.in_channels == C)
+        zk = None if (defer or dual is not None or lazyz) else z     # what the statistics call applies itself
         stats = torch.empty(4 * C, dtype=torch.float32, device=y.device)
         mask = None
         if relu and residual is not None:   # 1 bit per output instead of re-reading z in backward
@@ -803,35 +877,50 @@ class BatchNormActFunction(Function):
                                          ptr(stats), M, C, int(relu), code, ptr(sums), M * world, stream_of(y)),
                   'cn_bn_fwd_train_sums')
         elif ps is not None:   # statistics came out of the producing convolution's epilogue: no pass over y
-            PROFILER.run('bn_finalize+bn_apply (stats from conv epilogue)', 2 if ps.rows <= 512 else 3, 0.0,
-                         nb * (3 if residual is not None else 2) + (mask.numel() if mask is not None else 0)
-                         + ps.partial.numel() * 4,
+            PROFILER.run('bn_finalize+bn_apply (stats from conv epilogue)' if zk is not None
+                         else 'bn_finalize (stats from conv epilogue; applied by the junction)',
+                         (2 if ps.rows <= 512 else 3) - (0 if zk is not None else 1), 0.0,
+                         (nb * (3 if residual is not None else 2) + (mask.numel() if mask is not None else 0)
+                          if zk is not None else 0) + ps.partial.numel() * 4,
                          lambda: check((L.cn_bn_fwd_train_partials if ps.pivot is None
                                         else L.cn_bn_fwd_train_partials_centered)(
-                             ptr(y), ptr(residual), ptr(z), ptr(mask), ptr(gamma), ptr(beta),
+                             ptr(y), ptr(residual) if zk is not None else None, ptr(zk), ptr(mask) if zk is not None else None, ptr(gamma), ptr(beta),
                              ptr(mod.running_mean) if track else None, ptr(mod.running_var) if track else None,
                              ptr(mod.num_batches_tracked) if track else None, momentum, mod.eps, ptr(stats), M, C,
                              int(relu), code, ptr(ps.partial), ps.rows, ptr(ws), ws.numel() * 4, stream_of(y)),
                              'cn_bn_fwd_train_partials'),
                          y.device)
         else:
-            PROFILER.run('bn_stats+bn_finalize+bn_apply', 3, 0.0,
-                         nb * (4 if residual is not None else 3) + (mask.numel() if mask is not None else 0),
+            PROFILER.run('bn_stats+bn_finalize+bn_apply' if zk is not None else 'bn_stats+bn_finalize', 3 if zk is not None else 2, 0.0,
+                         nb * (4 if residual is not None else 3) + (mask.numel() if mask is not None else 0)
+                         if zk is not None else nb,
                          lambda: check(L.cn_bn_fwd_train(
-                             ptr(y), ptr(residual), ptr(z), ptr(mask), ptr(gamma), ptr(beta),
+                             ptr(y), ptr(residual) if zk is not None else None, ptr(zk), ptr(mask) if zk is not None else None, ptr(gamma), ptr(beta),
                              ptr(mod.running_mean) if track else None, ptr(mod.running_var) if track else None,
                              ptr(mod.num_batches_tracked) if track else None, momentum, mod.eps, ptr(stats), M, C,
                              int(relu), code, ptr(ws), ws.numel() * 4, stream_of(y)), 'cn_bn_fwd_train'),
                          y.device)
+        if lazyz:
+            cons.__dict__['_lazy_z'] = (z.data_ptr(), y, residual.contiguous(), stats, dual, z, mask, relu)
+        elif dual is not None:    # both BatchNorms finalised: one apply pass reads y and the shortcut's raw input
+            PROFILER.run('bn_apply (junction + projection-shortcut BatchNorm)', 1, 0.0,
+                         nb * 3 + (mask.numel() if mask is not None else 0),
+                         lambda: check(L.cn_bn_apply_dual(ptr(y), ptr(residual), ptr(z), ptr(mask), ptr(stats), ptr(dual),
+                                                          M, C, int(relu), code, stream_of(y)), 'cn_bn_apply_dual'),
+                         y.device)
+            COUNTERS['bn_fwd_dual'] = COUNTERS.get('bn_fwd_dual', 0) + 1
         ctx.mod = mod
         ctx.relu = relu
         ctx.has_res = residual is not None
-        ctx.out_ptr = z.data_ptr()
+        ctx.out_ptr = z.data_ptr() if z is not None else None
         mod._fwd_ctx = weakref.ref(ctx)      # lets the consumer conv's dgrad fuse this BN's backward reduction
         if mask is not None:
             ctx.save_for_backward(y, stats, mask)
         else:
             ctx.save_for_backward(y, stats)
+        if defer:
+            mod._deferred = (y.data_ptr(), stats)
+            return y     # (autograd hands back an alias of the input: same storage, this node as its grad_fn)
         return z
 
     @staticmethod
@@ -933,7 +1022,7 @@ class BatchNormActFunction(Function):
         if holder is not None:
             holder.dres, holder.sub = dres, 1
             holder.fused = False
-        return dy, None, None, dres, None, None
+        return dy, None, None, dres, None, None, None, None
 
 
 def batch_norm_infer(y, residual, mod, relu):

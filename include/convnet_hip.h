@@ -93,6 +93,16 @@ int cn_conv2d_fwd_bnstats_centered(const void* x, const void* w_krsc, void* y, c
                                    void* stream);
 /* dx[N,H,W,C] from dy[N,P,Q,K] and the transposed filter w_crsk[C][R][S][K]
  * (written by cn_weight_prep).  Strided convs run one launch per output-parity class. */
+/* "Lazy z" forward: the input of this 1x1 / stride-1 convolution (K <= 128 output channels, C <= 512) is the output of
+ * a residual junction that has been finalised (cn_bn_fwd_train* with z = NULL) but not applied:
+ *   z = relu?( bn_y*scale[c] + shift[c] + r ),  r = res  or, with res_stats, r = round_T(res*rscale[c] + rshift[c])
+ * (/root/reference models/resnet.py:141-165: bn3 -> += residual -> relu, then the next block's conv1).  The kernel forms z
+ * on its operand load, stores it to z (ReLU bits to z_mask, optional) and convolves: same bits as the apply pass followed
+ * by cn_conv2d_fwd_bnstats(_centered), minus that pass and this convolution's re-read of z.  stats / res_stats: the 4*C
+ * floats of the junction / shortcut BatchNorm; partial / partial_rows / pivot as cn_conv2d_fwd_bnstats(_centered), optional. */
+int cn_conv2d_fwd_lazyz(const void* bn_y, const void* res, const float* stats, const float* res_stats, int relu, void* z,
+                        unsigned char* z_mask, const void* w_krsc, void* y, int N, int H, int W, int C, int K, int dtype,
+                        float* partial, int partial_rows, const float* pivot, void* stream);
 /* conv forward on a BatchNorm INPUT: the operand is act(x*scale[c] + shift[c]) (xf = [scale | shift], 2*C floats =
  * stats_out + 2C of cn_bn_fwd_train*), rounded to dtype like cn_bn_fwd_train's z and applied on the operand load, so
  * an inner BatchNorm (models/resnet.py:143-152: bn -> relu -> next conv) needs no apply pass; C <= 512; partial
@@ -173,6 +183,14 @@ int cn_bn_fwd_train_partials_centered(const void* y, const void* residual, void*
 int cn_bn_fwd_infer(const void* y, const void* residual, void* z, const float* gamma, const float* beta,
                     const float* running_mean, const float* running_var, float eps, float* coeffs /*2C*/,
                     int M, int C, int relu, int dtype, void* stream);
+/* The apply pass of a residual junction behind a projection shortcut (conv + BatchNorm), both BatchNorms already
+ * finalised by cn_bn_fwd_train* with z = NULL (statistics, running statistics, scale / shift only; the reference applies
+ * them as two nn.BatchNorm2d calls and an add, /root/reference models/resnet.py:141-165):
+ *   z = relu?( y*scale[c] + shift[c] + round_T(res_y*rscale[c] + rshift[c]) )
+ * stats / res_stats: the 4*C floats cn_bn_fwd_train* wrote for the junction / shortcut BatchNorm.  Same bits as the
+ * shortcut BatchNorm's own apply followed by the junction's, one write + one read of the shortcut tensor less. */
+int cn_bn_apply_dual(const void* y, const void* res_y, void* z, unsigned char* relu_mask, const float* stats,
+                     const float* res_stats, int M, int C, int relu, int dtype, void* stream);
 /* relu_mask: the byte mask of cn_bn_fwd_train (needed when a residual was added), NULL => ReLU mask
  * recomputed from y.  dres (optional) receives the masked upstream gradient for the residual branch. */
 int cn_bn_bwd(const void* dz, const void* y, const unsigned char* relu_mask, const float* gamma, const float* stats,

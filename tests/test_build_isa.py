@@ -33,9 +33,11 @@ def test_bn_streaming_passes_really_use_nontemporal_accesses(table):
     # NT = true instantiations: the activation loads are `nt`, the plain ones left are coefficient loads
     for kern, sites in (('bn_apply_kernel', 'nt_load16'), ('bn_bwd_apply_kernel', 'nt_load16'),
                         ('bn_bwd_apply_kernel', 'nt_store16'), ('bn_bwd_reduce_kernel', 'nt_load16')):
-        for name, c in _find(table, kern + '<', ', true>'):
+        # (bn_apply_kernel<T, NT, DUAL>: the cache policy is its second parameter; the others end with it)
+        on, off = ((', true, ', ', false, ') if kern == 'bn_apply_kernel' else (', true>', ', false>'))
+        for name, c in _find(table, kern + '<', on):
             assert c[sites] > 0, (name, c)
-        for name, c in _find(table, kern + '<', ', false>'):
+        for name, c in _find(table, kern + '<', off):
             assert c['nt_load16'] == 0 and c['nt_store16'] == 0, (name, c)
     # z is stored with the default policy in both instantiations (its consumer follows at once)
     for name, c in _find(table, 'bn_apply_kernel'):
