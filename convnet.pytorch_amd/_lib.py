@@ -57,6 +57,9 @@ _SIGNATURES = {
     'cn_conv2d_fwd_lazyz': (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p] + [c_i] * 6 + [c_p, c_i, c_p, c_p]),
     'cn_conv2d_dgrad_lazy': (c_i, [c_p, c_p, c_p, c_p, c_p] + [c_i] * 11 + [c_i, c_p]),
     'cn_conv2d_wgrad_lazy': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i] + [c_i] * 11 + [c_i, c_f, c_f, c_p, c_sz, c_p]),
+    'cn_conv2d_bwd1x1_lazy_ok': (c_i, [c_i, c_i, c_i]),
+    'cn_conv2d_bwd1x1_lazy_workspace': (c_sz, [c_i] * 5),
+    'cn_conv2d_bwd1x1_lazy': (c_i, [c_p] * 7 + [c_i] * 6 + [c_f, c_f, c_p, c_sz, c_p]),
     'cn_bn_workspace': (c_sz, [c_i, c_i, c_i]),
     'cn_bn_fwd_train': (c_i, [c_p] * 9 + [c_f, c_f, c_p, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
     'cn_bn_fwd_train_partials': (c_i, [c_p] * 9 + [c_f, c_f, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_sz, c_p]),

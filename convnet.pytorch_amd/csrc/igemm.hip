@@ -128,7 +128,9 @@ __device__ __forceinline__ int ig_slot(int row, int chunk) {
 //     texture path is busy) right after the barrier, i.e. with the matrix pipe of all four SIMDs idle; interleaved,
 //     each one is issued while the MFMA before it executes.  Same instructions, same results (bit-identical).
 template <typename T, int WC, int WP, int TI, int TJ, int STAGES, bool OUTF32, bool GLDS, bool FRAGDB, bool EPI, int XF = 0, bool ILV = false>
-__global__ __launch_bounds__(WC * WP * 64) void igemm_kernel(IgemmParams p) {
+// (the eight-wave lazy-z tile is held to 128 VGPRs - four waves per SIMD, two workgroups per CU -: at 130 it ran one
+//  workgroup per CU and streamed at 3.5 instead of 5 TB/s)
+__global__ __launch_bounds__(WC * WP * 64, (XF != 0 && WC * WP == 8) ? 4 : 1) void igemm_kernel(IgemmParams p) {
   static_assert(!XF || (!GLDS && !EPI), "operand transform needs the register-staged path");
   static_assert(!ILV || (GLDS && STAGES == 2), "interleaved DMA issue: LDS-DMA double buffer");
   static_assert(!GLDS || STAGES == 2 || STAGES == 4, "LDS-DMA needs the double-buffered tile or the 4-deep ring");
@@ -898,9 +900,18 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
   }
   if (p.xf != nullptr) {   // operand transform: register-staged single buffer only
     if (epi || p.Ci > IG_XF_MAX) { cn_set_error("igemm: operand transform with an epilogue operand / more than %d channels", IG_XF_MAX); return CN_EINVAL; }
-    cn_set_last_kernel("igemm_kernel<%s, %s, 1, %s, false, false, false, true, false>", tname, p.Co <= 64 ? "1, 4, 2, 1" : "2, 2, 2, 2", OUTF32 ? "true" : "false");
+    // 128-channel outputs, 16-bit storage: the tile on eight waves held to 128 VGPRs (two workgroups = four waves per
+    // SIMD; the four-wave form needs 204 = two waves per SIMD).  Same tile, same accumulation order: same outputs.
+    // Knob "igemm_xf_8w" (A/B; whole step +0.15 % SLOWER with it, gpurun r3e: off by default).
+    bool w8 = false;
+    if constexpr (sizeof(T) == 2 && !OUTF32) w8 = p.Co > 64 && p.stats == nullptr && cn_get_option("igemm_xf_8w", 0) != 0;
+    cn_set_last_kernel("igemm_kernel<%s, %s, 1, %s, false, false, false, true, false>", tname,
+                       p.Co <= 64 ? "1, 4, 2, 1" : (w8 ? "2, 4, 2, 1" : "2, 2, 2, 2"), OUTF32 ? "true" : "false");
     if (p.Co <= 64) CN_LAUNCH((igemm_kernel<T, 1, 4, 2, 1, 1, OUTF32, false, false, false, 1>), grid, dim3(256), stream, p);
-    else CN_LAUNCH((igemm_kernel<T, 2, 2, 2, 2, 1, OUTF32, false, false, false, 1>), grid, dim3(256), stream, p);
+    else if (w8) {
+      if constexpr (sizeof(T) == 2 && !OUTF32)
+        CN_LAUNCH((igemm_kernel<T, 2, 4, 2, 1, 1, false, false, false, false, 1>), grid, dim3(512), stream, p);
+    } else CN_LAUNCH((igemm_kernel<T, 2, 2, 2, 2, 1, OUTF32, false, false, false, 1>), grid, dim3(256), stream, p);
     return cn_check_launch("igemm");
   }
   if constexpr (sizeof(T) == 2 && !OUTF32) {

@@ -39,8 +39,11 @@ struct WgradParams {
   int tap_dhdw[WG_MAX_TAPS];
 };
 
-template <typename T, int BI, int BJ, bool LAZY = false>
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
+template <typename T, int BI, int BJ, int LAZY = 0>
+// LAZY = 2: the lazy form with its 3 x CH per-thread coefficients read from an LDS table at each stage instead of held in
+// 24 registers, and the kernel held to 168 VGPRs (three workgroups per CU like the plain kernel; LAZY = 1 compiles to
+// 180 = two).  Same arithmetic, same bits.  Knob "wgrad_lazy_occ" (A/B).
+__global__ __launch_bounds__(256, LAZY == 2 ? 3 : 1) void wgrad_kernel(WgradParams p) {
   constexpr int EB = ElemTraits<T>::kBytes;
   constexpr int CH = ElemTraits<T>::kChunk;
   constexpr bool kBf16 = (EB == 2);
@@ -102,12 +105,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
 
   u32x4 regI[NI], regJ[NJ];
   u32x4 regI2[LAZY ? NI : 1];            // lazy dy: the BatchNorm input chunks (LAZY instantiations only: the plain
-  constexpr bool lazy = LAZY;            //  kernel keeps its register budget - 3 workgroups per CU)
+  constexpr bool lazy = LAZY != 0;       //  kernel keeps its register budget - 3 workgroups per CU)
+  __shared__ float s_coef[LAZY == 2 ? 3 * BI : 1];
   const cn_buf_t dy2buf = cn_make_buf(lazy ? p.dy2 : p.dy, p.dy_bytes);
   float lc1[CH], lc2[CH], lc3[CH];   // this thread's channel chunk is fixed: its coefficients live in registers
 #pragma unroll
   for (int e = 0; e < CH; ++e) { lc1[e] = 1.f; lc2[e] = 0.f; lc3[e] = 0.f; }
-  if (lazy && validI) {
+  if (LAZY == 2) {
+    for (int c = tid; c < 3 * BI; c += 256) {
+      const int k = c / BI, cc = c - k * BI;
+      s_coef[c] = (i0 + cc < p.Co) ? p.coef[k * p.Co + i0 + cc] : (k == 0 ? 1.f : 0.f);
+    }
+    __syncthreads();
+  } else if (lazy && validI) {
 #pragma unroll
     for (int e = 0; e < CH; ++e) {
       const int c = i0 + colI * CH + e;
@@ -155,6 +165,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   };
   auto store_stage = [&]() {
     if (lazy) {   // dy = c1*g + c2*y + c3 in bn_bwd_apply_kernel's operation order; rows past the split stay zero
+      if (LAZY == 2) {
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+          lc1[e] = s_coef[colI * CH + e];
+          lc2[e] = s_coef[BI + colI * CH + e];
+          lc3[e] = s_coef[2 * BI + colI * CH + e];
+        }
+      }
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
         float g[CH], v[CH];
@@ -615,6 +633,209 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, fl
 }
 
 // ------------------------------------------------------------------------------------------------
+// Junction pair (round 3): data gradient AND weight gradient of a 1x1 / stride-1 convolution whose upstream gradient
+// is a "lazy dy" (dy = c1*g + c2*y + c3, see WgradParams::dy2), in ONE pass over g and y.
+//
+// The two lazy kernels (cn_conv2d_dgrad_lazy on the backward chain, cn_conv2d_wgrad_lazy beside it) each read the two
+// junction-sized tensors g and y - at the 56x56 layers of ResNet-50 4 x 411 MB per convolution, the largest reads of
+// the step.  Here a workgroup owns a range of pixels and ALL channels: per stage of BM pixels it loads g, y (and the
+// convolution's input x) once, forms the dy tile in LDS, and feeds it to both products:
+//     dx[m][ci]  = sum_co dy[m][co] * W[co][ci]      (MFMA A = W rows (ci) from an LDS copy of the filter, B = dy rows)
+//     dW[co][ci] += sum_m dy[m][co] * x[m][ci]       (both operands pixel-major: LDS transpose reads, as wgrad_kernel)
+// (reads per pixel: 2*CO + CI elements instead of 4*CO + CI).  The dy tile is stored pixel-major at a pitch of
+// CO*2 + 64 bytes (four consecutive rows on four bank quarters: conflict-free transpose reads) with the 16-byte chunk
+// index XOR-ed by (row >> 2) & 3 inside each 64-byte granule, which leaves the transpose reads alone (their four rows
+// share row >> 2) and spreads the 16 rows a ds_read_b128 of the data-gradient product touches over all 16 bank
+// groups.  dx: same operand orientation and k order as igemm_kernel => the bits of cn_conv2d_dgrad_lazy.  dW partials
+// per pixel range go to the fp32 workspace; wgrad_reduce_kernel sums them in a fixed order.
+struct JbParams {
+  const char* g;      // [M][CO] masked upstream gradient of the BatchNorm
+  const char* y;      // [M][CO] BatchNorm input
+  const float* coef;  // [3][CO]
+  const char* w;      // [CI][CO] filter in data-gradient (CRSK) order
+  const char* x;      // [M][CI] convolution input
+  char* dx;           // [M][CI]
+  float* part;        // [nsplit][CO][CI]
+  int M, m_per_split, nsplit;
+  unsigned int gy_bytes, x_bytes;
+};
+
+template <typename T, int CO, int CI, int BM>
+__global__ __launch_bounds__(512) void jbwd_kernel(JbParams p) {
+  static_assert(sizeof(T) == 2, "16-bit storage");
+  static_assert(CO % 32 == 0 && CI % 32 == 0 && BM % 64 == 0, "tile shapes");
+  constexpr int PD = CO * 2 + 64;   // dy tile pitch (bytes)
+  constexpr int PX = CI * 2 + 64;   // x tile pitch
+  constexpr int PW = CO * 2;        // filter rows (ci), chunk-swizzled
+  constexpr int NCG = CO / 8;       // 16-byte chunks per g / y row
+  constexpr int NCX = CI / 8;
+  constexpr int RG = 512 / NCG, RX = 512 / NCX;   // rows per load pass
+  constexpr int NG = BM / RG, NX = BM / RX;
+  static_assert(NG >= 1 && NX >= 1 && BM % RG == 0 && BM % RX == 0, "load passes");
+  constexpr int NPT = BM / 32, NCT = CI / 32, NOT = CO / 32;   // 32 x 32 output tiles: dx is NPT x NCT, dW is NOT x NCT
+  static_assert(NPT * NCT == 8, "one data-gradient tile per wave");
+  static_assert(NOT == 8, "one weight-gradient row of tiles per wave");
+  __shared__ __attribute__((aligned(16))) char lds[BM * PD + BM * PX + CI * PW + 3 * CO * 4];
+  char* dyT = lds;
+  char* xT = lds + BM * PD;
+  char* wT = lds + BM * PD + BM * PX;
+  float* s_coef = (float*)(lds + BM * PD + BM * PX + CI * PW);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = cn_uniform(tid >> 6);
+  const int split = blockIdx.x;
+  const int m_begin = split * p.m_per_split;
+  int m_end = m_begin + p.m_per_split;
+  if (m_end > p.M) m_end = p.M;
+
+  // filter copy (whole launch) and the lazy-dy coefficients
+  for (int id = tid; id < CI * NCG; id += 512) {
+    const int row = id / NCG, c = id - row * NCG;
+    cn_st16(wT + row * PW + ((c ^ (row & (NCG - 1))) << 4), cn_ld16(p.w + ((size_t)row * CO + (size_t)c * 8) * 2));
+  }
+  for (int c = tid; c < 3 * CO; c += 512) s_coef[c] = p.coef[c];
+  __syncthreads();
+
+  const cn_buf_t gbuf = cn_make_buf(p.g, p.gy_bytes);
+  const cn_buf_t ybuf = cn_make_buf(p.y, p.gy_bytes);
+  const cn_buf_t xbuf = cn_make_buf(p.x, p.x_bytes);
+  const int colG = tid % NCG, rowG0 = tid / NCG;
+  const int colX = tid % NCX, rowX0 = tid / NCX;
+
+  u32x4 regG[NG], regY[NG], regX[NX];
+  unsigned int okG = 0;
+  auto load_stage = [&](int mb) {
+    okG = 0;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      const int m = mb + rowG0 + i * RG;
+      const bool ok = m < m_end;
+      const unsigned int o = ok ? ((unsigned int)m * (unsigned int)CO + (unsigned int)colG * 8u) * 2u : CN_OOB;
+      okG |= (ok ? 1u : 0u) << i;
+      regG[i] = cn_buf_ld16(gbuf, o);
+      regY[i] = cn_buf_ld16(ybuf, o);
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int m = mb + rowX0 + i * RX;
+      const unsigned int o = m < m_end ? ((unsigned int)m * (unsigned int)CI + (unsigned int)colX * 8u) * 2u : CN_OOB;
+      regX[i] = cn_buf_ld16(xbuf, o);
+    }
+  };
+  auto store_stage = [&]() {
+    float c1[8], c2[8], c3[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      c1[e] = s_coef[colG * 8 + e];
+      c2[e] = s_coef[CO + colG * 8 + e];
+      c3[e] = s_coef[2 * CO + colG * 8 + e];
+    }
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {   // dy = c1*g + c2*y + c3: bn_bwd_apply_kernel's operation order and rounding
+      float gg[8], vv[8];
+      Chunk<T>::unpack(regG[i], gg);
+      Chunk<T>::unpack(regY[i], vv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gg[e] = fmaf(c1[e], gg[e], fmaf(c2[e], vv[e], c3[e]));
+      const u32x4 o = Chunk<T>::pack(gg);
+      const int row = rowG0 + i * RG;
+      const int cs = (colG & ~3) | ((colG & 3) ^ ((row >> 2) & 3));
+      cn_st16(dyT + row * PD + (cs << 4), ((okG >> i) & 1u) ? o : cn_zero16());   // rows past the range stay zero
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) cn_st16(xT + (rowX0 + i * RX) * PX + colX * 16, regX[i]);
+  };
+
+  f32x16 accw[NCT];
+#pragma unroll
+  for (int b = 0; b < NCT; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accw[b][r] = 0.f;
+  const int L = lane & 15, g1 = (lane >> 4) & 1, h = lane >> 5;
+  const int pt = wave / NCT, ct = wave % NCT;   // this wave's data-gradient tile: pixels pt*32.., input channels ct*32..
+
+  auto mma = [&](const s16x8& a, const s16x8& b, f32x16& c) {
+    if constexpr (std::is_same<T, f16_t>::value) c = cn_mfma_32x32x16_f16(a, b, c);
+    else c = cn_mfma_32x32x16_bf16(a, b, c);
+  };
+  auto compute = [&](int mb) {
+    // ---- data gradient: D[i = ci][j = pixel], k = co ascending in steps of 16 (igemm_kernel's order)
+    f32x16 accd;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accd[r] = 0.f;
+    {
+      const int wrow = ct * 32 + (lane & 31);
+      const int prow = pt * 32 + (lane & 31);
+      const char* wbase = wT + wrow * PW;
+      const char* dbase = dyT + prow * PD;
+      const int wsw = wrow & (NCG - 1), dsw = (prow >> 2) & 3;
+#pragma unroll 4
+      for (int kk = 0; kk < CO / 16; ++kk) {
+        const int c = 2 * kk + h;
+        const s16x8 a = __builtin_bit_cast(s16x8, cn_ld16(wbase + ((c ^ wsw) << 4)));
+        const s16x8 b = __builtin_bit_cast(s16x8, cn_ld16(dbase + (((c & ~3) | ((c & 3) ^ dsw)) << 4)));
+        mma(a, b, accd);
+      }
+      const int m = mb + prow;
+      if (m < m_end) {
+        char* dst = p.dx + ((size_t)m * CI + (size_t)(ct * 32 + 4 * h)) * 2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {   // 4 consecutive input channels per lane and q
+          u32x2 pk;
+          pk[0] = cn_pack2<T>(accd[q * 4], accd[q * 4 + 1]);
+          pk[1] = cn_pack2<T>(accd[q * 4 + 2], accd[q * 4 + 3]);
+          *(u32x2*)(dst + q * 16) = pk;
+        }
+      }
+    }
+    // ---- weight gradient: D[i = co][j = ci], k = the BM pixels of this stage
+#pragma unroll
+    for (int kk = 0; kk < BM / 16; ++kk) {
+      const int rbase = kk * 16 + h * 8 + (L >> 2);
+      const int cbase = g1 * 16 + (L & 3) * 4;
+      const int col = wave * 32 + cbase;            // this wave's 32 output channels
+      const int chunk = col >> 3, within = (col & 7) * 2;
+      const int sw = (rbase >> 2) & 3;               // (rbase + 4) >> 2 = that + 1
+      const char* q0 = dyT + rbase * PD + ((((chunk & ~3) | ((chunk & 3) ^ sw)) << 4) + within);
+      const char* q1 = dyT + (rbase + 4) * PD + ((((chunk & ~3) | ((chunk & 3) ^ ((sw + 1) & 3))) << 4) + within);
+      const s16x4 lo = cn_lds_read_tr16_b64(q0);
+      const s16x4 hi = cn_lds_read_tr16_b64(q1);
+      const s16x8 af = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+      for (int b = 0; b < NCT; ++b) {
+        const char* qx = xT + rbase * PX + (b * 32 + cbase) * 2;
+        const s16x4 xl = cn_lds_read_tr16_b64(qx);
+        const s16x4 xh = cn_lds_read_tr16_b64(qx + 4 * PX);
+        const s16x8 bf = __builtin_shufflevector(xl, xh, 0, 1, 2, 3, 4, 5, 6, 7);
+        mma(af, bf, accw[b]);
+      }
+    }
+  };
+
+  if (m_begin < m_end) {
+    load_stage(m_begin);
+    for (int mb = m_begin; mb < m_end; mb += BM) {
+      store_stage();
+      __syncthreads();
+      if (mb + BM < m_end) load_stage(mb + BM);
+      compute(mb);
+      __syncthreads();
+    }
+  }
+  float* out = p.part + (size_t)split * (size_t)CO * (size_t)CI;
+#pragma unroll
+  for (int b = 0; b < NCT; ++b) {
+    const int col = b * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      out[(size_t)co * CI + col] = accw[b][r];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // 3x3 / stride 1 / pad 1 weight gradient with the activation staged ONCE per band of image rows (round 3).
 //
 // The tile kernels above treat every tap as its own block of GEMM columns: each (co, tap*ci) tile re-gathers its
@@ -990,8 +1211,9 @@ static void wg_launch(const WgradParams& p, const WgradPlan& pl, hipStream_t str
                      std::is_same<T, float>::value ? "float" : (std::is_same<T, f16_t>::value ? "f16_t" : "bf16_t"), pl.BI == 64 ? 64 : 128,
                      p.dy2 != nullptr ? ", true" : "");
   if (p.dy2 != nullptr) {
-    if (pl.BI == 64) CN_LAUNCH((wgrad_kernel<T, 64, 128, true>), grid, dim3(256), stream, p);
-    else CN_LAUNCH((wgrad_kernel<T, 128, 128, true>), grid, dim3(256), stream, p);
+    if (pl.BI == 64) CN_LAUNCH((wgrad_kernel<T, 64, 128, 1>), grid, dim3(256), stream, p);
+    else if (cn_get_option("wgrad_lazy_occ", 1) != 0) CN_LAUNCH((wgrad_kernel<T, 128, 128, 2>), grid, dim3(256), stream, p);
+    else CN_LAUNCH((wgrad_kernel<T, 128, 128, 1>), grid, dim3(256), stream, p);
     return;
   }
   if (pl.BI == 64) CN_LAUNCH((wgrad_kernel<T, 64, 128>), grid, dim3(256), stream, p);
@@ -1131,5 +1353,62 @@ static int wg_conv2d_wgrad(const void* x, const void* dy, float* dw_krsc, int C_
   if (nb > 8192) nb = 8192;
   CN_LAUNCH(wgrad_reduce_kernel, dim3(nb), dim3(256), (hipStream_t)stream, (const float*)workspace, dw_krsc,
             pl.nsplit, K, R * S, C, C_real, beta, scale);
+  return cn_check_launch("wgrad_reduce");
+}
+
+// Junction pair entry point (see jbwd_kernel): shapes it is instantiated for.
+extern "C" int cn_conv2d_bwd1x1_lazy_ok(int C, int K, int dtype) {
+  return (dtype == CN_BF16 || dtype == CN_F16) && K == 256 && C == 64 ? 1 : 0;
+}
+static int jb_splits(long long M) {
+  int ns = cn_get_option("jbwd_splits", 256);
+  if (ns < 1) ns = 1;
+  const long long stages = (M + 127) / 128;
+  if (ns > stages) ns = (int)stages;
+  return ns;
+}
+extern "C" size_t cn_conv2d_bwd1x1_lazy_workspace(int N, int H, int W, int C, int K) {
+  return (size_t)jb_splits((long long)N * H * W) * (size_t)K * (size_t)C * sizeof(float);
+}
+// dx = conv1x1 data gradient and dw_krsc = beta*dw + scale * weight gradient of y = conv1x1(x, w) (x [N,H,W,C],
+// K output channels) for the upstream gradient dy = c1*g + c2*bn_y + c3 (coef = [c1 | c2 | c3], 3*K floats), formed
+// on load: cn_conv2d_dgrad_lazy + cn_conv2d_wgrad_lazy in one pass over g and bn_y.  dx has the bits of
+// cn_conv2d_dgrad_lazy; dw differs from cn_conv2d_wgrad_lazy by fp32 summation order only (other pixel ranges).
+extern "C" int cn_conv2d_bwd1x1_lazy(const void* x, const void* g, const void* bn_y, const float* coef,
+                                     const void* w_crsk, void* dx, float* dw_krsc, int N, int H, int W, int C, int K,
+                                     int dtype, float beta, float scale, void* workspace, size_t ws_bytes,
+                                     void* stream) {
+  if (x == nullptr || g == nullptr || bn_y == nullptr || coef == nullptr || w_crsk == nullptr || dx == nullptr ||
+      dw_krsc == nullptr) { cn_set_error("conv2d_bwd1x1_lazy: null operand"); return CN_EINVAL; }
+  if (!cn_conv2d_bwd1x1_lazy_ok(C, K, dtype)) { cn_set_error("conv2d_bwd1x1_lazy: C=%d K=%d dtype %d is not an instantiated shape", C, K, dtype); return CN_ESHAPE; }
+  const long long M = (long long)N * H * W;
+  if (M <= 0) { cn_set_error("conv2d_bwd1x1_lazy: empty"); return CN_ESHAPE; }
+  const long long gyb = M * K * 2, xb = M * C * 2;
+  if (gyb >= (1ll << 31) || xb >= (1ll << 31)) { cn_set_error("conv2d_bwd1x1_lazy: operand exceeds the 2 GiB buffer-descriptor window"); return CN_ESHAPE; }
+  const int ns0 = jb_splits(M);
+  long long mps = (M + ns0 - 1) / ns0;
+  mps = (mps + 127) / 128 * 128;
+  const int nsplit = (int)((M + mps - 1) / mps);
+  if (workspace == nullptr || ws_bytes < (size_t)nsplit * K * C * sizeof(float)) { cn_set_error("conv2d_bwd1x1_lazy: workspace too small"); return CN_EWORKSPACE; }
+  JbParams p;
+  memset(&p, 0, sizeof(p));
+  p.g = (const char*)g; p.y = (const char*)bn_y; p.coef = coef; p.w = (const char*)w_crsk; p.x = (const char*)x;
+  p.dx = (char*)dx; p.part = (float*)workspace;
+  p.M = (int)M; p.m_per_split = (int)mps; p.nsplit = nsplit;
+  p.gy_bytes = (unsigned int)gyb; p.x_bytes = (unsigned int)xb;
+  hipStream_t st = (hipStream_t)stream;
+  const int phase = cn_get_option("wgrad_phase", 0);   // measurement only, as cn_conv2d_wgrad
+  if (phase != 2) {
+    cn_set_last_kernel("jbwd_kernel<%s, 256, 64, 128>", dtype == CN_F16 ? "f16_t" : "bf16_t");
+    if (dtype == CN_F16) CN_LAUNCH((jbwd_kernel<f16_t, 256, 64, 128>), dim3((unsigned)nsplit), dim3(512), st, p);
+    else CN_LAUNCH((jbwd_kernel<bf16_t, 256, 64, 128>), dim3((unsigned)nsplit), dim3(512), st, p);
+    int rc = cn_check_launch("jbwd");
+    if (rc) return rc;
+  }
+  if (phase == 1) return CN_OK;
+  long long total = (long long)K * C;
+  unsigned nb = (unsigned)((total + 255) / 256);
+  CN_LAUNCH(wgrad_reduce_kernel, dim3(nb), dim3(256), st, (const float*)workspace, dw_krsc, nsplit, K, 1, C, C, beta,
+            scale);
   return cn_check_launch("wgrad_reduce");
 }

@@ -284,6 +284,11 @@ DUAL_BN = os.environ.get('CONVNET_AMD_DUAL_BN', '1') == '1'
 LAZY_Z = os.environ.get('CONVNET_AMD_LAZY_Z', '1') == '1'
 LAZY_Z_MIN_MB = float(os.environ.get('CONVNET_AMD_LAZY_Z_MIN_MB', '150'))
 LAZY_Z_SCOPE = [0]
+# Junction pair (round 3): where lazy dy applies and the convolution has an instantiated shape (64 -> 256 channels: conv3
+# and the projection of ResNet-50's first stage), its data gradient and weight gradient run as ONE kernel on the backward
+# chain (cn_conv2d_bwd1x1_lazy): g and y are read once instead of twice.  dx bit-identical, dW differs by fp32
+# summation order.  CONVNET_AMD_JPAIR=0: the two lazy kernels (A/B).
+JPAIR = os.environ.get('CONVNET_AMD_JPAIR', '1') == '1'
 # junction fusion only for BN inputs of at least this many MB (A/B knob; 0 = every junction)
 FUSE_BN_BWD_JUNC_MIN_MB = float(os.environ.get('CONVNET_AMD_FUSE_BN_BWD_JUNC_MIN_MB', '0'))
 
@@ -507,6 +512,35 @@ def conv2d_wgrad_lazy(x, g, bn_y, coef, dw_krsc, c_real, K, R, S, stride, pad, b
                  x.device, detail=_conv_detail('wgrad', C, H, K, R, stride))
 
 
+def conv2d_bwd1x1_lazy(x, g, bn_y, coef, w_crsk, dw_krsc, K, beta=1.0, scale=1.0):
+    """dx and the weight gradient of a 1x1 / stride-1 convolution for the lazy upstream gradient (g, bn_y, coef), one
+    pass over g and bn_y (cn_conv2d_bwd1x1_lazy)."""
+    N, H, W, C = x.shape
+    code = dtype_code(x.dtype)
+    L = _L()
+    need = L.cn_conv2d_bwd1x1_lazy_workspace(N, H, W, C, K)
+    ws = workspace(need, x.device, 'main')
+    dx = torch.empty_like(x)
+
+    def call():
+        check(L.cn_conv2d_bwd1x1_lazy(ptr(x), ptr(g), ptr(bn_y), ptr(coef), ptr(w_crsk), ptr(dx), ptr(dw_krsc), N, H, W, C,
+                                      K, code, beta, scale, ptr(ws), ws.numel() * 4, stream_of(x)), 'cn_conv2d_bwd1x1_lazy')
+    if not (PROFILER.enabled and x.is_cuda):
+        call()
+        return dx
+    flops = 4.0 * g.numel() * C
+    detail = _conv_detail('dgrad+wgrad', C, H, K, 1, (1, 1))
+    L.cn_set_option(b'wgrad_phase', 1)
+    try:
+        PROFILER.run(_last_kernel(' [lazy dy]'), 1, flops, 2 * g.numel() * _esize(g) + 2 * x.numel() * _esize(x)
+                     + float(need), call, x.device, detail=detail)
+        L.cn_set_option(b'wgrad_phase', 2)
+        PROFILER.run('wgrad_reduce_kernel', 1, 0.0, float(need) + K * C * 4, call, x.device, detail=detail + ' [reduce]')
+    finally:
+        L.cn_set_option(b'wgrad_phase', 0)
+    return dx
+
+
 def weight_prep(w_master_krsc, w_krsc, w_crsk, Co, taps, c_real, c_pad):
     PROFILER.run('weight_prep', 1, 0.0, Co * taps * c_real * 4 + Co * taps * c_pad * _esize(w_krsc) * (2 if w_crsk is not None else 1),
                  lambda: check(_L().cn_weight_prep(ptr(w_master_krsc), ptr(w_krsc), ptr(w_crsk), Co, taps, c_real,
@@ -654,6 +688,19 @@ class Conv2dFunction(Function):
         R, S = mod.kernel_size
         if lazy is not None:
             g, bn_y, coef = lazy
+            if JPAIR and (R, S) == (1, 1) and mod.stride == (1, 1) and mod.padding == (0, 0) and ctx.needs_input_grad[0] \
+                    and mod.in_channels == x.shape[-1] \
+                    and _L().cn_conv2d_bwd1x1_lazy_ok(x.shape[-1], mod.out_channels, dtype_code(x.dtype)):
+                # junction pair: both gradients of this convolution in one pass over (g, bn_y), on the backward chain
+                holder = getattr(mod, '_res_holder', None)
+                if holder is not None and holder.dres is not None:
+                    raise _lib.ConvNetHipError('lazy dy met a fused-addend dgrad: the junction layout changed')
+                dx = conv2d_bwd1x1_lazy(x, g, bn_y, coef, mod.w_crsk, mod.grad_view('weight'), mod.out_channels)
+                mod._notify_grad_ready()
+                COUNTERS['jpair'] = COUNTERS.get('jpair', 0) + 1
+                if holder is not None:
+                    holder.dres, holder.sub, holder.fused = dx, 1, False
+                return dx, None, None, None
             if SIDE.active(x):
                 def launch():
                     conv2d_wgrad_lazy(x, g, bn_y, coef, mod.grad_view('weight'), mod.in_channels, mod.out_channels, R, S,

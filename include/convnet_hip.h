@@ -156,6 +156,16 @@ int cn_conv2d_dgrad_lazy(const void* g, const void* bn_y, const float* coef, con
 int cn_conv2d_wgrad_lazy(const void* x, const void* g, const void* bn_y, const float* coef, float* dw_krsc, int C_real,
                          int N, int H, int W, int C, int K, int R, int S, int stride_h, int stride_w, int pad_h,
                          int pad_w, int dtype, float beta, float scale, void* workspace, size_t ws_bytes, void* stream);
+/* Junction pair: cn_conv2d_dgrad_lazy + cn_conv2d_wgrad_lazy of one 1x1 / stride-1 convolution in ONE pass over g and
+ * bn_y (the two junction-sized reads of each are shared; /root/reference reaches both through loss.backward(),
+ * trainer.py:162, for models/resnet.py:126-132's conv3 and :176-181's projection).  dx: the bits of
+ * cn_conv2d_dgrad_lazy; dw_krsc = beta*dw + scale*wgrad, fp32 summation order of its own pixel ranges.  Instantiated
+ * shapes: cn_conv2d_bwd1x1_lazy_ok(C, K, dtype) != 0 (K = 256 output, C = 64 input channels, 16-bit storage). */
+int cn_conv2d_bwd1x1_lazy_ok(int C, int K, int dtype);
+size_t cn_conv2d_bwd1x1_lazy_workspace(int N, int H, int W, int C, int K);
+int cn_conv2d_bwd1x1_lazy(const void* x, const void* g, const void* bn_y, const float* coef, const void* w_crsk, void* dx,
+                          float* dw_krsc, int N, int H, int W, int C, int K, int dtype, float beta, float scale,
+                          void* workspace, size_t ws_bytes, void* stream);
 
 /* ---- nn.BatchNorm2d (+ fused residual add + ReLU) (models/resnet.py:128-134,141-165) -------- */
 size_t cn_bn_workspace(int M, int C, int dtype);

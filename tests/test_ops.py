@@ -1171,3 +1171,49 @@ def test_lazy_z_conv_equals_apply_then_conv(mode, dtype, dual):
         assert torch.equal(o.cpu(), o_ref.cpu())
         assert ps.rows == ps_ref.rows and torch.equal(ps.partial.cpu(), ps_ref.partial.cpu())
         assert float(o.float().abs().sum()) > 0
+
+
+@pytest.mark.parametrize('mode', MODES)
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_junction_pair_equals_lazy_dgrad_and_wgrad(mode, dtype):
+    """cn_conv2d_bwd1x1_lazy (data + weight gradient of a 64 -> 256 channel 1x1 convolution in one pass over g and y): dx
+    has the bits of cn_conv2d_dgrad_lazy, dW equals cn_conv2d_wgrad_lazy up to fp32 summation order (other pixel
+    ranges), and both agree with the CPU products of the dy the apply kernel would have stored."""
+    _f16_emul_subset(mode, dtype, keep=True)
+    dev = _dev(mode)
+    import convnet_amd as ca
+    ops = ca.ops
+    L = ca._lib.load()
+    C, K = 64, 256
+    shapes = [(1, 10, 13), (2, 16, 16)] if mode == 'emul' else [(3, 56, 56), (256, 56, 56), (5, 17, 9)]
+    for (N, H, W) in shapes:
+        g_ = torch.Generator().manual_seed(N * H + W)
+        gq = (torch.randn(N, H, W, K, generator=g_) * 0.5).to(dtype).to(dev)
+        yq = (torch.randn(N, H, W, K, generator=g_) * 1.2 + 0.1).to(dtype).to(dev)
+        x = torch.randn(N, H, W, C, generator=g_).to(dtype).to(dev)
+        coef = torch.cat([torch.rand(K, generator=g_) + 0.5, torch.randn(K, generator=g_) * 0.05,
+                          torch.randn(K, generator=g_) * 0.01]).to(dev)
+        w = (torch.randn(K, 1, 1, C, generator=g_) * (2.0 / C) ** 0.5).to(dtype).to(dev)
+        wc = w.permute(3, 1, 2, 0).contiguous()
+        L.cn_set_option(b'jbwd_splits', 3 if mode == 'emul' else 256)
+        try:
+            dw = torch.zeros(K, 1, 1, C, dtype=torch.float32, device=dev)
+            dx = ops.conv2d_bwd1x1_lazy(x, gq, yq, coef, wc, dw, K, beta=0.0)
+        finally:
+            L.cn_set_option(b'jbwd_splits', 256)
+        assert 'jbwd_kernel' in L.cn_last_kernel_name().decode() or 'reduce' in L.cn_last_kernel_name().decode()
+        dx_ref = ops.conv2d_dgrad_lazy(gq, yq, coef, wc, x.shape, K, 1, 1, (1, 1), (0, 0))
+        dw_ref = torch.zeros_like(dw)
+        ops.conv2d_wgrad_lazy(x, gq, yq, coef, dw_ref, C, K, 1, 1, (1, 1), (0, 0), beta=0.0)
+        if dtype == torch.bfloat16 or mode == 'emul':
+            assert torch.equal(dx.cpu(), dx_ref.cpu()), (N, H, W)
+        else:   # fp16 on the GPU: hipcc may fold the dy rounding into a mixed-precision FMA in one kernel and not in the
+            # other (single vs double rounding of a few elements in 10^4): equal to a few fp16 ulps, not bit for bit
+            assert rel_l2(dx.float().cpu(), dx_ref.float().cpu()) < 2e-4, (N, H, W)
+        assert rel_l2(dw.cpu(), dw_ref.cpu()) < (2e-6 if dtype == torch.bfloat16 or mode == 'emul' else 2e-4), (N, H, W, rel_l2(dw.cpu(), dw_ref.cpu()))
+        if N * H * W <= 12000:     # CPU products of the rounded dy
+            dy = (coef[:K].cpu() * gq.float().cpu() + (coef[K:2 * K].cpu() * yq.float().cpu() + coef[2 * K:].cpu())).to(dtype).float()
+            dw_cpu = dy.reshape(-1, K).t() @ x.float().cpu().reshape(-1, C)
+            dx_cpu = dy.reshape(-1, K) @ w.float().cpu().reshape(K, C)
+            assert rel_l2(dw.cpu().reshape(K, C), dw_cpu) < 1e-3
+            assert rel_l2(dx.float().cpu().reshape(-1, C), dx_cpu) < _tol(dtype)

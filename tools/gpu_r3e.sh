@@ -2,5 +2,19 @@
 export TMPDIR=/tmp
 OUT=gpurun_out/${1:-r3e}
 mkdir -p $OUT
-echo "== warm parity + local consistency"; timeout 1400 python -m pytest tests/test_warm_parity.py tests/test_step_local_consistency.py -m gpu -q --tb=short -p no:cacheprovider -s 2>&1 | grep -v "Warning\|warn\|detach\|total +=\|INFO\|^$" | tail -80 | tee $OUT/pytest_parity.txt
-echo "== done"; date
+timeout 600 python -m pytest tests/test_ops.py tests/test_trajectory.py -x -q -m gpu -k "lazy" 2>&1 | tail -3 | tee $OUT/pytest.txt
+run() { name=$1; shift; echo -n "$name: "; env "$@" timeout 300 python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-kernel-profile 2>&1 | grep '"metric"\|Error\|error' | head -2 | python -c "
+import sys,json
+t=sys.stdin.read()
+try:
+    d=json.loads(t); print(d['value'], d['ms_per_step'], d['config']['final_loss'])
+except Exception: print('FAILED', t[:300])"; }
+{
+run warm X=1
+for i in 1 2 3; do
+run new_$i X=1
+run wgocc0_$i CONVNET_AMD_OPTIONS=wgrad_lazy_occ=0
+run xf8w0_$i CONVNET_AMD_OPTIONS=igemm_xf_8w=0
+run both0_$i CONVNET_AMD_OPTIONS=wgrad_lazy_occ=0,igemm_xf_8w=0
+done
+} 2>&1 | tee $OUT/sched.txt

@@ -2,6 +2,18 @@
 export TMPDIR=/tmp
 OUT=gpurun_out/${1:-r3f}
 mkdir -p $OUT
-echo "== A/B c64 tile"; timeout 600 python tools/bench_ab.py --knob igemm_c64_bm256 --values 0,1,2 --only 2,4 2>&1 | grep -v amdgpu.ids | tee $OUT/ab_c64.txt
-echo "== A/B ilv fragdb"; timeout 600 python tools/bench_ab.py --knob igemm_ilv_fragdb --values 0,1 --only 12,15,16,17,20 2>&1 | grep -v amdgpu.ids | tee $OUT/ab_ilv_fragdb.txt
-echo "== done"; date
+timeout 900 python -m pytest tests/test_ops.py tests/test_trajectory.py tests/test_step_local_consistency.py -x -q -m gpu -k "junction_pair or local" 2>&1 | tail -8 | tee $OUT/pytest.txt
+run() { name=$1; shift; echo -n "$name: "; env "$@" timeout 300 python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-kernel-profile 2>&1 | grep '"metric"\|Error\|error' | head -2 | python -c "
+import sys,json
+t=sys.stdin.read()
+try:
+    d=json.loads(t); print(d['value'], d['ms_per_step'], d['config']['final_loss'])
+except Exception: print('FAILED', t[:300])"; }
+{
+run warm X=1
+for i in 1 2 3; do
+run pair_$i X=1
+run nopair_$i CONVNET_AMD_JPAIR=0
+run pair512_$i CONVNET_AMD_OPTIONS=jbwd_splits=512
+done
+} 2>&1 | tee $OUT/sched.txt
