@@ -48,6 +48,9 @@ _SIGNATURES = {
     'cn_conv2d_fwd_bnstats_centered': (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 11 + [c_i, c_i, c_p, c_i, c_p, c_p]),
     'cn_conv2d_fwd_xf': (c_i, [c_p, c_p, c_i, c_p, c_p] + [c_i] * 11 + [c_i, c_p, c_i, c_p]),
     'cn_conv2d_dgrad': (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 11 + [c_i, c_i, c_p]),
+    'cn_conv2d_dgrad_junction_ok': (c_i, [c_i, c_i, c_i]),
+    'cn_conv2d_dgrad_junction_rows': (c_i, [c_i] * 4),
+    'cn_conv2d_dgrad_junction': (c_i, [c_p, c_p, c_p, c_p, c_i] + [c_i] * 6 + [c_p, c_p, c_p, c_p, c_i, c_p]),
     'cn_conv2d_dgrad_bnbwd_rows': (c_i, [c_i] * 6),
     'cn_conv2d_dgrad_bnbwd': (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 11 + [c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_p]),
     'cn_conv2d_dgrad_sa': (c_i, [c_p, c_p, c_p, c_p, c_i] + [c_i] * 11 + [c_i, c_i, c_p]),

@@ -457,6 +457,15 @@ __device__ __forceinline__ int cn_uniform(int v) { return __builtin_amdgcn_readf
 static inline int cn_uniform(int v) { return v; }
 #endif
 
+// Wave-level rendezvous for data exchanged between the lanes of ONE wave through LDS (a wave's LDS operations execute
+// in order, so the hardware needs no instruction; the compiler must not move LDS accesses across it, and the emulator,
+// which runs every lane as its own fiber, has to line the lanes up).
+#ifndef CN_EMULATE
+__device__ __forceinline__ void cn_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+#else
+static inline void cn_wave_sync() { int x = 0; cn_emul::wave_gather(&x); cn_emul::wave_release(); }
+#endif
+
 // Scheduling fence: nothing is moved across it by hipcc's machine scheduler (used to keep the
 // fragment reads of the NEXT k-step ahead of the MFMAs of the current one).
 #ifndef CN_EMULATE

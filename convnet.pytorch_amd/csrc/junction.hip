@@ -1,0 +1,319 @@
+// junction.hip -- the data gradient of a residual block's first 1x1 convolution fused with everything that meets it at
+// the block input, as ONE streaming kernel (round 3; replaces the igemm_kernel<..., EPI> launches of the large
+// junctions).
+//
+// What happens at the block input in backward (/root/reference models/resnet.py:141-165 run in reverse by
+// loss.backward(), trainer.py:162): the gradient of conv1's input, dx = dy1 * W, is added to the gradient arriving over
+// the shortcut; the sum is masked by the ReLU of the junction that produced the block input; the result g is the
+// upstream gradient of that junction's BatchNorm, whose backward needs sum(g) and sum(g * xhat) per channel.
+// cn_conv2d_dgrad_bnbwd(_sa) does all of that in the epilogue of the tiled implicit-GEMM kernel.  That kernel is a GEMM
+// kernel: one 128 x 128 output tile per workgroup, half a dozen workgroup barriers per tile, a fresh workgroup (launch,
+// index tables) every ~100 KB - and this operation is not a GEMM but a STREAM: per output element 2 bytes of addend, 2
+// of BatchNorm input, 2 of g and 1/8 of mask against 2*KD flops with KD = 64 ... 128, i.e. 6+ bytes per 128 - 256 flops.
+// It ran at 3.5 TB/s alone where the streaming kernels of this library reach 5.
+//
+// Here a workgroup is persistent over a contiguous range of pixels and owns ALL CO output channels:
+//   * the filter (CO x KD) lives in registers as MFMA A-fragments for the whole launch (a wave owns 64 channels);
+//   * per stage of BM = 32 or 64 pixels the dy tile (BM x KD, a few KB) goes through a double-buffered LDS tile - one
+//     workgroup barrier per stage -; every wave multiplies its 64 channels x 32 pixels;
+//   * the accumulators are transposed to pixel rows through a WAVE-PRIVATE LDS patch (no workgroup barrier): a lane then
+//     holds 16 bytes of 8 consecutive channels of one pixel, so the addend / BatchNorm-input loads and the g stores are
+//     16 bytes per lane and 128 contiguous bytes per pixel row, and they are requested a stage AHEAD;
+//   * the BatchNorm-backward sums stay in registers for the whole pixel range: one partial row per workgroup (a few
+//     hundred rows per launch instead of one per 128 pixels: no row compression before the finalize).
+// g has the bits of cn_conv2d_dgrad_bnbwd_sa (same operand orientation, k order and rounding sequence); the partial sums
+// are associated differently (fp32).
+#include "cn_common.h"
+#include "cn_api_internal.h"
+#include <type_traits>
+
+struct JdParams {
+  const char* dy;                // [M][KD] upstream gradient of conv1's output
+  const char* w;                 // [CO][KD] filter in data-gradient order (CRSK of a 1x1 convolution)
+  const char* addend;            // [M][CO], or [N][add_H][add_W][CO] (addend_sub = 2: even (h, w) pixels only)
+  const char* bn_y;              // [M][CO] input of the BatchNorm whose output is conv1's input
+  const unsigned char* bn_mask;  // [M][CO / 8] ReLU bits of that junction
+  const float* bn_coef;          // [mean | invstd | scale | shift]
+  char* g;                       // [M][CO]
+  float* partial;                // [nsplit][2 * CO]
+  int M, m_per_split, nsplit;
+  int addend_sub, H, W, add_H, add_W;
+  FastDiv div_hw, div_w;
+  unsigned int dy_bytes, out_bytes, add_bytes, mask_bytes;
+};
+
+template <typename T, int KD, int CO>
+__global__ __launch_bounds__(512) void jdgrad_kernel(JdParams p) {
+  static_assert(sizeof(T) == 2, "16-bit storage");
+  constexpr int NCW = CO / 64;          // wave columns of 64 channels
+  static_assert(NCW == 4 || NCW == 8, "256 or 512 output channels");
+  constexpr int PH = 8 / NCW;           // 32-pixel groups per stage
+  constexpr int BM = 32 * PH;
+  constexpr int NKK = KD / 16;
+  constexpr int NCD = KD / 8;           // 16-byte chunks per dy row
+  constexpr int DYB = BM * KD * 2;      // bytes of one dy tile
+  constexpr int ND = BM * NCD / 512;    // dy chunks staged per thread
+  static_assert(ND >= 1 && BM * NCD % 512 == 0, "dy tile staging");
+  constexpr int PP = 144;               // pitch of the wave-private transposition patch (32 rows of 128 + 16 bytes)
+  constexpr int PRIV = 32 * PP;
+  __shared__ __attribute__((aligned(16))) char lds[2 * DYB + 8 * PRIV];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = cn_uniform(tid >> 6);
+  const int cw = wave % NCW, ph = wave / NCW;
+  const int h = lane >> 5;
+  char* priv = lds + 2 * DYB + wave * PRIV;
+
+  const int split = blockIdx.x;
+  const int m_begin = split * p.m_per_split;
+  int m_end = m_begin + p.m_per_split;
+  if (m_end > p.M) m_end = p.M;
+
+  // filter fragments: this wave's 2 x 32 channels (MFMA rows), all of k
+  s16x8 wf[2][NKK];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+      const int c = cw * 64 + t * 32 + (lane & 31);
+      wf[t][kk] = __builtin_bit_cast(s16x8, cn_ld16(p.w + ((size_t)c * KD + 16 * kk + 8 * h) * 2));
+    }
+
+  const cn_buf_t dybuf = cn_make_buf(p.dy, p.dy_bytes);
+  const cn_buf_t abuf = cn_make_buf(p.addend, p.add_bytes);
+  const cn_buf_t ybuf = cn_make_buf(p.bn_y, p.out_bytes);
+  // epilogue coordinates of this lane: pixel rows pass*8 + (lane >> 3) of the wave's 32, chunk (8 channels) lane & 7
+  const int ech = lane & 7, erow = lane >> 3;
+  const int cb = cw * 64 + ech * 8;     // first channel of the lane's chunk
+  const int HW = p.H * p.W;
+
+  struct Epi {
+    u32x4 a[4], y[4];
+    unsigned int bits[4];
+  };
+  u32x4 dreg[ND];
+  auto load_stage = [&](int mb, Epi& e) {
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const int id = tid + 512 * i;
+      const int row = id / NCD, c = id - row * NCD;
+      const int m = mb + row;
+      dreg[i] = cn_buf_ld16(dybuf, m < m_end ? ((unsigned int)m * (unsigned int)KD + (unsigned int)c * 8u) * 2u : CN_OOB);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int m = mb + ph * 32 + k * 8 + erow;
+      const bool ok = m < m_end;
+      const unsigned int o = ok ? ((unsigned int)m * (unsigned int)CO + (unsigned int)cb) * 2u : CN_OOB;
+      unsigned int oa = o;
+      if (p.addend_sub == 2) {   // the addend exists at even (h, w) only, stored compactly
+        const int mm = ok ? m : 0;
+        const int n = (int)cn_fastdiv((unsigned)mm, p.div_hw);
+        const int rem = mm - n * HW;
+        const int ho = (int)cn_fastdiv((unsigned)rem, p.div_w);
+        const int wo = rem - ho * p.W;
+        const bool even = ((ho | wo) & 1) == 0;
+        const int apx = (n * p.add_H + (ho >> 1)) * p.add_W + (wo >> 1);
+        oa = (ok && even) ? ((unsigned int)apx * (unsigned int)CO + (unsigned int)cb) * 2u : CN_OOB;
+      }
+      e.a[k] = cn_buf_ld16(abuf, oa);
+      e.y[k] = cn_buf_ld16(ybuf, o);
+      e.bits[k] = ok ? (unsigned int)p.bn_mask[(size_t)m * (CO / 8) + (cb >> 3)] : 0u;
+    }
+  };
+  auto store_dy = [&](int buf) {
+    char* t = lds + buf * DYB;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const int id = tid + 512 * i;
+      const int row = id / NCD, c = id - row * NCD;
+      const int cs = NCD == 8 ? (c ^ ((row >> 1) & 7)) : (c ^ (row & (NCD - 1)));
+      cn_st16(t + row * (KD * 2) + (cs << 4), dreg[i]);
+    }
+  };
+
+  float bs1[8], bs2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { bs1[e] = 0.f; bs2[e] = 0.f; }
+
+  auto compute = [&](int mb, int buf, const Epi& ep) {
+    const char* t = lds + buf * DYB;
+    f32x16 acc[2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+    const int prow = ph * 32 + (lane & 31);
+    const char* rowp = t + prow * (KD * 2);
+    const int sw = NCD == 8 ? ((prow >> 1) & 7) : (prow & (NCD - 1));
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+      const s16x8 b = __builtin_bit_cast(s16x8, cn_ld16(rowp + (((2 * kk + h) ^ sw) << 4)));
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+        if constexpr (std::is_same<T, f16_t>::value) acc[x] = cn_mfma_32x32x16_f16(wf[x][kk], b, acc[x]);
+        else acc[x] = cn_mfma_32x32x16_bf16(wf[x][kk], b, acc[x]);
+      }
+    }
+    // accumulators -> stored precision -> wave-private patch [32 pixels][64 channels]
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        u32x2 pk;
+        pk[0] = cn_pack2<T>(acc[x][q * 4], acc[x][q * 4 + 1]);
+        pk[1] = cn_pack2<T>(acc[x][q * 4 + 2], acc[x][q * 4 + 3]);
+        *(u32x2*)(priv + (lane & 31) * PP + (x * 32 + 8 * q + 4 * h) * 2) = pk;
+      }
+    cn_wave_sync();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int m = mb + ph * 32 + k * 8 + erow;
+      const u32x4 v0 = cn_ld16(priv + (k * 8 + erow) * PP + ech * 16);
+      if (m < m_end) {
+        float fv[8], fa[8], yv[8];
+        Chunk<T>::unpack(v0, fv);
+        Chunk<T>::unpack(ep.a[k], fa);
+        Chunk<T>::unpack(ep.y[k], yv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fv[e] += fa[e];
+        const unsigned int bits = ep.bits[k];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fv[e] = ((bits >> e) & 1u) ? fv[e] : 0.f;
+        const u32x4 v = Chunk<T>::pack(fv);
+        Chunk<T>::unpack(v, fv);     // statistics of the values as stored
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          bs1[e] += fv[e];
+          bs2[e] = fmaf(fv[e], yv[e], bs2[e]);
+        }
+        cn_st16(p.g + ((size_t)m * CO + (size_t)cb) * 2, v);
+      }
+    }
+    cn_wave_sync();   // the patch is rewritten by the next stage
+  };
+
+  if (m_begin < m_end) {
+    Epi cur, nxt;
+    load_stage(m_begin, cur);
+    int buf = 0;
+    for (int mb = m_begin; mb < m_end; mb += BM) {
+      store_dy(buf);
+      __syncthreads();    // (two dy tiles: the tile of stage s + 1 is written while stage s is still being read: one barrier per stage)
+      const bool more = mb + BM < m_end;
+      if (more) load_stage(mb + BM, nxt);
+      compute(mb, buf, cur);
+      if (more) cur = nxt;
+      buf ^= 1;
+    }
+  }
+  // ---- BatchNorm-backward partial sums of this workgroup's pixel range: [sum g | sum g * xhat]
+  float r1[8], r2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float mu = p.bn_coef[cb + e], is = p.bn_coef[CO + cb + e];
+    r1[e] = bs1[e];
+    r2[e] = is * (bs2[e] - mu * bs1[e]);
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+#pragma unroll
+    for (int msk = 8; msk <= 32; msk <<= 1) {   // the eight row groups of the wave hold the same channels
+      r1[e] += cn_shfl_xor(r1[e], msk);
+      r2[e] += cn_shfl_xor(r2[e], msk);
+    }
+  __syncthreads();
+  float* red = (float*)lds;   // [8 waves][64 channels][2]
+  if (lane < 8) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[(wave * 64 + lane * 8 + e) * 2] = r1[e];
+      red[(wave * 64 + lane * 8 + e) * 2 + 1] = r2[e];
+    }
+  }
+  __syncthreads();
+  if (tid < CO) {
+    const int c = tid, wcol = c / 64, cc = c % 64;
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int g2 = 0; g2 < PH; ++g2) {   // fixed order
+      a1 += red[((g2 * NCW + wcol) * 64 + cc) * 2];
+      a2 += red[((g2 * NCW + wcol) * 64 + cc) * 2 + 1];
+    }
+    float* dst = p.partial + (size_t)split * 2 * CO;
+    dst[c] = a1;
+    dst[CO + c] = a2;
+  }
+}
+
+static int jd_splits(long long M, int BM) {
+  int ns = cn_get_option("jdgrad_splits", 256);
+  if (ns < 1) ns = 1;
+  const long long stages = (M + BM - 1) / BM;
+  if (ns > stages) ns = (int)stages;
+  return ns;
+}
+static int jd_bm(int C) { return C == 256 ? 64 : 32; }
+// pixel ranges: whole stages per workgroup; returns the number of ranges (= partial rows) and their length
+static int jd_plan(long long M, int BM, long long* mps_out) {
+  const int ns0 = jd_splits(M, BM);
+  long long mps = (M + ns0 - 1) / ns0;
+  mps = (mps + BM - 1) / BM * BM;
+  if (mps_out != nullptr) *mps_out = mps;
+  return (int)((M + mps - 1) / mps);
+}
+
+// Shapes the streaming junction kernel is instantiated for: K channels of dy (conv1's outputs), C channels of g.
+extern "C" int cn_conv2d_dgrad_junction_ok(int C, int K, int dtype) {
+  if (dtype != CN_BF16 && dtype != CN_F16) return 0;
+  return ((C == 256 && (K == 64 || K == 128)) || (C == 512 && K == 128)) ? 1 : 0;
+}
+extern "C" int cn_conv2d_dgrad_junction_rows(int N, int H, int W, int C) {
+  return jd_plan((long long)N * H * W, jd_bm(C), nullptr);
+}
+
+// cn_conv2d_dgrad_bnbwd_sa for a 1x1 / stride-1 / unpadded convolution with K -> C channels of an instantiated shape,
+// ReLU bits given (bn_mask) and an addend (dense, or addend_sub = 2: the even pixels of a stride-2 projection's
+// gradient), as one persistent streaming kernel (see the head of this file).  partial: cn_conv2d_dgrad_junction_rows
+// rows of 2*C floats for cn_bn_bwd_partials.  g: the bits of cn_conv2d_dgrad_bnbwd_sa.
+extern "C" int cn_conv2d_dgrad_junction(const void* dy, const void* w_crsk, void* g, const void* addend, int addend_sub,
+                                        int N, int H, int W, int C, int K, int dtype, const void* bn_y,
+                                        const unsigned char* bn_mask, const float* bn_coef, float* partial,
+                                        int partial_rows, void* stream) {
+  if (!cn_conv2d_dgrad_junction_ok(C, K, dtype)) { cn_set_error("conv2d_dgrad_junction: K=%d -> C=%d dtype %d is not an instantiated shape", K, C, dtype); return CN_ESHAPE; }
+  if (dy == nullptr || w_crsk == nullptr || g == nullptr || addend == nullptr || bn_y == nullptr || bn_mask == nullptr ||
+      bn_coef == nullptr || partial == nullptr) { cn_set_error("conv2d_dgrad_junction: null operand"); return CN_EINVAL; }
+  if (addend_sub != 1 && addend_sub != 2) { cn_set_error("conv2d_dgrad_junction: addend subsampling %d (1 or 2)", addend_sub); return CN_EINVAL; }
+  const long long M = (long long)N * H * W;
+  if (M <= 0) { cn_set_error("conv2d_dgrad_junction: empty"); return CN_ESHAPE; }
+  const long long ob = M * C * 2, db = M * K * 2;
+  const int aH = (H + 1) / 2, aW = (W + 1) / 2;
+  const long long ab = addend_sub == 2 ? (long long)N * aH * aW * C * 2 : ob;
+  if (ob >= (1ll << 31) || db >= (1ll << 31)) { cn_set_error("conv2d_dgrad_junction: operand exceeds the 2 GiB buffer-descriptor window"); return CN_ESHAPE; }
+  const int BM = jd_bm(C);
+  long long mps = 0;
+  const int nsplit = jd_plan(M, BM, &mps);
+  if (partial_rows < nsplit) { cn_set_error("conv2d_dgrad_junction: partial buffer of %d rows < %d", partial_rows, nsplit); return CN_EWORKSPACE; }
+  JdParams p;
+  memset(&p, 0, sizeof(p));
+  p.dy = (const char*)dy; p.w = (const char*)w_crsk; p.addend = (const char*)addend; p.bn_y = (const char*)bn_y;
+  p.bn_mask = bn_mask; p.bn_coef = bn_coef; p.g = (char*)g; p.partial = partial;
+  p.M = (int)M; p.m_per_split = (int)mps; p.nsplit = nsplit;
+  p.addend_sub = addend_sub; p.H = H; p.W = W; p.add_H = aH; p.add_W = aW;
+  p.div_hw = cn_make_fastdiv((unsigned)(H * W)); p.div_w = cn_make_fastdiv((unsigned)W);
+  p.dy_bytes = (unsigned int)db; p.out_bytes = (unsigned int)ob; p.add_bytes = (unsigned int)ab;
+  hipStream_t st = (hipStream_t)stream;
+  const char* tn = dtype == CN_F16 ? "f16_t" : "bf16_t";
+  cn_set_last_kernel("jdgrad_kernel<%s, %d, %d>", tn, K, C);
+  dim3 grid((unsigned)nsplit);
+#define JD_GO(KD, CO)                                                                               \
+  do {                                                                                              \
+    if (dtype == CN_F16) CN_LAUNCH((jdgrad_kernel<f16_t, KD, CO>), grid, dim3(512), st, p);          \
+    else CN_LAUNCH((jdgrad_kernel<bf16_t, KD, CO>), grid, dim3(512), st, p);                         \
+  } while (0)
+  if (C == 256 && K == 64) JD_GO(64, 256);
+  else if (C == 256 && K == 128) JD_GO(128, 256);
+  else JD_GO(128, 512);
+#undef JD_GO
+  return cn_check_launch("jdgrad");
+}

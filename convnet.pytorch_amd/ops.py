@@ -289,6 +289,11 @@ LAZY_Z_SCOPE = [0]
 # chain (cn_conv2d_bwd1x1_lazy): g and y are read once instead of twice.  dx bit-identical, dW differs by fp32
 # summation order.  CONVNET_AMD_JPAIR=0: the two lazy kernels (A/B).
 JPAIR = os.environ.get('CONVNET_AMD_JPAIR', '1') == '1'
+# Streaming junction kernel (round 3): the fused junction data gradient (conv1's dgrad + shortcut gradient + ReLU mask +
+# BatchNorm-backward sums) of the instantiated large shapes runs as one persistent streaming kernel
+# (cn_conv2d_dgrad_junction, csrc/junction.hip) instead of the tiled GEMM kernel's epilogue.  g bit-identical, the
+# partial sums in another fp32 association.  CONVNET_AMD_JDGRAD=0: the tiled kernel everywhere (A/B).
+JDGRAD = os.environ.get('CONVNET_AMD_JDGRAD', '1') == '1'
 # junction fusion only for BN inputs of at least this many MB (A/B knob; 0 = every junction)
 FUSE_BN_BWD_JUNC_MIN_MB = float(os.environ.get('CONVNET_AMD_FUSE_BN_BWD_JUNC_MIN_MB', '0'))
 
@@ -443,6 +448,18 @@ def conv2d_dgrad(dy, w_crsk, x_shape, K, R, S, stride, pad, addend=None, bn=None
         return dx
     bn_y, bn_mask, bn_stats, bn_relu = bn
     L = _L()
+    if JDGRAD and (R, S) == (1, 1) and tuple(stride) == (1, 1) and tuple(pad) == (0, 0) and bn_mask is not None \
+            and addend is not None and L.cn_conv2d_dgrad_junction_ok(C, K, dtype_code(dy.dtype)):
+        rows = L.cn_conv2d_dgrad_junction_rows(N, H, W, C)
+        partial = torch.empty((rows, 2 * C), dtype=torch.float32, device=dy.device)
+        PROFILER.run(_last_kernel(), 1, flops, nbytes + dx.numel() * _esize(dx) + partial.numel() * 4,
+                     lambda: check(L.cn_conv2d_dgrad_junction(ptr(dy), ptr(w_crsk), ptr(dx), ptr(addend), int(addend_sub), N,
+                                                              H, W, C, K, dtype_code(dy.dtype), ptr(bn_y), ptr(bn_mask),
+                                                              ptr(bn_stats), ptr(partial), rows, stream_of(dy)),
+                                   'cn_conv2d_dgrad_junction'),
+                     dy.device, detail=detail)
+        COUNTERS['jdgrad'] = COUNTERS.get('jdgrad', 0) + 1
+        return dx, partial, rows
     rows = L.cn_conv2d_dgrad_bnbwd_rows(N, H, W, C, stride[0], stride[1])
     partial = torch.empty((rows, 2 * C), dtype=torch.float32, device=dy.device)
     PROFILER.run(name, stride[0] * stride[1], flops, nbytes + dx.numel() * _esize(dx) + partial.numel() * 4,

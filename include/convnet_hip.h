@@ -135,6 +135,17 @@ int cn_conv2d_dgrad_bnbwd_sa(const void* dy, const void* w_crsk, void* g, const 
                              int H, int W, int C, int K, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w,
                              int dtype, const void* bn_y, const unsigned char* bn_mask, const float* bn_coef,
                              int bn_relu, float* partial, int partial_rows, void* stream);
+/* The same operation for the LARGE junctions as one persistent streaming kernel (csrc/junction.hip): 1x1 / stride-1 /
+ * unpadded convolution with K -> C channels of an instantiated shape (cn_conv2d_dgrad_junction_ok: 64 or 128 -> 256,
+ * 128 -> 512; 16-bit storage), ReLU bits (bn_mask) and an addend required (addend_sub as cn_conv2d_dgrad_sa).  The
+ * filter stays in registers, a workgroup owns a pixel range and all C channels, epilogue operands are requested a stage
+ * ahead; partial: cn_conv2d_dgrad_junction_rows(N, H, W, C) rows of 2*C floats (one per workgroup) for
+ * cn_bn_bwd_partials.  g: the bits of cn_conv2d_dgrad_bnbwd_sa; the partial sums differ by fp32 association. */
+int cn_conv2d_dgrad_junction_ok(int C, int K, int dtype);
+int cn_conv2d_dgrad_junction_rows(int N, int H, int W, int C);
+int cn_conv2d_dgrad_junction(const void* dy, const void* w_crsk, void* g, const void* addend, int addend_sub, int N, int H,
+                             int W, int C, int K, int dtype, const void* bn_y, const unsigned char* bn_mask,
+                             const float* bn_coef, float* partial, int partial_rows, void* stream);
 /* dw[K,R,S,C_real] (fp32) = beta*dw + scale * sum_pixels dy (x) x ; split reduction through
  * `workspace` (cn_conv2d_wgrad_workspace bytes), fixed summation order. */
 size_t cn_conv2d_wgrad_workspace(int N, int H, int W, int C, int K, int R, int S, int stride_h, int stride_w,

@@ -1217,3 +1217,63 @@ def test_junction_pair_equals_lazy_dgrad_and_wgrad(mode, dtype):
             dx_cpu = dy.reshape(-1, K) @ w.float().cpu().reshape(K, C)
             assert rel_l2(dw.cpu().reshape(K, C), dw_cpu) < 1e-3
             assert rel_l2(dx.float().cpu().reshape(-1, C), dx_cpu) < _tol(dtype)
+
+
+@pytest.mark.parametrize('mode', MODES)
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_streaming_junction_dgrad_equals_tiled_epilogue_kernel(mode, dtype):
+    """cn_conv2d_dgrad_junction (csrc/junction.hip) against cn_conv2d_dgrad_bnbwd_sa on every instantiated shape, with a
+    dense and with a subsampled addend, pixel counts that are not whole stages, few and many workgroups: g bit for bit,
+    the partial rows' column sums to fp32 association, and both against the definition on the CPU."""
+    _f16_emul_subset(mode, dtype, keep=True)
+    dev = _dev(mode)
+    import convnet_amd as ca
+    ops, L = ca.ops, ca._lib.load()
+    if mode == 'emul':
+        cases = [(1, 6, 10, 256, 64, 1, 3), (2, 6, 6, 256, 128, 2, 2), (1, 5, 9, 512, 128, 1, 5)]
+    else:
+        cases = [(8, 56, 56, 256, 64, 1, 256), (8, 56, 56, 256, 128, 2, 256), (16, 28, 28, 512, 128, 1, 256),
+                 (3, 17, 13, 256, 64, 2, 7), (2, 9, 11, 512, 128, 1, 256)]
+    for (N, H, W, C, K, sub, splits) in cases:
+        g_ = torch.Generator().manual_seed(C + K + H)
+        M = N * H * W
+        dyh = (torch.randn(N, H, W, K, generator=g_)).to(dtype).to(dev)
+        wc = (torch.randn(C, 1, 1, K, generator=g_) * (2.0 / K) ** 0.5).to(dtype).to(dev)
+        bn_y = (torch.randn(N, H, W, C, generator=g_) * 1.5 + 0.3).to(dtype).to(dev)
+        if sub == 2:
+            addend = torch.randn(N, (H + 1) // 2, (W + 1) // 2, C, generator=g_).to(dtype).to(dev)
+        else:
+            addend = torch.randn(N, H, W, C, generator=g_).to(dtype).to(dev)
+        yf = bn_y.float().reshape(M, C)
+        mean, var = yf.mean(0), yf.var(0, unbiased=False)
+        invstd = 1.0 / torch.sqrt(var + 1e-5)
+        gamma = (torch.rand(C, generator=g_) + 0.5).to(dev)
+        beta = (torch.randn(C, generator=g_) * 0.2).to(dev)
+        stats = torch.cat([mean, invstd, gamma * invstd, beta - mean * gamma * invstd]).contiguous()
+        on = torch.rand(M, C, generator=g_).to(dev) > 0.4
+        w8 = (2 ** torch.arange(8, device=dev)).view(1, 1, 8)
+        bits = (on.view(M, C // 8, 8).long() * w8).sum(-1).to(torch.uint8).contiguous()
+        saved = ops.JDGRAD
+        try:
+            ops.JDGRAD = False
+            g0, p0, r0 = ops.conv2d_dgrad(dyh, wc, (N, H, W, C), K, 1, 1, (1, 1), (0, 0), addend=addend,
+                                          bn=(bn_y, bits, stats, True), addend_sub=sub)
+            assert 'igemm_kernel' in L.cn_last_kernel_name().decode()
+            ops.JDGRAD = True
+            L.cn_set_option(b'jdgrad_splits', splits)
+            g1, p1, r1 = ops.conv2d_dgrad(dyh, wc, (N, H, W, C), K, 1, 1, (1, 1), (0, 0), addend=addend,
+                                          bn=(bn_y, bits, stats, True), addend_sub=sub)
+            assert 'jdgrad_kernel' in L.cn_last_kernel_name().decode()
+        finally:
+            ops.JDGRAD = saved
+            L.cn_set_option(b'jdgrad_splits', 256)
+        assert r1 == L.cn_conv2d_dgrad_junction_rows(N, H, W, C) or splits != 256
+        assert tuple(p1.shape) == (r1, 2 * C) and r1 <= max(splits, 1)
+        assert torch.equal(g1.cpu(), g0.cpu()), (N, H, W, C, K, sub)
+        s0, s1 = p0.double().sum(0), p1.double().sum(0)
+        assert rel_l2(s1[:C].cpu(), s0[:C].cpu()) < 1e-5 and rel_l2(s1[C:].cpu(), s0[C:].cpu()) < 5e-5
+        gd = g1.float().reshape(M, C).double()
+        xhat = ((yf - mean) * invstd).double()
+        assert rel_l2(s1[:C].cpu(), gd.sum(0).cpu()) < 1e-5
+        assert rel_l2(s1[C:].cpu(), (gd * xhat).sum(0).cpu()) < 5e-5
+        assert float(gd.abs().sum()) > 0
