@@ -63,6 +63,12 @@ _SIGNATURES = {
     'cn_conv2d_bwd1x1_lazy_ok': (c_i, [c_i, c_i, c_i]),
     'cn_conv2d_bwd1x1_lazy_workspace': (c_sz, [c_i] * 5),
     'cn_conv2d_bwd1x1_lazy': (c_i, [c_p] * 7 + [c_i] * 6 + [c_f, c_f, c_p, c_sz, c_p]),
+    'cn_stem_fwd_ok': (c_i, [c_i] * 5),
+    'cn_stem_fwd_rows': (c_i, [c_i, c_i]),
+    'cn_stem_fwd': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
+    'cn_stem_wgrad_ok': (c_i, [c_i] * 5),
+    'cn_stem_wgrad_workspace': (c_sz, [c_i, c_i]),
+    'cn_stem_wgrad': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_p, c_sz, c_p]),
     'cn_bn_workspace': (c_sz, [c_i, c_i, c_i]),
     'cn_bn_fwd_train': (c_i, [c_p] * 9 + [c_f, c_f, c_p, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
     'cn_bn_fwd_train_partials': (c_i, [c_p] * 9 + [c_f, c_f, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_sz, c_p]),

@@ -251,6 +251,8 @@ FUSE_BN_STATS = os.environ.get('CONVNET_AMD_FUSE_BN_STATS', '1') != '0'
 FUSE_BN_STATS_MIN_MB = float(os.environ.get('CONVNET_AMD_FUSE_BN_STATS_MIN_MB', '0'))
 # A/B switch: 0 = the stem runs as a 49-tap conv on a 3->8 channel padded image instead of the pixel-pair form
 STEM_PAIRS = os.environ.get('CONVNET_AMD_STEM_PAIRS', '1') != '0'
+# A/B switch: 0 = the pixel-pair stem runs through the tiled implicit-GEMM kernel instead of the halo kernel (csrc/stem.hip)
+STEM_HALO = os.environ.get('CONVNET_AMD_STEM_HALO', '1') != '0'
 # A/B switch: 0 = the stem's bn1 -> relu -> maxpool runs as separate BatchNorm and max-pool passes
 FUSE_STEM_POOL = os.environ.get('CONVNET_AMD_FUSE_STEM_POOL', '1') != '0'
 # A/B switch: 0 = BatchNorm backward always runs its own reduction pass over (dz, y)
@@ -837,9 +839,23 @@ class StemPairConvFunction(Function):
         wp = torch.empty(K * R * S2 * 8, dtype=torch.bfloat16, device=x_pairs.device)
         check(L.cn_weight_prep_pairs(ptr(mod.master_view('weight')), ptr(wp), K, R, S, mod.in_channels,
                                      stream_of(x_pairs)), 'cn_weight_prep_pairs')
-        y = conv2d_fwd(x_pairs, wp, None, K, R, S2, (mod.stride[0], 1), (0, 0),
-                       bn_stats=FUSE_BN_STATS and mod.training and getattr(mod, 'feeds_batchnorm', False),
-                       pivot=stats_pivot(mod))
+        want_stats = FUSE_BN_STATS and mod.training and getattr(mod, 'feeds_batchnorm', False)
+        N_, Hp_, Jp_, _ = x_pairs.shape
+        if STEM_HALO and want_stats and stats_pivot(mod) is None and mod.stride[0] == 2 and x_pairs.dtype == torch.bfloat16 \
+                and L.cn_stem_fwd_ok(K, R, S2, Jp_, dtype_code(x_pairs.dtype)):
+            P_, Q_ = (Hp_ - R) // 2 + 1, Jp_ - S2 + 1
+            y = torch.empty((N_, P_, Q_, K), dtype=x_pairs.dtype, device=x_pairs.device)
+            rows = L.cn_stem_fwd_rows(N_, P_)
+            partial = torch.empty((rows, 2 * K), dtype=torch.float32, device=x_pairs.device)
+            PROFILER.run(_last_kernel(), 1, 2.0 * N_ * P_ * Q_ * K * 8 * R * S2,
+                         x_pairs.numel() * 2 + y.numel() * 2 + wp.numel() * 2 + partial.numel() * 4,
+                         lambda: check(L.cn_stem_fwd(ptr(x_pairs), ptr(wp), ptr(y), N_, Hp_, Jp_, dtype_code(x_pairs.dtype),
+                                                     ptr(partial), rows, stream_of(x_pairs)), 'cn_stem_fwd'),
+                         x_pairs.device, detail=_conv_detail('fwd', 8, Hp_, K, R, (2, 1)))
+            _park_stats(y, partial, rows, None)
+        else:
+            y = conv2d_fwd(x_pairs, wp, None, K, R, S2, (mod.stride[0], 1), (0, 0), bn_stats=want_stats,
+                           pivot=stats_pivot(mod))
         ctx.mod = mod
         ctx.save_for_backward(x_pairs)
         return y
@@ -855,7 +871,30 @@ class StemPairConvFunction(Function):
 
         def run(tag):
             tmp = torch.empty(K * R * S2 * 8, dtype=torch.float32, device=x.device)
-            conv2d_wgrad(x, dy, tmp, 8, K, R, S2, (mod.stride[0], 1), (0, 0), beta=0.0, tag=tag)
+            N_, Hp_, Jp_, _ = x.shape
+            code = dtype_code(x.dtype)
+            if STEM_HALO and mod.stride[0] == 2 and x.dtype == torch.bfloat16 and L.cn_stem_wgrad_ok(K, R, S2, Jp_, code):
+                need = L.cn_stem_wgrad_workspace(N_, Hp_)
+                ws = workspace(need, x.device, tag)
+
+                def call():
+                    check(L.cn_stem_wgrad(ptr(x), ptr(dy), ptr(tmp), N_, Hp_, Jp_, code, 0.0, 1.0, ptr(ws), ws.numel() * 4,
+                                          stream_of(x)), 'cn_stem_wgrad')
+                if PROFILER.enabled and x.is_cuda:
+                    detail = _conv_detail('wgrad', 8, Hp_, K, R, (2, 1))
+                    L.cn_set_option(b'wgrad_phase', 1)
+                    try:
+                        PROFILER.run(_last_kernel(), 1, 2.0 * dy.numel() * 8 * R * S2,
+                                     x.numel() * 2 + dy.numel() * 2 + float(need), call, x.device, detail=detail)
+                        L.cn_set_option(b'wgrad_phase', 2)
+                        PROFILER.run('wgrad_reduce_kernel', 1, 0.0, float(need) + tmp.numel() * 4, call, x.device,
+                                     detail=detail + ' [reduce]')
+                    finally:
+                        L.cn_set_option(b'wgrad_phase', 0)
+                else:
+                    call()
+            else:
+                conv2d_wgrad(x, dy, tmp, 8, K, R, S2, (mod.stride[0], 1), (0, 0), beta=0.0, tag=tag)
             check(L.cn_wgrad_unpack_pairs(ptr(tmp), ptr(mod.grad_view('weight')), K, R, S, mod.in_channels, 1.0,
                                           stream_of(x)), 'cn_wgrad_unpack_pairs')
             return tmp

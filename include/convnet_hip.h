@@ -91,6 +91,24 @@ int cn_conv2d_fwd_bnstats_centered(const void* x, const void* w_krsc, void* y, c
                                    int C, int K, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w,
                                    int dtype, int relu, float* partial, int partial_rows, const float* pivot,
                                    void* stream);
+/* The 7x7 / stride-2 stem (/root/reference models/resnet.py:226) on the pixel-pair image of cn_nchw_to_pairs as a halo
+ * kernel (csrc/stem.hip): y[n][oy][ox][k] = sum_{r<7, s2<4, e<8} xp[n][2*oy + r][ox + s2][e] * wp[k][r][s2][e], i.e.
+ * cn_conv2d_fwd_bnstats on the pair image (R = 7, S = 4, stride (2, 1), no padding) with 64 output channels; the input
+ * rows a band of output rows needs are staged in LDS once and the MFMA fragments are read straight out of that halo.
+ * wp: cn_weight_prep_pairs.  partial: cn_stem_fwd_rows(N, P) rows of 128 floats [sum | sum of squares] of the stored
+ * outputs.  Same output bits as the tiled kernel.  cn_stem_fwd_ok: shapes it is built for. */
+int cn_stem_fwd_ok(int K, int R, int S2, int Jp, int dtype);
+int cn_stem_fwd_rows(int N, int P);
+int cn_stem_fwd(const void* xp, const void* wp, void* y, int N, int Hp, int Jp, int dtype, float* partial,
+                int partial_rows, void* stream);
+/* The stem's weight gradient on the pair image as a halo kernel: dwp [64][7][4][8] fp32 (what cn_wgrad_unpack_pairs takes)
+ * = beta*dwp + scale * sum_{n,oy,ox} dy[n][oy][ox][k] * xp[n][2*oy + r][ox + s2][e]; both MFMA operands are LDS transpose
+ * reads, the activation straight out of the band's halo.  cn_conv2d_wgrad on the pair image up to fp32 summation order.
+ * Needs (Jp - 3) % 16 == 0 (cn_stem_wgrad_ok). */
+int cn_stem_wgrad_ok(int K, int R, int S2, int Jp, int dtype);
+size_t cn_stem_wgrad_workspace(int N, int Hp);
+int cn_stem_wgrad(const void* xp, const void* dy, float* dwp, int N, int Hp, int Jp, int dtype, float beta, float scale,
+                  void* workspace, size_t ws_bytes, void* stream);
 /* dx[N,H,W,C] from dy[N,P,Q,K] and the transposed filter w_crsk[C][R][S][K]
  * (written by cn_weight_prep).  Strided convs run one launch per output-parity class. */
 /* "Lazy z" forward: the input of this 1x1 / stride-1 convolution (K <= 128 output channels, C <= 512) is the output of

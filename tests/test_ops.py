@@ -243,7 +243,11 @@ def test_dgrad_epilogue_bn_backward_reduction(mode, dtype):
                                             bn=(bn_y, bits, stats, True))
         g_ref = torch.where(on.view(N, H, W, C), dx_plain, torch.zeros_like(dx_plain))
         assert torch.equal(g.cpu(), g_ref.cpu()), (N, H, W, C, K, R, st)
-        assert rows == L.cn_conv2d_dgrad_bnbwd_rows(N, H, W, C, st, st) and tuple(partial.shape) == (rows, 2 * C)
+        if 'jdgrad_kernel' in L.cn_last_kernel_name().decode():    # the large 1x1 junctions run on the streaming kernel
+            assert rows == L.cn_conv2d_dgrad_junction_rows(N, H, W, C)
+        else:
+            assert rows == L.cn_conv2d_dgrad_bnbwd_rows(N, H, W, C, st, st)
+        assert tuple(partial.shape) == (rows, 2 * C)
         gd = g.float().reshape(M, C).double()
         xhat = ((yf - mean) * invstd).double()
         s1, s2 = partial[:, :C].double().sum(0), partial[:, C:].double().sum(0)
@@ -1277,3 +1281,82 @@ def test_streaming_junction_dgrad_equals_tiled_epilogue_kernel(mode, dtype):
         assert rel_l2(s1[:C].cpu(), gd.sum(0).cpu()) < 1e-5
         assert rel_l2(s1[C:].cpu(), (gd * xhat).sum(0).cpu()) < 5e-5
         assert float(gd.abs().sum()) > 0
+
+
+@pytest.mark.parametrize('mode', MODES)
+def test_stem_halo_kernel_equals_tiled_kernel_on_the_pair_image(mode):
+    """cn_stem_fwd (csrc/stem.hip: input rows staged in LDS once, MFMA fragments read straight out of the halo) against
+    cn_conv2d_fwd_bnstats on the same pixel-pair image: output bit for bit, the statistics partials' column sums to fp32
+    association, and the output against F.conv2d.  Image heights that are not whole bands of 8 output rows included."""
+    dev = _dev(mode)
+    import convnet_amd as ca
+    from convnet_amd._lib import ptr, dtype_code, stream_of, check
+    ops, L = ca.ops, ca._lib.load()
+    cases = [(2, 20, 24), (1, 38, 18)] if mode == 'emul' else [(4, 224, 224), (3, 70, 50), (256, 224, 224)]
+    K, R, S, C, pad = 64, 7, 7, 3, 3
+    S2 = 4
+    for (N, H, W) in cases:
+        g = torch.Generator().manual_seed(H + W)
+        x = _q(torch.randn(N, C, H, W, generator=g), torch.bfloat16).to(dev)
+        w = _q(torch.randn(K, R, S, C, generator=g) * (2.0 / (C * R * S)) ** 0.5, torch.bfloat16).to(dev)
+        xp = ops.nchw_to_pairs(x, (pad, pad))
+        Hp, Jp = xp.shape[1], xp.shape[2]
+        wp = torch.empty(K * R * S2 * 8, dtype=torch.bfloat16, device=dev)
+        check(L.cn_weight_prep_pairs(ptr(w.float().contiguous()), ptr(wp), K, R, S, C, stream_of(xp)), 'cn_weight_prep_pairs')
+        y0 = ops.conv2d_fwd(xp, wp, None, K, R, S2, (2, 1), (0, 0), bn_stats=True)
+        ps0 = ops.take_pending_stats(y0)
+        assert L.cn_stem_fwd_ok(K, R, S2, Jp, dtype_code(torch.bfloat16))
+        P, Q = (Hp - R) // 2 + 1, Jp - S2 + 1
+        assert tuple(y0.shape) == (N, P, Q, K)
+        y1 = torch.zeros_like(y0)
+        rows = L.cn_stem_fwd_rows(N, P)
+        part = torch.empty((rows, 2 * K), dtype=torch.float32, device=dev)
+        check(L.cn_stem_fwd(ptr(xp), ptr(wp), ptr(y1), N, Hp, Jp, dtype_code(torch.bfloat16), ptr(part), rows,
+                            stream_of(xp)), 'cn_stem_fwd')
+        assert 'stem_fwd_kernel' in L.cn_last_kernel_name().decode()
+        assert torch.equal(y1.cpu(), y0.cpu()), (N, H, W)
+        s0, s1 = ps0.partial.double().sum(0), part.double().sum(0)
+        assert rel_l2(s1.cpu(), s0.cpu()) < 1e-5
+        if N * H * W < 300000:
+            y_ref = F.conv2d(x.float().cpu(), w.float().cpu().permute(0, 3, 1, 2), stride=2, padding=pad)
+            assert rel_l2(y1.float().cpu().permute(0, 3, 1, 2), y_ref) < 1e-2
+
+
+@pytest.mark.parametrize('mode', MODES)
+def test_stem_halo_weight_gradient_equals_tiled_kernel(mode):
+    """cn_stem_wgrad (both MFMA operands as LDS transpose reads, the activation straight out of the band's halo) against
+    cn_conv2d_wgrad on the same pixel-pair image and against the CPU weight gradient of the 7x7/2 convolution."""
+    dev = _dev(mode)
+    import convnet_amd as ca
+    from convnet_amd._lib import ptr, dtype_code, stream_of, check
+    ops, L = ca.ops, ca._lib.load()
+    cases = [(2, 26, 32, 3), (1, 42, 64, 2)] if mode == 'emul' else [(4, 224, 224, 512), (3, 70, 96, 5), (64, 224, 224, 512)]
+    K, R, S, C, pad, S2 = 64, 7, 7, 3, 3, 4
+    code = dtype_code(torch.bfloat16)
+    for (N, H, W, wgs) in cases:
+        g = torch.Generator().manual_seed(H + W)
+        x = _q(torch.randn(N, C, H, W, generator=g), torch.bfloat16)
+        xp = ops.nchw_to_pairs(x.to(dev), (pad, pad))
+        Hp, Jp = xp.shape[1], xp.shape[2]
+        assert L.cn_stem_wgrad_ok(K, R, S2, Jp, code), Jp
+        P, Q = (Hp - R) // 2 + 1, Jp - S2 + 1
+        dy = _q(torch.randn(N, K, P, Q, generator=g), torch.bfloat16)
+        dyh = _nhwc(dy, torch.bfloat16, dev)
+        t0 = torch.zeros(K * R * S2 * 8, dtype=torch.float32, device=dev)
+        ops.conv2d_wgrad(xp, dyh, t0, 8, K, R, S2, (2, 1), (0, 0), beta=0.0)
+        t1 = torch.full_like(t0, 7.0)
+        L.cn_set_option(b'stem_wgrad_wgs', wgs)
+        try:
+            ws = ops.workspace(L.cn_stem_wgrad_workspace(N, Hp), dev, 'main')
+            check(L.cn_stem_wgrad(ptr(xp), ptr(dyh), ptr(t1), N, Hp, Jp, code, 0.0, 1.0, ptr(ws), ws.numel() * 4,
+                                  stream_of(xp)), 'cn_stem_wgrad')
+        finally:
+            L.cn_set_option(b'stem_wgrad_wgs', 512)
+        assert rel_l2(t1.cpu(), t0.cpu()) < 1e-5, (N, H, W, rel_l2(t1.cpu(), t0.cpu()))
+        if N * H * W < 300000:
+            xr = x.clone()
+            wr = torch.zeros(K, C, R, S, requires_grad=True)
+            F.conv2d(xr, wr, stride=2, padding=pad).backward(dy)
+            dw = torch.zeros(K, R, S, C, device=dev)
+            check(L.cn_wgrad_unpack_pairs(ptr(t1), ptr(dw), K, R, S, C, 0.0, stream_of(t1)), 'cn_wgrad_unpack_pairs')
+            assert rel_l2(dw.cpu().permute(0, 3, 1, 2), wr.grad) < 2e-3
