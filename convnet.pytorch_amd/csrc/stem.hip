@@ -88,15 +88,27 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // the two fragments of filter row r + 1 are requested before the MFMAs of row r (hipcc serialises every MFMA behind
+    // its own ds_read otherwise)
+    s16x8 bq[2][2];
 #pragma unroll
-    for (int kk = 0; kk < STEM_NKK; ++kk) {
-      const int q = 2 * kk + h;
-      const s16x8 b = __builtin_bit_cast(s16x8, cn_ld16(base + ((q >> 2) * Jp + (q & 3)) * 16));
+    for (int j = 0; j < 2; ++j) bq[0][j] = __builtin_bit_cast(s16x8, cn_ld16(base + (2 * j + h) * 16));
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        if constexpr (std::is_same<T, f16_t>::value) acc[t] = cn_mfma_32x32x16_f16(wf[t][kk], b, acc[t]);
-        else acc[t] = cn_mfma_32x32x16_bf16(wf[t][kk], b, acc[t]);
+    for (int r = 0; r < STEM_R; ++r) {
+      const int cur = r & 1, nxt = cur ^ 1;
+      if (r + 1 < STEM_R) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bq[nxt][j] = __builtin_bit_cast(s16x8, cn_ld16(base + ((r + 1) * Jp + 2 * j + h) * 16));
       }
+      cn_sched_fence();
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          if constexpr (std::is_same<T, f16_t>::value) acc[t] = cn_mfma_32x32x16_f16(wf[t][2 * r + j], bq[cur][j], acc[t]);
+          else acc[t] = cn_mfma_32x32x16_bf16(wf[t][2 * r + j], bq[cur][j], acc[t]);
+        }
+      cn_sched_fence();
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t)

@@ -253,6 +253,9 @@ FUSE_BN_STATS_MIN_MB = float(os.environ.get('CONVNET_AMD_FUSE_BN_STATS_MIN_MB', 
 STEM_PAIRS = os.environ.get('CONVNET_AMD_STEM_PAIRS', '1') != '0'
 # A/B switch: 0 = the pixel-pair stem runs through the tiled implicit-GEMM kernel instead of the halo kernel (csrc/stem.hip)
 STEM_HALO = os.environ.get('CONVNET_AMD_STEM_HALO', '1') != '0'
+# A/B switch: 0 = the 64 -> 64 channel 3x3 convolutions run through the tiled implicit-GEMM kernel instead of the halo
+# kernel (csrc/conv3x3.hip)
+CONV3X3_HALO = os.environ.get('CONVNET_AMD_CONV3X3_HALO', '1') != '0'
 # A/B switch: 0 = the stem's bn1 -> relu -> maxpool runs as separate BatchNorm and max-pool passes
 FUSE_STEM_POOL = os.environ.get('CONVNET_AMD_FUSE_STEM_POOL', '1') != '0'
 # A/B switch: 0 = BatchNorm backward always runs its own reduction pass over (dz, y)
@@ -341,10 +344,28 @@ def stats_pivot(conv_mod):
     return bn.running_mean
 
 
+def _halo3x3_ok(x, C, K, R, S, stride, pad):
+    return (CONV3X3_HALO and (R, S) == (3, 3) and tuple(stride) == (1, 1) and tuple(pad) == (1, 1)
+            and _L().cn_conv3x3_c64_ok(x.shape[1], x.shape[2], C, K, dtype_code(x.dtype)))
+
+
 def conv2d_fwd(x, w_krsc, bias, K, R, S, stride, pad, out_f32=False, relu=False, bn_stats=False, pivot=None):
     N, H, W, C = x.shape
     P, Q = conv_out_hw(H, W, R, S, stride, pad)
     y = torch.empty((N, P, Q, K), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+    if bias is None and not out_f32 and not relu and pivot is None and _halo3x3_ok(x, C, K, R, S, stride, pad):
+        L = _L()
+        want = bn_stats and y.numel() * _esize(y) >= FUSE_BN_STATS_MIN_MB * 2 ** 20
+        rows = L.cn_conv3x3_c64_rows(N, H) if want else 0
+        partial = torch.empty((rows, 2 * K), dtype=torch.float32, device=x.device) if want else None
+        PROFILER.run(_last_kernel(), 1, 2.0 * N * P * Q * K * C * R * S,
+                     x.numel() * _esize(x) + y.numel() * _esize(y) + K * R * S * C * _esize(x),
+                     lambda: check(L.cn_conv3x3_c64(ptr(x), ptr(w_krsc), ptr(y), N, H, W, dtype_code(x.dtype), 0,
+                                                    ptr(partial), rows, stream_of(x)), 'cn_conv3x3_c64'),
+                     x.device, detail=_conv_detail('fwd', C, H, K, R, stride))
+        if want:
+            _park_stats(y, partial, rows, None)
+        return y
     if bn_stats and not out_f32 and y.numel() * _esize(y) >= FUSE_BN_STATS_MIN_MB * 2 ** 20:
         L = _L()
         rows = L.cn_conv2d_bnstats_rows(N * P * Q)
@@ -441,6 +462,12 @@ def conv2d_dgrad(dy, w_crsk, x_shape, K, R, S, stride, pad, addend=None, bn=None
         + (addend.numel() * _esize(addend) if addend is not None else 0)
     if addend is not None and addend_sub == 2:
         assert tuple(addend.shape) == (N, (H + 1) // 2, (W + 1) // 2, C), 'subsampled addend shape'
+    if bn is None and addend is None and _halo3x3_ok(dy, K, C, R, S, stride, pad) and tuple(dy.shape[1:3]) == (H, W):
+        PROFILER.run(name, 1, flops, nbytes,
+                     lambda: check(_L().cn_conv3x3_c64(ptr(dy), ptr(w_crsk), ptr(dx), N, H, W, dtype_code(dy.dtype), 1, None,
+                                                       0, stream_of(dy)), 'cn_conv3x3_c64'),
+                     dy.device, detail=detail)
+        return dx
     if bn is None:
         PROFILER.run(name, stride[0] * stride[1], flops, nbytes,
                      lambda: check(_L().cn_conv2d_dgrad_sa(ptr(dy), ptr(w_crsk), ptr(dx), ptr(addend), int(addend_sub), N, H,

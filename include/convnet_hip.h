@@ -91,6 +91,16 @@ int cn_conv2d_fwd_bnstats_centered(const void* x, const void* w_krsc, void* y, c
                                    int C, int K, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w,
                                    int dtype, int relu, float* partial, int partial_rows, const float* pivot,
                                    void* stream);
+/* 3x3 / stride-1 / pad-1 convolution with 64 -> 64 channels (the first stage's conv2, /root/reference
+ * models/resnet.py:126-132) as a halo kernel (csrc/conv3x3.hip): a band's input rows are staged in LDS once and the MFMA
+ * fragments of all nine taps are read straight out of that halo; filter in registers.  flip = 0: forward, w = KRSC
+ * filter; flip = 1: data gradient, x = dy, w = CRSK filter.  partial (optional, forward): cn_conv3x3_c64_rows(N, H) rows
+ * of 128 floats [sum | sum of squares] for cn_bn_fwd_train_partials.  Same output bits as cn_conv2d_fwd /
+ * cn_conv2d_dgrad.  cn_conv3x3_c64_ok: W <= 56, 16-bit storage. */
+int cn_conv3x3_c64_ok(int H, int W, int C, int K, int dtype);
+int cn_conv3x3_c64_rows(int N, int H);
+int cn_conv3x3_c64(const void* x, const void* w, void* y, int N, int H, int W, int dtype, int flip, float* partial,
+                   int partial_rows, void* stream);
 /* The 7x7 / stride-2 stem (/root/reference models/resnet.py:226) on the pixel-pair image of cn_nchw_to_pairs as a halo
  * kernel (csrc/stem.hip): y[n][oy][ox][k] = sum_{r<7, s2<4, e<8} xp[n][2*oy + r][ox + s2][e] * wp[k][r][s2][e], i.e.
  * cn_conv2d_fwd_bnstats on the pair image (R = 7, S = 4, stride (2, 1), no padding) with 64 output channels; the input

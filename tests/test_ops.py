@@ -1360,3 +1360,51 @@ def test_stem_halo_weight_gradient_equals_tiled_kernel(mode):
             dw = torch.zeros(K, R, S, C, device=dev)
             check(L.cn_wgrad_unpack_pairs(ptr(t1), ptr(dw), K, R, S, C, 0.0, stream_of(t1)), 'cn_wgrad_unpack_pairs')
             assert rel_l2(dw.cpu().permute(0, 3, 1, 2), wr.grad) < 2e-3
+
+
+@pytest.mark.parametrize('mode', MODES)
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_conv3x3_halo_kernel_equals_tiled_kernel(mode, dtype):
+    """cn_conv3x3_c64 (csrc/conv3x3.hip: the band's input rows staged in LDS once, all nine taps' MFMA fragments read
+    straight out of the halo) against the tiled implicit-GEMM kernel, forward (with the statistics partials) and data
+    gradient: outputs bit for bit, column sums of the partials to fp32 association, and both against F.conv2d."""
+    _f16_emul_subset(mode, dtype, keep=True)
+    dev = _dev(mode)
+    import convnet_amd as ca
+    ops, L = ca.ops, ca._lib.load()
+    C = K = 64
+    cases = [(1, 9, 7, 2), (2, 5, 12, 256)] if mode == 'emul' else [(4, 56, 56, 256), (3, 13, 21, 5), (256, 56, 56, 256)]
+    for (N, H, W, wgs) in cases:
+        g = torch.Generator().manual_seed(H * W)
+        x = _q(torch.randn(N, C, H, W, generator=g), dtype)
+        w = _q(torch.randn(K, C, 3, 3, generator=g) * (2.0 / (C * 9)) ** 0.5, dtype)
+        dy = _q(torch.randn(N, K, H, W, generator=g), dtype)
+        xh, dyh = _nhwc(x, dtype, dev), _nhwc(dy, dtype, dev)
+        wk = w.permute(0, 2, 3, 1).contiguous().to(dtype).to(dev)     # KRSC
+        wc = w.permute(1, 2, 3, 0).contiguous().to(dtype).to(dev)     # CRSK
+        saved = ops.CONV3X3_HALO
+        try:
+            ops.CONV3X3_HALO = False
+            y0 = ops.conv2d_fwd(xh, wk, None, K, 3, 3, (1, 1), (1, 1), bn_stats=True)
+            ps0 = ops.take_pending_stats(y0)
+            d0 = ops.conv2d_dgrad(dyh, wc, (N, H, W, C), K, 3, 3, (1, 1), (1, 1))
+            assert 'igemm_kernel' in L.cn_last_kernel_name().decode()
+            ops.CONV3X3_HALO = True
+            L.cn_set_option(b'conv3x3_wgs', wgs)
+            y1 = ops.conv2d_fwd(xh, wk, None, K, 3, 3, (1, 1), (1, 1), bn_stats=True)
+            assert 'conv3x3_c64_kernel' in L.cn_last_kernel_name().decode()
+            ps1 = ops.take_pending_stats(y1)
+            d1 = ops.conv2d_dgrad(dyh, wc, (N, H, W, C), K, 3, 3, (1, 1), (1, 1))
+            assert 'conv3x3_c64_kernel' in L.cn_last_kernel_name().decode()
+        finally:
+            ops.CONV3X3_HALO = saved
+            L.cn_set_option(b"conv3x3_wgs", 512)
+        assert torch.equal(y1.cpu(), y0.cpu()), (N, H, W)
+        assert torch.equal(d1.cpu(), d0.cpu()), (N, H, W)
+        assert rel_l2(ps1.partial.double().sum(0).cpu(), ps0.partial.double().sum(0).cpu()) < 1e-5
+        if N * H * W < 20000:
+            xr = x.clone().requires_grad_(True)
+            yr = F.conv2d(xr, w, padding=1)
+            yr.backward(dy)
+            assert rel_l2(y1.float().cpu().permute(0, 3, 1, 2), yr.detach()) < _tol(dtype)
+            assert rel_l2(d1.float().cpu().permute(0, 3, 1, 2), xr.grad) < _tol(dtype)
