@@ -74,18 +74,22 @@ class KernelProfiler(object):
         e.record()
         if callable(name):
             name = name()
-        self.records.append((name, launches, flops, nbytes, s, e, detail))
+        # (which stream the call was launched on: the weight-gradient side stream's launches are told apart)
+        self.records.append((name, launches, flops, nbytes, s, e, detail, torch.cuda.current_stream(device).cuda_stream))
         return out
 
     def summary(self, by_detail=False):
         torch.cuda.synchronize()
         agg = {}
-        for name, launches, flops, nbytes, s, e, detail in self.records:
+        main = getattr(self, 'main_stream', None)
+        for name, launches, flops, nbytes, s, e, detail, stream in self.records:
             if by_detail and detail is None:
                 continue
             a = agg.setdefault(detail if by_detail else name,
-                               {'calls': 0, 'launches': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0, 'records': []})
+                               {'calls': 0, 'launches': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0, 'records': [], 'side_ms': 0.0})
             ms = s.elapsed_time(e)
+            if main is not None and stream != main:
+                a['side_ms'] += ms
             a['calls'] += 1
             a['launches'] += launches
             a['ms'] += ms

@@ -61,6 +61,15 @@ def test_round3_kernels_are_what_they_claim(table):
         assert c['mfma'] >= 9 and c['tr_read'] >= 20 and c['lds_dma'] > 0, (name, c)
     ilv = _find(table, 'igemm_kernel<bf16_t', ', true>(IgemmParams)')       # last template argument: ILV
     assert all(c['lds_dma'] >= 8 and c['mfma'] >= 16 for _, c in ilv), ilv
-    lazy = _find(table, 'wgrad_kernel<bf16_t', ', true>(WgradParams)')
-    plain = _find(table, 'wgrad_kernel<bf16_t', ', false>(WgradParams)')
-    assert all(c['plain_load16'] > 0 for _, c in lazy) and all(c['plain_load16'] == 0 for _, c in plain)
+    lazy = _find(table, 'wgrad_kernel<bf16_t', ', 1>(WgradParams)') + _find(table, 'wgrad_kernel<bf16_t', ', 2>(WgradParams)')
+    plain = _find(table, 'wgrad_kernel<bf16_t', ', 0>(WgradParams)')      # last template argument: LAZY (0 / 1 / 2)
+    assert lazy and plain and all(c['mfma'] >= 4 and c['tr_read'] >= 4 for _, c in lazy + plain)
+    # round 3, second half: the streaming junction kernels and the halo kernels are MFMA kernels whose filter operand
+    # never passes through LDS-DMA, with 16-byte global stores; the junction pair and the stem weight gradient use the
+    # LDS transpose read
+    for kern in ('jdgrad_kernel<bf16_t', 'stem_fwd_kernel<bf16_t', 'conv3x3_c64_kernel<bf16_t'):
+        for name, c in _find(table, kern):
+            assert c['mfma'] >= 4 and c['lds_dma'] == 0 and c['plain_store16'] > 0, (name, c)
+    for kern in ('jbwd_kernel<bf16_t', 'stem_wgrad_kernel<bf16_t'):
+        for name, c in _find(table, kern):
+            assert c['mfma'] >= 2 and c['tr_read'] >= 4, (name, c)

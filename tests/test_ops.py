@@ -998,7 +998,10 @@ def test_conv_with_batchnorm_apply_folded_into_the_operand_load(mode, dtype):
             # the stored outputs are the same bits; the plain convolution may run the eight-wave form of the tile
             # (igemm_8w), which associates the per-tile statistics over 512 instead of 256 threads
             assert torch.equal(got_s.cpu(), ref_s.cpu())
-            assert torch.allclose(pg.partial.cpu(), pr.partial.cpu(), rtol=1e-5, atol=1e-4)
+            if pg.partial.shape == pr.partial.shape:
+                assert torch.allclose(pg.partial.cpu(), pr.partial.cpu(), rtol=1e-5, atol=1e-4)
+            else:   # (the 64-channel 3x3 layers run on the halo kernel: one partial row per workgroup, not per 128 pixels)
+                assert rel_l2(pg.partial.double().sum(0).cpu(), pr.partial.double().sum(0).cpu()) < 1e-5
         finally:
             L.cn_set_option(b'igemm_variant', 0)
 
