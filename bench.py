@@ -205,7 +205,6 @@ def main():
         # every rank runs the profiled steps (they contain the gradient all-reduce: a rank-0-only pass would
         # wait for collectives the other ranks never enter); only rank 0 reports
         P = ca.ops.PROFILER
-        P.main_stream = torch.cuda.current_stream(device).cuda_stream
         P.records, P.enabled, P.fold_streams = [], True, False
         tr.train(loader(nprof))
         P.enabled = False
@@ -262,7 +261,8 @@ def main():
         # soaks up what the backward chain leaves of the chip, their overlapped durations are stretched by design (they
         # are listed in kernels_overlapped with side_stream = true, and the largest of them is priced in
         # roofline.side_stream_kernel)
-        dom = next(k for k in kernels_ovl if ' + ' not in k and not kernels_ovl[k]['side_stream'])
+        dom = next((k for k in kernels_ovl if ' + ' not in k and not kernels_ovl[k]['side_stream']),
+                   next(k for k in kernels_ovl if ' + ' not in k))
         k = kernels_ovl[dom]
         ka = kernels.get(dom, {})
         if k['tflops'] and k['tflops'] / PEAK_TFLOPS[args.dtype] >= k['gbs'] / PEAK_HBM_GBS:

@@ -1127,10 +1127,10 @@ static Wg3Plan wg3_plan(int N, int H, int W, int C, int K, int R, int S, int str
   return pl;
 }
 
-static WgradPlan wg_plan(int M, int Co, int ntaps, int Ci, int dtype, bool simple) {
+static WgradPlan wg_plan(int M, int Co, int ntaps, int Ci, int dtype, bool simple, bool lazy = false) {
   WgradPlan pl;
   pl.ncols = ntaps * Ci;
-  if (wg_use_256(M, Co, pl.ncols, dtype, simple)) {
+  if (!lazy && wg_use_256(M, Co, pl.ncols, dtype, simple)) {   // (lazy dy: register-staged tiles only)
     pl.BI = 256; pl.BJ = 256; pl.BKP = 64;
     pl.n_itiles = (Co + 255) / 256;
     pl.n_jtiles = (pl.ncols + 255) / 256;
@@ -1307,7 +1307,7 @@ static int wg_conv2d_wgrad(const void* x, const void* dy, float* dw_krsc, int C_
               p3.nsplit, K, 9, C, C_real, beta, scale);
     return cn_check_launch("wgrad_reduce");
   }
-  WgradPlan pl = wg_plan(N * P * Q, K, R * S, C, dtype, simple_gather);
+  WgradPlan pl = wg_plan(N * P * Q, K, R * S, C, dtype, simple_gather, lazy_y != nullptr);
   if (lazy_y != nullptr && pl.BI == 256) { cn_set_error("conv2d_wgrad_lazy: not with the 256 x 256 tile (knob wgrad_256sq)"); return CN_EINVAL; }
   size_t need = (size_t)pl.nsplit * (size_t)K * (size_t)pl.ncols * sizeof(float);
   if (ws_bytes < need || workspace == nullptr) {

@@ -81,7 +81,12 @@ class KernelProfiler(object):
     def summary(self, by_detail=False):
         torch.cuda.synchronize()
         agg = {}
-        main = getattr(self, 'main_stream', None)
+        # the stream the step runs along = the one most calls were launched on (the trainer's own high-priority stream);
+        # everything else is the weight-gradient side stream
+        cnt = {}
+        for r in self.records:
+            cnt[r[7]] = cnt.get(r[7], 0) + 1
+        main = max(cnt, key=cnt.get) if cnt else None
         for name, launches, flops, nbytes, s, e, detail, stream in self.records:
             if by_detail and detail is None:
                 continue
@@ -505,8 +510,14 @@ def conv2d_dgrad(dy, w_crsk, x_shape, K, R, S, stride, pad, addend=None, bn=None
     return dx, partial, rows
 
 
+# measurement only (wrong results): weight gradients not computed at all - how much of the step the side stream costs
+_SKIP_WGRAD = os.environ.get('CONVNET_AMD_DEBUG_SKIP_WGRAD', '0') == '1'
+
+
 def conv2d_wgrad(x, dy, dw_krsc, c_real, K, R, S, stride, pad, beta=1.0, scale=1.0, tag='main'):
     """dw_krsc (fp32, [K][R][S][c_real] memory order) = beta*dw + scale*wgrad."""
+    if _SKIP_WGRAD:
+        return
     N, H, W, C = x.shape
     code = dtype_code(x.dtype)
     L = _L()
@@ -549,6 +560,8 @@ def conv2d_dgrad_lazy(g, bn_y, coef, w_crsk, x_shape, K, R, S, stride, pad):
 
 def conv2d_wgrad_lazy(x, g, bn_y, coef, dw_krsc, c_real, K, R, S, stride, pad, beta=1.0, scale=1.0, tag='main'):
     """wgrad whose dy operand is formed on load from (g, bn_y, coef) (cn_conv2d_wgrad_lazy)."""
+    if _SKIP_WGRAD:
+        return
     N, H, W, C = x.shape
     code = dtype_code(x.dtype)
     L = _L()

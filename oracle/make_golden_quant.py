@@ -187,7 +187,18 @@ def full():
     trajectory('r50_quant_full', dict(depth=50), B=16, size=224, classes=1000, steps=2, seed=43)
 
 
+def big_batch(B=128):
+    """Full-size ResNet-50, quantize=True, at a bench-scale batch (B=128: what the build container's 62 GB hold for the
+    reference's fp32 autograd graph; the bench runs B=256): 2 steps.  For the bf16 / fp32 parity test at a batch where
+    the RangeBN chunks span 8 samples each and the activation quantisers average over 128 per-sample ranges."""
+    trajectory('r50_quant_b%d' % B, dict(depth=50), B=B, size=224, classes=1000, steps=2, seed=47)
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'big':
+        big_batch(int(sys.argv[2]) if len(sys.argv) > 2 else 128)
+        assert not os.path.exists(os.path.join(REF, '__pycache__')), 'bytecode leaked into the reference tree'
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'full':
         full()
         assert not os.path.exists(os.path.join(REF, '__pycache__')), 'bytecode leaked into the reference tree'

@@ -315,3 +315,42 @@ def test_full_size_quantised_resnet50_follows_the_reference(reference_noise):
     for k in ('conv1.weight', 'layer1.0.conv1.weight', 'bn1.running_mean', 'bn1.running_var',
               'conv1.quantize_input.running_range', 'fc.quantize_input.running_range'):
         assert rel_l2(sd[k].float().cpu(), final[k]) < 0.15, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_bench_scale_quantised_resnet50_follows_the_reference(dtype, reference_noise):
+    """Config 5 at a bench-scale batch: ResNet-50 quantize=True, B=128, 224x224 (the largest batch whose reference
+    autograd graph fits the build container; the bench runs B=256), fp32 AND bf16 storage, against the reference
+    Trainer's fp32 records (tests/golden/traj_r50_quant_b128.json) on the reference's rounding-noise stream, with a
+    bound on loss and gradient norm at EVERY step (measured: fp32 5e-5 / 4e-4 and 4e-3 / 1e-4; bf16 4e-4 / 3e-4 and
+    3e-3 / 3e-3):
+        fp32:  loss abs 1e-3 (step 0) / 5e-3, gradient norm rel 2e-2
+        bf16:  loss abs 5e-3 at both steps,   gradient norm rel 2e-2
+    and rel-L2 0.06 on the tensors the fixture keeps after two steps at lr 0.1 on 8-bit grids (measured <= 0.03), except
+    the stem BatchNorm's running mean in bf16 (a near-zero mean of rounded activations: 0.14 measured, bound 0.25)."""
+    path = os.path.join(GOLDEN, 'traj_r50_quant_b128.json')
+    if not os.path.exists(path):
+        pytest.skip('fixture not generated (oracle/make_golden_quant.py big 128)')
+    dev = _dev('gpu')
+    import convnet_amd as ca
+    meta = json.load(open(path))
+    torch.manual_seed(123)
+    model = ca.models.resnet(dataset='imagenet', quantize=True, depth=50)
+    tr = ca.Trainer(model, ca.CrossEntropyLoss(), ca.OptimRegime(model, model.regime), device=str(dev), dtype=dtype,
+                    grad_clip=1e9, print_freq=10 ** 9)
+    g = torch.Generator().manual_seed(meta['seed'])
+    data = [(torch.randn(meta['B'], 3, meta['size'], meta['size'], generator=g),
+             torch.randint(0, meta['classes'], (meta['B'],), generator=g)) for _ in range(meta['steps'])]
+    f32 = dtype == torch.float32
+    for i, ((x, t), gr) in enumerate(zip(data, meta['records'])):
+        r = tr.train([(x, t)])
+        print('step', i, dtype, float(r['loss']), gr['loss'], float(r['grad']), gr['grad'])
+        assert float(r['loss']) == pytest.approx(gr['loss'], abs=(1e-3 if i == 0 else 5e-3) if f32 else 5e-3), (i, r, gr)
+        assert float(r['grad']) == pytest.approx(gr['grad'], rel=2e-2), (i, r, gr)
+    final = torch.load(os.path.join(GOLDEN, 'traj_r50_quant_b128_final.pt'))
+    sd = model.state_dict()
+    for k in ('conv1.weight', 'layer1.0.conv1.weight', 'bn1.running_mean', 'bn1.running_var',
+              'conv1.quantize_input.running_range', 'fc.quantize_input.running_range'):
+        print(k, rel_l2(sd[k].float().cpu(), final[k]))
+        assert rel_l2(sd[k].float().cpu(), final[k]) < (0.25 if (k == 'bn1.running_mean' and not f32) else 0.06), k
