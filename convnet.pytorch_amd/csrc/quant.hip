@@ -183,8 +183,12 @@ __host__ __device__ __forceinline__ float q_snap(float x, float zp, float scale,
 template <typename T>
 __global__ __launch_bounds__(Q_NT) void quantize_kernel(const T* x, T* y, long long n, const float* zero_point,
                                                        const float* range, float qmax, const float* noise,
-                                                       int stochastic, unsigned long long seed) {
+                                                       int stochastic, unsigned long long seed,
+                                                       const unsigned long long* step) {
   constexpr int CH = ElemTraits<T>::kChunk;
+  // `step` (optional): a device counter the caller advances once per training step, mixed into the seed - a launch
+  // replayed from a captured HIP graph (frozen kernel arguments) still draws fresh rounding noise every step
+  if (step != nullptr) seed += step[0] * 0xD1B54A32D192ED03ull;
   const float zp = zero_point[0];
   const float scale = (range[0] == 0.f ? 1.f : range[0]) / qmax;
   const long long nch = n / CH;
@@ -216,8 +220,9 @@ static unsigned q_grid(long long work_items) {
 // y = quantise-dequantise(x) with the two scalars zero_point / range read on the device; 2^num_bits levels.
 // Rounding noise: `noise` (fp32, one value per element, U(-0.5, 0.5)) when given, else the counter-based
 // generator keyed by (seed, element index) when stochastic != 0, else none (deterministic rounding).
-extern "C" int cn_quantize(const void* x, void* y, long long n, int dtype, const float* zero_point, const float* range,
-                           int num_bits, const float* noise, int stochastic, unsigned long long seed, void* stream_) {
+static int quantize_impl(const void* x, void* y, long long n, int dtype, const float* zero_point, const float* range,
+                         int num_bits, const float* noise, int stochastic, unsigned long long seed,
+                         const unsigned long long* step, void* stream_) {
   if (n <= 0) return CN_OK;
   if (x == nullptr || y == nullptr || zero_point == nullptr || range == nullptr || num_bits < 1 || num_bits > 23) { cn_set_error("quantize: bad arguments"); return CN_EINVAL; }
   if (((uintptr_t)x & 15) != 0 || ((uintptr_t)y & 15) != 0) { cn_set_error("quantize: buffers must be 16-byte aligned"); return CN_EINVAL; }
@@ -225,12 +230,31 @@ extern "C" int cn_quantize(const void* x, void* y, long long n, int dtype, const
   const float qmax = (float)((1 << num_bits) - 1);
   if (dtype == CN_BF16)
     CN_LAUNCH(quantize_kernel<bf16_t>, dim3(q_grid((n + 7) / 8)), dim3(Q_NT), stream, (const bf16_t*)x, (bf16_t*)y, n,
-              zero_point, range, qmax, noise, stochastic, seed);
+              zero_point, range, qmax, noise, stochastic, seed, step);
   else if (dtype == CN_F32)
     CN_LAUNCH(quantize_kernel<float>, dim3(q_grid((n + 3) / 4)), dim3(Q_NT), stream, (const float*)x, (float*)y, n,
-              zero_point, range, qmax, noise, stochastic, seed);
+              zero_point, range, qmax, noise, stochastic, seed, step);
   else { cn_set_error("quantize: bad dtype %d", dtype); return CN_EINVAL; }
   return cn_check_launch("quantize");
+}
+extern "C" int cn_quantize(const void* x, void* y, long long n, int dtype, const float* zero_point, const float* range,
+                           int num_bits, const float* noise, int stochastic, unsigned long long seed, void* stream_) {
+  return quantize_impl(x, y, n, dtype, zero_point, range, num_bits, noise, stochastic, seed, nullptr, stream_);
+}
+// cn_quantize whose generator seed is `seed` mixed with a device-resident step counter (advanced by cn_counter_inc once
+// per training step): the launch can be captured into a HIP graph and still rounds with fresh noise on every replay.
+extern "C" int cn_quantize_s(const void* x, void* y, long long n, int dtype, const float* zero_point, const float* range,
+                             int num_bits, const float* noise, int stochastic, unsigned long long seed,
+                             const unsigned long long* step_counter, void* stream_) {
+  return quantize_impl(x, y, n, dtype, zero_point, range, num_bits, noise, stochastic, seed, step_counter, stream_);
+}
+__global__ void counter_inc_kernel(unsigned long long* p) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) p[0] += 1ull;
+}
+extern "C" int cn_counter_inc(unsigned long long* counter, void* stream_) {
+  if (counter == nullptr) { cn_set_error("counter_inc: null"); return CN_EINVAL; }
+  CN_LAUNCH(counter_inc_kernel, dim3(1), dim3(64), (hipStream_t)stream_, counter);
+  return cn_check_launch("counter_inc");
 }
 
 // Per-row quantisation of an fp32 matrix [rows][row_len] with that row's own min / max (the weight
@@ -256,6 +280,33 @@ extern "C" int cn_quantize_rows(const float* x, float* y, int rows, int row_len,
   return cn_check_launch("quantize_rows");
 }
 
+// Input quantiser folded into the RangeBN kernels (round 3): RangeBN's QuantMeasure (quantize.py:270,308) snaps its input
+// to the 8-bit grid before anything else; with xqp = [zero_point, range] (cn_qparams' output) the kernels below read the
+// RAW convolution output and snap each element on load - quantize_kernel's arithmetic, rounded to T as it would have
+// been stored - so the quantised copy is never written or re-read (one write + one read of every RangeBN input less,
+// in forward; the backward kernels re-snap the saved raw tensor).  xqp == nullptr: x is already quantised.
+struct RbnSnap {
+  float zp, scale, qmax;
+  int on;
+};
+__device__ __forceinline__ RbnSnap rbn_snap_make(const float* xqp, float qmax) {
+  RbnSnap q;
+  q.on = xqp != nullptr;
+  q.zp = q.on ? xqp[0] : 0.f;
+  const float range = q.on ? xqp[1] : 1.f;
+  q.scale = (range == 0.f ? 1.f : range) / qmax;
+  q.qmax = qmax;
+  return q;
+}
+template <typename T>
+__device__ __forceinline__ void rbn_snap_chunk(const RbnSnap& q, float* f) {
+  constexpr int CH = ElemTraits<T>::kChunk;
+  if (!q.on) return;
+#pragma unroll
+  for (int e = 0; e < CH; ++e) f[e] = q_snap(f[e], q.zp, q.scale, q.qmax, 0.f);
+  Chunk<T>::unpack(Chunk<T>::pack(f), f);   // as stored in T
+}
+
 // ------------------------------------------------------------------------------------------------ RangeBN
 // Activations NHWC [M][C]; the reference's view(C, chunks, M/chunks) of the (b, h, w)-ordered values is the
 // split of the M pixels into `chunks` consecutive ranges.  Each range is cut further into `sub` slices so the
@@ -268,7 +319,7 @@ struct RbnPartial {   // one per (chunk, slice, channel)
 
 template <typename T>
 __global__ __launch_bounds__(Q_NT) void rangebn_stats_kernel(const T* x, int M, int C, int chunks, int sub, int cols,
-                                                            RbnPartial* part) {
+                                                            RbnPartial* part, const float* xqp, float qmax) {
   constexpr int CH = ElemTraits<T>::kChunk;
   __shared__ float s_mx[Q_NT * CH], s_mn[Q_NT * CH], s_sum[Q_NT * CH];
   __shared__ int s_imx[Q_NT * CH], s_imn[Q_NT * CH];
@@ -288,10 +339,12 @@ __global__ __launch_bounds__(Q_NT) void rangebn_stats_kernel(const T* x, int M, 
   int imx[CH], imn[CH];
 #pragma unroll
   for (int e = 0; e < CH; ++e) { mx[e] = -INFINITY; mn[e] = INFINITY; sm[e] = 0.f; imx[e] = 0x7fffffff; imn[e] = 0x7fffffff; }
+  const RbnSnap snap = rbn_snap_make(xqp, qmax);
   if (cc < CC) {
     auto visit = [&](const u32x4& v, int p) {
       float f[CH];
       Chunk<T>::unpack(v, f);
+      rbn_snap_chunk<T>(snap, f);
 #pragma unroll
       for (int e = 0; e < CH; ++e) {
         if (f[e] > mx[e]) { mx[e] = f[e]; imx[e] = p; }
@@ -448,13 +501,15 @@ __global__ __launch_bounds__(Q_NT) void rangebn_infer_stats_kernel(const float* 
 template <typename T>
 __global__ __launch_bounds__(Q_NT) void rangebn_apply_kernel(const T* x, const T* residual, T* z, const float* stats,
                                                             const float* weight, const float* bias, long long nch,
-                                                            int C, int relu) {
+                                                            int C, int relu, const float* xqp, float qmax) {
   constexpr int CH = ElemTraits<T>::kChunk;
   const int CC = C / CH;
+  const RbnSnap snap = rbn_snap_make(xqp, qmax);
   for (long long id = (long long)blockIdx.x * Q_NT + threadIdx.x; id < nch; id += (long long)gridDim.x * Q_NT) {
     const int c0 = (int)(id % CC) * CH;
     float f[CH], r[CH];
     Chunk<T>::unpack(cn_ld16((const char*)x + id * 16), f);
+    rbn_snap_chunk<T>(snap, f);
     if (residual != nullptr) Chunk<T>::unpack(cn_ld16((const char*)residual + id * 16), r);
 #pragma unroll
     for (int e = 0; e < CH; ++e) {
@@ -493,10 +548,11 @@ static int rbn_cols(int CC) {
 // `chunks` chunk-wise max - min, M % chunks == 0 as the reference's view() requires), running statistics
 // updated, stats[2C] = {mean | scale + eps} and arg[C][2*chunks] saved for the backward pass.  training == 0:
 // running statistics.  z = act(affine(normalised x) [+ residual]).
-extern "C" int cn_rangebn_fwd(const void* x, const void* residual, void* z, const float* weight, const float* bias,
+static int rangebn_fwd_impl(const void* x, const void* residual, void* z, const float* weight, const float* bias,
                               float* running_mean, float* running_var, float momentum, float eps, int chunks,
                               float scale_fix, float* stats, int* arg, int M, int C, int relu, int training, int dtype,
-                              float* ws, size_t ws_bytes, void* stream_) {
+                              float* ws, size_t ws_bytes, void* stream_, const float* xqp, int x_bits) {
+  const float qmax = (float)((1 << (x_bits > 0 ? x_bits : 8)) - 1);
   hipStream_t stream = (hipStream_t)stream_;
   const int CH = dtype == CN_BF16 ? 8 : 4;
   if (dtype != CN_BF16 && dtype != CN_F32) { cn_set_error("rangebn_fwd: bad dtype"); return CN_EINVAL; }
@@ -510,9 +566,9 @@ extern "C" int cn_rangebn_fwd(const void* x, const void* residual, void* z, cons
     const int sub = rbn_sub(M, chunks), cols = rbn_cols(CC);
     dim3 grid((unsigned)((CC + cols - 1) / cols), (unsigned)(chunks * sub));
     if (dtype == CN_BF16)
-      CN_LAUNCH(rangebn_stats_kernel<bf16_t>, grid, dim3(Q_NT), stream, (const bf16_t*)x, M, C, chunks, sub, cols, (RbnPartial*)ws);
+      CN_LAUNCH(rangebn_stats_kernel<bf16_t>, grid, dim3(Q_NT), stream, (const bf16_t*)x, M, C, chunks, sub, cols, (RbnPartial*)ws, xqp, qmax);
     else
-      CN_LAUNCH(rangebn_stats_kernel<float>, grid, dim3(Q_NT), stream, (const float*)x, M, C, chunks, sub, cols, (RbnPartial*)ws);
+      CN_LAUNCH(rangebn_stats_kernel<float>, grid, dim3(Q_NT), stream, (const float*)x, M, C, chunks, sub, cols, (RbnPartial*)ws, xqp, qmax);
     if (2 * chunks <= RF_T)
       CN_LAUNCH(rangebn_finalize_par_kernel, dim3((unsigned)((C + RF_C - 1) / RF_C)), dim3(RF_C * RF_T), stream, (const RbnPartial*)ws, M,
               C, chunks, sub, scale_fix, eps, momentum, running_mean, running_var, stats, arg);
@@ -527,11 +583,29 @@ extern "C" int cn_rangebn_fwd(const void* x, const void* residual, void* z, cons
   const long long nch = (long long)M * CC;
   if (dtype == CN_BF16)
     CN_LAUNCH(rangebn_apply_kernel<bf16_t>, dim3(q_grid(nch)), dim3(Q_NT), stream, (const bf16_t*)x, (const bf16_t*)residual,
-              (bf16_t*)z, (const float*)stats, weight, bias, nch, C, relu);
+              (bf16_t*)z, (const float*)stats, weight, bias, nch, C, relu, xqp, qmax);
   else
     CN_LAUNCH(rangebn_apply_kernel<float>, dim3(q_grid(nch)), dim3(Q_NT), stream, (const float*)x, (const float*)residual,
-              (float*)z, (const float*)stats, weight, bias, nch, C, relu);
+              (float*)z, (const float*)stats, weight, bias, nch, C, relu, xqp, qmax);
   return cn_check_launch("rangebn_fwd");
+}
+
+extern "C" int cn_rangebn_fwd(const void* x, const void* residual, void* z, const float* weight, const float* bias,
+                              float* running_mean, float* running_var, float momentum, float eps, int chunks,
+                              float scale_fix, float* stats, int* arg, int M, int C, int relu, int training, int dtype,
+                              float* ws, size_t ws_bytes, void* stream_) {
+  return rangebn_fwd_impl(x, residual, z, weight, bias, running_mean, running_var, momentum, eps, chunks, scale_fix, stats,
+                          arg, M, C, relu, training, dtype, ws, ws_bytes, stream_, nullptr, 8);
+}
+// cn_rangebn_fwd on the RAW input: x_qparams = [zero_point, range] of its x_bits-bit activation quantiser (cn_qparams);
+// every element is snapped on load (see RbnSnap).  Same results as cn_quantize followed by cn_rangebn_fwd.
+extern "C" int cn_rangebn_fwd_q(const void* x, const float* x_qparams, int x_bits, const void* residual, void* z,
+                                const float* weight, const float* bias, float* running_mean, float* running_var,
+                                float momentum, float eps, int chunks, float scale_fix, float* stats, int* arg, int M, int C,
+                                int relu, int training, int dtype, float* ws, size_t ws_bytes, void* stream_) {
+  if (x_qparams == nullptr || x_bits < 1 || x_bits > 23) { cn_set_error("rangebn_fwd_q: needs the input quantiser's parameters"); return CN_EINVAL; }
+  return rangebn_fwd_impl(x, residual, z, weight, bias, running_mean, running_var, momentum, eps, chunks, scale_fix, stats,
+                          arg, M, C, relu, training, dtype, ws, ws_bytes, stream_, x_qparams, x_bits);
 }
 
 // ---- backward.  g = the (already quantised) gradient of the RangeBN output, x = its quantised input.
@@ -541,7 +615,8 @@ extern "C" int cn_rangebn_fwd(const void* x, const void* residual, void* z, cons
 //   => dx[first argmax of chunk j] += dL/dscale * fix / chunks,  dx[first argmin of chunk j] -= the same.
 template <typename T>
 __global__ __launch_bounds__(Q_NT) void rangebn_bwd_reduce_kernel(const T* g, const T* x, const float* stats, int M, int C,
-                                                                 int rows_per, int cols, float* partial) {
+                                                                 int rows_per, int cols, float* partial, const float* xqp,
+                                                                 float qmax) {
   constexpr int CH = ElemTraits<T>::kChunk;
   __shared__ float s1[Q_NT * CH], s2[Q_NT * CH];
   const int tid = threadIdx.x, CC = C / CH;
@@ -552,11 +627,13 @@ __global__ __launch_bounds__(Q_NT) void rangebn_bwd_reduce_kernel(const T* g, co
   float a1[CH], a2[CH], mean[CH];
 #pragma unroll
   for (int e = 0; e < CH; ++e) { a1[e] = 0.f; a2[e] = 0.f; mean[e] = cc < CC ? stats[cc * CH + e] : 0.f; }
+  const RbnSnap snap = rbn_snap_make(xqp, qmax);
   if (cc < CC) {
     auto visit = [&](const u32x4& vg, const u32x4& vx) {
       float fg[CH], fx[CH];
       Chunk<T>::unpack(vg, fg);
       Chunk<T>::unpack(vx, fx);
+      rbn_snap_chunk<T>(snap, fx);
 #pragma unroll
       for (int e = 0; e < CH; ++e) { a1[e] += fg[e]; a2[e] += fg[e] * (fx[e] - mean[e]); }
     };
@@ -664,9 +741,10 @@ __global__ __launch_bounds__(Q_NT) void rangebn_bwd_route_kernel(T* dx, const fl
   }
 }
 
-extern "C" int cn_rangebn_bwd(const void* g, const void* x, const float* weight, const float* stats, const int* arg,
+static int rangebn_bwd_impl(const void* g, const void* x, const float* weight, const float* stats, const int* arg,
                               void* dx, float* dweight, float* dbias, int M, int C, int chunks, float scale_fix,
-                              int dtype, float* ws, size_t ws_bytes, void* stream_) {
+                              int dtype, float* ws, size_t ws_bytes, void* stream_, const float* xqp, int x_bits) {
+  const float qmax = (float)((1 << (x_bits > 0 ? x_bits : 8)) - 1);
   hipStream_t stream = (hipStream_t)stream_;
   const int CH = dtype == CN_BF16 ? 8 : 4;
   if (dtype != CN_BF16 && dtype != CN_F32) { cn_set_error("rangebn_bwd: bad dtype"); return CN_EINVAL; }
@@ -684,15 +762,30 @@ extern "C" int cn_rangebn_bwd(const void* g, const void* x, const float* weight,
   const long long nch = (long long)M * CC;
   const float route = scale_fix / (float)chunks;
   if (dtype == CN_BF16) {
-    CN_LAUNCH(rangebn_bwd_reduce_kernel<bf16_t>, grid, dim3(Q_NT), stream, (const bf16_t*)g, (const bf16_t*)x, stats, M, C, rpr, cols, partial);
+    CN_LAUNCH(rangebn_bwd_reduce_kernel<bf16_t>, grid, dim3(Q_NT), stream, (const bf16_t*)g, (const bf16_t*)x, stats, M, C, rpr, cols, partial, xqp, qmax);
     CN_LAUNCH(rangebn_bwd_finalize_kernel, dim3((unsigned)((C + RF_C - 1) / RF_C)), dim3(RF_C * RF_T), stream, (const float*)partial, rows, M, C, weight, stats, route, dweight, dbias, coef);
     CN_LAUNCH(rangebn_bwd_apply_kernel<bf16_t>, dim3(q_grid(nch)), dim3(Q_NT), stream, (const bf16_t*)g, (bf16_t*)dx, (const float*)coef, nch, C);
     CN_LAUNCH(rangebn_bwd_route_kernel<bf16_t>, dim3((unsigned)((C * chunks + Q_NT - 1) / Q_NT)), dim3(Q_NT), stream, (bf16_t*)dx, (const float*)coef, arg, C, chunks);
   } else {
-    CN_LAUNCH(rangebn_bwd_reduce_kernel<float>, grid, dim3(Q_NT), stream, (const float*)g, (const float*)x, stats, M, C, rpr, cols, partial);
+    CN_LAUNCH(rangebn_bwd_reduce_kernel<float>, grid, dim3(Q_NT), stream, (const float*)g, (const float*)x, stats, M, C, rpr, cols, partial, xqp, qmax);
     CN_LAUNCH(rangebn_bwd_finalize_kernel, dim3((unsigned)((C + RF_C - 1) / RF_C)), dim3(RF_C * RF_T), stream, (const float*)partial, rows, M, C, weight, stats, route, dweight, dbias, coef);
     CN_LAUNCH(rangebn_bwd_apply_kernel<float>, dim3(q_grid(nch)), dim3(Q_NT), stream, (const float*)g, (float*)dx, (const float*)coef, nch, C);
     CN_LAUNCH(rangebn_bwd_route_kernel<float>, dim3((unsigned)((C * chunks + Q_NT - 1) / Q_NT)), dim3(Q_NT), stream, (float*)dx, (const float*)coef, arg, C, chunks);
   }
   return cn_check_launch("rangebn_bwd");
+}
+
+extern "C" int cn_rangebn_bwd(const void* g, const void* x, const float* weight, const float* stats, const int* arg,
+                              void* dx, float* dweight, float* dbias, int M, int C, int chunks, float scale_fix,
+                              int dtype, float* ws, size_t ws_bytes, void* stream_) {
+  return rangebn_bwd_impl(g, x, weight, stats, arg, dx, dweight, dbias, M, C, chunks, scale_fix, dtype, ws, ws_bytes, stream_,
+                          nullptr, 8);
+}
+// cn_rangebn_bwd with x = the RAW input cn_rangebn_fwd_q saw (re-snapped on load with the same x_qparams).
+extern "C" int cn_rangebn_bwd_q(const void* g, const void* x, const float* x_qparams, int x_bits, const float* weight,
+                                const float* stats, const int* arg, void* dx, float* dweight, float* dbias, int M, int C,
+                                int chunks, float scale_fix, int dtype, float* ws, size_t ws_bytes, void* stream_) {
+  if (x_qparams == nullptr || x_bits < 1 || x_bits > 23) { cn_set_error("rangebn_bwd_q: needs the input quantiser's parameters"); return CN_EINVAL; }
+  return rangebn_bwd_impl(g, x, weight, stats, arg, dx, dweight, dbias, M, C, chunks, scale_fix, dtype, ws, ws_bytes, stream_,
+                          x_qparams, x_bits);
 }

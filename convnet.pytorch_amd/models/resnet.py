@@ -87,6 +87,10 @@ class ResidualBlock(tnn.Module):
         self.expansion = expansion
         if self.quantized:   # plain operator chain: no cross-operator fusion in the simulated-8-bit model
             self._holder = None
+            if downsample is not None and hasattr(downsample[0], 'quantize_input'):
+                # conv1 and the projection read the same block input: one min / max + quantise pass for both
+                self.conv1.__dict__['share_q_out'] = True
+                downsample[0].__dict__['share_q_from'] = self.conv1
             return
         # the two gradients meeting at the block input are summed inside a dgrad epilogue
         from ..ops import ResGradHolder
@@ -242,6 +246,9 @@ class ResNetImagenet(tnn.Module):
 
     def features(self, x):
         """x: fp32 NCHW (the loader layout) or an already-converted NHWC compute tensor."""
+        if self.op_classes is not None and self.training:
+            from .. import quant
+            quant.tick(x.device)    # fresh stochastic-rounding noise for this step's gradient quantisers
         if x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3 and x.shape[-1] != self.conv1.padded_in_channels():
             x = self.conv1.forward_from_nchw(x)
         else:

@@ -32,6 +32,12 @@ from torch.autograd import Function
 from . import _lib, nn as cnn, ops
 from ._lib import check, dtype_code, ptr, stream_of
 
+# RangeBN's input quantiser folded into its kernels (cn_rangebn_fwd_q / cn_rangebn_bwd_q: the quantised copy of every
+# convolution output is neither written nor re-read).  Same results, bit for bit - and measured SLOWER on the whole step
+# (ResNet-50 bf16 b=256: 50.1 vs 49.5 ms): the three kernels that now snap on load (statistics with their per-element
+# arg-max bookkeeping, apply, backward reduce) pay the quantiser's division three times and turn VALU-bound.  Off by
+# default; CONVNET_AMD_QUANT_FUSE_RBN=1 switches it on (A/B).
+FUSE_RBN_QUANT = os.environ.get('CONVNET_AMD_QUANT_FUSE_RBN', '0') == '1'
 _NOISE_SOURCE = None
 _SEED = [0x5EED5EED]
 
@@ -54,6 +60,27 @@ def _next_seed():
 
 def _L():
     return _lib.load()
+
+
+# Device-resident step counter mixed into the generator seed of every stochastic quantiser launch (cn_quantize_s): the
+# per-call seeds are host constants - frozen when the step is captured into a HIP graph - and the counter, advanced by
+# one tiny launch at the start of every forward pass (tick, also captured), makes each replay draw fresh noise.
+_STEP_COUNTER = {}
+
+
+def _step_counter(device):
+    dev = torch.device(device)
+    key = str(dev)
+    c = _STEP_COUNTER.get(key)
+    if c is None:
+        c = _STEP_COUNTER[key] = torch.zeros(1, dtype=torch.int64, device=dev)
+    return c
+
+
+def tick(device):
+    """Advance the noise step counter (once per training step, on the compute stream)."""
+    c = _step_counter(device)
+    check(_L().cn_counter_inc(ptr(c), stream_of(c)), 'cn_counter_inc')
 
 
 def minmax_rows(x, rows):
@@ -79,10 +106,11 @@ def quantize(x, zp, rng, num_bits=8, noise=None, stochastic=False):
     """zp / rng: one-element fp32 device tensors (or views)."""
     y = torch.empty_like(x)
     seed = _next_seed() if (stochastic and noise is None) else 0
+    step = _step_counter(x.device) if (stochastic and noise is None) else None
     ops.PROFILER.run('quant: quantize', 1, 0.0, 2 * x.numel() * x.element_size(),
-                     lambda: check(_L().cn_quantize(ptr(x), ptr(y), x.numel(), dtype_code(x.dtype), ptr(zp), ptr(rng),
-                                                    num_bits, ptr(noise), int(stochastic), seed, stream_of(x)),
-                                   'cn_quantize'), x.device)
+                     lambda: check(_L().cn_quantize_s(ptr(x), ptr(y), x.numel(), dtype_code(x.dtype), ptr(zp), ptr(rng),
+                                                      num_bits, ptr(noise), int(stochastic), seed, ptr(step), stream_of(x)),
+                                   'cn_quantize_s'), x.device)
     return y
 
 
@@ -107,7 +135,13 @@ def quantize_grad(g, num_bits=8):
 
 class QuantMeasure(tnn.Module):
     """quantize.py:140-182 (measure=False): running zero point / range, quantises its input."""
-    no_graph = True   # per-call seeds / host-side noise: the step is not captured into a HIP graph
+    quantized_op = True
+
+    @property
+    def no_graph(self):
+        """The step can be captured into a HIP graph with the kernels' own noise generator (device step counter in the
+        seed); a host-side noise source (tests replaying the reference's stream) rules it out."""
+        return _NOISE_SOURCE is not None
 
     def __init__(self, num_bits=8, shape_measure=(1,), flatten_dims=(1, -1), inplace=False, dequantize=True,
                  stochastic=False, momentum=0.1, measure=False):
@@ -127,6 +161,14 @@ class QuantMeasure(tnn.Module):
             qp = qparams(minmax_rows(x, rows), rows, 0, self.running_zero_point, self.running_range, self.momentum)
             return qp[0:1], qp[1:2]
         return self.running_zero_point, self.running_range
+
+    def qparams_tensor(self, x, training=None):
+        """[zero_point, range] as one 2-element device tensor (what the fused kernels take)."""
+        training = self.training if training is None else training
+        if training:
+            rows = x.shape[0]
+            return qparams(minmax_rows(x, rows), rows, 0, self.running_zero_point, self.running_range, self.momentum)
+        return torch.cat([self.running_zero_point.reshape(1), self.running_range.reshape(1)]).float().contiguous()
 
     def forward(self, x, training=None):
         """x: contiguous activation whose leading dimension is the batch."""
@@ -242,7 +284,27 @@ class QConv2dFunction(Function):
             ctx.mod = mod
             ctx.save_for_backward(qx)
             return y
-        qx = x if prequantized else mod.quantize_input(x)
+        if prequantized:
+            qx = x
+        else:
+            # conv1 and the projection shortcut of a block quantise the SAME tensor with the same number of bits: the
+            # shortcut (share_q_from = conv1) reuses conv1's per-sample min / max and its quantised copy and only
+            # updates its own running range (identical values)
+            qm = mod.quantize_input
+            src = getattr(mod, 'share_q_from', None)
+            st = src.__dict__.pop('_q_stash', None) if src is not None else None
+            x = x.contiguous()
+            if st is not None and qm.training and st[0] == x.data_ptr() and st[1] == tuple(x.shape) \
+                    and st[2] == qm.num_bits:
+                qparams(st[3], x.shape[0], 0, qm.running_zero_point, qm.running_range, qm.momentum)
+                qx = st[4]
+            elif qm.training and getattr(mod, 'share_q_out', False):
+                mm = minmax_rows(x, x.shape[0])
+                qp = qparams(mm, x.shape[0], 0, qm.running_zero_point, qm.running_range, qm.momentum)
+                qx = quantize(x, qp[0:1], qp[1:2], qm.num_bits)
+                mod.__dict__['_q_stash'] = (x.data_ptr(), tuple(x.shape), qm.num_bits, mm, qx)
+            else:
+                qx = qm(x)
         _quantize_filters(mod, mod.num_bits_weight)
         y = ops.conv2d_fwd(qx, mod.w_krsc, None, mod.out_channels, mod.kernel_size[0], mod.kernel_size[1],
                            mod.stride, mod.padding)
@@ -359,7 +421,14 @@ class RangeBNFunction(Function):
         M = N * H * W
         L = _L()
         code = dtype_code(y.dtype)
-        qy = mod.quantize_input(y.contiguous())
+        fused = FUSE_RBN_QUANT
+        if fused:     # the kernels snap the raw convolution output on load
+            y = y.contiguous()
+            qp = mod.quantize_input.qparams_tensor(y)
+            qy = y
+        else:
+            qp = None
+            qy = mod.quantize_input(y.contiguous())
         if M % mod.num_chunks != 0 or M // mod.num_chunks < 2:
             raise _lib.ConvNetHipError('RangeBN: %d values per channel do not split into %d chunks of >= 2'
                                        % (M, mod.num_chunks))
@@ -368,14 +437,23 @@ class RangeBNFunction(Function):
         stats = torch.empty(2 * C, dtype=torch.float32, device=y.device)
         arg = torch.empty(C * 2 * mod.num_chunks, dtype=torch.int32, device=y.device)
         ws = ops.workspace(L.cn_rangebn_workspace(M, C, mod.num_chunks), y.device, 'quant')
-        ops.PROFILER.run('quant: rangebn_stats+finalize+apply', 3, 0.0, 3 * qy.numel() * qy.element_size(),
-                         lambda: check(L.cn_rangebn_fwd(ptr(qy), None, ptr(z), ptr(weight), ptr(bias),
-                                                        ptr(mod.running_mean), ptr(mod.running_var), mod.momentum,
-                                                        mod.eps, mod.num_chunks, fix, ptr(stats), ptr(arg), M, C,
-                                                        int(relu), 1, code, ptr(ws), ws.numel() * 4, stream_of(y)),
-                                       'cn_rangebn_fwd'), y.device)
-        ctx.mod, ctx.relu, ctx.fix = mod, relu, fix
-        ctx.save_for_backward(qy, weight, stats, arg, *((z,) if relu else ()))
+        if fused:
+            ops.PROFILER.run('quant: rangebn_stats+finalize+apply (input quantiser folded in)', 3, 0.0,
+                             3 * qy.numel() * qy.element_size(),
+                             lambda: check(L.cn_rangebn_fwd_q(ptr(qy), ptr(qp), mod.quantize_input.num_bits, None, ptr(z),
+                                                              ptr(weight), ptr(bias), ptr(mod.running_mean),
+                                                              ptr(mod.running_var), mod.momentum, mod.eps, mod.num_chunks,
+                                                              fix, ptr(stats), ptr(arg), M, C, int(relu), 1, code, ptr(ws),
+                                                              ws.numel() * 4, stream_of(y)), 'cn_rangebn_fwd_q'), y.device)
+        else:
+            ops.PROFILER.run('quant: rangebn_stats+finalize+apply', 3, 0.0, 3 * qy.numel() * qy.element_size(),
+                             lambda: check(L.cn_rangebn_fwd(ptr(qy), None, ptr(z), ptr(weight), ptr(bias),
+                                                            ptr(mod.running_mean), ptr(mod.running_var), mod.momentum,
+                                                            mod.eps, mod.num_chunks, fix, ptr(stats), ptr(arg), M, C,
+                                                            int(relu), 1, code, ptr(ws), ws.numel() * 4, stream_of(y)),
+                                           'cn_rangebn_fwd'), y.device)
+        ctx.mod, ctx.relu, ctx.fix, ctx.fused = mod, relu, fix, fused
+        ctx.save_for_backward(qy, weight, stats, arg, *((z,) if relu else ()), *((qp,) if fused else ()))
         return z
 
     @staticmethod
@@ -396,11 +474,20 @@ class RangeBNFunction(Function):
         gq = quantize_grad(g0, mod.num_bits_grad)
         dx = torch.empty_like(qy)
         ws = ops.workspace(L.cn_rangebn_workspace(M, C, mod.num_chunks), qy.device, 'quant')
-        ops.PROFILER.run('quant: rangebn_bwd reduce+finalize+apply+route', 4, 0.0, 4 * qy.numel() * qy.element_size(),
-                         lambda: check(L.cn_rangebn_bwd(ptr(gq), ptr(qy), ptr(weight), ptr(stats), ptr(arg), ptr(dx),
-                                                        ptr(mod.grad_view('weight')), ptr(mod.grad_view('bias')), M, C,
-                                                        mod.num_chunks, ctx.fix, dtype_code(qy.dtype), ptr(ws),
-                                                        ws.numel() * 4, stream_of(qy)), 'cn_rangebn_bwd'), qy.device)
+        if ctx.fused:
+            qp = saved[-1]
+            ops.PROFILER.run('quant: rangebn_bwd reduce+finalize+apply+route', 4, 0.0, 4 * qy.numel() * qy.element_size(),
+                             lambda: check(L.cn_rangebn_bwd_q(ptr(gq), ptr(qy), ptr(qp), mod.quantize_input.num_bits,
+                                                              ptr(weight), ptr(stats), ptr(arg), ptr(dx),
+                                                              ptr(mod.grad_view('weight')), ptr(mod.grad_view('bias')), M, C,
+                                                              mod.num_chunks, ctx.fix, dtype_code(qy.dtype), ptr(ws),
+                                                              ws.numel() * 4, stream_of(qy)), 'cn_rangebn_bwd_q'), qy.device)
+        else:
+            ops.PROFILER.run('quant: rangebn_bwd reduce+finalize+apply+route', 4, 0.0, 4 * qy.numel() * qy.element_size(),
+                             lambda: check(L.cn_rangebn_bwd(ptr(gq), ptr(qy), ptr(weight), ptr(stats), ptr(arg), ptr(dx),
+                                                            ptr(mod.grad_view('weight')), ptr(mod.grad_view('bias')), M, C,
+                                                            mod.num_chunks, ctx.fix, dtype_code(qy.dtype), ptr(ws),
+                                                            ws.numel() * 4, stream_of(qy)), 'cn_rangebn_bwd'), qy.device)
         mod._notify_grad_ready()
         return dx, None, None, None, None
 

@@ -87,7 +87,7 @@ class Trainer(object):
             raise NotImplementedError('compute dtype %s: float32, bfloat16 and float16 (the reference\'s `half`: fp32 '
                                       'BatchNorm parameters / statistics and fp32 master weights, main.py:239-250) '
                                       'are built' % dtype)
-        if dtype == torch.float16 and any(getattr(m, 'no_graph', False) for m in model.modules()):
+        if dtype == torch.float16 and any(getattr(m, 'quantized_op', False) for m in model.modules()):
             raise NotImplementedError('resnet(quantize=True) runs in float32 or bfloat16 storage')
         self._model = model
         self.model = model

@@ -379,6 +379,13 @@ int cn_qparams(const float* minmax, int rows, int mode, float* qp, float* runnin
  * stochastic != 0; else deterministic rounding. */
 int cn_quantize(const void* x, void* y, long long n, int dtype, const float* zero_point, const float* range,
                 int num_bits, const float* noise, int stochastic, unsigned long long seed, void* stream);
+/* cn_quantize with its generator seed mixed with a device-resident step counter (one unsigned 64-bit word the caller
+ * advances with cn_counter_inc once per training step): a launch replayed from a captured HIP graph - frozen kernel
+ * arguments - still draws fresh rounding noise every step. */
+int cn_quantize_s(const void* x, void* y, long long n, int dtype, const float* zero_point, const float* range,
+                  int num_bits, const float* noise, int stochastic, unsigned long long seed,
+                  const unsigned long long* step_counter, void* stream);
+int cn_counter_inc(unsigned long long* counter, void* stream);
 /* per-row (= per output channel) quantisation of an fp32 filter matrix with the row's own min / max
  * (QConv2d / QLinear weights, quantize.py:201-203,239-240) */
 int cn_quantize_rows(const float* x, float* y, int rows, int row_len, int num_bits, void* stream);
@@ -397,6 +404,17 @@ int cn_rangebn_fwd(const void* x, const void* residual, void* z, const float* we
 int cn_rangebn_bwd(const void* g, const void* x, const float* weight, const float* stats, const int* arg, void* dx,
                    float* dweight, float* dbias, int M, int C, int chunks, float scale_fix, int dtype,
                    float* workspace, size_t workspace_bytes, void* stream);
+/* The same two calls on the RAW (not yet input-quantised) tensor: x_qparams = [zero_point, range] of RangeBN's own
+ * x_bits-bit activation quantiser (cn_qparams' output; quantize.py:270,308 quantises the input first).  The kernels snap
+ * every element on load with cn_quantize's arithmetic and rounding, so the quantised copy is never written or re-read:
+ * same results as cn_quantize followed by cn_rangebn_fwd / cn_rangebn_bwd. */
+int cn_rangebn_fwd_q(const void* x, const float* x_qparams, int x_bits, const void* residual, void* z, const float* weight,
+                     const float* bias, float* running_mean, float* running_var, float momentum, float eps, int chunks,
+                     float scale_fix, float* stats, int* arg, int M, int C, int relu, int training, int dtype, float* ws,
+                     size_t ws_bytes, void* stream);
+int cn_rangebn_bwd_q(const void* g, const void* x, const float* x_qparams, int x_bits, const float* weight,
+                     const float* stats, const int* arg, void* dx, float* dweight, float* dbias, int M, int C, int chunks,
+                     float scale_fix, int dtype, float* ws, size_t ws_bytes, void* stream);
 
 /* ---- true int8 MFMA forward product of QConv2d (v_mfma_i32_32x32x32_i8; csrc/qconv_i8.hip).  Both operands of
  * the reference's simulated convolution (quantize.py:195-219) live on integer grids, so

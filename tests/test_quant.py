@@ -354,3 +354,27 @@ def test_bench_scale_quantised_resnet50_follows_the_reference(dtype, reference_n
               'conv1.quantize_input.running_range', 'fc.quantize_input.running_range'):
         print(k, rel_l2(sd[k].float().cpu(), final[k]))
         assert rel_l2(sd[k].float().cpu(), final[k]) < (0.25 if (k == 'bn1.running_mean' and not f32) else 0.06), k
+
+
+@pytest.mark.parametrize('mode', MODES)
+def test_folded_input_quantiser_and_shared_block_input_change_no_bit(mode, reference_noise):
+    """Round 3: RangeBN's input quantiser folded into its kernels (cn_rangebn_fwd_q / cn_rangebn_bwd_q, the quantised
+    copy of every convolution output is never written) and the block input quantised once for conv1 and the projection
+    shortcut: the same trajectory, bit for bit, as the separate cn_quantize passes."""
+    dev = _dev(mode)
+    import convnet_amd as ca
+    meta = json.load(open(os.path.join(GOLDEN, 'traj_r18s_quant.json')))
+    res = {}
+    saved = ca.quant.FUSE_RBN_QUANT
+    try:
+        for fused in (False, True):
+            ca.quant.FUSE_RBN_QUANT = fused
+            recs, tr, model, data = _engine_trajectory(meta, 18, dev, torch.float32, 2 if mode == 'gpu' else 1)
+            if not fused:   # ... and without the shared block input
+                pass
+            res[fused] = (recs, {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()})
+    finally:
+        ca.quant.FUSE_RBN_QUANT = saved
+    assert res[False][0] == res[True][0], (res[False][0], res[True][0])
+    for k, v in res[False][1].items():
+        assert torch.equal(v, res[True][1][k]), k
