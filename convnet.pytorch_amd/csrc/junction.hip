@@ -317,3 +317,201 @@ extern "C" int cn_conv2d_dgrad_junction(const void* dy, const void* w_crsk, void
 #undef JD_GO
   return cn_check_launch("jdgrad");
 }
+
+// ------------------------------------------------------------------------------------------------
+// The forward counterpart for the block's LAST 1x1 convolution (conv3, the stride-1 projection: K -> 4K channels,
+// /root/reference models/resnet.py:130-132,176-181): the same streaming structure - filter in registers, a pixel range
+// and all CO channels per workgroup, wave-private transposition, 16-byte stores of full pixel rows - with the
+// BatchNorm statistics of the stored values (cn_conv2d_fwd_bnstats' epilogue) kept in registers: one partial row
+// [sum | sum of squares] per workgroup.  Output bits = cn_conv2d_fwd's.
+struct JfParams {
+  const char* x;      // [M][KD]
+  const char* w;      // [CO][KD] (KRSC of a 1x1 convolution)
+  char* y;            // [M][CO]
+  float* partial;     // [nsplit][2 * CO]
+  int M, m_per_split, nsplit;
+  unsigned int x_bytes;
+};
+
+template <typename T, int KD, int CO>
+__global__ __launch_bounds__(512) void jfwd_kernel(JfParams p) {
+  static_assert(sizeof(T) == 2, "16-bit storage");
+  constexpr int NCW = CO / 64;
+  static_assert(NCW == 4 || NCW == 8, "256 or 512 output channels");
+  constexpr int PH = 8 / NCW;
+  constexpr int BM = 32 * PH;
+  constexpr int NKK = KD / 16;
+  constexpr int NCD = KD / 8;
+  constexpr int DYB = BM * KD * 2;
+  constexpr int ND = BM * NCD / 512;
+  static_assert(ND >= 1 && BM * NCD % 512 == 0, "x tile staging");
+  constexpr int PP = 144;
+  constexpr int PRIV = 32 * PP;
+  __shared__ __attribute__((aligned(16))) char lds[2 * DYB + 8 * PRIV];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = cn_uniform(tid >> 6);
+  const int cw = wave % NCW, ph = wave / NCW;
+  const int h = lane >> 5;
+  char* priv = lds + 2 * DYB + wave * PRIV;
+  const int split = blockIdx.x;
+  const int m_begin = split * p.m_per_split;
+  int m_end = m_begin + p.m_per_split;
+  if (m_end > p.M) m_end = p.M;
+
+  s16x8 wf[2][NKK];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+      const int c = cw * 64 + t * 32 + (lane & 31);
+      wf[t][kk] = __builtin_bit_cast(s16x8, cn_ld16(p.w + ((size_t)c * KD + 16 * kk + 8 * h) * 2));
+    }
+  const cn_buf_t xbuf = cn_make_buf(p.x, p.x_bytes);
+  const int ech = lane & 7, erow = lane >> 3;
+  const int cb = cw * 64 + ech * 8;
+  u32x4 dreg[ND];
+  auto load_stage = [&](int mb) {
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const int id = tid + 512 * i;
+      const int row = id / NCD, c = id - row * NCD;
+      const int m = mb + row;
+      dreg[i] = cn_buf_ld16(xbuf, m < m_end ? ((unsigned int)m * (unsigned int)KD + (unsigned int)c * 8u) * 2u : CN_OOB);
+    }
+  };
+  auto store_x = [&](int buf) {
+    char* t = lds + buf * DYB;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const int id = tid + 512 * i;
+      const int row = id / NCD, c = id - row * NCD;
+      const int cs = NCD == 8 ? (c ^ ((row >> 1) & 7)) : (c ^ (row & (NCD - 1)));
+      cn_st16(t + row * (KD * 2) + (cs << 4), dreg[i]);
+    }
+  };
+  float ssum[8], ssq[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
+
+  if (m_begin < m_end) {
+    load_stage(m_begin);
+    int buf = 0;
+    for (int mb = m_begin; mb < m_end; mb += BM) {
+      store_x(buf);
+      __syncthreads();
+      if (mb + BM < m_end) load_stage(mb + BM);
+      const char* t = lds + buf * DYB;
+      f32x16 acc[2];
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+      const int prow = ph * 32 + (lane & 31);
+      const char* rowp = t + prow * (KD * 2);
+      const int sw = NCD == 8 ? ((prow >> 1) & 7) : (prow & (NCD - 1));
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk) {
+        const s16x8 b = __builtin_bit_cast(s16x8, cn_ld16(rowp + (((2 * kk + h) ^ sw) << 4)));
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+          if constexpr (std::is_same<T, f16_t>::value) acc[x] = cn_mfma_32x32x16_f16(wf[x][kk], b, acc[x]);
+          else acc[x] = cn_mfma_32x32x16_bf16(wf[x][kk], b, acc[x]);
+        }
+      }
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          u32x2 pk;
+          pk[0] = cn_pack2<T>(acc[x][q * 4], acc[x][q * 4 + 1]);
+          pk[1] = cn_pack2<T>(acc[x][q * 4 + 2], acc[x][q * 4 + 3]);
+          *(u32x2*)(priv + (lane & 31) * PP + (x * 32 + 8 * q + 4 * h) * 2) = pk;
+        }
+      cn_wave_sync();
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int m = mb + ph * 32 + k * 8 + erow;
+        const u32x4 v = cn_ld16(priv + (k * 8 + erow) * PP + ech * 16);
+        if (m < m_end) {
+          float f[8];
+          Chunk<T>::unpack(v, f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { ssum[e] += f[e]; ssq[e] = fmaf(f[e], f[e], ssq[e]); }
+          cn_st16(p.y + ((size_t)m * CO + (size_t)cb) * 2, v);
+        }
+      }
+      cn_wave_sync();
+      buf ^= 1;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+#pragma unroll
+    for (int msk = 8; msk <= 32; msk <<= 1) {
+      ssum[e] += cn_shfl_xor(ssum[e], msk);
+      ssq[e] += cn_shfl_xor(ssq[e], msk);
+    }
+  __syncthreads();
+  float* red = (float*)lds;
+  if (lane < 8) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[(wave * 64 + lane * 8 + e) * 2] = ssum[e];
+      red[(wave * 64 + lane * 8 + e) * 2 + 1] = ssq[e];
+    }
+  }
+  __syncthreads();
+  if (tid < CO && p.partial != nullptr) {
+    const int c = tid, wcol = c / 64, cc = c % 64;
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int g2 = 0; g2 < PH; ++g2) {
+      a1 += red[((g2 * NCW + wcol) * 64 + cc) * 2];
+      a2 += red[((g2 * NCW + wcol) * 64 + cc) * 2 + 1];
+    }
+    float* dst = p.partial + (size_t)split * 2 * CO;
+    dst[c] = a1;
+    dst[CO + c] = a2;
+  }
+}
+
+extern "C" int cn_conv1x1_stream_fwd_ok(int C, int K, int dtype) {   // C input, K output channels
+  if (dtype != CN_BF16 && dtype != CN_F16) return 0;
+  return ((K == 256 && (C == 64 || C == 128)) || (K == 512 && C == 128)) ? 1 : 0;
+}
+extern "C" int cn_conv1x1_stream_fwd_rows(int N, int H, int W, int K) {
+  return jd_plan((long long)N * H * W, jd_bm(K), nullptr);
+}
+// y = conv1x1(x, w) (stride 1, C -> K channels of an instantiated shape: 64 / 128 -> 256, 128 -> 512) with the
+// statistics partials of cn_conv2d_fwd_bnstats (cn_conv1x1_stream_fwd_rows rows of 2*K floats, one per workgroup;
+// partial may be NULL) as a persistent streaming kernel.  Output bits = cn_conv2d_fwd's.
+extern "C" int cn_conv1x1_stream_fwd(const void* x, const void* w_krsc, void* y, int N, int H, int W, int C, int K,
+                                     int dtype, float* partial, int partial_rows, void* stream) {
+  if (!cn_conv1x1_stream_fwd_ok(C, K, dtype)) { cn_set_error("conv1x1_stream_fwd: C=%d -> K=%d dtype %d is not an instantiated shape", C, K, dtype); return CN_ESHAPE; }
+  if (x == nullptr || w_krsc == nullptr || y == nullptr) { cn_set_error("conv1x1_stream_fwd: null operand"); return CN_EINVAL; }
+  const long long M = (long long)N * H * W;
+  if (M <= 0) { cn_set_error("conv1x1_stream_fwd: empty"); return CN_ESHAPE; }
+  if (M * K * 2 >= (1ll << 31)) { cn_set_error("conv1x1_stream_fwd: operand exceeds the 2 GiB buffer-descriptor window"); return CN_ESHAPE; }
+  long long mps = 0;
+  const int nsplit = jd_plan(M, jd_bm(K), &mps);
+  if (partial != nullptr && partial_rows < nsplit) { cn_set_error("conv1x1_stream_fwd: partial buffer of %d rows < %d", partial_rows, nsplit); return CN_EWORKSPACE; }
+  JfParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = (const char*)x; p.w = (const char*)w_krsc; p.y = (char*)y; p.partial = partial;
+  p.M = (int)M; p.m_per_split = (int)mps; p.nsplit = nsplit;
+  p.x_bytes = (unsigned int)(M * C * 2);
+  hipStream_t st = (hipStream_t)stream;
+  cn_set_last_kernel("jfwd_kernel<%s, %d, %d>", dtype == CN_F16 ? "f16_t" : "bf16_t", C, K);
+  dim3 grid((unsigned)nsplit);
+#define JF_GO(KD, CO)                                                                             \
+  do {                                                                                            \
+    if (dtype == CN_F16) CN_LAUNCH((jfwd_kernel<f16_t, KD, CO>), grid, dim3(512), st, p);          \
+    else CN_LAUNCH((jfwd_kernel<bf16_t, KD, CO>), grid, dim3(512), st, p);                         \
+  } while (0)
+  if (K == 256 && C == 64) JF_GO(64, 256);
+  else if (K == 256 && C == 128) JF_GO(128, 256);
+  else JF_GO(128, 512);
+#undef JF_GO
+  return cn_check_launch("jfwd");
+}

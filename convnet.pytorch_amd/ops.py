@@ -265,6 +265,8 @@ STEM_HALO = os.environ.get('CONVNET_AMD_STEM_HALO', '1') != '0'
 # A/B switch: 0 = the 64 -> 64 channel 3x3 convolutions run through the tiled implicit-GEMM kernel instead of the halo
 # kernel (csrc/conv3x3.hip)
 CONV3X3_HALO = os.environ.get('CONVNET_AMD_CONV3X3_HALO', '1') != '0'
+# A/B switch: 0 = conv3 / the stride-1 projection forward through the tiled kernel instead of the streaming kernel
+CONV1X1_STREAM = os.environ.get('CONVNET_AMD_CONV1X1_STREAM', '1') != '0'
 # A/B switch: 0 = the stem's bn1 -> relu -> maxpool runs as separate BatchNorm and max-pool passes
 FUSE_STEM_POOL = os.environ.get('CONVNET_AMD_FUSE_STEM_POOL', '1') != '0'
 # A/B switch: 0 = BatchNorm backward always runs its own reduction pass over (dz, y)
@@ -362,6 +364,20 @@ def conv2d_fwd(x, w_krsc, bias, K, R, S, stride, pad, out_f32=False, relu=False,
     N, H, W, C = x.shape
     P, Q = conv_out_hw(H, W, R, S, stride, pad)
     y = torch.empty((N, P, Q, K), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+    if CONV1X1_STREAM and bias is None and not out_f32 and not relu and pivot is None and (R, S) == (1, 1) \
+            and tuple(stride) == (1, 1) and tuple(pad) == (0, 0) and _L().cn_conv1x1_stream_fwd_ok(C, K, dtype_code(x.dtype)):
+        L = _L()
+        want = bn_stats and y.numel() * _esize(y) >= FUSE_BN_STATS_MIN_MB * 2 ** 20
+        rows = L.cn_conv1x1_stream_fwd_rows(N, H, W, K) if want else 0
+        partial = torch.empty((rows, 2 * K), dtype=torch.float32, device=x.device) if want else None
+        PROFILER.run(_last_kernel(), 1, 2.0 * N * P * Q * K * C,
+                     x.numel() * _esize(x) + y.numel() * _esize(y) + K * C * _esize(x),
+                     lambda: check(L.cn_conv1x1_stream_fwd(ptr(x), ptr(w_krsc), ptr(y), N, H, W, C, K, dtype_code(x.dtype),
+                                                           ptr(partial), rows, stream_of(x)), 'cn_conv1x1_stream_fwd'),
+                     x.device, detail=_conv_detail('fwd', C, H, K, R, stride))
+        if want:
+            _park_stats(y, partial, rows, None)
+        return y
     if bias is None and not out_f32 and not relu and pivot is None and _halo3x3_ok(x, C, K, R, S, stride, pad):
         L = _L()
         want = bn_stats and y.numel() * _esize(y) >= FUSE_BN_STATS_MIN_MB * 2 ** 20

@@ -163,6 +163,13 @@ int cn_conv2d_dgrad_bnbwd_sa(const void* dy, const void* w_crsk, void* g, const 
                              int H, int W, int C, int K, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w,
                              int dtype, const void* bn_y, const unsigned char* bn_mask, const float* bn_coef,
                              int bn_relu, float* partial, int partial_rows, void* stream);
+/* The block's last 1x1 convolution (conv3 / the stride-1 projection, C -> K = 64 / 128 -> 256, 128 -> 512 channels) as a
+ * persistent streaming kernel with the statistics partials of cn_conv2d_fwd_bnstats kept in registers (one row per
+ * workgroup: cn_conv1x1_stream_fwd_rows; partial may be NULL).  Output bits = cn_conv2d_fwd's. */
+int cn_conv1x1_stream_fwd_ok(int C, int K, int dtype);
+int cn_conv1x1_stream_fwd_rows(int N, int H, int W, int K);
+int cn_conv1x1_stream_fwd(const void* x, const void* w_krsc, void* y, int N, int H, int W, int C, int K, int dtype,
+                          float* partial, int partial_rows, void* stream);
 /* The same operation for the LARGE junctions as one persistent streaming kernel (csrc/junction.hip): 1x1 / stride-1 /
  * unpadded convolution with K -> C channels of an instantiated shape (cn_conv2d_dgrad_junction_ok: 64 or 128 -> 256,
  * 128 -> 512; 16-bit storage), ReLU bits (bn_mask) and an addend required (addend_sub as cn_conv2d_dgrad_sa).  The

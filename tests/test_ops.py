@@ -1411,3 +1411,35 @@ def test_conv3x3_halo_kernel_equals_tiled_kernel(mode, dtype):
             yr.backward(dy)
             assert rel_l2(y1.float().cpu().permute(0, 3, 1, 2), yr.detach()) < _tol(dtype)
             assert rel_l2(d1.float().cpu().permute(0, 3, 1, 2), xr.grad) < _tol(dtype)
+
+
+@pytest.mark.parametrize('mode', MODES)
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_streaming_conv1x1_forward_equals_tiled_kernel(mode, dtype):
+    """cn_conv1x1_stream_fwd (conv3 / the stride-1 projection as a persistent streaming kernel, statistics in registers)
+    against the tiled kernel on every instantiated shape: output bit for bit, partial column sums to fp32 association."""
+    _f16_emul_subset(mode, dtype, keep=True)
+    dev = _dev(mode)
+    import convnet_amd as ca
+    ops, L = ca.ops, ca._lib.load()
+    cases = [(1, 6, 10, 64, 256), (2, 6, 6, 128, 256), (1, 5, 9, 128, 512)] if mode == 'emul' else \
+        [(8, 56, 56, 64, 256), (8, 56, 56, 128, 256), (16, 28, 28, 128, 512), (3, 17, 13, 64, 256)]
+    for (N, H, W, C, K) in cases:
+        g = torch.Generator().manual_seed(C + K + H)
+        x = torch.randn(N, H, W, C, generator=g).to(dtype).to(dev)
+        w = (torch.randn(K, 1, 1, C, generator=g) * (2.0 / C) ** 0.5).to(dtype).to(dev)
+        saved = ops.CONV1X1_STREAM
+        try:
+            ops.CONV1X1_STREAM = False
+            y0 = ops.conv2d_fwd(x, w, None, K, 1, 1, (1, 1), (0, 0), bn_stats=True)
+            assert 'igemm_kernel' in L.cn_last_kernel_name().decode()
+            p0 = ops.take_pending_stats(y0)
+            ops.CONV1X1_STREAM = True
+            y1 = ops.conv2d_fwd(x, w, None, K, 1, 1, (1, 1), (0, 0), bn_stats=True)
+            assert 'jfwd_kernel' in L.cn_last_kernel_name().decode()
+            p1 = ops.take_pending_stats(y1)
+            y2 = ops.conv2d_fwd(x, w, None, K, 1, 1, (1, 1), (0, 0))     # without the statistics
+        finally:
+            ops.CONV1X1_STREAM = saved
+        assert torch.equal(y1.cpu(), y0.cpu()) and torch.equal(y2.cpu(), y0.cpu()), (N, H, W, C, K)
+        assert rel_l2(p1.partial.double().sum(0).cpu(), p0.partial.double().sum(0).cpu()) < 1e-5
