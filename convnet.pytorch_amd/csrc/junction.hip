@@ -328,8 +328,9 @@ struct JfParams {
   const char* x;      // [M][KD]
   const char* w;      // [CO][KD] (KRSC of a 1x1 convolution)
   char* y;            // [M][CO]
-  float* partial;     // [nsplit][2 * CO]
+  float* partial;     // [nsplit][2 * co_total]
   int M, m_per_split, nsplit;
+  int co_total;       // output channels of the convolution; a workgroup computes the CO of them from blockIdx.y * CO on
   unsigned int x_bytes;
 };
 
@@ -355,6 +356,7 @@ __global__ __launch_bounds__(512) void jfwd_kernel(JfParams p) {
   const int h = lane >> 5;
   char* priv = lds + 2 * DYB + wave * PRIV;
   const int split = blockIdx.x;
+  const int co0 = blockIdx.y * CO, COT = p.co_total;
   const int m_begin = split * p.m_per_split;
   int m_end = m_begin + p.m_per_split;
   if (m_end > p.M) m_end = p.M;
@@ -364,12 +366,12 @@ __global__ __launch_bounds__(512) void jfwd_kernel(JfParams p) {
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int kk = 0; kk < NKK; ++kk) {
-      const int c = cw * 64 + t * 32 + (lane & 31);
+      const int c = co0 + cw * 64 + t * 32 + (lane & 31);
       wf[t][kk] = __builtin_bit_cast(s16x8, cn_ld16(p.w + ((size_t)c * KD + 16 * kk + 8 * h) * 2));
     }
   const cn_buf_t xbuf = cn_make_buf(p.x, p.x_bytes);
   const int ech = lane & 7, erow = lane >> 3;
-  const int cb = cw * 64 + ech * 8;
+  const int cb = co0 + cw * 64 + ech * 8;
   u32x4 dreg[ND];
   auto load_stage = [&](int mb) {
 #pragma unroll
@@ -438,7 +440,7 @@ __global__ __launch_bounds__(512) void jfwd_kernel(JfParams p) {
           Chunk<T>::unpack(v, f);
 #pragma unroll
           for (int e = 0; e < 8; ++e) { ssum[e] += f[e]; ssq[e] = fmaf(f[e], f[e], ssq[e]); }
-          cn_st16(p.y + ((size_t)m * CO + (size_t)cb) * 2, v);
+          cn_st16(p.y + ((size_t)m * COT + (size_t)cb) * 2, v);
         }
       }
       cn_wave_sync();
@@ -470,20 +472,21 @@ __global__ __launch_bounds__(512) void jfwd_kernel(JfParams p) {
       a1 += red[((g2 * NCW + wcol) * 64 + cc) * 2];
       a2 += red[((g2 * NCW + wcol) * 64 + cc) * 2 + 1];
     }
-    float* dst = p.partial + (size_t)split * 2 * CO;
-    dst[c] = a1;
-    dst[CO + c] = a2;
+    float* dst = p.partial + (size_t)split * 2 * COT;
+    dst[co0 + c] = a1;
+    dst[COT + co0 + c] = a2;
   }
 }
 
 extern "C" int cn_conv1x1_stream_fwd_ok(int C, int K, int dtype) {   // C input, K output channels
   if (dtype != CN_BF16 && dtype != CN_F16) return 0;
-  return ((K == 256 && (C == 64 || C == 128)) || (K == 512 && C == 128)) ? 1 : 0;
+  return ((K == 256 && (C == 64 || C == 128)) || (K == 512 && C == 128) || (K == 1024 && C == 256)) ? 1 : 0;
 }
 extern "C" int cn_conv1x1_stream_fwd_rows(int N, int H, int W, int K) {
-  return jd_plan((long long)N * H * W, jd_bm(K), nullptr);
+  return jd_plan((long long)N * H * W, jd_bm(K >= 512 ? 512 : K), nullptr);
 }
-// y = conv1x1(x, w) (stride 1, C -> K channels of an instantiated shape: 64 / 128 -> 256, 128 -> 512) with the
+// y = conv1x1(x, w) (stride 1, C -> K channels of an instantiated shape: 64 / 128 -> 256, 128 -> 512, 256 -> 1024 - the
+// last in two 512-channel slices, grid.y) with the
 // statistics partials of cn_conv2d_fwd_bnstats (cn_conv1x1_stream_fwd_rows rows of 2*K floats, one per workgroup;
 // partial may be NULL) as a persistent streaming kernel.  Output bits = cn_conv2d_fwd's.
 extern "C" int cn_conv1x1_stream_fwd(const void* x, const void* w_krsc, void* y, int N, int H, int W, int C, int K,
@@ -494,16 +497,17 @@ extern "C" int cn_conv1x1_stream_fwd(const void* x, const void* w_krsc, void* y,
   if (M <= 0) { cn_set_error("conv1x1_stream_fwd: empty"); return CN_ESHAPE; }
   if (M * K * 2 >= (1ll << 31)) { cn_set_error("conv1x1_stream_fwd: operand exceeds the 2 GiB buffer-descriptor window"); return CN_ESHAPE; }
   long long mps = 0;
-  const int nsplit = jd_plan(M, jd_bm(K), &mps);
+  const int nsplit = jd_plan(M, jd_bm(K >= 512 ? 512 : K), &mps);
   if (partial != nullptr && partial_rows < nsplit) { cn_set_error("conv1x1_stream_fwd: partial buffer of %d rows < %d", partial_rows, nsplit); return CN_EWORKSPACE; }
   JfParams p;
   memset(&p, 0, sizeof(p));
   p.x = (const char*)x; p.w = (const char*)w_krsc; p.y = (char*)y; p.partial = partial;
   p.M = (int)M; p.m_per_split = (int)mps; p.nsplit = nsplit;
+  p.co_total = K;
   p.x_bytes = (unsigned int)(M * C * 2);
   hipStream_t st = (hipStream_t)stream;
   cn_set_last_kernel("jfwd_kernel<%s, %d, %d>", dtype == CN_F16 ? "f16_t" : "bf16_t", C, K);
-  dim3 grid((unsigned)nsplit);
+  dim3 grid((unsigned)nsplit, (unsigned)(K > 512 ? K / 512 : 1));
 #define JF_GO(KD, CO)                                                                             \
   do {                                                                                            \
     if (dtype == CN_F16) CN_LAUNCH((jfwd_kernel<f16_t, KD, CO>), grid, dim3(512), st, p);          \
@@ -511,7 +515,8 @@ extern "C" int cn_conv1x1_stream_fwd(const void* x, const void* w_krsc, void* y,
   } while (0)
   if (K == 256 && C == 64) JF_GO(64, 256);
   else if (K == 256 && C == 128) JF_GO(128, 256);
-  else JF_GO(128, 512);
+  else if (K == 512) JF_GO(128, 512);
+  else JF_GO(256, 512);
 #undef JF_GO
   return cn_check_launch("jfwd");
 }

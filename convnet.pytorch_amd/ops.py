@@ -267,6 +267,7 @@ STEM_HALO = os.environ.get('CONVNET_AMD_STEM_HALO', '1') != '0'
 CONV3X3_HALO = os.environ.get('CONVNET_AMD_CONV3X3_HALO', '1') != '0'
 # A/B switch: 0 = conv3 / the stride-1 projection forward through the tiled kernel instead of the streaming kernel
 CONV1X1_STREAM = os.environ.get('CONVNET_AMD_CONV1X1_STREAM', '1') != '0'
+CONV1X1_STREAM_MAXK = int(os.environ.get('CONVNET_AMD_CONV1X1_STREAM_MAXK', '1024'))   # (A/B: 512 = without the 256 -> 1024 form)
 # A/B switch: 0 = the stem's bn1 -> relu -> maxpool runs as separate BatchNorm and max-pool passes
 FUSE_STEM_POOL = os.environ.get('CONVNET_AMD_FUSE_STEM_POOL', '1') != '0'
 # A/B switch: 0 = BatchNorm backward always runs its own reduction pass over (dz, y)
@@ -365,7 +366,8 @@ def conv2d_fwd(x, w_krsc, bias, K, R, S, stride, pad, out_f32=False, relu=False,
     P, Q = conv_out_hw(H, W, R, S, stride, pad)
     y = torch.empty((N, P, Q, K), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
     if CONV1X1_STREAM and bias is None and not out_f32 and not relu and pivot is None and (R, S) == (1, 1) \
-            and tuple(stride) == (1, 1) and tuple(pad) == (0, 0) and _L().cn_conv1x1_stream_fwd_ok(C, K, dtype_code(x.dtype)):
+            and tuple(stride) == (1, 1) and tuple(pad) == (0, 0) and K <= CONV1X1_STREAM_MAXK \
+            and _L().cn_conv1x1_stream_fwd_ok(C, K, dtype_code(x.dtype)):
         L = _L()
         want = bn_stats and y.numel() * _esize(y) >= FUSE_BN_STATS_MIN_MB * 2 ** 20
         rows = L.cn_conv1x1_stream_fwd_rows(N, H, W, K) if want else 0

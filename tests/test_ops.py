@@ -1422,8 +1422,8 @@ def test_streaming_conv1x1_forward_equals_tiled_kernel(mode, dtype):
     dev = _dev(mode)
     import convnet_amd as ca
     ops, L = ca.ops, ca._lib.load()
-    cases = [(1, 6, 10, 64, 256), (2, 6, 6, 128, 256), (1, 5, 9, 128, 512)] if mode == 'emul' else \
-        [(8, 56, 56, 64, 256), (8, 56, 56, 128, 256), (16, 28, 28, 128, 512), (3, 17, 13, 64, 256)]
+    cases = [(1, 6, 10, 64, 256), (2, 6, 6, 128, 256), (1, 5, 9, 128, 512), (1, 5, 7, 256, 1024)] if mode == 'emul' else \
+        [(8, 56, 56, 64, 256), (8, 56, 56, 128, 256), (16, 28, 28, 128, 512), (3, 17, 13, 64, 256), (64, 14, 14, 256, 1024)]
     for (N, H, W, C, K) in cases:
         g = torch.Generator().manual_seed(C + K + H)
         x = torch.randn(N, H, W, C, generator=g).to(dtype).to(dev)

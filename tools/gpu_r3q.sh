@@ -12,7 +12,7 @@ except Exception: print('FAILED', t[:300])"; }
 {
 run warm X=1
 for i in 1 2 3; do
-run stream_$i X=1
-run tiled_$i CONVNET_AMD_CONV1X1_STREAM=0
+run k1024_$i X=1
+run k512_$i CONVNET_AMD_CONV1X1_STREAM_MAXK=512
 done
 } 2>&1 | tee $OUT/sched.txt
