@@ -37,12 +37,16 @@ struct JdParams {
   char* g;                       // [M][CO]
   float* partial;                // [nsplit][2 * CO]
   int M, m_per_split, nsplit;
+  int co_total;                  // channels of g (a workgroup computes CO of them, from blockIdx.y * CO on)
   int addend_sub, H, W, add_H, add_W;
   FastDiv div_hw, div_w;
   unsigned int dy_bytes, out_bytes, add_bytes, mask_bytes;
 };
 
-template <typename T, int KD, int CO>
+// PF: the epilogue operands of stage s + 1 are requested before stage s is processed (72 more registers); PF = false
+// (the 256-channel reductions, whose filter fragments take 128 registers): they are requested at the start of their own
+// stage, ahead of its MFMAs.  A workgroup computes the CO channels from blockIdx.y * CO on of p.co_total.
+template <typename T, int KD, int CO, bool PF = true>
 __global__ __launch_bounds__(512) void jdgrad_kernel(JdParams p) {
   static_assert(sizeof(T) == 2, "16-bit storage");
   constexpr int NCW = CO / 64;          // wave columns of 64 channels
@@ -65,6 +69,7 @@ __global__ __launch_bounds__(512) void jdgrad_kernel(JdParams p) {
   char* priv = lds + 2 * DYB + wave * PRIV;
 
   const int split = blockIdx.x;
+  const int co0 = blockIdx.y * CO, COT = p.co_total;
   const int m_begin = split * p.m_per_split;
   int m_end = m_begin + p.m_per_split;
   if (m_end > p.M) m_end = p.M;
@@ -75,7 +80,7 @@ __global__ __launch_bounds__(512) void jdgrad_kernel(JdParams p) {
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int kk = 0; kk < NKK; ++kk) {
-      const int c = cw * 64 + t * 32 + (lane & 31);
+      const int c = co0 + cw * 64 + t * 32 + (lane & 31);
       wf[t][kk] = __builtin_bit_cast(s16x8, cn_ld16(p.w + ((size_t)c * KD + 16 * kk + 8 * h) * 2));
     }
 
@@ -84,7 +89,7 @@ __global__ __launch_bounds__(512) void jdgrad_kernel(JdParams p) {
   const cn_buf_t ybuf = cn_make_buf(p.bn_y, p.out_bytes);
   // epilogue coordinates of this lane: pixel rows pass*8 + (lane >> 3) of the wave's 32, chunk (8 channels) lane & 7
   const int ech = lane & 7, erow = lane >> 3;
-  const int cb = cw * 64 + ech * 8;     // first channel of the lane's chunk
+  const int cb = co0 + cw * 64 + ech * 8;     // first channel of the lane's chunk
   const int HW = p.H * p.W;
 
   struct Epi {
@@ -92,7 +97,7 @@ __global__ __launch_bounds__(512) void jdgrad_kernel(JdParams p) {
     unsigned int bits[4];
   };
   u32x4 dreg[ND];
-  auto load_stage = [&](int mb, Epi& e) {
+  auto load_dy = [&](int mb) {
 #pragma unroll
     for (int i = 0; i < ND; ++i) {
       const int id = tid + 512 * i;
@@ -100,11 +105,13 @@ __global__ __launch_bounds__(512) void jdgrad_kernel(JdParams p) {
       const int m = mb + row;
       dreg[i] = cn_buf_ld16(dybuf, m < m_end ? ((unsigned int)m * (unsigned int)KD + (unsigned int)c * 8u) * 2u : CN_OOB);
     }
+  };
+  auto load_epi = [&](int mb, Epi& e) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int m = mb + ph * 32 + k * 8 + erow;
       const bool ok = m < m_end;
-      const unsigned int o = ok ? ((unsigned int)m * (unsigned int)CO + (unsigned int)cb) * 2u : CN_OOB;
+      const unsigned int o = ok ? ((unsigned int)m * (unsigned int)COT + (unsigned int)cb) * 2u : CN_OOB;
       unsigned int oa = o;
       if (p.addend_sub == 2) {   // the addend exists at even (h, w) only, stored compactly
         const int mm = ok ? m : 0;
@@ -114,11 +121,11 @@ __global__ __launch_bounds__(512) void jdgrad_kernel(JdParams p) {
         const int wo = rem - ho * p.W;
         const bool even = ((ho | wo) & 1) == 0;
         const int apx = (n * p.add_H + (ho >> 1)) * p.add_W + (wo >> 1);
-        oa = (ok && even) ? ((unsigned int)apx * (unsigned int)CO + (unsigned int)cb) * 2u : CN_OOB;
+        oa = (ok && even) ? ((unsigned int)apx * (unsigned int)COT + (unsigned int)cb) * 2u : CN_OOB;
       }
       e.a[k] = cn_buf_ld16(abuf, oa);
       e.y[k] = cn_buf_ld16(ybuf, o);
-      e.bits[k] = ok ? (unsigned int)p.bn_mask[(size_t)m * (CO / 8) + (cb >> 3)] : 0u;
+      e.bits[k] = ok ? (unsigned int)p.bn_mask[(size_t)m * (COT / 8) + (cb >> 3)] : 0u;
     }
   };
   auto store_dy = [&](int buf) {
@@ -187,7 +194,7 @@ __global__ __launch_bounds__(512) void jdgrad_kernel(JdParams p) {
           bs1[e] += fv[e];
           bs2[e] = fmaf(fv[e], yv[e], bs2[e]);
         }
-        cn_st16(p.g + ((size_t)m * CO + (size_t)cb) * 2, v);
+        cn_st16(p.g + ((size_t)m * COT + (size_t)cb) * 2, v);
       }
     }
     cn_wave_sync();   // the patch is rewritten by the next stage
@@ -195,15 +202,17 @@ __global__ __launch_bounds__(512) void jdgrad_kernel(JdParams p) {
 
   if (m_begin < m_end) {
     Epi cur, nxt;
-    load_stage(m_begin, cur);
+    load_dy(m_begin);
+    if (PF) load_epi(m_begin, cur);
     int buf = 0;
     for (int mb = m_begin; mb < m_end; mb += BM) {
       store_dy(buf);
       __syncthreads();    // (two dy tiles: the tile of stage s + 1 is written while stage s is still being read: one barrier per stage)
       const bool more = mb + BM < m_end;
-      if (more) load_stage(mb + BM, nxt);
+      if (!PF) load_epi(mb, cur);
+      if (more) { load_dy(mb + BM); if (PF) load_epi(mb + BM, nxt); }
       compute(mb, buf, cur);
-      if (more) cur = nxt;
+      if (PF && more) cur = nxt;
       buf ^= 1;
     }
   }
@@ -211,7 +220,7 @@ __global__ __launch_bounds__(512) void jdgrad_kernel(JdParams p) {
   float r1[8], r2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    const float mu = p.bn_coef[cb + e], is = p.bn_coef[CO + cb + e];
+    const float mu = p.bn_coef[cb + e], is = p.bn_coef[COT + cb + e];
     r1[e] = bs1[e];
     r2[e] = is * (bs2[e] - mu * bs1[e]);
   }
@@ -240,9 +249,9 @@ __global__ __launch_bounds__(512) void jdgrad_kernel(JdParams p) {
       a1 += red[((g2 * NCW + wcol) * 64 + cc) * 2];
       a2 += red[((g2 * NCW + wcol) * 64 + cc) * 2 + 1];
     }
-    float* dst = p.partial + (size_t)split * 2 * CO;
-    dst[c] = a1;
-    dst[CO + c] = a2;
+    float* dst = p.partial + (size_t)split * 2 * COT;
+    dst[co0 + c] = a1;
+    dst[COT + co0 + c] = a2;
   }
 }
 
@@ -253,7 +262,7 @@ static int jd_splits(long long M, int BM) {
   if (ns > stages) ns = (int)stages;
   return ns;
 }
-static int jd_bm(int C) { return C == 256 ? 64 : 32; }
+static int jd_bm(int C) { return C == 256 ? 64 : 32; }   // (C >= 512: 512-channel slices of 32-pixel stages)
 // pixel ranges: whole stages per workgroup; returns the number of ranges (= partial rows) and their length
 static int jd_plan(long long M, int BM, long long* mps_out) {
   const int ns0 = jd_splits(M, BM);
@@ -266,6 +275,10 @@ static int jd_plan(long long M, int BM, long long* mps_out) {
 // Shapes the streaming junction kernel is instantiated for: K channels of dy (conv1's outputs), C channels of g.
 extern "C" int cn_conv2d_dgrad_junction_ok(int C, int K, int dtype) {
   if (dtype != CN_BF16 && dtype != CN_F16) return 0;
+  // 256-channel reductions (the 28x28 -> 14x14 and 14x14 junctions) in 512-channel slices without the stage-ahead
+  // epilogue prefetch: 128 filter registers + the epilogue operands spill (20 VGPRs) and the step does not move
+  // (17.75 vs 17.76 ms): built and tested, OFF by default (knob "jdgrad_k256")
+  if ((C == 512 || C == 1024) && K == 256) return cn_get_option("jdgrad_k256", 0) != 0 ? 1 : 0;
   return ((C == 256 && (K == 64 || K == 128)) || (C == 512 && K == 128)) ? 1 : 0;
 }
 extern "C" int cn_conv2d_dgrad_junction_rows(int N, int H, int W, int C) {
@@ -299,21 +312,23 @@ extern "C" int cn_conv2d_dgrad_junction(const void* dy, const void* w_crsk, void
   p.dy = (const char*)dy; p.w = (const char*)w_crsk; p.addend = (const char*)addend; p.bn_y = (const char*)bn_y;
   p.bn_mask = bn_mask; p.bn_coef = bn_coef; p.g = (char*)g; p.partial = partial;
   p.M = (int)M; p.m_per_split = (int)mps; p.nsplit = nsplit;
+  p.co_total = C;
   p.addend_sub = addend_sub; p.H = H; p.W = W; p.add_H = aH; p.add_W = aW;
   p.div_hw = cn_make_fastdiv((unsigned)(H * W)); p.div_w = cn_make_fastdiv((unsigned)W);
   p.dy_bytes = (unsigned int)db; p.out_bytes = (unsigned int)ob; p.add_bytes = (unsigned int)ab;
   hipStream_t st = (hipStream_t)stream;
   const char* tn = dtype == CN_F16 ? "f16_t" : "bf16_t";
   cn_set_last_kernel("jdgrad_kernel<%s, %d, %d>", tn, K, C);
-  dim3 grid((unsigned)nsplit);
-#define JD_GO(KD, CO)                                                                               \
+  dim3 grid((unsigned)nsplit, (unsigned)(C > 512 ? C / 512 : 1));
+#define JD_GO(KD, CO, PF)                                                                           \
   do {                                                                                              \
-    if (dtype == CN_F16) CN_LAUNCH((jdgrad_kernel<f16_t, KD, CO>), grid, dim3(512), st, p);          \
-    else CN_LAUNCH((jdgrad_kernel<bf16_t, KD, CO>), grid, dim3(512), st, p);                         \
+    if (dtype == CN_F16) CN_LAUNCH((jdgrad_kernel<f16_t, KD, CO, PF>), grid, dim3(512), st, p);      \
+    else CN_LAUNCH((jdgrad_kernel<bf16_t, KD, CO, PF>), grid, dim3(512), st, p);                     \
   } while (0)
-  if (C == 256 && K == 64) JD_GO(64, 256);
-  else if (C == 256 && K == 128) JD_GO(128, 256);
-  else JD_GO(128, 512);
+  if (C == 256 && K == 64) JD_GO(64, 256, true);
+  else if (C == 256 && K == 128) JD_GO(128, 256, true);
+  else if (K == 128) JD_GO(128, 512, true);
+  else JD_GO(256, 512, false);
 #undef JD_GO
   return cn_check_launch("jdgrad");
 }
