@@ -304,13 +304,22 @@ def main():
             except Exception:
                 pm = None
         if pm is not None:
-            for kn, kv in pm['kernels'].items():
-                if kn.replace('void ', '').startswith(dom.split(' (')[0].split(' [')[0]):
-                    roof['traffic'] = round(kv['hbm_bytes_per_launch'])
-                    roof['traffic_unit'] = 'bytes/launch (avg), ' + pm['source']
-                    roof['traffic_source'] = 'live: rocprofv3 --pmc passes run by this command' if live else \
-                        'static: committed rocprofv3 --pmc passes (%s), not this run' % pm_file
-                    break
+            # a call label may name several kernels ('bn_bwd_reduce+bn_bwd_finalize+bn_bwd_apply': one BatchNorm-backward
+            # call = three launches): the traffic per launch is the launch-weighted mean over the kernels it names
+            base = dom.split(' (')[0].split(' [')[0]
+            parts = [q.strip() for q in base.split('+')] if ('+' in base and '<' not in base) else [base]
+            tot_b = tot_n = 0.0
+            for part in parts:
+                for kn, kv in pm['kernels'].items():
+                    name = kn.replace('void ', '')
+                    if name.startswith(part + '_kernel') or (len(parts) == 1 and name.startswith(part)):
+                        tot_b += kv['hbm_bytes_per_launch'] * kv['launches']
+                        tot_n += kv['launches']
+            if tot_n > 0:
+                roof['traffic'] = round(tot_b / tot_n)
+                roof['traffic_unit'] = 'bytes/launch (avg over the launches of the kernels this call label names), ' + pm['source']
+                roof['traffic_source'] = 'live: rocprofv3 --pmc passes run by this command' if live else \
+                    'static: committed rocprofv3 --pmc passes (%s), not this run' % pm_file
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import convnet_oracle as O
