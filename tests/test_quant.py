@@ -361,6 +361,8 @@ def test_folded_input_quantiser_and_shared_block_input_change_no_bit(mode, refer
     """Round 3: RangeBN's input quantiser folded into its kernels (cn_rangebn_fwd_q / cn_rangebn_bwd_q, the quantised
     copy of every convolution output is never written) and the block input quantised once for conv1 and the projection
     shortcut: the same trajectory, bit for bit, as the separate cn_quantize passes."""
+    if mode == 'emul':
+        pytest.skip('GPU suite (85 s on the emulator; the folded form is off by default)')
     dev = _dev(mode)
     import convnet_amd as ca
     meta = json.load(open(os.path.join(GOLDEN, 'traj_r18s_quant.json')))
