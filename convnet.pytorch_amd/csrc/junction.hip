@@ -535,3 +535,159 @@ extern "C" int cn_conv1x1_stream_fwd(const void* x, const void* w_krsc, void* y,
 #undef JF_GO
   return cn_check_launch("jfwd");
 }
+
+// ------------------------------------------------------------------------------------------------
+// "Lazy dy" data gradient of a 1x1 convolution with a LONG reduction as a streaming kernel (conv3 of the second stage:
+// 512 gradient channels -> 128 input channels): dx[m][c] = sum_k dy[m][k] * W[k][c] with dy = c1*g + c2*y + c3 formed
+// on load (cn_conv2d_dgrad_lazy's contract).  The streams are g and y (2 x 1 KB per pixel); the product is small.  A
+// workgroup owns a pixel range: per stage of 32 pixels every thread loads, transforms and stages its share of the dy tile
+// (LDS, double-buffered, requested a stage ahead); waves 0-3 own one 32-channel output tile each with their 128 x 32
+// filter slice in registers (32 A-fragments) and multiply; the accumulators leave through a wave-private patch as
+// 16-byte stores.  Operand orientation, k order and rounding of igemm_kernel: the same bits.
+struct JlParams {
+  const char* g;      // [M][KD]
+  const char* y;      // [M][KD]
+  const float* coef;  // [3][KD]
+  const char* w;      // [CO][KD] (CRSK of the 1x1 convolution: rows = its input channels)
+  char* dx;           // [M][CO]
+  int M, m_per_split, nsplit;
+  unsigned int gy_bytes;
+};
+
+template <typename T, int KD, int CO>
+__global__ __launch_bounds__(512) void jdlazy_kernel(JlParams p) {
+  static_assert(sizeof(T) == 2 && CO == 128 && KD % 64 == 0, "16-bit storage, four 32-channel output tiles");
+  constexpr int BM = 32;
+  constexpr int NKK = KD / 16;
+  constexpr int NCD = KD / 8;             // 16-byte chunks per row
+  constexpr int TB = BM * KD * 2;         // dy tile bytes
+  constexpr int ND = BM * NCD / 512;      // chunks per thread and operand
+  static_assert(512 % NCD == 0 && BM * NCD % 512 == 0, "a thread keeps one chunk column");
+  constexpr int RS = 512 / NCD;           // rows per staging pass
+  constexpr int PP = 80;                  // patch pitch: 32 channels * 2 bytes + 16
+  __shared__ __attribute__((aligned(16))) char lds[2 * TB + 4 * 32 * PP];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = cn_uniform(tid >> 6);
+  const int h = lane >> 5;
+  const int split = blockIdx.x;
+  const int m_begin = split * p.m_per_split;
+  int m_end = m_begin + p.m_per_split;
+  if (m_end > p.M) m_end = p.M;
+
+  s16x8 wf[NKK];
+  if (wave < 4) {
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+      const int c = wave * 32 + (lane & 31);
+      wf[kk] = __builtin_bit_cast(s16x8, cn_ld16(p.w + ((size_t)c * KD + 16 * kk + 8 * h) * 2));
+    }
+  }
+  const cn_buf_t gbuf = cn_make_buf(p.g, p.gy_bytes);
+  const cn_buf_t ybuf = cn_make_buf(p.y, p.gy_bytes);
+  const int col = tid % NCD, row0 = tid / NCD;
+  float c1[8], c2[8], c3[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    c1[e] = p.coef[col * 8 + e];
+    c2[e] = p.coef[KD + col * 8 + e];
+    c3[e] = p.coef[2 * KD + col * 8 + e];
+  }
+  u32x4 rg[ND], ry[ND];
+  unsigned int okm = 0;
+  auto load_stage = [&](int mb) {
+    okm = 0;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const int m = mb + row0 + i * RS;
+      const bool ok = m < m_end;
+      const unsigned int o = ok ? ((unsigned int)m * (unsigned int)KD + (unsigned int)col * 8u) * 2u : CN_OOB;
+      okm |= (ok ? 1u : 0u) << i;
+      rg[i] = cn_buf_ld16(gbuf, o);
+      ry[i] = cn_buf_ld16(ybuf, o);
+    }
+  };
+  auto store_stage = [&](int buf) {
+    char* t = lds + buf * TB;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {   // dy = c1*g + c2*y + c3: bn_bwd_apply_kernel's operation order and rounding
+      float gg[8], vv[8];
+      Chunk<T>::unpack(rg[i], gg);
+      Chunk<T>::unpack(ry[i], vv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gg[e] = fmaf(c1[e], gg[e], fmaf(c2[e], vv[e], c3[e]));
+      const u32x4 o = Chunk<T>::pack(gg);
+      const int row = row0 + i * RS;
+      cn_st16(t + row * (KD * 2) + ((col ^ (row & (NCD - 1))) << 4), ((okm >> i) & 1u) ? o : cn_zero16());
+    }
+  };
+  char* priv = lds + 2 * TB + (wave & 3) * (32 * PP);
+  const int ech = lane & 3, erow = lane >> 2;
+
+  if (m_begin < m_end) {
+    load_stage(m_begin);
+    int buf = 0;
+    for (int mb = m_begin; mb < m_end; mb += BM) {
+      store_stage(buf);
+      __syncthreads();
+      if (mb + BM < m_end) load_stage(mb + BM);
+      if (wave < 4) {
+        const char* t = lds + buf * TB;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const int prow = lane & 31;
+        const char* rowp = t + prow * (KD * 2);
+        const int sw = prow & (NCD - 1);
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+          const s16x8 b = __builtin_bit_cast(s16x8, cn_ld16(rowp + (((2 * kk + h) ^ sw) << 4)));
+          if constexpr (std::is_same<T, f16_t>::value) acc = cn_mfma_32x32x16_f16(wf[kk], b, acc);
+          else acc = cn_mfma_32x32x16_bf16(wf[kk], b, acc);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          u32x2 pk;
+          pk[0] = cn_pack2<T>(acc[q * 4], acc[q * 4 + 1]);
+          pk[1] = cn_pack2<T>(acc[q * 4 + 2], acc[q * 4 + 3]);
+          *(u32x2*)(priv + (lane & 31) * PP + (8 * q + 4 * h) * 2) = pk;
+        }
+        cn_wave_sync();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int pl = k * 16 + erow;
+          const int m = mb + pl;
+          const u32x4 v = cn_ld16(priv + pl * PP + ech * 16);
+          if (m < m_end) cn_st16(p.dx + ((size_t)m * CO + (size_t)(wave * 32 + ech * 8)) * 2, v);
+        }
+        cn_wave_sync();
+      }
+      buf ^= 1;
+    }
+  }
+}
+
+extern "C" int cn_conv2d_dgrad_lazy_stream_ok(int C, int K, int dtype) {   // K gradient channels -> C input channels
+  return (dtype == CN_BF16 || dtype == CN_F16) && C == 128 && K == 512 && cn_get_option("jdlazy", 1) != 0 ? 1 : 0;
+}
+// cn_conv2d_dgrad_lazy for a 1x1 / stride-1 convolution of an instantiated shape (512 -> 128 channels) as a persistent
+// streaming kernel.  Same bits.
+extern "C" int cn_conv2d_dgrad_lazy_stream(const void* g, const void* bn_y, const float* coef, const void* w_crsk, void* dx,
+                                           int N, int H, int W, int C, int K, int dtype, void* stream) {
+  if (!cn_conv2d_dgrad_lazy_stream_ok(C, K, dtype)) { cn_set_error("conv2d_dgrad_lazy_stream: K=%d -> C=%d dtype %d is not an instantiated shape", K, C, dtype); return CN_ESHAPE; }
+  if (g == nullptr || bn_y == nullptr || coef == nullptr || w_crsk == nullptr || dx == nullptr) { cn_set_error("conv2d_dgrad_lazy_stream: null operand"); return CN_EINVAL; }
+  const long long M = (long long)N * H * W;
+  if (M <= 0) { cn_set_error("conv2d_dgrad_lazy_stream: empty"); return CN_ESHAPE; }
+  if (M * K * 2 >= (1ll << 31)) { cn_set_error("conv2d_dgrad_lazy_stream: operand exceeds the 2 GiB buffer-descriptor window"); return CN_ESHAPE; }
+  long long mps = 0;
+  const int nsplit = jd_plan(M, 32, &mps);
+  JlParams p;
+  memset(&p, 0, sizeof(p));
+  p.g = (const char*)g; p.y = (const char*)bn_y; p.coef = coef; p.w = (const char*)w_crsk; p.dx = (char*)dx;
+  p.M = (int)M; p.m_per_split = (int)mps; p.nsplit = nsplit;
+  p.gy_bytes = (unsigned int)(M * K * 2);
+  cn_set_last_kernel("jdlazy_kernel<%s, %d, %d>", dtype == CN_F16 ? "f16_t" : "bf16_t", K, C);
+  if (dtype == CN_F16) CN_LAUNCH((jdlazy_kernel<f16_t, 512, 128>), dim3((unsigned)nsplit), dim3(512), (hipStream_t)stream, p);
+  else CN_LAUNCH((jdlazy_kernel<bf16_t, 512, 128>), dim3((unsigned)nsplit), dim3(512), (hipStream_t)stream, p);
+  return cn_check_launch("jdlazy");
+}

@@ -567,6 +567,15 @@ def conv2d_dgrad_lazy(g, bn_y, coef, w_crsk, x_shape, K, R, S, stride, pad):
     """dgrad whose upstream gradient dy = c1*g + c2*bn_y + c3 is formed on the operand load (cn_conv2d_dgrad_lazy)."""
     N, H, W, C = x_shape
     dx = torch.empty((N, H, W, C), dtype=g.dtype, device=g.device)
+    if (R, S) == (1, 1) and tuple(stride) == (1, 1) and tuple(pad) == (0, 0) and tuple(g.shape[1:3]) == (H, W) \
+            and _L().cn_conv2d_dgrad_lazy_stream_ok(C, K, dtype_code(g.dtype)):
+        PROFILER.run(_last_kernel(' [lazy dy]'), 1, 2.0 * g.numel() * C,
+                     2 * g.numel() * _esize(g) + dx.numel() * _esize(dx) + K * C * _esize(g),
+                     lambda: check(_L().cn_conv2d_dgrad_lazy_stream(ptr(g), ptr(bn_y), ptr(coef), ptr(w_crsk), ptr(dx), N, H, W,
+                                                                    C, K, dtype_code(g.dtype), stream_of(g)),
+                                   'cn_conv2d_dgrad_lazy_stream'),
+                     g.device, detail=_conv_detail('dgrad', C, H, K, R, stride))
+        return dx
     PROFILER.run(_last_kernel(' [lazy dy]'), stride[0] * stride[1], 2.0 * g.numel() * C * R * S,
                  2 * g.numel() * _esize(g) + dx.numel() * _esize(dx) + K * R * S * C * _esize(g),
                  lambda: check(_L().cn_conv2d_dgrad_lazy(ptr(g), ptr(bn_y), ptr(coef), ptr(w_crsk), ptr(dx), N, H, W, C, K,

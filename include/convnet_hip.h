@@ -202,6 +202,11 @@ int cn_conv2d_dgrad_lazy(const void* g, const void* bn_y, const float* coef, con
 int cn_conv2d_wgrad_lazy(const void* x, const void* g, const void* bn_y, const float* coef, float* dw_krsc, int C_real,
                          int N, int H, int W, int C, int K, int R, int S, int stride_h, int stride_w, int pad_h,
                          int pad_w, int dtype, float beta, float scale, void* workspace, size_t ws_bytes, void* stream);
+/* cn_conv2d_dgrad_lazy for a 1x1 / stride-1 convolution with K = 512 gradient channels and C = 128 input channels (conv3 of
+ * the second stage) as a persistent streaming kernel (csrc/junction.hip: jdlazy_kernel).  Same output bits. */
+int cn_conv2d_dgrad_lazy_stream_ok(int C, int K, int dtype);
+int cn_conv2d_dgrad_lazy_stream(const void* g, const void* bn_y, const float* coef, const void* w_crsk, void* dx, int N,
+                                int H, int W, int C, int K, int dtype, void* stream);
 /* Junction pair: cn_conv2d_dgrad_lazy + cn_conv2d_wgrad_lazy of one 1x1 / stride-1 convolution in ONE pass over g and
  * bn_y (the two junction-sized reads of each are shared; /root/reference reaches both through loss.backward(),
  * trainer.py:162, for models/resnet.py:126-132's conv3 and :176-181's projection).  dx: the bits of

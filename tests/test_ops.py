@@ -1462,3 +1462,36 @@ def test_streaming_conv1x1_forward_equals_tiled_kernel(mode, dtype):
             ops.CONV1X1_STREAM = saved
         assert torch.equal(y1.cpu(), y0.cpu()) and torch.equal(y2.cpu(), y0.cpu()), (N, H, W, C, K)
         assert rel_l2(p1.partial.double().sum(0).cpu(), p0.partial.double().sum(0).cpu()) < 1e-5
+
+
+@pytest.mark.parametrize('mode', MODES)
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_streaming_lazy_dgrad_equals_tiled_kernel(mode, dtype):
+    """cn_conv2d_dgrad_lazy_stream (512 -> 128 channels, csrc/junction.hip: jdlazy_kernel) against the tiled lazy data
+    gradient: bit for bit (bf16; fp16 to a few ulps on the GPU, see the junction-pair test), pixel counts that are not
+    whole stages included."""
+    _f16_emul_subset(mode, dtype, keep=True)
+    dev = _dev(mode)
+    import convnet_amd as ca
+    ops, L = ca.ops, ca._lib.load()
+    C, K = 128, 512
+    for (N, H, W) in ([(1, 5, 9), (2, 4, 8)] if mode == 'emul' else [(16, 28, 28), (3, 17, 13), (256, 28, 28)]):
+        g_ = torch.Generator().manual_seed(N * H + W)
+        gq = (torch.randn(N, H, W, K, generator=g_) * 0.5).to(dtype).to(dev)
+        yq = (torch.randn(N, H, W, K, generator=g_) * 1.2 + 0.1).to(dtype).to(dev)
+        coef = torch.cat([torch.rand(K, generator=g_) + 0.5, torch.randn(K, generator=g_) * 0.05,
+                          torch.randn(K, generator=g_) * 0.01]).to(dev)
+        wc = (torch.randn(C, 1, 1, K, generator=g_) * (2.0 / K) ** 0.5).to(dtype).to(dev)
+        L.cn_set_option(b'jdlazy', 0)
+        try:
+            d0 = ops.conv2d_dgrad_lazy(gq, yq, coef, wc, (N, H, W, C), K, 1, 1, (1, 1), (0, 0))
+            assert 'igemm_kernel' in L.cn_last_kernel_name().decode()
+        finally:
+            L.cn_set_option(b'jdlazy', 1)
+        d1 = ops.conv2d_dgrad_lazy(gq, yq, coef, wc, (N, H, W, C), K, 1, 1, (1, 1), (0, 0))
+        assert 'jdlazy_kernel' in L.cn_last_kernel_name().decode()
+        if dtype == torch.bfloat16 or mode == 'emul':
+            assert torch.equal(d1.cpu(), d0.cpu()), (N, H, W)
+        else:
+            assert rel_l2(d1.float().cpu(), d0.float().cpu()) < 2e-4
+        assert float(d1.float().abs().sum()) > 0
