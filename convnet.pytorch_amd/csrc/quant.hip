@@ -45,12 +45,21 @@ __global__ __launch_bounds__(Q_NT) void minmax_partial_kernel(const T* x, long l
     const long long nch = row_len / CH;
     const long long per = (nch + splits - 1) / splits;
     const long long c0 = (long long)s * per, c1 = c0 + per < nch ? c0 + per : nch;
-    for (long long c = c0 + tid; c < c1; c += Q_NT) {
+    auto visit = [&](const u32x4& v) {
       float f[CH];
-      Chunk<T>::unpack(cn_ld16((const char*)row + c * 16), f);
+      Chunk<T>::unpack(v, f);
 #pragma unroll
       for (int e = 0; e < CH; ++e) { mn = fminf(mn, f[e]); mx = fmaxf(mx, f[e]); }
+    };
+    long long c = c0 + tid;
+    for (; c + 3 * Q_NT < c1; c += 4 * Q_NT) {   // four loads in flight per thread (one alone leaves HBM latency exposed)
+      u32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = cn_ld16((const char*)row + (c + u * Q_NT) * 16);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) visit(v[u]);
     }
+    for (; c < c1; c += Q_NT) visit(cn_ld16((const char*)row + c * 16));
   } else {
     const long long per = (row_len + splits - 1) / splits;
     const long long e0 = (long long)s * per, e1 = e0 + per < row_len ? e0 + per : row_len;
@@ -161,13 +170,22 @@ extern "C" int cn_qparams(const float* minmax, int rows, int mode, float* qp, fl
 }
 
 // ------------------------------------------------------------------------------------------------ quantise
-// Counter-based uniform noise in (-0.5, 0.5) for stochastic rounding when no noise tensor is supplied.
-__host__ __device__ __forceinline__ float q_hash_noise(unsigned long long seed, unsigned long long idx) {
-  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+// Counter-based uniform noise in (-0.5, 0.5) for stochastic rounding when no noise tensor is supplied: a 32-bit
+// integer hash (two multiply / xor-shift rounds) of the element index under a per-launch key.  (The first version used
+// a 64-bit splitmix round per element: ~30 VALU instructions each, which made the gradient quantiser issue-bound at
+// ~3 TB/s instead of HBM-bound.)
+__host__ __device__ __forceinline__ unsigned int q_noise_key(unsigned long long seed) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  return ((float)(unsigned int)(z >> 40) + 0.5f) * (1.0f / 16777216.0f) - 0.5f;
+  return (unsigned int)(z ^ (z >> 31));
+}
+__host__ __device__ __forceinline__ float q_hash_noise(unsigned int key, unsigned long long idx) {
+  unsigned int h = ((unsigned int)idx ^ key) + (unsigned int)(idx >> 32) * 0x9E3779B1u;
+  h ^= h >> 16; h *= 0x7feb352du;
+  h ^= h >> 15; h *= 0x846ca68bu;
+  h ^= h >> 16;
+  return ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f) - 0.5f;
 }
 
 // UniformQuantize.forward, unsigned, dequantised (quantize.py:55-76), operation for operation:
@@ -189,27 +207,44 @@ __global__ __launch_bounds__(Q_NT) void quantize_kernel(const T* x, T* y, long l
   // `step` (optional): a device counter the caller advances once per training step, mixed into the seed - a launch
   // replayed from a captured HIP graph (frozen kernel arguments) still draws fresh rounding noise every step
   if (step != nullptr) seed += step[0] * 0xD1B54A32D192ED03ull;
+  const unsigned int key = q_noise_key(seed);
   const float zp = zero_point[0];
   const float scale = (range[0] == 0.f ? 1.f : range[0]) / qmax;
   const long long nch = n / CH;
-  for (long long c = (long long)blockIdx.x * Q_NT + threadIdx.x; c < nch; c += (long long)gridDim.x * Q_NT) {
+  auto snap_chunk = [&](const u32x4& v, long long c) {
     float f[CH];
-    Chunk<T>::unpack(cn_ld16((const char*)x + c * 16), f);
+    Chunk<T>::unpack(v, f);
 #pragma unroll
     for (int e = 0; e < CH; ++e) {
       const long long i = c * CH + e;
-      const float nz = noise != nullptr ? noise[i] : (stochastic ? q_hash_noise(seed, (unsigned long long)i) : 0.f);
+      const float nz = noise != nullptr ? noise[i] : (stochastic ? q_hash_noise(key, (unsigned long long)i) : 0.f);
       f[e] = q_snap(f[e], zp, scale, qmax, nz);
     }
     cn_st16((char*)y + c * 16, Chunk<T>::pack(f));
+  };
+  const long long stride = (long long)gridDim.x * Q_NT;
+  long long c = (long long)blockIdx.x * Q_NT + threadIdx.x;
+  for (; c + stride < nch; c += 2 * stride) {   // two loads in flight per thread
+    const u32x4 v0 = cn_ld16((const char*)x + c * 16);
+    const u32x4 v1 = cn_ld16((const char*)x + (c + stride) * 16);
+    snap_chunk(v0, c);
+    snap_chunk(v1, c + stride);
   }
+  for (; c < nch; c += stride) snap_chunk(cn_ld16((const char*)x + c * 16), c);
   // ragged tail (tensors that are not whole chunks: biases, the 3-channel image)
   for (long long i = nch * CH + (long long)blockIdx.x * Q_NT + threadIdx.x; i < n; i += (long long)gridDim.x * Q_NT) {
-    const float nz = noise != nullptr ? noise[i] : (stochastic ? q_hash_noise(seed, (unsigned long long)i) : 0.f);
+    const float nz = noise != nullptr ? noise[i] : (stochastic ? q_hash_noise(key, (unsigned long long)i) : 0.f);
     cn_store_elem<T>(y + i, q_snap(cn_load_elem<T>(x + i), zp, scale, qmax, nz));
   }
 }
 
+// q_grid rounded so that gridDim.x * Q_NT is a multiple of `cols` chunk columns (cols <= 2 * Q_NT in every model here)
+static unsigned q_grid(long long work_items);
+static unsigned q_grid_cols(long long work_items, int cols) {
+  unsigned nb = q_grid(work_items);
+  if (cols > Q_NT && cols % Q_NT == 0) { const unsigned m = (unsigned)(cols / Q_NT); nb = (nb + m - 1) / m * m; }
+  return nb;
+}
 static unsigned q_grid(long long work_items) {
   long long nb = (work_items + Q_NT - 1) / Q_NT;
   if (nb > 8192) nb = 8192;
@@ -505,22 +540,47 @@ __global__ __launch_bounds__(Q_NT) void rangebn_apply_kernel(const T* x, const T
   constexpr int CH = ElemTraits<T>::kChunk;
   const int CC = C / CH;
   const RbnSnap snap = rbn_snap_make(xqp, qmax);
-  for (long long id = (long long)blockIdx.x * Q_NT + threadIdx.x; id < nch; id += (long long)gridDim.x * Q_NT) {
+  const long long stride = (long long)gridDim.x * Q_NT;
+  // the grid stride is a multiple of the chunk columns in every launch the host makes (q_grid_cols): a thread stays on
+  // one chunk column, so its 4 x CH coefficients are loaded once (they were re-read from L1 for every chunk: 32 loads
+  // beside the one 16-byte load that carries the data)
+  const bool fixed_col = stride % CC == 0;
+  float mean[CH], den[CH], w[CH], b[CH];
+  auto load_coef = [&](long long id) {
     const int c0 = (int)(id % CC) * CH;
+#pragma unroll
+    for (int e = 0; e < CH; ++e) { mean[e] = stats[c0 + e]; den[e] = stats[C + c0 + e]; w[e] = weight[c0 + e]; b[e] = bias[c0 + e]; }
+  };
+  auto apply = [&](const u32x4& vx, const u32x4& vr, long long id) {
     float f[CH], r[CH];
-    Chunk<T>::unpack(cn_ld16((const char*)x + id * 16), f);
+    Chunk<T>::unpack(vx, f);
     rbn_snap_chunk<T>(snap, f);
-    if (residual != nullptr) Chunk<T>::unpack(cn_ld16((const char*)residual + id * 16), r);
+    if (residual != nullptr) Chunk<T>::unpack(vr, r);
 #pragma unroll
     for (int e = 0; e < CH; ++e) {
-      float v = (f[e] - stats[c0 + e]) / stats[C + c0 + e];
-      v = v * weight[c0 + e];
-      v = v + bias[c0 + e];
+      float v = (f[e] - mean[e]) / den[e];
+      v = v * w[e];
+      v = v + b[e];
       if (residual != nullptr) v = v + r[e];
       if (relu) v = v > 0.f ? v : 0.f;
       f[e] = v;
     }
     cn_st16((char*)z + id * 16, Chunk<T>::pack(f));
+  };
+  long long id = (long long)blockIdx.x * Q_NT + threadIdx.x;
+  if (id < nch) load_coef(id);
+  if (fixed_col) {
+    for (; id + stride < nch; id += 2 * stride) {   // two (four with a residual) loads in flight
+      const u32x4 v0 = cn_ld16((const char*)x + id * 16), v1 = cn_ld16((const char*)x + (id + stride) * 16);
+      u32x4 r0 = cn_zero16(), r1 = cn_zero16();
+      if (residual != nullptr) { r0 = cn_ld16((const char*)residual + id * 16); r1 = cn_ld16((const char*)residual + (id + stride) * 16); }
+      apply(v0, r0, id);
+      apply(v1, r1, id + stride);
+    }
+  }
+  for (; id < nch; id += stride) {
+    if (!fixed_col) load_coef(id);
+    apply(cn_ld16((const char*)x + id * 16), residual != nullptr ? cn_ld16((const char*)residual + id * 16) : cn_zero16(), id);
   }
 }
 
@@ -582,10 +642,10 @@ static int rangebn_fwd_impl(const void* x, const void* residual, void* z, const 
   }
   const long long nch = (long long)M * CC;
   if (dtype == CN_BF16)
-    CN_LAUNCH(rangebn_apply_kernel<bf16_t>, dim3(q_grid(nch)), dim3(Q_NT), stream, (const bf16_t*)x, (const bf16_t*)residual,
+    CN_LAUNCH(rangebn_apply_kernel<bf16_t>, dim3(q_grid_cols(nch, C / 8)), dim3(Q_NT), stream, (const bf16_t*)x, (const bf16_t*)residual,
               (bf16_t*)z, (const float*)stats, weight, bias, nch, C, relu, xqp, qmax);
   else
-    CN_LAUNCH(rangebn_apply_kernel<float>, dim3(q_grid(nch)), dim3(Q_NT), stream, (const float*)x, (const float*)residual,
+    CN_LAUNCH(rangebn_apply_kernel<float>, dim3(q_grid_cols(nch, C / 4)), dim3(Q_NT), stream, (const float*)x, (const float*)residual,
               (float*)z, (const float*)stats, weight, bias, nch, C, relu, xqp, qmax);
   return cn_check_launch("rangebn_fwd");
 }
@@ -710,13 +770,33 @@ template <typename T>
 __global__ __launch_bounds__(Q_NT) void rangebn_bwd_apply_kernel(const T* g, T* dx, const float* coef, long long nch, int C) {
   constexpr int CH = ElemTraits<T>::kChunk;
   const int CC = C / CH;
-  for (long long id = (long long)blockIdx.x * Q_NT + threadIdx.x; id < nch; id += (long long)gridDim.x * Q_NT) {
+  const long long stride = (long long)gridDim.x * Q_NT;
+  const bool fixed_col = stride % CC == 0;   // see rangebn_apply_kernel
+  float a[CH], b[CH];
+  auto load_coef = [&](long long id) {
     const int c0 = (int)(id % CC) * CH;
-    float f[CH];
-    Chunk<T>::unpack(cn_ld16((const char*)g + id * 16), f);
 #pragma unroll
-    for (int e = 0; e < CH; ++e) f[e] = f[e] * coef[c0 + e] + coef[C + c0 + e];
+    for (int e = 0; e < CH; ++e) { a[e] = coef[c0 + e]; b[e] = coef[C + c0 + e]; }
+  };
+  auto apply = [&](const u32x4& v, long long id) {
+    float f[CH];
+    Chunk<T>::unpack(v, f);
+#pragma unroll
+    for (int e = 0; e < CH; ++e) f[e] = f[e] * a[e] + b[e];
     cn_st16((char*)dx + id * 16, Chunk<T>::pack(f));
+  };
+  long long id = (long long)blockIdx.x * Q_NT + threadIdx.x;
+  if (id < nch) load_coef(id);
+  if (fixed_col) {
+    for (; id + stride < nch; id += 2 * stride) {
+      const u32x4 v0 = cn_ld16((const char*)g + id * 16), v1 = cn_ld16((const char*)g + (id + stride) * 16);
+      apply(v0, id);
+      apply(v1, id + stride);
+    }
+  }
+  for (; id < nch; id += stride) {
+    if (!fixed_col) load_coef(id);
+    apply(cn_ld16((const char*)g + id * 16), id);
   }
 }
 
@@ -764,12 +844,12 @@ static int rangebn_bwd_impl(const void* g, const void* x, const float* weight, c
   if (dtype == CN_BF16) {
     CN_LAUNCH(rangebn_bwd_reduce_kernel<bf16_t>, grid, dim3(Q_NT), stream, (const bf16_t*)g, (const bf16_t*)x, stats, M, C, rpr, cols, partial, xqp, qmax);
     CN_LAUNCH(rangebn_bwd_finalize_kernel, dim3((unsigned)((C + RF_C - 1) / RF_C)), dim3(RF_C * RF_T), stream, (const float*)partial, rows, M, C, weight, stats, route, dweight, dbias, coef);
-    CN_LAUNCH(rangebn_bwd_apply_kernel<bf16_t>, dim3(q_grid(nch)), dim3(Q_NT), stream, (const bf16_t*)g, (bf16_t*)dx, (const float*)coef, nch, C);
+    CN_LAUNCH(rangebn_bwd_apply_kernel<bf16_t>, dim3(q_grid_cols(nch, C / 8)), dim3(Q_NT), stream, (const bf16_t*)g, (bf16_t*)dx, (const float*)coef, nch, C);
     CN_LAUNCH(rangebn_bwd_route_kernel<bf16_t>, dim3((unsigned)((C * chunks + Q_NT - 1) / Q_NT)), dim3(Q_NT), stream, (bf16_t*)dx, (const float*)coef, arg, C, chunks);
   } else {
     CN_LAUNCH(rangebn_bwd_reduce_kernel<float>, grid, dim3(Q_NT), stream, (const float*)g, (const float*)x, stats, M, C, rpr, cols, partial, xqp, qmax);
     CN_LAUNCH(rangebn_bwd_finalize_kernel, dim3((unsigned)((C + RF_C - 1) / RF_C)), dim3(RF_C * RF_T), stream, (const float*)partial, rows, M, C, weight, stats, route, dweight, dbias, coef);
-    CN_LAUNCH(rangebn_bwd_apply_kernel<float>, dim3(q_grid(nch)), dim3(Q_NT), stream, (const float*)g, (float*)dx, (const float*)coef, nch, C);
+    CN_LAUNCH(rangebn_bwd_apply_kernel<float>, dim3(q_grid_cols(nch, C / 4)), dim3(Q_NT), stream, (const float*)g, (float*)dx, (const float*)coef, nch, C);
     CN_LAUNCH(rangebn_bwd_route_kernel<float>, dim3((unsigned)((C * chunks + Q_NT - 1) / Q_NT)), dim3(Q_NT), stream, (float*)dx, (const float*)coef, arg, C, chunks);
   }
   return cn_check_launch("rangebn_bwd");
