@@ -48,6 +48,13 @@ TRAIN_GFLOP_PER_IMG = {50: 24.2991, 18: 10.6484}
 MODEL_MB_PER_IMG = {(50, 'bf16'): 347.7, (18, 'f32'): 151.4}
 
 
+def _pmc_file_order(name):
+    """profiles/rNN[x]_pmc_traffic.json: by round, the round's closing set (no letter) last."""
+    import re
+    m = re.match(r'r(\d+)([a-z]*)_', name)
+    return (int(m.group(1)), m.group(2) == '', name) if m else (-1, False, name)
+
+
 LIVE_PMC = {'pm': None}      # per-kernel traffic measured by this command (--pmc), shared by the two places that quote it
 
 
@@ -314,7 +321,8 @@ def main():
             # HBM traffic per launch NOT measured in this run (PMC counters need rocprofv3 passes of their own:
             # `--pmc`): the latest committed PMC result (profiles/*_pmc_traffic.json) is quoted and tagged static
             try:
-                cands = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('pmc_traffic.json'))
+                cands = sorted((f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('pmc_traffic.json')),
+                               key=_pmc_file_order)
                 pm_file = cands[-1]
                 pm = json.load(open(os.path.join(ROOT, 'profiles', pm_file)))
             except Exception:
@@ -373,7 +381,8 @@ def main():
         # measured HBM traffic of the whole step (all kernels, latest committed PMC passes: static, like
         # roofline.traffic) over this run's step time: how close the step as a whole runs to the memory system
         try:
-            cands = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('pmc_traffic.json'))
+            cands = sorted((f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('pmc_traffic.json')),
+                               key=_pmc_file_order)
             if LIVE_PMC.get('pm') is not None:
                 pm, cands = LIVE_PMC['pm'], ['live: rocprofv3 --pmc passes run by this command']
             else:
