@@ -347,9 +347,14 @@ struct JfParams {
   int M, m_per_split, nsplit;
   int co_total;       // output channels of the convolution; a workgroup computes the CO of them from blockIdx.y * CO on
   unsigned int x_bytes;
+  // XF ("lazy a"): x is the INPUT of the BatchNorm in front of this convolution; the kernel forms
+  // a = relu?(x * scale + shift) on its way to the LDS tile (bn_apply_kernel's arithmetic) and writes it to a_out
+  const float* xf;    // [scale | shift] (2 * KD)
+  char* a_out;        // [M][KD]
+  int relu;
 };
 
-template <typename T, int KD, int CO>
+template <typename T, int KD, int CO, bool XF = false>
 __global__ __launch_bounds__(512) void jfwd_kernel(JfParams p) {
   static_assert(sizeof(T) == 2, "16-bit storage");
   constexpr int NCW = CO / 64;
@@ -397,13 +402,32 @@ __global__ __launch_bounds__(512) void jfwd_kernel(JfParams p) {
       dreg[i] = cn_buf_ld16(xbuf, m < m_end ? ((unsigned int)m * (unsigned int)KD + (unsigned int)c * 8u) * 2u : CN_OOB);
     }
   };
-  auto store_x = [&](int buf) {
+  // XF: the thread's chunk column is fixed (512 % NCD == 0): its 2 x 8 coefficients live in registers
+  float xsc[XF ? 8 : 1], xsh[XF ? 8 : 1];
+  if constexpr (XF) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { xsc[e] = p.xf[(tid % NCD) * 8 + e]; xsh[e] = p.xf[KD + (tid % NCD) * 8 + e]; }
+  }
+  auto store_x = [&](int mb, int buf) {
     char* t = lds + buf * DYB;
 #pragma unroll
     for (int i = 0; i < ND; ++i) {
       const int id = tid + 512 * i;
       const int row = id / NCD, c = id - row * NCD;
       const int cs = NCD == 8 ? (c ^ ((row >> 1) & 7)) : (c ^ (row & (NCD - 1)));
+      if constexpr (XF) {
+        float f[8];
+        Chunk<T>::unpack(dreg[i], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = fmaf(f[e], xsc[e], xsh[e]);
+        if (p.relu) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] = f[e] > 0.f ? f[e] : 0.f;
+        }
+        dreg[i] = Chunk<T>::pack(f);
+        const int m = mb + row;
+        if (m < m_end && blockIdx.y == 0) cn_st16(p.a_out + ((size_t)m * KD + (size_t)c * 8) * 2, dreg[i]);
+      }
       cn_st16(t + row * (KD * 2) + (cs << 4), dreg[i]);
     }
   };
@@ -415,7 +439,7 @@ __global__ __launch_bounds__(512) void jfwd_kernel(JfParams p) {
     load_stage(m_begin);
     int buf = 0;
     for (int mb = m_begin; mb < m_end; mb += BM) {
-      store_x(buf);
+      store_x(mb, buf);
       __syncthreads();
       if (mb + BM < m_end) load_stage(mb + BM);
       const char* t = lds + buf * DYB;
@@ -504,29 +528,35 @@ extern "C" int cn_conv1x1_stream_fwd_rows(int N, int H, int W, int K) {
 // last in two 512-channel slices, grid.y) with the
 // statistics partials of cn_conv2d_fwd_bnstats (cn_conv1x1_stream_fwd_rows rows of 2*K floats, one per workgroup;
 // partial may be NULL) as a persistent streaming kernel.  Output bits = cn_conv2d_fwd's.
-extern "C" int cn_conv1x1_stream_fwd(const void* x, const void* w_krsc, void* y, int N, int H, int W, int C, int K,
-                                     int dtype, float* partial, int partial_rows, void* stream) {
-  if (!cn_conv1x1_stream_fwd_ok(C, K, dtype)) { cn_set_error("conv1x1_stream_fwd: C=%d -> K=%d dtype %d is not an instantiated shape", C, K, dtype); return CN_ESHAPE; }
-  if (x == nullptr || w_krsc == nullptr || y == nullptr) { cn_set_error("conv1x1_stream_fwd: null operand"); return CN_EINVAL; }
+static int jfwd_impl(const char* who, const void* x, const float* xf, int relu, void* a_out, const void* w_krsc, void* y,
+                     int N, int H, int W, int C, int K, int dtype, float* partial, int partial_rows, void* stream) {
+  if (!cn_conv1x1_stream_fwd_ok(C, K, dtype)) { cn_set_error("%s: C=%d -> K=%d dtype %d is not an instantiated shape", who, C, K, dtype); return CN_ESHAPE; }
+  if (x == nullptr || w_krsc == nullptr || y == nullptr) { cn_set_error("%s: null operand", who); return CN_EINVAL; }
   const long long M = (long long)N * H * W;
-  if (M <= 0) { cn_set_error("conv1x1_stream_fwd: empty"); return CN_ESHAPE; }
-  if (M * K * 2 >= (1ll << 31)) { cn_set_error("conv1x1_stream_fwd: operand exceeds the 2 GiB buffer-descriptor window"); return CN_ESHAPE; }
+  if (M <= 0) { cn_set_error("%s: empty", who); return CN_ESHAPE; }
+  if (M * K * 2 >= (1ll << 31)) { cn_set_error("%s: operand exceeds the 2 GiB buffer-descriptor window", who); return CN_ESHAPE; }
   long long mps = 0;
   const int nsplit = jd_plan(M, jd_bm(K >= 512 ? 512 : K), &mps);
-  if (partial != nullptr && partial_rows < nsplit) { cn_set_error("conv1x1_stream_fwd: partial buffer of %d rows < %d", partial_rows, nsplit); return CN_EWORKSPACE; }
+  if (partial != nullptr && partial_rows < nsplit) { cn_set_error("%s: partial buffer of %d rows < %d", who, partial_rows, nsplit); return CN_EWORKSPACE; }
   JfParams p;
   memset(&p, 0, sizeof(p));
   p.x = (const char*)x; p.w = (const char*)w_krsc; p.y = (char*)y; p.partial = partial;
   p.M = (int)M; p.m_per_split = (int)mps; p.nsplit = nsplit;
   p.co_total = K;
   p.x_bytes = (unsigned int)(M * C * 2);
+  p.xf = xf; p.a_out = (char*)a_out; p.relu = relu;
   hipStream_t st = (hipStream_t)stream;
-  cn_set_last_kernel("jfwd_kernel<%s, %d, %d>", dtype == CN_F16 ? "f16_t" : "bf16_t", C, K);
+  cn_set_last_kernel(xf != nullptr ? "jfwd_kernel<%s, %d, %d, true>" : "jfwd_kernel<%s, %d, %d>", dtype == CN_F16 ? "f16_t" : "bf16_t", C, K);
   dim3 grid((unsigned)nsplit, (unsigned)(K > 512 ? K / 512 : 1));
 #define JF_GO(KD, CO)                                                                             \
   do {                                                                                            \
-    if (dtype == CN_F16) CN_LAUNCH((jfwd_kernel<f16_t, KD, CO>), grid, dim3(512), st, p);          \
-    else CN_LAUNCH((jfwd_kernel<bf16_t, KD, CO>), grid, dim3(512), st, p);                         \
+    if (xf != nullptr) {                                                                          \
+      if (dtype == CN_F16) CN_LAUNCH((jfwd_kernel<f16_t, KD, CO, true>), grid, dim3(512), st, p);  \
+      else CN_LAUNCH((jfwd_kernel<bf16_t, KD, CO, true>), grid, dim3(512), st, p);                 \
+    } else {                                                                                      \
+      if (dtype == CN_F16) CN_LAUNCH((jfwd_kernel<f16_t, KD, CO>), grid, dim3(512), st, p);        \
+      else CN_LAUNCH((jfwd_kernel<bf16_t, KD, CO>), grid, dim3(512), st, p);                       \
+    }                                                                                             \
   } while (0)
   if (K == 256 && C == 64) JF_GO(64, 256);
   else if (K == 256 && C == 128) JF_GO(128, 256);
@@ -534,6 +564,23 @@ extern "C" int cn_conv1x1_stream_fwd(const void* x, const void* w_krsc, void* y,
   else JF_GO(256, 512);
 #undef JF_GO
   return cn_check_launch("jfwd");
+}
+extern "C" int cn_conv1x1_stream_fwd(const void* x, const void* w_krsc, void* y, int N, int H, int W, int C, int K,
+                                     int dtype, float* partial, int partial_rows, void* stream) {
+  return jfwd_impl("conv1x1_stream_fwd", x, nullptr, 0, nullptr, w_krsc, y, N, H, W, C, K, dtype, partial, partial_rows, stream);
+}
+// "Lazy a": cn_conv1x1_stream_fwd whose input is still the INPUT bn_y of the BatchNorm in front of the convolution
+// (statistics finalised: stats = [mean | invstd | scale | shift], cn_bn_fwd_train*'s layout): the kernel forms
+// a = relu?(bn_y * scale + shift) on its way into the LDS tile - bn_apply_kernel's arithmetic and rounding - and writes
+// it to a_out [M][C] (the convolution's saved input for the weight gradient), so the apply pass of an inner BatchNorm
+// (one read of bn_y + one write of a, then the convolution's read of a) becomes one read of bn_y + one write of a.
+// Same a and y bits as cn_bn_fwd_train's apply pass + cn_conv1x1_stream_fwd.
+extern "C" int cn_conv1x1_stream_fwd_lazya(const void* bn_y, const float* stats, int relu, void* a_out, const void* w_krsc,
+                                           void* y, int N, int H, int W, int C, int K, int dtype, float* partial,
+                                           int partial_rows, void* stream) {
+  if (stats == nullptr || a_out == nullptr) { cn_set_error("conv1x1_stream_fwd_lazya: null operand"); return CN_EINVAL; }
+  return jfwd_impl("conv1x1_stream_fwd_lazya", bn_y, stats + 2 * C, relu, a_out, w_krsc, y, N, H, W, C, K, dtype, partial,
+                   partial_rows, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

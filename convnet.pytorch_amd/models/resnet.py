@@ -107,6 +107,13 @@ class ResidualBlock(tnn.Module):
     def last_bn(self):
         return getattr(self, 'bn%d' % self.n_convs)
 
+    def link_inner_consumers(self):
+        """bn_{n-1} -> relu -> conv_n run back to back in forward(): when conv_n is a 1x1 convolution on the streaming
+        kernel it applies that BatchNorm on its operand path (ops.LAZY_A)."""
+        if not self.quantized and self.n_convs >= 2:
+            getattr(self, 'bn%d' % (self.n_convs - 1)).__dict__['inner_consumer_conv'] = \
+                getattr(self, 'conv%d' % self.n_convs)
+
     def set_input_bn(self, bn):
         """The block input is the output of `bn` (the previous block's last BN, ReLU and residual fused):
         whichever of conv1 / downsample conv completes the input gradient reduces it for that BN."""
@@ -189,6 +196,7 @@ class ResNetImagenet(tnn.Module):
             if isinstance(m, ResidualBlock):
                 if prev is not None:
                     m.set_input_bn(prev.last_bn())
+                m.link_inner_consumers()
                 prev = m
         self.avgpool = cnn.AdaptiveAvgPool2d(1)
         self.fc = Dense(width[-1] * expansion, num_classes)

@@ -468,6 +468,44 @@ def conv2d_fwd_lazyz(lz, w_krsc, K, bn_stats=False, pivot=None):
     return out
 
 
+# "Lazy a" (round 3, third session): an INNER BatchNorm (no residual, ReLU) whose consumer is a 1x1 convolution on the
+# streaming forward kernel only finalises its statistics; the convolution forms a = relu(y * scale + shift) on its
+# operand path and writes it as a side output (cn_conv1x1_stream_fwd_lazya): the apply pass - one read of y, one write
+# of a - and the convolution's read of a become one read of y and one write of a.  Same scope rule as lazy z (the
+# consumer runs next by construction of the block's forward).  CONVNET_AMD_LAZY_A=0 disables it (A/B).
+LAZY_A = os.environ.get('CONVNET_AMD_LAZY_A', '1') == '1'
+
+
+def lazy_a_consumer_ok(conv, C, dtype):
+    """conv (the module behind an inner BatchNorm of C channels) will run on the streaming 1x1 forward kernel."""
+    return (conv is not None and CONV1X1_STREAM and getattr(conv, 'kernel_size', None) == (1, 1)
+            and getattr(conv, 'stride', None) == (1, 1) and getattr(conv, 'padding', None) == (0, 0)
+            and getattr(conv, 'bias', None) is None and conv.training and not getattr(conv, 'out_f32', False)
+            and conv.in_channels == C and conv.out_channels <= CONV1X1_STREAM_MAXK and stats_pivot(conv) is None
+            and dtype in (torch.bfloat16, torch.float16)
+            and bool(_L().cn_conv1x1_stream_fwd_ok(C, conv.out_channels, dtype_code(dtype))))
+
+
+def conv2d_fwd_lazya(la, w_krsc, K, bn_stats=False):
+    """la = (bn_y, stats, a, relu) parked by BatchNormActFunction: y = conv1x1(relu?(bn_y * scale + shift)), a written."""
+    bn_y, stats, a, relu = la
+    N, H, W, C = bn_y.shape
+    L = _L()
+    y = torch.empty((N, H, W, K), dtype=bn_y.dtype, device=bn_y.device)
+    want = bn_stats and y.numel() * _esize(y) >= FUSE_BN_STATS_MIN_MB * 2 ** 20
+    rows = L.cn_conv1x1_stream_fwd_rows(N, H, W, K) if want else 0
+    partial = torch.empty((rows, 2 * K), dtype=torch.float32, device=bn_y.device) if want else None
+    PROFILER.run(_last_kernel(' [lazy a]'), 1, 2.0 * N * H * W * K * C,
+                 2 * bn_y.numel() * _esize(bn_y) + y.numel() * _esize(y) + K * C * _esize(bn_y),
+                 lambda: check(L.cn_conv1x1_stream_fwd_lazya(ptr(bn_y), ptr(stats), int(relu), ptr(a), ptr(w_krsc), ptr(y),
+                                                             N, H, W, C, K, dtype_code(bn_y.dtype), ptr(partial), rows,
+                                                             stream_of(bn_y)), 'cn_conv1x1_stream_fwd_lazya'),
+                 bn_y.device, detail=_conv_detail('fwd', C, H, K, 1, (1, 1)))
+    if want:
+        _park_stats(y, partial, rows, None)
+    return y
+
+
 def lazy_z_consumer_ok(conv):
     """conv can take an unapplied junction as its input (cn_conv2d_fwd_lazyz's shape limits)."""
     return (conv is not None and getattr(conv, 'kernel_size', None) == (1, 1) and getattr(conv, 'stride', None) == (1, 1)
@@ -759,6 +797,13 @@ class Conv2dFunction(Function):
                                  bn_stats=FUSE_BN_STATS and mod.training and getattr(mod, 'feeds_batchnorm', False),
                                  pivot=stats_pivot(mod))
             COUNTERS['lazy_z'] = COUNTERS.get('lazy_z', 0) + 1
+        elif mod.__dict__.get('_lazy_a') is not None:   # x is an inner BatchNorm's output that exists only as (y, statistics)
+            la = mod.__dict__.pop('_lazy_a')
+            if la[0] != x.data_ptr() or bias is not None:
+                raise _lib.ConvNetHipError('lazy a: the parked BatchNorm output is not this convolution\'s input')
+            y = conv2d_fwd_lazya(la[1:], mod.w_krsc, mod.out_channels,
+                                 bn_stats=FUSE_BN_STATS and mod.training and getattr(mod, 'feeds_batchnorm', False))
+            COUNTERS['lazy_a'] = COUNTERS.get('lazy_a', 0) + 1
         else:
             y = conv2d_fwd(x, mod.w_krsc, bias, mod.out_channels, mod.kernel_size[0], mod.kernel_size[1],
                            mod.stride, mod.padding, out_f32=mod.out_f32,
@@ -1020,7 +1065,10 @@ class BatchNormActFunction(Function):
                  and _sync_group(mod) is None and y.numel() * _esize(y) >= LAZY_Z_MIN_MB * 2 ** 20
                  and tuple(residual.shape) == tuple(y.shape) and residual.dtype == y.dtype and lazy_z_consumer_ok(cons)
                  and cons.in_channels == C)
-        zk = None if (defer or dual is not None or lazyz) else z     # what the statistics call applies itself
+        icons = getattr(mod, 'inner_consumer_conv', None)
+        lazya = (LAZY_A and LAZY_Z_SCOPE[0] > 0 and not defer and relu and residual is None and _sync_group(mod) is None
+                 and mod.training and lazy_a_consumer_ok(icons, C, y.dtype))
+        zk = None if (defer or dual is not None or lazyz or lazya) else z     # what the statistics call applies itself
         stats = torch.empty(4 * C, dtype=torch.float32, device=y.device)
         mask = None
         if relu and residual is not None:   # 1 bit per output instead of re-reading z in backward
@@ -1076,6 +1124,8 @@ class BatchNormActFunction(Function):
                          y.device)
         if lazyz:
             cons.__dict__['_lazy_z'] = (z.data_ptr(), y, residual.contiguous(), stats, dual, z, mask, relu)
+        elif lazya:
+            icons.__dict__['_lazy_a'] = (z.data_ptr(), y, stats, z, relu)
         elif dual is not None:    # both BatchNorms finalised: one apply pass reads y and the shortcut's raw input
             PROFILER.run('bn_apply (junction + projection-shortcut BatchNorm)', 1, 0.0,
                          nb * 3 + (mask.numel() if mask is not None else 0),

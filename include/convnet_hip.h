@@ -170,6 +170,13 @@ int cn_conv1x1_stream_fwd_ok(int C, int K, int dtype);
 int cn_conv1x1_stream_fwd_rows(int N, int H, int W, int K);
 int cn_conv1x1_stream_fwd(const void* x, const void* w_krsc, void* y, int N, int H, int W, int C, int K, int dtype,
                           float* partial, int partial_rows, void* stream);
+/* "Lazy a": cn_conv1x1_stream_fwd reading the INPUT bn_y of the BatchNorm in front of the convolution (statistics
+ * finalised, stats = [mean | invstd | scale | shift]); the kernel forms a = relu?(bn_y * scale + shift) on its operand path
+ * (the bits of cn_bn_fwd_train's apply pass), writes it to a_out [M][C] and multiplies: the inner BatchNorm's apply pass disappears.  Replaces
+ * the bn2 -> relu -> conv3 sequence of /root/reference models/resnet.py:126-132. */
+int cn_conv1x1_stream_fwd_lazya(const void* bn_y, const float* stats, int relu, void* a_out, const void* w_krsc, void* y,
+                                int N, int H, int W, int C, int K, int dtype, float* partial, int partial_rows,
+                                void* stream);
 /* The same operation for the LARGE junctions as one persistent streaming kernel (csrc/junction.hip): 1x1 / stride-1 /
  * unpadded convolution with K -> C channels of an instantiated shape (cn_conv2d_dgrad_junction_ok: 64 or 128 -> 256,
  * 128 -> 512; 16-bit storage), ReLU bits (bn_mask) and an addend required (addend_sub as cn_conv2d_dgrad_sa).  The

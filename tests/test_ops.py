@@ -1466,6 +1466,47 @@ def test_streaming_conv1x1_forward_equals_tiled_kernel(mode, dtype):
 
 @pytest.mark.parametrize('mode', MODES)
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_lazy_a_conv_equals_apply_then_conv(mode, dtype):
+    """cn_conv1x1_stream_fwd_lazya (an inner BatchNorm's apply + ReLU formed on the streaming 1x1 kernel's operand path,
+    a written as a side output) against cn_bn_fwd_train (statistics + apply) followed by cn_conv1x1_stream_fwd: a, y and the statistics partials
+    bit for bit, on every instantiated shape, pixel counts that are not whole stages included."""
+    _f16_emul_subset(mode, dtype, keep=True)
+    dev = _dev(mode)
+    import convnet_amd as ca
+    ops, L = ca.ops, ca._lib.load()
+    cases = [(1, 6, 10, 64, 256), (2, 6, 6, 128, 256), (1, 5, 9, 128, 512), (1, 5, 7, 256, 1024)] if mode == 'emul' else \
+        [(8, 56, 56, 64, 256), (8, 56, 56, 128, 256), (16, 28, 28, 128, 512), (3, 17, 13, 64, 256), (64, 14, 14, 256, 1024)]
+    for relu in (True, False):
+        for (N, H, W, C, K) in cases:
+            g = torch.Generator().manual_seed(C + K + H + int(relu))
+            y2 = (torch.randn(N, H, W, C, generator=g) * 1.5 + 0.3).to(dtype).to(dev)
+            w = (torch.randn(K, 1, 1, C, generator=g) * (2.0 / C) ** 0.5).to(dtype).to(dev)
+            gamma = (torch.rand(C, generator=g) + 0.5).to(dev)
+            beta = (torch.randn(C, generator=g) * 0.3).to(dev)
+            stats = torch.empty(4 * C, dtype=torch.float32, device=dev)
+            M = N * H * W
+            a0 = torch.empty_like(y2)
+            code = ca._lib.dtype_code(dtype)
+            ws = ops.workspace(L.cn_bn_workspace(M, C, code), dev)
+            ca._lib.check(L.cn_bn_fwd_train(ca._lib.ptr(y2), None, ca._lib.ptr(a0), None, ca._lib.ptr(gamma),
+                                            ca._lib.ptr(beta), None, None, None, 0.1, 1e-5, ca._lib.ptr(stats), M, C,
+                                            int(relu), code, ca._lib.ptr(ws), ws.numel() * 4, ca._lib.stream_of(y2)),
+                          'cn_bn_fwd_train')
+            out0 = ops.conv2d_fwd(a0, w, None, K, 1, 1, (1, 1), (0, 0), bn_stats=True)
+            assert 'jfwd_kernel' in L.cn_last_kernel_name().decode()
+            p0 = ops.take_pending_stats(out0)
+            a1 = torch.full_like(y2, float('nan'))
+            out1 = ops.conv2d_fwd_lazya((y2, stats, a1, relu), w, K, bn_stats=True)
+            assert L.cn_last_kernel_name().decode().endswith(', true>')
+            p1 = ops.take_pending_stats(out1)
+            assert torch.equal(a1.cpu().view(torch.int16), a0.cpu().view(torch.int16)), (N, H, W, C, K, relu)
+            assert torch.equal(out1.cpu(), out0.cpu()), (N, H, W, C, K, relu)
+            if p0 is not None or p1 is not None:
+                assert p0.rows == p1.rows and torch.equal(p1.partial.cpu(), p0.partial.cpu())
+
+
+@pytest.mark.parametrize('mode', MODES)
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 def test_streaming_lazy_dgrad_equals_tiled_kernel(mode, dtype):
     """cn_conv2d_dgrad_lazy_stream (512 -> 128 channels, csrc/junction.hip: jdlazy_kernel) against the tiled lazy data
     gradient: bit for bit (bf16; fp16 to a few ulps on the GPU, see the junction-pair test), pixel counts that are not
