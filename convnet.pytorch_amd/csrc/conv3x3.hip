@@ -27,13 +27,19 @@ struct C3Params {
   float* partial;   // optional [nwg][128]: sum | sum of squares of the stored outputs
   int N, H, W, nbands, nwork, flip;
   FastDiv div_w;
+  // XF ("lazy a", forward only): x is the INPUT of the BatchNorm in front of this convolution; a = relu?(x * scale + shift)
+  // is formed on the way into the halo (bn_apply_kernel's arithmetic; rows / columns outside the image stay zero) and
+  // the band's own rows are written to a_out
+  const float* xf;   // [scale | shift] (2 * 64)
+  char* a_out;       // [N][H][W][64]
+  int relu;
 };
 
 #define C3_ROWS 4
 #define C3_PPOS 144     /* bytes per halo position */
 #define C3_MAXW 56
 
-template <typename T>
+template <typename T, bool XF = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C3Params p) {
   static_assert(sizeof(T) == 2, "16-bit storage");
   constexpr int HR = C3_ROWS + 2;
@@ -61,6 +67,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C3Params p) {
     cn_st16(halo + (row * WP + (side ? W + 1 : 0)) * C3_PPOS + c * 16, cn_zero16());
   }
 
+  // XF: the thread's chunk (tid & 7) is fixed; its coefficients are re-read from an LDS table per batch (held in
+  // registers across the MFMA phase they pushed the kernel over its 256-VGPR budget)
+  __shared__ float s_xf[XF ? 128 : 1];
+  if constexpr (XF) {
+    if (tid < 128) s_xf[tid] = p.xf[tid];
+  }
   const int nchunks = HR * W * 8;
   auto stage_halo = [&](int work) {   // global -> LDS, a batch of four 16-byte chunks per thread in flight
     const int band = work % p.nbands, n = work / p.nbands;
@@ -78,10 +90,42 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C3Params p) {
         const bool ok = id < nchunks && (unsigned)iy < (unsigned)H;
         v[i] = ok ? cn_ld16(p.x + ((((size_t)n * H + (size_t)iy) * W + (size_t)col) * 64 + (size_t)c * 8) * 2) : cn_zero16();
         dst[i] = id < nchunks ? (row * WP + col + 1) * C3_PPOS + c * 16 : -1;
+        if constexpr (XF) {   // bit 30: an image row; bit 29: one of the band's own rows (written to a_out)
+          if (ok) dst[i] |= (1 << 30) | ((row >= 1 && row <= C3_ROWS) ? (1 << 29) : 0);
+        }
+      }
+      float xsc[XF ? 8 : 1], xsh[XF ? 8 : 1];
+      if constexpr (XF) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { xsc[e] = s_xf[(tid & 7) * 8 + e]; xsh[e] = s_xf[64 + (tid & 7) * 8 + e]; }
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (dst[i] >= 0) cn_st16(halo + dst[i], v[i]);
+      for (int i = 0; i < 4; ++i) {
+        if (dst[i] < 0) continue;
+        if constexpr (XF) {
+          const int flags = dst[i];
+          dst[i] &= (1 << 29) - 1;
+          if (flags & (1 << 30)) {
+            float f[8];
+            Chunk<T>::unpack(v[i], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = fmaf(f[e], xsc[e], xsh[e]);
+            if (p.relu) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) f[e] = f[e] > 0.f ? f[e] : 0.f;
+            }
+            v[i] = Chunk<T>::pack(f);
+            if (flags & (1 << 29)) {
+              const int id = id0 + 256 * i;
+              const int pos = id >> 3, c = id & 7;
+              const int row = (int)cn_fastdiv((unsigned)pos, p.div_w);
+              const int col = pos - row * W;
+              cn_st16(p.a_out + ((((size_t)n * H + (size_t)(oy0 - 1 + row)) * W + (size_t)col) * 64 + (size_t)c * 8) * 2, v[i]);
+            }
+          }
+        }
+        cn_st16(halo + dst[i], v[i]);
+      }
     }
   };
 
@@ -207,10 +251,10 @@ extern "C" int cn_conv3x3_c64_rows(int N, int H) { return c3_wgs(N * ((H + C3_RO
 // flip = 1: data gradient (x = dy, w = the CRSK filter: rows = input channels of the convolution).  partial (optional,
 // forward): cn_conv3x3_c64_rows(N, H) rows of 128 floats [sum | sum of squares] of the stored outputs for
 // cn_bn_fwd_train_partials.  Same output bits as cn_conv2d_fwd / cn_conv2d_dgrad.
-extern "C" int cn_conv3x3_c64(const void* x, const void* w, void* y, int N, int H, int W, int dtype, int flip,
-                              float* partial, int partial_rows, void* stream) {
-  if (x == nullptr || w == nullptr || y == nullptr) { cn_set_error("conv3x3_c64: null operand"); return CN_EINVAL; }
-  if (!cn_conv3x3_c64_ok(H, W, 64, 64, dtype) || N <= 0) { cn_set_error("conv3x3_c64: unsupported shape"); return CN_ESHAPE; }
+static int c3_impl(const char* who, const void* x, const float* xf, int relu, void* a_out, const void* w, void* y, int N,
+                   int H, int W, int dtype, int flip, float* partial, int partial_rows, void* stream) {
+  if (x == nullptr || w == nullptr || y == nullptr) { cn_set_error("%s: null operand", who); return CN_EINVAL; }
+  if (!cn_conv3x3_c64_ok(H, W, 64, 64, dtype) || N <= 0) { cn_set_error("%s: unsupported shape", who); return CN_ESHAPE; }
   C3Params p;
   memset(&p, 0, sizeof(p));
   p.x = (const char*)x; p.w = (const char*)w; p.y = (char*)y; p.partial = partial;
@@ -218,10 +262,29 @@ extern "C" int cn_conv3x3_c64(const void* x, const void* w, void* y, int N, int 
   p.nbands = (H + C3_ROWS - 1) / C3_ROWS;
   p.nwork = N * p.nbands;
   p.div_w = cn_make_fastdiv((unsigned)W);
+  p.xf = xf; p.a_out = (char*)a_out; p.relu = relu;
   const int nwg = c3_wgs(p.nwork);
-  if (partial != nullptr && partial_rows < nwg) { cn_set_error("conv3x3_c64: partial buffer of %d rows < %d", partial_rows, nwg); return CN_EWORKSPACE; }
-  cn_set_last_kernel("conv3x3_c64_kernel<%s>%s", dtype == CN_F16 ? "f16_t" : "bf16_t", flip ? " [dgrad]" : "");
-  if (dtype == CN_F16) CN_LAUNCH((conv3x3_c64_kernel<f16_t>), dim3((unsigned)nwg), dim3(256), (hipStream_t)stream, p);
-  else CN_LAUNCH((conv3x3_c64_kernel<bf16_t>), dim3((unsigned)nwg), dim3(256), (hipStream_t)stream, p);
+  if (partial != nullptr && partial_rows < nwg) { cn_set_error("%s: partial buffer of %d rows < %d", who, partial_rows, nwg); return CN_EWORKSPACE; }
+  cn_set_last_kernel("conv3x3_c64_kernel<%s%s>%s", dtype == CN_F16 ? "f16_t" : "bf16_t", xf != nullptr ? ", true" : "", flip ? " [dgrad]" : "");
+  if (xf != nullptr) {
+    if (dtype == CN_F16) CN_LAUNCH((conv3x3_c64_kernel<f16_t, true>), dim3((unsigned)nwg), dim3(256), (hipStream_t)stream, p);
+    else CN_LAUNCH((conv3x3_c64_kernel<bf16_t, true>), dim3((unsigned)nwg), dim3(256), (hipStream_t)stream, p);
+  } else {
+    if (dtype == CN_F16) CN_LAUNCH((conv3x3_c64_kernel<f16_t>), dim3((unsigned)nwg), dim3(256), (hipStream_t)stream, p);
+    else CN_LAUNCH((conv3x3_c64_kernel<bf16_t>), dim3((unsigned)nwg), dim3(256), (hipStream_t)stream, p);
+  }
   return cn_check_launch("conv3x3_c64");
+}
+extern "C" int cn_conv3x3_c64(const void* x, const void* w, void* y, int N, int H, int W, int dtype, int flip,
+                              float* partial, int partial_rows, void* stream) {
+  return c3_impl("conv3x3_c64", x, nullptr, 0, nullptr, w, y, N, H, W, dtype, flip, partial, partial_rows, stream);
+}
+// "Lazy a" (forward): cn_conv3x3_c64 whose input is still the INPUT bn_y of the BatchNorm in front of the convolution
+// (stats = [mean | invstd | scale | shift] of 64 channels): a = relu?(bn_y * scale + shift) is formed on the way into the
+// halo and written to a_out [N][H][W][64] (cn_conv1x1_stream_fwd_lazya's contract for the 3x3 halo kernel; padding stays
+// zero: it pads a, not bn_y).  Same a and y bits as the apply pass followed by cn_conv3x3_c64.
+extern "C" int cn_conv3x3_c64_lazya(const void* bn_y, const float* stats, int relu, void* a_out, const void* w, void* y,
+                                    int N, int H, int W, int dtype, float* partial, int partial_rows, void* stream) {
+  if (stats == nullptr || a_out == nullptr) { cn_set_error("conv3x3_c64_lazya: null operand"); return CN_EINVAL; }
+  return c3_impl("conv3x3_c64_lazya", bn_y, stats + 2 * 64, relu, a_out, w, y, N, H, W, dtype, 0, partial, partial_rows, stream);
 }

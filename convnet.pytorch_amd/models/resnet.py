@@ -108,11 +108,11 @@ class ResidualBlock(tnn.Module):
         return getattr(self, 'bn%d' % self.n_convs)
 
     def link_inner_consumers(self):
-        """bn_{n-1} -> relu -> conv_n run back to back in forward(): when conv_n is a 1x1 convolution on the streaming
-        kernel it applies that BatchNorm on its operand path (ops.LAZY_A)."""
-        if not self.quantized and self.n_convs >= 2:
-            getattr(self, 'bn%d' % (self.n_convs - 1)).__dict__['inner_consumer_conv'] = \
-                getattr(self, 'conv%d' % self.n_convs)
+        """bn_i -> relu -> conv_{i+1} run back to back in forward(): a 1x1 convolution on the streaming kernel / a 3x3
+        convolution on the 64-channel halo kernel applies that BatchNorm on its operand path (ops.LAZY_A)."""
+        if not self.quantized:
+            for i in range(1, self.n_convs):
+                getattr(self, 'bn%d' % i).__dict__['inner_consumer_conv'] = getattr(self, 'conv%d' % (i + 1))
 
     def set_input_bn(self, bn):
         """The block input is the output of `bn` (the previous block's last BN, ReLU and residual fused):

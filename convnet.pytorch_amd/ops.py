@@ -473,26 +473,46 @@ def conv2d_fwd_lazyz(lz, w_krsc, K, bn_stats=False, pivot=None):
 # operand path and writes it as a side output (cn_conv1x1_stream_fwd_lazya): the apply pass - one read of y, one write
 # of a - and the convolution's read of a become one read of y and one write of a.  Same scope rule as lazy z (the
 # consumer runs next by construction of the block's forward).  CONVNET_AMD_LAZY_A=0 disables it (A/B).
-LAZY_A = os.environ.get('CONVNET_AMD_LAZY_A', '1') == '1'
+LAZY_A = os.environ.get('CONVNET_AMD_LAZY_A', '1') != '0'
+LAZY_A_3X3 = os.environ.get('CONVNET_AMD_LAZY_A', '1') != '1x1'      # ('1x1': the streaming 1x1 consumers only, A/B)
 
 
-def lazy_a_consumer_ok(conv, C, dtype):
-    """conv (the module behind an inner BatchNorm of C channels) will run on the streaming 1x1 forward kernel."""
-    return (conv is not None and CONV1X1_STREAM and getattr(conv, 'kernel_size', None) == (1, 1)
-            and getattr(conv, 'stride', None) == (1, 1) and getattr(conv, 'padding', None) == (0, 0)
-            and getattr(conv, 'bias', None) is None and conv.training and not getattr(conv, 'out_f32', False)
-            and conv.in_channels == C and conv.out_channels <= CONV1X1_STREAM_MAXK and stats_pivot(conv) is None
-            and dtype in (torch.bfloat16, torch.float16)
-            and bool(_L().cn_conv1x1_stream_fwd_ok(C, conv.out_channels, dtype_code(dtype))))
+def lazy_a_consumer_ok(conv, y):
+    """conv (the module behind an inner BatchNorm whose input is y, NHWC) will run on the streaming 1x1 forward kernel
+    or on the 64-channel 3x3 halo kernel."""
+    C, dtype = y.shape[-1], y.dtype
+    if conv is None or getattr(conv, 'bias', None) is not None or not conv.training or getattr(conv, 'out_f32', False) \
+            or conv.in_channels != C or stats_pivot(conv) is not None or dtype not in (torch.bfloat16, torch.float16) \
+            or getattr(conv, 'stride', None) != (1, 1):
+        return False
+    if getattr(conv, 'kernel_size', None) == (1, 1) and conv.padding == (0, 0):
+        return (CONV1X1_STREAM and conv.out_channels <= CONV1X1_STREAM_MAXK
+                and bool(_L().cn_conv1x1_stream_fwd_ok(C, conv.out_channels, dtype_code(dtype))))
+    if getattr(conv, 'kernel_size', None) == (3, 3) and conv.padding == (1, 1):
+        return (CONV3X3_HALO and LAZY_A_3X3 and bool(_L().cn_conv3x3_c64_ok(y.shape[1], y.shape[2], C, conv.out_channels, dtype_code(dtype))))
+    return False
 
 
-def conv2d_fwd_lazya(la, w_krsc, K, bn_stats=False):
-    """la = (bn_y, stats, a, relu) parked by BatchNormActFunction: y = conv1x1(relu?(bn_y * scale + shift)), a written."""
+def conv2d_fwd_lazya(la, w_krsc, K, bn_stats=False, kernel=(1, 1)):
+    """la = (bn_y, stats, a, relu) parked by BatchNormActFunction: y = conv(relu?(bn_y * scale + shift)), a written
+    (1x1: the streaming kernel; 3x3: the 64-channel halo kernel)."""
     bn_y, stats, a, relu = la
     N, H, W, C = bn_y.shape
     L = _L()
     y = torch.empty((N, H, W, K), dtype=bn_y.dtype, device=bn_y.device)
     want = bn_stats and y.numel() * _esize(y) >= FUSE_BN_STATS_MIN_MB * 2 ** 20
+    if tuple(kernel) == (3, 3):
+        rows = L.cn_conv3x3_c64_rows(N, H) if want else 0
+        partial = torch.empty((rows, 2 * K), dtype=torch.float32, device=bn_y.device) if want else None
+        PROFILER.run(_last_kernel(' [lazy a]'), 1, 2.0 * N * H * W * K * C * 9,
+                     2 * bn_y.numel() * _esize(bn_y) + y.numel() * _esize(y) + K * 9 * C * _esize(bn_y),
+                     lambda: check(L.cn_conv3x3_c64_lazya(ptr(bn_y), ptr(stats), int(relu), ptr(a), ptr(w_krsc), ptr(y),
+                                                          N, H, W, dtype_code(bn_y.dtype), ptr(partial), rows,
+                                                          stream_of(bn_y)), 'cn_conv3x3_c64_lazya'),
+                     bn_y.device, detail=_conv_detail('fwd', C, H, K, 3, (1, 1)))
+        if want:
+            _park_stats(y, partial, rows, None)
+        return y
     rows = L.cn_conv1x1_stream_fwd_rows(N, H, W, K) if want else 0
     partial = torch.empty((rows, 2 * K), dtype=torch.float32, device=bn_y.device) if want else None
     PROFILER.run(_last_kernel(' [lazy a]'), 1, 2.0 * N * H * W * K * C,
@@ -802,7 +822,8 @@ class Conv2dFunction(Function):
             if la[0] != x.data_ptr() or bias is not None:
                 raise _lib.ConvNetHipError('lazy a: the parked BatchNorm output is not this convolution\'s input')
             y = conv2d_fwd_lazya(la[1:], mod.w_krsc, mod.out_channels,
-                                 bn_stats=FUSE_BN_STATS and mod.training and getattr(mod, 'feeds_batchnorm', False))
+                                 bn_stats=FUSE_BN_STATS and mod.training and getattr(mod, 'feeds_batchnorm', False),
+                                 kernel=mod.kernel_size)
             COUNTERS['lazy_a'] = COUNTERS.get('lazy_a', 0) + 1
         else:
             y = conv2d_fwd(x, mod.w_krsc, bias, mod.out_channels, mod.kernel_size[0], mod.kernel_size[1],
@@ -1067,7 +1088,7 @@ class BatchNormActFunction(Function):
                  and cons.in_channels == C)
         icons = getattr(mod, 'inner_consumer_conv', None)
         lazya = (LAZY_A and LAZY_Z_SCOPE[0] > 0 and not defer and relu and residual is None and _sync_group(mod) is None
-                 and mod.training and lazy_a_consumer_ok(icons, C, y.dtype))
+                 and mod.training and lazy_a_consumer_ok(icons, y))
         zk = None if (defer or dual is not None or lazyz or lazya) else z     # what the statistics call applies itself
         stats = torch.empty(4 * C, dtype=torch.float32, device=y.device)
         mask = None

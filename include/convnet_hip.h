@@ -101,6 +101,11 @@ int cn_conv3x3_c64_ok(int H, int W, int C, int K, int dtype);
 int cn_conv3x3_c64_rows(int N, int H);
 int cn_conv3x3_c64(const void* x, const void* w, void* y, int N, int H, int W, int dtype, int flip, float* partial,
                    int partial_rows, void* stream);
+/* "Lazy a" for the 3x3 halo kernel (forward): the input is the INPUT bn_y of the BatchNorm in front of the convolution;
+ * a = relu?(bn_y * scale + shift) is formed on the way into the halo (zero padding pads a) and written to a_out.  Replaces
+ * the bn1 -> relu -> conv2 sequence of /root/reference models/resnet.py:122-128 in the first stage. */
+int cn_conv3x3_c64_lazya(const void* bn_y, const float* stats, int relu, void* a_out, const void* w, void* y, int N, int H,
+                         int W, int dtype, float* partial, int partial_rows, void* stream);
 /* The 7x7 / stride-2 stem (/root/reference models/resnet.py:226) on the pixel-pair image of cn_nchw_to_pairs as a halo
  * kernel (csrc/stem.hip): y[n][oy][ox][k] = sum_{r<7, s2<4, e<8} xp[n][2*oy + r][ox + s2][e] * wp[k][r][s2][e], i.e.
  * cn_conv2d_fwd_bnstats on the pair image (R = 7, S = 4, stride (2, 1), no padding) with 64 output channels; the input

@@ -1507,6 +1507,46 @@ def test_lazy_a_conv_equals_apply_then_conv(mode, dtype):
 
 @pytest.mark.parametrize('mode', MODES)
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_lazy_a_conv3x3_halo_equals_apply_then_conv(mode, dtype):
+    """cn_conv3x3_c64_lazya (bn1 + ReLU formed on the way into the halo of the 64-channel 3x3 kernel; zero padding pads
+    a, not the BatchNorm input) against cn_bn_fwd_train followed by cn_conv3x3_c64: a, y and the statistics partials bit
+    for bit; heights that are not whole bands included."""
+    _f16_emul_subset(mode, dtype, keep=True)
+    dev = _dev(mode)
+    import convnet_amd as ca
+    ops, L = ca.ops, ca._lib.load()
+    C = K = 64
+    for relu in (True, False):
+        for (N, H, W) in ([(1, 6, 7), (2, 5, 4)] if mode == 'emul' else [(8, 56, 56), (3, 17, 13), (2, 9, 56)]):
+            g = torch.Generator().manual_seed(N * H + W + int(relu))
+            y1 = (torch.randn(N, H, W, C, generator=g) * 1.5 + 0.3).to(dtype).to(dev)
+            w = (torch.randn(K, 3, 3, C, generator=g) * (2.0 / (9 * C)) ** 0.5).to(dtype).to(dev)
+            gamma = (torch.rand(C, generator=g) + 0.5).to(dev)
+            beta = (torch.randn(C, generator=g) * 0.3 + 0.2).to(dev)   # relu(shift) != 0: a transformed pad would show
+            stats = torch.empty(4 * C, dtype=torch.float32, device=dev)
+            M = N * H * W
+            a0 = torch.empty_like(y1)
+            code = ca._lib.dtype_code(dtype)
+            ws = ops.workspace(L.cn_bn_workspace(M, C, code), dev)
+            ca._lib.check(L.cn_bn_fwd_train(ca._lib.ptr(y1), None, ca._lib.ptr(a0), None, ca._lib.ptr(gamma),
+                                            ca._lib.ptr(beta), None, None, None, 0.1, 1e-5, ca._lib.ptr(stats), M, C,
+                                            int(relu), code, ca._lib.ptr(ws), ws.numel() * 4, ca._lib.stream_of(y1)),
+                          'cn_bn_fwd_train')
+            out0 = ops.conv2d_fwd(a0, w, None, K, 3, 3, (1, 1), (1, 1), bn_stats=True)
+            assert 'conv3x3_c64_kernel' in L.cn_last_kernel_name().decode()
+            p0 = ops.take_pending_stats(out0)
+            a1 = torch.full_like(y1, float('nan'))
+            out1 = ops.conv2d_fwd_lazya((y1, stats, a1, relu), w, K, bn_stats=True, kernel=(3, 3))
+            assert ', true>' in L.cn_last_kernel_name().decode()
+            p1 = ops.take_pending_stats(out1)
+            assert torch.equal(a1.cpu().view(torch.int16), a0.cpu().view(torch.int16)), (N, H, W, relu)
+            assert torch.equal(out1.cpu(), out0.cpu()), (N, H, W, relu)
+            if p0 is not None or p1 is not None:
+                assert p0.rows == p1.rows and torch.equal(p1.partial.cpu(), p0.partial.cpu())
+
+
+@pytest.mark.parametrize('mode', MODES)
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 def test_streaming_lazy_dgrad_equals_tiled_kernel(mode, dtype):
     """cn_conv2d_dgrad_lazy_stream (512 -> 128 channels, csrc/junction.hip: jdlazy_kernel) against the tiled lazy data
     gradient: bit for bit (bf16; fp16 to a few ulps on the GPU, see the junction-pair test), pixel counts that are not
