@@ -22,15 +22,19 @@ R50 = [(1, 8, 224, 64, 7, 2, 3), (1, 64, 56, 64, 1, 1, 0), (3, 64, 56, 64, 3, 1,
 
 
 def timeit(fn, iters):
-    fn()
-    torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(iters):
+    for _ in range(3):      # (one warm call left the very first row of a cold box at clock-ramp speed: 10 ms for the stem)
         fn()
-    e.record()
     torch.cuda.synchronize()
-    return s.elapsed_time(e) / iters
+    ms = None
+    for _ in range(2):      # the first timed round of a process absorbs a one-time ~40 ms event (first event pair): discarded
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(iters):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        ms = s.elapsed_time(e) / iters
+    return ms
 
 
 def main():

@@ -15,7 +15,7 @@ echo "== b8"; timeout 300 python bench.py --batch 8 --steps 20 --warmup 5 --no-c
 echo "== host inputs"; timeout 300 python bench.py --host-inputs --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-profile 2>/dev/null | grep '"metric"' | tee $OUT/bench_host_inputs.json | cut -c1-250
 echo "== world-1 RCCL"; BENCH_FORCE_DIST=1 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-profile 2>/dev/null | grep '"metric"' | tee $OUT/bench_dist1.json | cut -c1-300
 echo "== R18 fp32"; timeout 600 python bench.py --depth 18 --dtype f32 --steps 6 --warmup 4 --no-cpu-baseline 2>/dev/null | grep '"metric"' | tee $OUT/bench_r18_f32.json | cut -c1-250
-echo "== R101 bf16"; timeout 600 python bench.py --depth 101 --steps 8 --warmup 5 --no-cpu-baseline --no-kernel-profile 2>/dev/null | grep '"metric"' | tee $OUT/bench_r101.json | cut -c1-250
+echo "== R101 bf16"; timeout 600 python bench.py --depth 101 --steps 20 --warmup 10 --no-cpu-baseline --no-kernel-profile 2>/dev/null | grep '"metric"' | tee $OUT/bench_r101.json | cut -c1-250
 echo "== config 5"; timeout 600 python bench.py --quantize --steps 6 --warmup 3 --no-cpu-baseline 2>/dev/null | grep '"metric"' | tee $OUT/bench_config5.json | cut -c1-250
 echo "== rocprof"
 CONVNET_AMD_GRAPH=0 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o r50 -- python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-kernel-profile > $OUT/rocprof.log 2>&1
