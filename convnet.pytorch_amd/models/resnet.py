@@ -96,6 +96,7 @@ class ResidualBlock(tnn.Module):
         from ..ops import ResGradHolder
         self._holder = ResGradHolder()
         self.conv1._res_holder = self._holder
+        self.conv1.__dict__['junction_conv1'] = True   # (never a lazy-dy consumer: ops._lazy_dy_ok)
         if downsample is None:
             self.last_bn()._res_holder = self._holder     # identity: last BN's dres + conv1 dgrad
         else:

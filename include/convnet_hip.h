@@ -106,6 +106,10 @@ int cn_conv3x3_c64(const void* x, const void* w, void* y, int N, int H, int W, i
  * the bn1 -> relu -> conv2 sequence of /root/reference models/resnet.py:122-128 in the first stage. */
 int cn_conv3x3_c64_lazya(const void* bn_y, const float* stats, int relu, void* a_out, const void* w, void* y, int N, int H,
                          int W, int dtype, float* partial, int partial_rows, void* stream);
+/* cn_conv2d_dgrad_bnbwd_sa's contract (no addend, ReLU recomputed from bn_y: bn_mask = NULL, relu = 1) on the halo kernel:
+ * g = dx * relu_mask and cn_conv3x3_c64_rows partial rows [sum g | sum g * xhat] for cn_bn_bwd_partials. */
+int cn_conv3x3_c64_dgrad_bnbwd(const void* dy, const void* w_crsk, void* g, int N, int H, int W, int dtype, const void* bn_y,
+                               const float* bn_stats, float* partial, int partial_rows, void* stream);
 /* The 7x7 / stride-2 stem (/root/reference models/resnet.py:226) on the pixel-pair image of cn_nchw_to_pairs as a halo
  * kernel (csrc/stem.hip): y[n][oy][ox][k] = sum_{r<7, s2<4, e<8} xp[n][2*oy + r][ox + s2][e] * wp[k][r][s2][e], i.e.
  * cn_conv2d_fwd_bnstats on the pair image (R = 7, S = 4, stride (2, 1), no padding) with 64 output channels; the input

@@ -1507,6 +1507,39 @@ def test_lazy_a_conv_equals_apply_then_conv(mode, dtype):
 
 @pytest.mark.parametrize('mode', MODES)
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_conv3x3_halo_dgrad_with_bn_backward_reduction_equals_tiled_kernel(mode, dtype):
+    """cn_conv3x3_c64_dgrad_bnbwd (the halo data gradient masking with the ReLU of the BatchNorm in front of the
+    convolution and reducing for its backward) against the tiled cn_conv2d_dgrad_bnbwd_sa: g bit for bit, the partial
+    column sums to fp32 association."""
+    _f16_emul_subset(mode, dtype, keep=True)
+    dev = _dev(mode)
+    import convnet_amd as ca
+    ops, L = ca.ops, ca._lib.load()
+    C = K = 64
+    for (N, H, W) in ([(1, 6, 7), (2, 5, 4)] if mode == 'emul' else [(8, 56, 56), (3, 17, 13), (2, 9, 56)]):
+        g_ = torch.Generator().manual_seed(N * H + W)
+        dy = torch.randn(N, H, W, K, generator=g_).to(dtype).to(dev)
+        wc = (torch.randn(C, 3, 3, K, generator=g_) * (2.0 / (9 * K)) ** 0.5).to(dtype).to(dev)
+        bn_y = (torch.randn(N, H, W, C, generator=g_) * 1.5 + 0.2).to(dtype).to(dev)
+        stats = torch.cat([torch.randn(C, generator=g_) * 0.3, torch.rand(C, generator=g_) + 0.5,
+                           torch.rand(C, generator=g_) + 0.5, torch.randn(C, generator=g_) * 0.4]).to(dev)
+        saved = ops.HALO_DGRAD_BN
+        try:
+            ops.HALO_DGRAD_BN = False
+            g0, p0, r0 = ops.conv2d_dgrad(dy, wc, (N, H, W, C), K, 3, 3, (1, 1), (1, 1), bn=(bn_y, None, stats, True))
+            assert 'igemm_kernel' in L.cn_last_kernel_name().decode()
+            ops.HALO_DGRAD_BN = True
+            g1, p1, r1 = ops.conv2d_dgrad(dy, wc, (N, H, W, C), K, 3, 3, (1, 1), (1, 1), bn=(bn_y, None, stats, True))
+            assert 'conv3x3_c64_kernel' in L.cn_last_kernel_name().decode() and 'false, true' in L.cn_last_kernel_name().decode()
+        finally:
+            ops.HALO_DGRAD_BN = saved
+        assert torch.equal(g1.cpu(), g0.cpu()), (N, H, W)
+        s0, s1 = p0[:r0].double().sum(0).cpu(), p1[:r1].double().sum(0).cpu()
+        assert rel_l2(s1[:C], s0[:C]) < 1e-5 and rel_l2(s1[C:], s0[C:]) < 1e-4, (N, H, W)
+
+
+@pytest.mark.parametrize('mode', MODES)
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 def test_lazy_a_conv3x3_halo_equals_apply_then_conv(mode, dtype):
     """cn_conv3x3_c64_lazya (bn1 + ReLU formed on the way into the halo of the 64-channel 3x3 kernel; zero padding pads
     a, not the BatchNorm input) against cn_bn_fwd_train followed by cn_conv3x3_c64: a, y and the statistics partials bit
