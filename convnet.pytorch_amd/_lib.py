@@ -80,6 +80,7 @@ _SIGNATURES = {
     'cn_conv1x1_stream_fwd_lazya': (c_i, [c_p, c_p, c_i, c_p, c_p, c_p] + [c_i] * 6 + [c_p, c_i, c_p]),
     'cn_conv3x3_c64_lazya': (c_i, [c_p, c_p, c_i, c_p, c_p, c_p] + [c_i] * 4 + [c_p, c_i, c_p]),
     'cn_conv3x3_c64_dgrad_bnbwd': (c_i, [c_p, c_p, c_p] + [c_i] * 4 + [c_p, c_p, c_p, c_i, c_p]),
+    'cn_conv2d_dgrad_junction_rows_k': (c_i, [c_i] * 5),
     'cn_bn_workspace': (c_sz, [c_i, c_i, c_i]),
     'cn_bn_fwd_train': (c_i, [c_p] * 9 + [c_f, c_f, c_p, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
     'cn_bn_fwd_train_partials': (c_i, [c_p] * 9 + [c_f, c_f, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_sz, c_p]),

@@ -255,6 +255,185 @@ __global__ __launch_bounds__(512) void jdgrad_kernel(JdParams p) {
   }
 }
 
+// The 256-channel reductions (the 28x28 -> 14x14 and the 14x14 junctions: K = 256 gradient channels, C = 512 / 1024) with
+// a wave owning 32 channels instead of 64: the filter fragments of a wave are 64 registers instead of 128, so the
+// stage-ahead prefetch of the epilogue operands fits without spills (the 64-channel form above needs PF = false and
+// still spills 20 registers).  A workgroup owns a pixel range and a 256-channel slice (blockIdx.y) - eight waves of 32
+// channels, all 32 pixels of a stage each -; the dy tile (16 KB per stage) is read once per slice (C / 256 times, from
+// L2 after the first).  Epilogue accesses are 64 contiguous bytes per pixel row and wave.  Same g bits.
+template <typename T, int KD>
+__global__ __launch_bounds__(512) void jdgrad_w32_kernel(JdParams p) {
+  static_assert(sizeof(T) == 2, "16-bit storage");
+  constexpr int CO = 256, BM = 32;
+  constexpr int NKK = KD / 16;
+  constexpr int NCD = KD / 8;
+  constexpr int DYB = BM * KD * 2;
+  constexpr int ND = BM * NCD / 512;
+  static_assert(ND >= 1 && BM * NCD % 512 == 0 && 512 % NCD == 0, "dy tile staging");
+  constexpr int PP = 80;                // patch pitch: 32 channels * 2 bytes + 16
+  constexpr int PRIV = 32 * PP;
+  __shared__ __attribute__((aligned(16))) char lds[2 * DYB + 8 * PRIV];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = cn_uniform(tid >> 6);
+  const int h = lane >> 5;
+  char* priv = lds + 2 * DYB + wave * PRIV;
+  const int split = blockIdx.x;
+  const int co0 = blockIdx.y * CO, COT = p.co_total;
+  const int m_begin = split * p.m_per_split;
+  int m_end = m_begin + p.m_per_split;
+  if (m_end > p.M) m_end = p.M;
+
+  s16x8 wf[NKK];
+#pragma unroll
+  for (int kk = 0; kk < NKK; ++kk) {
+    const int c = co0 + wave * 32 + (lane & 31);
+    wf[kk] = __builtin_bit_cast(s16x8, cn_ld16(p.w + ((size_t)c * KD + 16 * kk + 8 * h) * 2));
+  }
+  const cn_buf_t dybuf = cn_make_buf(p.dy, p.dy_bytes);
+  const cn_buf_t abuf = cn_make_buf(p.addend, p.add_bytes);
+  const cn_buf_t ybuf = cn_make_buf(p.bn_y, p.out_bytes);
+  const int ech = lane & 3, erow = lane >> 2;      // epilogue: pixel rows k*16 + erow, chunk (8 channels) ech of the wave's 4
+  const int cb = co0 + wave * 32 + ech * 8;
+  const int HW = p.H * p.W;
+  struct Epi {
+    u32x4 a[2], y[2];
+    unsigned int bits[2];
+  };
+  u32x4 dreg[ND];
+  auto load_dy = [&](int mb) {
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const int id = tid + 512 * i;
+      const int row = id / NCD, c = id - row * NCD;
+      const int m = mb + row;
+      dreg[i] = cn_buf_ld16(dybuf, m < m_end ? ((unsigned int)m * (unsigned int)KD + (unsigned int)c * 8u) * 2u : CN_OOB);
+    }
+  };
+  auto load_epi = [&](int mb, Epi& e) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int m = mb + k * 16 + erow;
+      const bool ok = m < m_end;
+      const unsigned int o = ok ? ((unsigned int)m * (unsigned int)COT + (unsigned int)cb) * 2u : CN_OOB;
+      unsigned int oa = o;
+      if (p.addend_sub == 2) {
+        const int mm = ok ? m : 0;
+        const int n = (int)cn_fastdiv((unsigned)mm, p.div_hw);
+        const int rem = mm - n * HW;
+        const int ho = (int)cn_fastdiv((unsigned)rem, p.div_w);
+        const int wo = rem - ho * p.W;
+        const bool even = ((ho | wo) & 1) == 0;
+        const int apx = (n * p.add_H + (ho >> 1)) * p.add_W + (wo >> 1);
+        oa = (ok && even) ? ((unsigned int)apx * (unsigned int)COT + (unsigned int)cb) * 2u : CN_OOB;
+      }
+      e.a[k] = cn_buf_ld16(abuf, oa);
+      e.y[k] = cn_buf_ld16(ybuf, o);
+      e.bits[k] = ok ? (unsigned int)p.bn_mask[(size_t)m * (COT / 8) + (cb >> 3)] : 0u;
+    }
+  };
+  auto store_dy = [&](int buf) {
+    char* t = lds + buf * DYB;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const int id = tid + 512 * i;
+      const int row = id / NCD, c = id - row * NCD;
+      cn_st16(t + row * (KD * 2) + ((c ^ (row & (NCD - 1))) << 4), dreg[i]);
+    }
+  };
+  float bs1[8], bs2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { bs1[e] = 0.f; bs2[e] = 0.f; }
+
+  auto compute = [&](int mb, int buf, const Epi& ep) {
+    const char* t = lds + buf * DYB;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int prow = lane & 31;
+    const char* rowp = t + prow * (KD * 2);
+    const int sw = prow & (NCD - 1);
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+      const s16x8 b = __builtin_bit_cast(s16x8, cn_ld16(rowp + (((2 * kk + h) ^ sw) << 4)));
+      if constexpr (std::is_same<T, f16_t>::value) acc = cn_mfma_32x32x16_f16(wf[kk], b, acc);
+      else acc = cn_mfma_32x32x16_bf16(wf[kk], b, acc);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      u32x2 pk;
+      pk[0] = cn_pack2<T>(acc[q * 4], acc[q * 4 + 1]);
+      pk[1] = cn_pack2<T>(acc[q * 4 + 2], acc[q * 4 + 3]);
+      *(u32x2*)(priv + (lane & 31) * PP + (8 * q + 4 * h) * 2) = pk;
+    }
+    cn_wave_sync();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int pl = k * 16 + erow;
+      const int m = mb + pl;
+      const u32x4 v0 = cn_ld16(priv + pl * PP + ech * 16);
+      if (m < m_end) {
+        float fv[8], fa[8], yv[8];
+        Chunk<T>::unpack(v0, fv);
+        Chunk<T>::unpack(ep.a[k], fa);
+        Chunk<T>::unpack(ep.y[k], yv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fv[e] += fa[e];
+        const unsigned int bits = ep.bits[k];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fv[e] = ((bits >> e) & 1u) ? fv[e] : 0.f;
+        const u32x4 v = Chunk<T>::pack(fv);
+        Chunk<T>::unpack(v, fv);     // statistics of the values as stored
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          bs1[e] += fv[e];
+          bs2[e] = fmaf(fv[e], yv[e], bs2[e]);
+        }
+        cn_st16(p.g + ((size_t)m * COT + (size_t)cb) * 2, v);
+      }
+    }
+    cn_wave_sync();
+  };
+
+  if (m_begin < m_end) {
+    Epi cur, nxt;
+    load_dy(m_begin);
+    load_epi(m_begin, cur);
+    int buf = 0;
+    for (int mb = m_begin; mb < m_end; mb += BM) {
+      store_dy(buf);
+      __syncthreads();
+      const bool more = mb + BM < m_end;
+      if (more) { load_dy(mb + BM); load_epi(mb + BM, nxt); }
+      compute(mb, buf, cur);
+      if (more) cur = nxt;
+      buf ^= 1;
+    }
+  }
+  float r1[8], r2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float mu = p.bn_coef[cb + e], is = p.bn_coef[COT + cb + e];
+    r1[e] = bs1[e];
+    r2[e] = is * (bs2[e] - mu * bs1[e]);
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+#pragma unroll
+    for (int msk = 4; msk <= 32; msk <<= 1) {   // the sixteen row groups of the wave hold the same channels
+      r1[e] += cn_shfl_xor(r1[e], msk);
+      r2[e] += cn_shfl_xor(r2[e], msk);
+    }
+  if (lane < 4) {     // a channel belongs to exactly one wave: no cross-wave sum
+    float* dst = p.partial + (size_t)split * 2 * COT;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      dst[cb + e] = r1[e];
+      dst[COT + cb + e] = r2[e];
+    }
+  }
+}
+
 static int jd_splits(long long M, int BM) {
   int ns = cn_get_option("jdgrad_splits", 256);
   if (ns < 1) ns = 1;
@@ -263,9 +442,11 @@ static int jd_splits(long long M, int BM) {
   return ns;
 }
 static int jd_bm(int C) { return C == 256 ? 64 : 32; }   // (C >= 512: 512-channel slices of 32-pixel stages)
+static int jd_k256_mode() { return cn_get_option("jdgrad_k256", 2); }   // 0 tiled kernel, 1 64-channel waves, 2 32-channel waves
 // pixel ranges: whole stages per workgroup; returns the number of ranges (= partial rows) and their length
-static int jd_plan(long long M, int BM, long long* mps_out) {
-  const int ns0 = jd_splits(M, BM);
+static int jd_plan(long long M, int BM, long long* mps_out, int slices = 1) {
+  int ns0 = jd_splits(M, BM);
+  if (slices > 1) { ns0 = (ns0 + slices - 1) / slices; if (ns0 < 1) ns0 = 1; }   // (slices x ranges workgroups in all)
   long long mps = (M + ns0 - 1) / ns0;
   mps = (mps + BM - 1) / BM * BM;
   if (mps_out != nullptr) *mps_out = mps;
@@ -278,11 +459,18 @@ extern "C" int cn_conv2d_dgrad_junction_ok(int C, int K, int dtype) {
   // 256-channel reductions (the 28x28 -> 14x14 and 14x14 junctions) in 512-channel slices without the stage-ahead
   // epilogue prefetch: 128 filter registers + the epilogue operands spill (20 VGPRs) and the step does not move
   // (17.75 vs 17.76 ms): built and tested, OFF by default (knob "jdgrad_k256")
-  if ((C == 512 || C == 1024) && K == 256) return cn_get_option("jdgrad_k256", 0) != 0 ? 1 : 0;
+  if ((C == 512 || C == 1024) && K == 256) return jd_k256_mode() != 0 ? 1 : 0;   // (mode 2: jdgrad_w32_kernel)
+  // 512-channel reductions (the last stage's junctions) on the same kernel: 128 filter registers, 28 spilled - the step
+  // is 0.3 % SLOWER with it (17.62 vs 17.55 ms): built, tested, OFF (knob "jdgrad_k512")
+  if ((C == 1024 || C == 2048) && K == 512) return (jd_k256_mode() == 2 && cn_get_option("jdgrad_k512", 0) != 0) ? 1 : 0;
   return ((C == 256 && (K == 64 || K == 128)) || (C == 512 && K == 128)) ? 1 : 0;
 }
-extern "C" int cn_conv2d_dgrad_junction_rows(int N, int H, int W, int C) {
+extern "C" int cn_conv2d_dgrad_junction_rows(int N, int H, int W, int C) {   // (the K <= 128 forms)
   return jd_plan((long long)N * H * W, jd_bm(C), nullptr);
+}
+// partial rows cn_conv2d_dgrad_junction writes for K -> C channels (the 256-channel reductions plan per channel slice)
+extern "C" int cn_conv2d_dgrad_junction_rows_k(int N, int H, int W, int C, int K) {
+  return jd_plan((long long)N * H * W, jd_bm(C), nullptr, (K >= 256 && jd_k256_mode() == 2) ? C / 256 : 1);
 }
 
 // cn_conv2d_dgrad_bnbwd_sa for a 1x1 / stride-1 / unpadded convolution with K -> C channels of an instantiated shape,
@@ -304,8 +492,9 @@ extern "C" int cn_conv2d_dgrad_junction(const void* dy, const void* w_crsk, void
   const long long ab = addend_sub == 2 ? (long long)N * aH * aW * C * 2 : ob;
   if (ob >= (1ll << 31) || db >= (1ll << 31)) { cn_set_error("conv2d_dgrad_junction: operand exceeds the 2 GiB buffer-descriptor window"); return CN_ESHAPE; }
   const int BM = jd_bm(C);
+  const bool w32 = K >= 256 && jd_k256_mode() == 2;
   long long mps = 0;
-  const int nsplit = jd_plan(M, BM, &mps);
+  const int nsplit = jd_plan(M, BM, &mps, w32 ? C / 256 : 1);
   if (partial_rows < nsplit) { cn_set_error("conv2d_dgrad_junction: partial buffer of %d rows < %d", partial_rows, nsplit); return CN_EWORKSPACE; }
   JdParams p;
   memset(&p, 0, sizeof(p));
@@ -318,6 +507,18 @@ extern "C" int cn_conv2d_dgrad_junction(const void* dy, const void* w_crsk, void
   p.dy_bytes = (unsigned int)db; p.out_bytes = (unsigned int)ob; p.add_bytes = (unsigned int)ab;
   hipStream_t st = (hipStream_t)stream;
   const char* tn = dtype == CN_F16 ? "f16_t" : "bf16_t";
+  if (w32) {
+    cn_set_last_kernel("jdgrad_w32_kernel<%s, %d> [%d channels]", tn, K, C);
+    dim3 g32((unsigned)nsplit, (unsigned)(C / 256));
+    if (K == 256) {
+      if (dtype == CN_F16) CN_LAUNCH((jdgrad_w32_kernel<f16_t, 256>), g32, dim3(512), st, p);
+      else CN_LAUNCH((jdgrad_w32_kernel<bf16_t, 256>), g32, dim3(512), st, p);
+    } else {
+      if (dtype == CN_F16) CN_LAUNCH((jdgrad_w32_kernel<f16_t, 512>), g32, dim3(512), st, p);
+      else CN_LAUNCH((jdgrad_w32_kernel<bf16_t, 512>), g32, dim3(512), st, p);
+    }
+    return cn_check_launch("jdgrad_w32");
+  }
   cn_set_last_kernel("jdgrad_kernel<%s, %d, %d>", tn, K, C);
   dim3 grid((unsigned)nsplit, (unsigned)(C > 512 ? C / 512 : 1));
 #define JD_GO(KD, CO, PF)                                                                           \

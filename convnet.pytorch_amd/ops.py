@@ -587,7 +587,7 @@ def conv2d_dgrad(dy, w_crsk, x_shape, K, R, S, stride, pad, addend=None, bn=None
         return dx, partial, rows
     if JDGRAD and (R, S) == (1, 1) and tuple(stride) == (1, 1) and tuple(pad) == (0, 0) and bn_mask is not None \
             and addend is not None and L.cn_conv2d_dgrad_junction_ok(C, K, dtype_code(dy.dtype)):
-        rows = L.cn_conv2d_dgrad_junction_rows(N, H, W, C)
+        rows = L.cn_conv2d_dgrad_junction_rows_k(N, H, W, C, K)
         partial = torch.empty((rows, 2 * C), dtype=torch.float32, device=dy.device)
         PROFILER.run(_last_kernel(), 1, flops, nbytes + dx.numel() * _esize(dx) + partial.numel() * 4,
                      lambda: check(L.cn_conv2d_dgrad_junction(ptr(dy), ptr(w_crsk), ptr(dx), ptr(addend), int(addend_sub), N,

@@ -194,6 +194,7 @@ int cn_conv1x1_stream_fwd_lazya(const void* bn_y, const float* stats, int relu, 
  * cn_bn_bwd_partials.  g: the bits of cn_conv2d_dgrad_bnbwd_sa; the partial sums differ by fp32 association. */
 int cn_conv2d_dgrad_junction_ok(int C, int K, int dtype);
 int cn_conv2d_dgrad_junction_rows(int N, int H, int W, int C);
+int cn_conv2d_dgrad_junction_rows_k(int N, int H, int W, int C, int K);   /* ... for K -> C channels (K = 256: per channel slice) */
 int cn_conv2d_dgrad_junction(const void* dy, const void* w_crsk, void* g, const void* addend, int addend_sub, int N, int H,
                              int W, int C, int K, int dtype, const void* bn_y, const unsigned char* bn_mask,
                              const float* bn_coef, float* partial, int partial_rows, void* stream);

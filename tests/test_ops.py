@@ -1253,11 +1253,11 @@ def test_streaming_junction_dgrad_equals_tiled_epilogue_kernel(mode, dtype):
     ops, L = ca.ops, ca._lib.load()
     if mode == 'emul':
         cases = [(1, 6, 10, 256, 64, 1, 3), (2, 6, 6, 256, 128, 2, 2), (1, 5, 9, 512, 128, 1, 5), (1, 4, 6, 512, 256, 2, 2),
-                 (1, 3, 5, 1024, 256, 1, 3)]
+                 (1, 3, 5, 1024, 256, 1, 3), (1, 3, 3, 1024, 512, 2, 2)]
     else:
         cases = [(8, 56, 56, 256, 64, 1, 256), (8, 56, 56, 256, 128, 2, 256), (16, 28, 28, 512, 128, 1, 256),
                  (3, 17, 13, 256, 64, 2, 7), (2, 9, 11, 512, 128, 1, 256), (16, 28, 28, 512, 256, 2, 256),
-                 (32, 14, 14, 1024, 256, 1, 256)]
+                 (32, 14, 14, 1024, 256, 1, 256), (32, 7, 7, 2048, 512, 1, 256), (8, 14, 14, 1024, 512, 2, 256)]
     for (N, H, W, C, K, sub, splits) in cases:
         g_ = torch.Generator().manual_seed(C + K + H)
         M = N * H * W
@@ -1285,15 +1285,23 @@ def test_streaming_junction_dgrad_equals_tiled_epilogue_kernel(mode, dtype):
             assert 'igemm_kernel' in L.cn_last_kernel_name().decode()
             ops.JDGRAD = True
             L.cn_set_option(b'jdgrad_splits', splits)
-            L.cn_set_option(b'jdgrad_k256', 1)      # (the 256-channel-reduction form is off by default)
+            L.cn_set_option(b'jdgrad_k512', 1)      # (the 512-channel-reduction form is off by default)
             g1, p1, r1 = ops.conv2d_dgrad(dyh, wc, (N, H, W, C), K, 1, 1, (1, 1), (0, 0), addend=addend,
                                           bn=(bn_y, bits, stats, True), addend_sub=sub)
-            assert 'jdgrad_kernel' in L.cn_last_kernel_name().decode()
+            assert ('jdgrad_w32_kernel' if K >= 256 else 'jdgrad_kernel') in L.cn_last_kernel_name().decode()
+            assert r1 == L.cn_conv2d_dgrad_junction_rows_k(N, H, W, C, K)
+            if K == 256:      # the 64-channel-wave form of the 256-channel reductions (knob jdgrad_k256 = 1): same bits
+                L.cn_set_option(b'jdgrad_k256', 1)
+                g2, p2, r2 = ops.conv2d_dgrad(dyh, wc, (N, H, W, C), K, 1, 1, (1, 1), (0, 0), addend=addend,
+                                              bn=(bn_y, bits, stats, True), addend_sub=sub)
+                assert 'jdgrad_kernel' in L.cn_last_kernel_name().decode()
+                assert torch.equal(g2.cpu(), g0.cpu()), (N, H, W, C, K, sub)
+                assert rel_l2(p2.double().sum(0).cpu(), p1.double().sum(0).cpu()) < 5e-5
         finally:
             ops.JDGRAD = saved
             L.cn_set_option(b'jdgrad_splits', 256)
-            L.cn_set_option(b'jdgrad_k256', 0)
-        assert r1 == L.cn_conv2d_dgrad_junction_rows(N, H, W, C) or splits != 256
+            L.cn_set_option(b'jdgrad_k256', 2)
+            L.cn_set_option(b'jdgrad_k512', 0)
         assert tuple(p1.shape) == (r1, 2 * C) and r1 <= max(splits, 1)
         assert torch.equal(g1.cpu(), g0.cpu()), (N, H, W, C, K, sub)
         s0, s1 = p0.double().sum(0), p1.double().sum(0)
