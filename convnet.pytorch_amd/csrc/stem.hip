@@ -322,7 +322,7 @@ __global__ __launch_bounds__(512, 4) void stem_wgrad_kernel(StemWgParams p) {
 }
 
 static int stem_wg_count(int nwork) {
-  int n = cn_get_option("stem_wgrad_wgs", 512);
+  int n = cn_get_option("stem_wgrad_wgs", 256);
   if (n < 1) n = 1;
   return n < nwork ? n : nwork;
 }
