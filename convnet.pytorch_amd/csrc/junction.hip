@@ -804,7 +804,8 @@ struct JlParams {
 
 template <typename T, int KD, int CO>
 __global__ __launch_bounds__(512) void jdlazy_kernel(JlParams p) {
-  static_assert(sizeof(T) == 2 && CO == 128 && KD % 64 == 0, "16-bit storage, four 32-channel output tiles");
+  static_assert(sizeof(T) == 2 && (CO == 128 || CO == 256) && KD % 64 == 0, "16-bit storage, four or eight 32-channel output tiles");
+  constexpr int NW = CO / 32;           // waves that own an output tile (registers are allocated for all eight anyway)
   constexpr int BM = 32;
   constexpr int NKK = KD / 16;
   constexpr int NCD = KD / 8;             // 16-byte chunks per row
@@ -813,7 +814,7 @@ __global__ __launch_bounds__(512) void jdlazy_kernel(JlParams p) {
   static_assert(512 % NCD == 0 && BM * NCD % 512 == 0, "a thread keeps one chunk column");
   constexpr int RS = 512 / NCD;           // rows per staging pass
   constexpr int PP = 80;                  // patch pitch: 32 channels * 2 bytes + 16
-  __shared__ __attribute__((aligned(16))) char lds[2 * TB + 4 * 32 * PP];
+  __shared__ __attribute__((aligned(16))) char lds[2 * TB + NW * 32 * PP];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = cn_uniform(tid >> 6);
@@ -824,7 +825,7 @@ __global__ __launch_bounds__(512) void jdlazy_kernel(JlParams p) {
   if (m_end > p.M) m_end = p.M;
 
   s16x8 wf[NKK];
-  if (wave < 4) {
+  if (wave < NW) {
 #pragma unroll
     for (int kk = 0; kk < NKK; ++kk) {
       const int c = wave * 32 + (lane & 31);
@@ -869,7 +870,7 @@ __global__ __launch_bounds__(512) void jdlazy_kernel(JlParams p) {
       cn_st16(t + row * (KD * 2) + ((col ^ (row & (NCD - 1))) << 4), ((okm >> i) & 1u) ? o : cn_zero16());
     }
   };
-  char* priv = lds + 2 * TB + (wave & 3) * (32 * PP);
+  char* priv = lds + 2 * TB + (wave & (NW - 1)) * (32 * PP);
   const int ech = lane & 3, erow = lane >> 2;
 
   if (m_begin < m_end) {
@@ -879,7 +880,7 @@ __global__ __launch_bounds__(512) void jdlazy_kernel(JlParams p) {
       store_stage(buf);
       __syncthreads();
       if (mb + BM < m_end) load_stage(mb + BM);
-      if (wave < 4) {
+      if (wave < NW) {
         const char* t = lds + buf * TB;
         f32x16 acc;
 #pragma unroll
@@ -916,10 +917,14 @@ __global__ __launch_bounds__(512) void jdlazy_kernel(JlParams p) {
 }
 
 extern "C" int cn_conv2d_dgrad_lazy_stream_ok(int C, int K, int dtype) {   // K gradient channels -> C input channels
-  return (dtype == CN_BF16 || dtype == CN_F16) && C == 128 && K == 512 && cn_get_option("jdlazy", 1) != 0 ? 1 : 0;
+  // 0 off, 1 both shapes, 2 only 512 -> 128 (default: the 512 -> 256 launch - the second stage's projection, once per
+  // step - goes from ~276 to ~130 us on this kernel and the step does not move, 17.56 vs 17.57 ms: by then the side
+  // stream's weight gradients are what the step waits for; profiles/r03_ab_second_session_whole_step.txt)
+  const int mode = cn_get_option("jdlazy", 2);
+  return (dtype == CN_BF16 || dtype == CN_F16) && K == 512 && (C == 128 || (C == 256 && mode == 1)) && mode != 0 ? 1 : 0;
 }
-// cn_conv2d_dgrad_lazy for a 1x1 / stride-1 convolution of an instantiated shape (512 -> 128 channels) as a persistent
-// streaming kernel.  Same bits.
+// cn_conv2d_dgrad_lazy for a 1x1 / stride-1 convolution of an instantiated shape (512 -> 128 or 256 channels) as a
+// persistent streaming kernel.  Same bits.
 extern "C" int cn_conv2d_dgrad_lazy_stream(const void* g, const void* bn_y, const float* coef, const void* w_crsk, void* dx,
                                            int N, int H, int W, int C, int K, int dtype, void* stream) {
   if (!cn_conv2d_dgrad_lazy_stream_ok(C, K, dtype)) { cn_set_error("conv2d_dgrad_lazy_stream: K=%d -> C=%d dtype %d is not an instantiated shape", K, C, dtype); return CN_ESHAPE; }
@@ -935,7 +940,12 @@ extern "C" int cn_conv2d_dgrad_lazy_stream(const void* g, const void* bn_y, cons
   p.M = (int)M; p.m_per_split = (int)mps; p.nsplit = nsplit;
   p.gy_bytes = (unsigned int)(M * K * 2);
   cn_set_last_kernel("jdlazy_kernel<%s, %d, %d>", dtype == CN_F16 ? "f16_t" : "bf16_t", K, C);
-  if (dtype == CN_F16) CN_LAUNCH((jdlazy_kernel<f16_t, 512, 128>), dim3((unsigned)nsplit), dim3(512), (hipStream_t)stream, p);
-  else CN_LAUNCH((jdlazy_kernel<bf16_t, 512, 128>), dim3((unsigned)nsplit), dim3(512), (hipStream_t)stream, p);
+  if (C == 128) {
+    if (dtype == CN_F16) CN_LAUNCH((jdlazy_kernel<f16_t, 512, 128>), dim3((unsigned)nsplit), dim3(512), (hipStream_t)stream, p);
+    else CN_LAUNCH((jdlazy_kernel<bf16_t, 512, 128>), dim3((unsigned)nsplit), dim3(512), (hipStream_t)stream, p);
+  } else {   // (the stride-2 projection of the second stage on its coarse grid: 512 -> 256)
+    if (dtype == CN_F16) CN_LAUNCH((jdlazy_kernel<f16_t, 512, 256>), dim3((unsigned)nsplit), dim3(512), (hipStream_t)stream, p);
+    else CN_LAUNCH((jdlazy_kernel<bf16_t, 512, 256>), dim3((unsigned)nsplit), dim3(512), (hipStream_t)stream, p);
+  }
   return cn_check_launch("jdlazy");
 }

@@ -1589,16 +1589,17 @@ def test_lazy_a_conv3x3_halo_equals_apply_then_conv(mode, dtype):
 @pytest.mark.parametrize('mode', MODES)
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 def test_streaming_lazy_dgrad_equals_tiled_kernel(mode, dtype):
-    """cn_conv2d_dgrad_lazy_stream (512 -> 128 channels, csrc/junction.hip: jdlazy_kernel) against the tiled lazy data
+    """cn_conv2d_dgrad_lazy_stream (512 -> 128 / 256 channels, csrc/junction.hip: jdlazy_kernel) against the tiled lazy data
     gradient: bit for bit (bf16; fp16 to a few ulps on the GPU, see the junction-pair test), pixel counts that are not
     whole stages included."""
     _f16_emul_subset(mode, dtype, keep=True)
     dev = _dev(mode)
     import convnet_amd as ca
     ops, L = ca.ops, ca._lib.load()
-    C, K = 128, 512
-    for (N, H, W) in ([(1, 5, 9), (2, 4, 8)] if mode == 'emul' else [(16, 28, 28), (3, 17, 13), (256, 28, 28)]):
-        g_ = torch.Generator().manual_seed(N * H + W)
+    K = 512
+    for (N, H, W, C) in ([(1, 5, 9, 128), (2, 4, 8, 128), (1, 6, 7, 256)] if mode == 'emul' else
+                         [(16, 28, 28, 128), (3, 17, 13, 128), (256, 28, 28, 128), (3, 17, 13, 256), (64, 28, 28, 256)]):
+        g_ = torch.Generator().manual_seed(N * H + W + C)
         gq = (torch.randn(N, H, W, K, generator=g_) * 0.5).to(dtype).to(dev)
         yq = (torch.randn(N, H, W, K, generator=g_) * 1.2 + 0.1).to(dtype).to(dev)
         coef = torch.cat([torch.rand(K, generator=g_) + 0.5, torch.randn(K, generator=g_) * 0.05,
@@ -1608,12 +1609,13 @@ def test_streaming_lazy_dgrad_equals_tiled_kernel(mode, dtype):
         try:
             d0 = ops.conv2d_dgrad_lazy(gq, yq, coef, wc, (N, H, W, C), K, 1, 1, (1, 1), (0, 0))
             assert 'igemm_kernel' in L.cn_last_kernel_name().decode()
+            L.cn_set_option(b'jdlazy', 1)      # (1: both shapes; the default, 2, keeps 512 -> 256 on the tiled kernel)
+            d1 = ops.conv2d_dgrad_lazy(gq, yq, coef, wc, (N, H, W, C), K, 1, 1, (1, 1), (0, 0))
+            assert 'jdlazy_kernel' in L.cn_last_kernel_name().decode()
         finally:
-            L.cn_set_option(b'jdlazy', 1)
-        d1 = ops.conv2d_dgrad_lazy(gq, yq, coef, wc, (N, H, W, C), K, 1, 1, (1, 1), (0, 0))
-        assert 'jdlazy_kernel' in L.cn_last_kernel_name().decode()
+            L.cn_set_option(b'jdlazy', 2)
         if dtype == torch.bfloat16 or mode == 'emul':
-            assert torch.equal(d1.cpu(), d0.cpu()), (N, H, W)
+            assert torch.equal(d1.cpu(), d0.cpu()), (N, H, W, C)
         else:
             assert rel_l2(d1.float().cpu(), d0.float().cpu()) < 2e-4
         assert float(d1.float().abs().sum()) > 0
