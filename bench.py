@@ -352,6 +352,16 @@ def main():
                'sample': 'oracle/convnet_oracle.py (CPU restatement of the reference Trainer step; the reference tree '
                          'itself is not on the GPU box) ResNet-%d fp32 training, batch 32, 1 warm-up + %d timed steps '
                          '(%.2f s/step)' % (args.depth, args.cpu_steps, r['s_per_step'])}
+        try:   # how the port compares with the REAL reference Trainer on the same cores (measured in the build container)
+            with open(os.path.join(ROOT, 'tests', 'golden', 'reference_cpu_timing.json')) as f:
+                rt = json.load(f)
+            cpu['port_over_reference'] = rt['oracle_over_reference']
+            cpu['port_over_reference_source'] = ('oracle/time_reference_cpu.py: reference Trainer %.2f img/s vs port %.2f '
+                                                 'img/s on %d threads of the build container (ResNet-50 fp32, batch %d)'
+                                                 % (rt['reference_trainer_img_s'], rt['oracle_img_s'], rt['threads'],
+                                                    rt['batch']))
+        except Exception:
+            pass
 
     if rank == 0:
         img_s = B * world * args.steps / elapsed
