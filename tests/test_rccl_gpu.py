@@ -15,6 +15,8 @@
   "direct RCCL ... 2 ranks".  These make the first multi-rank execution of cn_comm_allreduce_bucket a test,
   not the scaling bench.
 * A failing set-up stops the job: there is no silent second transport (CONVNET_AMD_COMM=torch is explicit).
+  bench.py alone recovers - loudly: stderr + the JSON line's transport carry the reason - so that a scaling run is
+  not left without a number.
 """
 import json
 import os
@@ -201,3 +203,23 @@ dist.destroy_process_group()
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert 'RAISED' in r.stdout and 'load librccl' in r.stdout, r.stdout[-2000:]
+
+
+def test_bench_recovers_loudly_when_the_direct_communicator_cannot_be_built(tmp_path):
+    """bench.py ONLY (the product stops, see the test above): when the direct RCCL communicator cannot be built - here
+    the loader is pointed at a file that is not there - the bench continues on the torch.distributed collectives, says so
+    on stderr and labels the JSON line's transport with the reason, instead of leaving a scaling run without a number."""
+    env = dict(os.environ, BENCH_FORCE_DIST='1', CONVNET_AMD_EMULATE='0', MASTER_ADDR='127.0.0.1', MASTER_PORT='29561',
+               CN_RCCL_LIB=str(tmp_path / 'no_such_librccl.so'))
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'CONVNET_AMD_COMM'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '2',
+                        '--no-cpu-baseline', '--no-kernel-profile'], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.split('\n') if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    tr = rec['config']['transport']
+    assert rec['n_gpus'] == 1 and rec['value'] > 0
+    assert 'torch.distributed' in tr and 'direct RCCL communicator failed' in tr and 'load librccl' in tr, tr
+    assert 'bench.py[rank 0]' in r.stderr and 'direct RCCL communicator failed' in r.stderr
