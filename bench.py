@@ -10,7 +10,9 @@ batch of 256 images 3x224x224 per GPU.  Inputs are resident in HBM when the time
 (a pool of pre-staged device batches is cycled; the reference's per-step H2D copy is excluded).
 Weak scaling: per-GPU batch fixed, value = images of all ranks / max-over-ranks time.
 
-Rank 0 prints ONE JSON line.  Extra objects:
+Rank 0 prints ONE compact JSON line (the contract object, < 4 KB, the LAST line of stdout).  The per-kernel and
+per-layer tables (`kernels`, `kernels_overlapped`, `conv_layers`) go to a detail file (`--detail-out`, default
+gpurun_out/bench_detail.json; `--detail-stdout` prints them as an EARLIER {"detail": ...} line).  Objects:
   roofline     : live HIP-event timing (a separate profiled pass after the timed region) of the
                  dominant kernel family: algorithmic FLOPs (2*MACs of
                  conv/fc fwd+dgrad+wgrad) or bytes per launch / measured launch time vs the
@@ -120,6 +122,9 @@ def main():
                     help='also measure roofline.traffic LIVE: two extra rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; '
                          'kernel trace only) of a 3-step run of this same workload, ~2-4 min (N=1 only)')
     ap.add_argument('--pmc-out', default=None, help='where --pmc writes the per-kernel traffic JSON (for profiles/)')
+    ap.add_argument('--detail-out', default=os.path.join(ROOT, 'gpurun_out', 'bench_detail.json'),
+                    help='file for the per-kernel / per-layer tables (never part of the contract line)')
+    ap.add_argument('--detail-stdout', action='store_true', help='also print the tables as an earlier {"detail": ...} line')
     ap.add_argument('--cpu-steps', type=int, default=5, help='timed steps of the CPU baseline (batch 32, 1 warm-up)')
     args = ap.parse_args()
 
@@ -278,40 +283,41 @@ def main():
                          'tflops': round(a['flops'] / sec / 1e12, 1), 'gbs': round(a['bytes'] / sec / 1e9, 1),
                          'bound': 'mfma' if t_mfma >= t_hbm else 'hbm',
                          'roof_frac': round(max(t_hbm, t_mfma) / sec, 3)}
-        # the dominant single HIP kernel of the OVERLAPPED step (' + ' labels are calls that launched several different
-        # kernels: reported in the tables, never chosen as "the" kernel)
-        # ... of the stream the step's wall time runs along: the weight-gradient kernels are launched on a side stream that
-        # soaks up what the backward chain leaves of the chip, their overlapped durations are stretched by design (they
-        # are listed in kernels_overlapped with side_stream = true, and the largest of them is priced in
-        # roofline.side_stream_kernel)
-        dom = next((k for k in kernels_ovl if ' + ' not in k and not kernels_ovl[k]['side_stream']),
-                   next(k for k in kernels_ovl if ' + ' not in k))
-        k = kernels_ovl[dom]
-        ka = kernels.get(dom, {})
-        if k['tflops'] and k['tflops'] / PEAK_TFLOPS[args.dtype] >= k['gbs'] / PEAK_HBM_GBS:
-            roof = {'kernel': dom, 'bound': 'mfma', 'achieved': k['tflops'], 'peak': PEAK_TFLOPS[args.dtype],
-                    'unit': 'TFLOP/s', 'frac': round(k['tflops'] / PEAK_TFLOPS[args.dtype], 4), 'traffic': None}
-        else:
-            roof = {'kernel': dom, 'bound': 'hbm', 'achieved': k['gbs'], 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                    'frac': round(k['gbs'] / PEAK_HBM_GBS, 4), 'traffic': None}
-        roof['avg_us_per_launch'] = k['avg_us_per_launch']
-        roof['launches_per_step'] = k['launches_per_step']
-        roof['frac_per_launch_roof'] = k['roof_frac']   # each launch against max(HBM, MFMA) time instead of one blended bound
-        roof['alone'] = {f: ka.get(f) for f in ('avg_us_per_launch', 'gbs', 'tflops', 'roof_frac')}
+        # `roofline.kernel`: the SINGLE HIP kernel with the largest total time in the OVERLAPPED step, whichever stream it
+        # is launched on (the weight-gradient side stream included), priced there; `alone` = the same launches with the
+        # side stream folded in.  Call labels that name several kernels ('a+b+c': one BatchNorm-backward call = three
+        # launches; 'x + y': a strided dgrad's parity classes) are never "the" kernel: the largest such call of the
+        # main stream is listed beside it as `main_stream_call`.
+        def single(label):
+            base = label.split(' (')[0].split(' [')[0]
+            depth, plus = 0, False
+            for ch in base:
+                depth += (ch == '<') - (ch == '>')
+                plus = plus or (ch == '+' and depth == 0)
+            return not plus
+
+        def priced(lbl, tab, tab_alone):
+            kk, ka = tab[lbl], tab_alone.get(lbl, {})
+            if kk['tflops'] and kk['tflops'] / PEAK_TFLOPS[args.dtype] >= kk['gbs'] / PEAK_HBM_GBS:
+                r = {'kernel': lbl, 'bound': 'mfma', 'achieved': kk['tflops'], 'peak': PEAK_TFLOPS[args.dtype],
+                     'unit': 'TFLOP/s', 'frac': round(kk['tflops'] / PEAK_TFLOPS[args.dtype], 4)}
+            else:
+                r = {'kernel': lbl, 'bound': 'hbm', 'achieved': kk['gbs'], 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                     'frac': round(kk['gbs'] / PEAK_HBM_GBS, 4)}
+            r.update({'avg_us_per_launch': kk['avg_us_per_launch'], 'launches_per_step': kk['launches_per_step'],
+                      'ms_per_step': kk['ms_per_step'], 'side_stream': kk['side_stream'],
+                      'frac_per_launch_roof': kk['roof_frac'],   # each launch against max(HBM, MFMA) time
+                      'alone': {f: ka.get(f) for f in ('avg_us_per_launch', 'gbs', 'tflops', 'roof_frac')}})
+            return r
+        dom = next(k for k in kernels_ovl if single(k))
+        roof = priced(dom, kernels_ovl, kernels)
+        roof['traffic'] = None
         roof['algorithmic_bytes_per_launch'] = round(agg_ovl[dom]['bytes'] / max(agg_ovl[dom]['launches'], 1))
-        roof['timing'] = ('HIP events on the launching stream around every launch of a profiled pass that keeps the '
-                          'two-stream schedule of the timed region (the kernel with the largest total time there among the '
-                          'launches of the main stream, i.e. of the chain the step time runs along; `alone` = the same '
-                          'launches with the side stream folded in); rocprofv3 of the same command: profiles/')
-        side = next((kk for kk in kernels_ovl if ' + ' not in kk and kernels_ovl[kk]['side_stream']), None)
-        if side is not None:
-            ks, ksa = kernels_ovl[side], kernels.get(side, {})
-            roof['side_stream_kernel'] = {
-                'kernel': side, 'ms_per_step': ks['ms_per_step'], 'launches_per_step': ks['launches_per_step'],
-                'avg_us_per_launch': ks['avg_us_per_launch'], 'gbs': ks['gbs'], 'frac': round(ks['gbs'] / PEAK_HBM_GBS, 4),
-                'alone': {f: ksa.get(f) for f in ('avg_us_per_launch', 'gbs', 'tflops', 'roof_frac')},
-                'note': 'largest total time among the weight-gradient launches that run BESIDE the backward chain on the '
-                        'side stream (overlapped durations include waiting for the share of the chip the chain leaves)'}
+        roof['timing'] = ('HIP events on the launching stream around every launch, in a profiled pass that keeps the '
+                          "timed region's two-stream schedule; alone = side stream folded in; rocprofv3: profiles/")
+        main_call = next((k for k in kernels_ovl if not kernels_ovl[k]['side_stream']), None)
+        if main_call is not None and main_call != dom:
+            roof['main_stream_call'] = priced(main_call, kernels_ovl, kernels)
         pm, pm_file, live = None, None, False
         if args.pmc and world == 1:
             pm = run_pmc_passes(args)
@@ -341,24 +347,23 @@ def main():
                         tot_n += kv['launches']
             if tot_n > 0:
                 roof['traffic'] = round(tot_b / tot_n)
-                roof['traffic_unit'] = 'bytes/launch (avg over the launches of the kernels this call label names), ' + pm['source']
-                roof['traffic_source'] = 'live: rocprofv3 --pmc passes run by this command' if live else \
-                    'static: committed rocprofv3 --pmc passes (%s), not this run' % pm_file
+                roof['traffic_unit'] = 'HBM bytes/launch, rocprofv3 --pmc FETCH_SIZE x2 (gfx950) + WRITE_SIZE, separate passes'
+                roof['traffic_source'] = 'live: --pmc passes run by this command' if live else \
+                    'static: profiles/%s' % pm_file
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import convnet_oracle as O
         r = O.time_cpu_baseline(depth=args.depth, batch=32, steps=args.cpu_steps, warmup=1, size=224)
         cpu = {'value': round(r['img_per_s'], 2), 'unit': 'images/sec', 'cores': r['cores'], 'kind': 'port',
-               'sample': 'oracle/convnet_oracle.py (CPU restatement of the reference Trainer step; the reference tree '
-                         'itself is not on the GPU box) ResNet-%d fp32 training, batch 32, 1 warm-up + %d timed steps '
-                         '(%.2f s/step)' % (args.depth, args.cpu_steps, r['s_per_step'])}
+               'sample': 'oracle/convnet_oracle.py (CPU restatement of the reference Trainer step) ResNet-%d fp32 training, '
+                         'batch 32, 1 warm-up + %d timed steps (%.2f s/step)' % (args.depth, args.cpu_steps, r['s_per_step'])}
         try:   # how the port compares with the REAL reference Trainer on the same cores (measured in the build container)
             with open(os.path.join(ROOT, 'tests', 'golden', 'reference_cpu_timing.json')) as f:
                 rt = json.load(f)
             cpu['port_over_reference'] = rt['oracle_over_reference']
-            cpu['port_over_reference_source'] = ('oracle/time_reference_cpu.py: reference Trainer %.2f img/s vs port %.2f '
-                                                 'img/s on %d threads of the build container (ResNet-50 fp32, batch %d)'
-                                                 % (rt['reference_trainer_img_s'], rt['oracle_img_s'], rt['threads'],
+            cpu['port_over_reference_source'] = ('%d-core ratio, build container: reference Trainer %.2f vs port %.2f img/s '
+                                                 '(oracle/time_reference_cpu.py, batch %d)'
+                                                 % (rt['threads'], rt['reference_trainer_img_s'], rt['oracle_img_s'],
                                                     rt['batch']))
         except Exception:
             pass
@@ -385,8 +390,10 @@ def main():
             'hbm_frac_whole_step': round(MODEL_MB_PER_IMG[(args.depth, args.dtype)] * 1e6 * B / (elapsed / args.steps)
                                          / (PEAK_HBM_GBS * 1e9), 4)
             if (args.depth, args.dtype) in MODEL_MB_PER_IMG and not args.quantize else None,
-            'roofline': roof, 'cpu_baseline': cpu, 'kernels': kernels, 'kernels_overlapped': kernels_ovl,
-            'conv_layers': layers,
+            # true when the run is NOT on the product's direct-RCCL transport (a DP number produced that way says
+            # nothing about csrc/comm.hip)
+            'transport_fallback': comm_note is not None,
+            'roofline': roof, 'cpu_baseline': cpu,
         }
         # measured HBM traffic of the whole step (all kernels, latest committed PMC passes: static, like
         # roofline.traffic) over this run's step time: how close the step as a whole runs to the memory system
@@ -405,11 +412,26 @@ def main():
                     'traffic_gb_per_step': round(pm['hbm_bytes_per_step'] / 1e9, 1), 'rate_gbs': round(rate, 0),
                     'frac_of_peak': round(rate / PEAK_HBM_GBS, 4),
                     'frac_of_streaming_rate': round(rate / 5100.0, 4),
-                    'note': 'traffic: %s (FETCH_SIZE / WRITE_SIZE over every kernel of the step); 5100 GB/s = '
-                            'the 2-read + 1-write streaming rate measured on this part (tools/bench_skew.py)' % cands[-1]}
+                    'note': 'traffic: %s (all kernels of a step); streaming rate = 5100 GB/s (tools/bench_skew.py)'
+                            % cands[-1]}
         except Exception:
             pass
-        print(json.dumps(out))
+        detail = {'kernels': kernels, 'kernels_overlapped': kernels_ovl, 'conv_layers': layers}
+        if kernels:
+            try:
+                os.makedirs(os.path.dirname(os.path.abspath(args.detail_out)), exist_ok=True)
+                with open(args.detail_out, 'w') as f:
+                    json.dump(dict(out, **detail), f, indent=1)
+                out['detail_file'] = os.path.relpath(os.path.abspath(args.detail_out), ROOT)
+            except OSError as e:
+                sys.stderr.write('bench.py: detail tables not written: %s\n' % e)
+            if args.detail_stdout:
+                print(json.dumps({'detail': detail}))
+        line = json.dumps(out)
+        # the contract line must stay readable by whatever tails stdout: compact, and the LAST line
+        assert len(line) < 8192, 'contract line grew to %d bytes' % len(line)
+        sys.stdout.flush()
+        print(line, flush=True)
     if distributed:
         dist.destroy_process_group()
 
