@@ -8,18 +8,26 @@ OUT=..
 if [ "$1" != "emul-only" ]; then
   # CN_EXTRA_FLAGS / CN_LIB_NAME: A/B builds (e.g. CN_EXTRA_FLAGS=-DCN_NT_STORES CN_LIB_NAME=libconvnet_hip_nt.so)
   LIB=${CN_LIB_NAME:-libconvnet_hip.so}
-  # one object per source, compiled in parallel (igemm.hip alone is most of the serial build), unchanged objects reused
-  ODIR=${CN_OBJ_DIR:-/tmp/cn_hip_obj}${CN_EXTRA_FLAGS:+_ab}
+  # one object per source, compiled in parallel (igemm.hip alone is most of the serial build).  The object cache is
+  # keyed by THIS source directory and the extra flags (two checkouts or two A/B builds never share objects), and an
+  # object is reused only when the content hash of its source + every header it can see (csrc/*.h and the public
+  # include/convnet_hip.h) + the flags equals the hash stored beside it - never on mtimes.
+  KEY=$(printf '%s|%s' "$(pwd -P)" "$CN_EXTRA_FLAGS" | sha1sum | cut -c1-12)
+  ODIR=${CN_OBJ_DIR:-/tmp/cn_hip_obj}_$KEY
   mkdir -p $ODIR
+  HDRS=$(cat *.h ../../include/convnet_hip.h | sha1sum | cut -c1-40)
   pids=""
   for s in $SRCS; do
     o=$ODIR/${s%.hip}.o
-    if [ ! -f $o ] || [ $s -nt $o ] || [ -n "$(find . -maxdepth 1 -name '*.h' -newer $o)" ] || [ -n "$CN_EXTRA_FLAGS" ]; then
-      /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result $CN_EXTRA_FLAGS -c $s -o $o &
+    h=$(printf '%s|%s|%s' "$(sha1sum < $s)" "$HDRS" "$CN_EXTRA_FLAGS" | sha1sum | cut -c1-40)
+    if [ ! -f $o ] || [ "$(cat $o.sha 2>/dev/null)" != "$h" ]; then
+      rm -f $o.sha
+      ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result $CN_EXTRA_FLAGS -c $s -o $o \
+        && echo $h > $o.sha ) &
       pids="$pids $!"
     fi
   done
-  for p in $pids; do wait $p; done
+  for p in $pids; do wait $p || { echo "build failed" >&2; exit 1; }; done
   OBJS=""
   for s in $SRCS; do OBJS="$OBJS $ODIR/${s%.hip}.o"; done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared $OBJS -ldl -o $OUT/$LIB

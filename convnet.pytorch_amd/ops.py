@@ -828,6 +828,11 @@ def _zero_like_placeholder(x):
     return z.expand(x.shape)
 
 
+def _is_zero_placeholder(t):
+    z = _ZEROS.get((t.device, t.dtype))
+    return z is not None and t.data_ptr() == z.data_ptr() and t.dim() > 0 and all(st == 0 for st in t.stride())
+
+
 class Conv2dFunction(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, mod):
@@ -856,6 +861,9 @@ class Conv2dFunction(Function):
         ctx.mod = mod
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x)
+        # the lazy-dy mailbox is matched against THIS output in backward; an entry left by an aborted backward dies here
+        ctx.out_ptr, ctx.out_shape = y.data_ptr(), tuple(y.shape)
+        mod._lazy_dy = None
         return y
 
     @staticmethod
@@ -865,8 +873,14 @@ class Conv2dFunction(Function):
         lazy = getattr(mod, '_lazy_dy', None)     # (g, bn_y, coef): the BatchNorm behind this conv left dy unformed
         mod._lazy_dy = None
         R, S = mod.kernel_size
+        if lazy is None and _is_zero_placeholder(dy):
+            raise _lib.ConvNetHipError('lazy dy: the gradient placeholder reached a convolution with an empty mailbox '
+                                       '(the BatchNorm that parked the gradient is not this convolution\'s consumer)')
         if lazy is not None:
             g, bn_y, coef = lazy
+            if bn_y.data_ptr() != ctx.out_ptr or tuple(bn_y.shape) != ctx.out_shape or tuple(g.shape) != tuple(dy.shape):
+                raise _lib.ConvNetHipError('lazy dy: the parked gradient does not belong to this convolution\'s output '
+                                           '(stale mailbox entry or a second consumer)')
             if JPAIR and (R, S) == (1, 1) and mod.stride == (1, 1) and mod.padding == (0, 0) and ctx.needs_input_grad[0] \
                     and mod.in_channels == x.shape[-1] \
                     and _L().cn_conv2d_bwd1x1_lazy_ok(x.shape[-1], mod.out_channels, dtype_code(x.dtype)):

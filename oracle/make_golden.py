@@ -15,6 +15,19 @@ import sys
 sys.dont_write_bytecode = True
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF = '/root/reference'
+
+_T_START = __import__('time').time()
+
+
+def assert_no_new_bytecode():
+    """/root/reference is read-only: nothing this process imports from it may leave bytecode behind.  (Round 3's
+    oracle/time_reference_cpu.py ran without sys.dont_write_bytecode and left *.pyc there, stamped 2026-09-26 18:25;
+    this tree does not own the reference and cannot delete them, so only files written since this process started count.)"""
+    for d, _, files in os.walk(REF):
+        if os.path.basename(d) == '__pycache__':
+            new = [f for f in files if os.path.getmtime(os.path.join(d, f)) >= _T_START - 1.0]
+            assert not new, 'bytecode leaked into the reference tree: %s/%s' % (d, new[:3])
+
 sys.path.insert(0, REF)
 sys.path.insert(0, os.path.join(HERE, 'refshim'))
 
@@ -311,7 +324,7 @@ def warm(which=('small', 'r18', 'r50')):
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] in ('big', 'warm'):
         big() if sys.argv[1] == 'big' else warm(tuple(sys.argv[2:]) or ('small', 'r18', 'r50'))
-        assert not os.path.exists(os.path.join(REF, '__pycache__')), 'bytecode leaked into the reference tree'
+        assert_no_new_bytecode()
         sys.exit(0)
     structure()
     trajectory('r50s', dict(depth=50, **SMALL), B=8, size=32, classes=16, steps=4, seed=11)
@@ -324,4 +337,4 @@ if __name__ == '__main__':
     mnist_trajectory()
     big()
     warm()
-    assert not os.path.exists(os.path.join(REF, '__pycache__')), 'bytecode leaked into the reference tree'
+    assert_no_new_bytecode()

@@ -25,6 +25,19 @@ import sys
 sys.dont_write_bytecode = True
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF = '/root/reference'
+
+_T_START = __import__('time').time()
+
+
+def assert_no_new_bytecode():
+    """/root/reference is read-only: nothing this process imports from it may leave bytecode behind.  (Round 3's
+    oracle/time_reference_cpu.py ran without sys.dont_write_bytecode and left *.pyc there, stamped 2026-09-26 18:25;
+    this tree does not own the reference and cannot delete them, so only files written since this process started count.)"""
+    for d, _, files in os.walk(REF):
+        if os.path.basename(d) == '__pycache__':
+            new = [f for f in files if os.path.getmtime(os.path.join(d, f)) >= _T_START - 1.0]
+            assert not new, 'bytecode leaked into the reference tree: %s/%s' % (d, new[:3])
+
 sys.path.insert(0, REF)
 sys.path.insert(0, os.path.join(HERE, 'refshim'))
 
@@ -197,11 +210,11 @@ def big_batch(B=128):
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'big':
         big_batch(int(sys.argv[2]) if len(sys.argv) > 2 else 128)
-        assert not os.path.exists(os.path.join(REF, '__pycache__')), 'bytecode leaked into the reference tree'
+        assert_no_new_bytecode()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'full':
         full()
-        assert not os.path.exists(os.path.join(REF, '__pycache__')), 'bytecode leaked into the reference tree'
+        assert_no_new_bytecode()
         sys.exit(0)
     op_vectors()
     trajectory('r50s_quant', dict(depth=50, **SMALL), B=16, size=64, classes=16, steps=3, seed=41)
@@ -213,4 +226,4 @@ if __name__ == '__main__':
                dtype=torch.double)
     trajectory('r18s_quant_f64', dict(depth=18, **SMALL), B=16, size=64, classes=16, steps=3, seed=42,
                dtype=torch.double)
-    assert not os.path.exists(os.path.join(REF, '__pycache__')), 'bytecode leaked into the reference tree'
+    assert_no_new_bytecode()

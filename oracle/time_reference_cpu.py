@@ -14,9 +14,24 @@ import os
 import sys
 import time
 
+sys.dont_write_bytecode = True      # /root/reference is read-only: importing it must not leave __pycache__ behind
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 REF = os.environ.get('CONVNET_REFERENCE', '/root/reference')
+
+_T_START = __import__('time').time()
+
+
+def assert_no_new_bytecode():
+    """/root/reference is read-only: nothing this process imports from it may leave bytecode behind.  (Round 3's
+    oracle/time_reference_cpu.py ran without sys.dont_write_bytecode and left *.pyc there, stamped 2026-09-26 18:25;
+    this tree does not own the reference and cannot delete them, so only files written since this process started count.)"""
+    for d, _, files in os.walk(REF):
+        if os.path.basename(d) == '__pycache__':
+            new = [f for f in files if os.path.getmtime(os.path.join(d, f)) >= _T_START - 1.0]
+            assert not new, 'bytecode leaked into the reference tree: %s/%s' % (d, new[:3])
+
 sys.path.insert(0, REF)
 sys.path.insert(0, os.path.join(HERE, 'refshim'))
 
@@ -56,6 +71,7 @@ def main():
     with open(os.path.join(ROOT, 'tests', 'golden', 'reference_cpu_timing.json'), 'w') as f:
         json.dump(out, f, indent=1, sort_keys=True)
     print(json.dumps(out))
+    assert_no_new_bytecode()
 
 
 if __name__ == '__main__':
