@@ -216,10 +216,14 @@ def main():
     torch.cuda.synchronize()
     fence()
     elapsed = time.perf_counter() - t0
+    rank_devices = [local_rank]
     if distributed:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # which HIP device every rank ran on, by rank (one process per GPU: rank r -> device r on a full node)
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, torch.cuda.current_device())
 
     # ---- live per-kernel timing: two profiled passes after the timed region, HIP events on the launch stream ----
     #  (1) overlapped: the step keeps its two-stream schedule; the events sit on the stream each call is launched on.
@@ -382,7 +386,7 @@ def main():
                                    '%s' % (args.depth, args.depth, B, args.dtype,
                                            'dp%d gradient all-reduce' % world if world > 1 else '1 MI355X'),
                        'global_batch': B * world, 'final_loss': round(float(res['loss']), 4),
-                       'parallelism': 'dp%d' % world,
+                       'parallelism': 'dp%d' % world, 'rank_devices': rank_devices,
                        'transport': (tr.reducer.describe() if tr.reducer is not None else None) if comm_note is None
                        else '%s [%s]' % (tr.reducer.describe() if tr.reducer is not None else None, comm_note)},
             'mfma_frac_whole_step': round(step_tflops / (elapsed / args.steps) / PEAK_TFLOPS[args.dtype], 4)

@@ -46,7 +46,6 @@ _SIGNATURES = {
     'cn_conv2d_bnstats_rows': (c_i, [c_ll]),
     'cn_conv2d_fwd_bnstats': (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 11 + [c_i, c_i, c_p, c_i, c_p]),
     'cn_conv2d_fwd_bnstats_centered': (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 11 + [c_i, c_i, c_p, c_i, c_p, c_p]),
-    'cn_conv2d_fwd_xf': (c_i, [c_p, c_p, c_i, c_p, c_p] + [c_i] * 11 + [c_i, c_p, c_i, c_p]),
     'cn_conv2d_dgrad': (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 11 + [c_i, c_i, c_p]),
     'cn_conv2d_dgrad_junction_ok': (c_i, [c_i, c_i, c_i]),
     'cn_conv2d_dgrad_junction_rows': (c_i, [c_i] * 4),
@@ -79,7 +78,6 @@ _SIGNATURES = {
     'cn_conv2d_dgrad_lazy_stream': (c_i, [c_p] * 5 + [c_i] * 6 + [c_p]),
     'cn_conv1x1_stream_fwd_lazya': (c_i, [c_p, c_p, c_i, c_p, c_p, c_p] + [c_i] * 6 + [c_p, c_i, c_p]),
     'cn_conv3x3_c64_lazya': (c_i, [c_p, c_p, c_i, c_p, c_p, c_p] + [c_i] * 4 + [c_p, c_i, c_p]),
-    'cn_conv3x3_c64_dgrad_bnbwd': (c_i, [c_p, c_p, c_p] + [c_i] * 4 + [c_p, c_p, c_p, c_i, c_p]),
     'cn_conv2d_dgrad_junction_rows_k': (c_i, [c_i] * 5),
     'cn_bn_workspace': (c_sz, [c_i, c_i, c_i]),
     'cn_bn_fwd_train': (c_i, [c_p] * 9 + [c_f, c_f, c_p, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),

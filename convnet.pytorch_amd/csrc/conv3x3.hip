@@ -33,18 +33,13 @@ struct C3Params {
   const float* xf;   // [scale | shift] (2 * 64)
   char* a_out;       // [N][H][W][64]
   int relu;
-  // BNB (data gradient only): y is the gradient of the OUTPUT of a BatchNorm + ReLU whose input is bn_y: the epilogue masks
-  // it with that ReLU (fmaf(bn_y, scale, shift) > 0, bn_bwd_reduce_kernel's expression), stores g and keeps the
-  // BatchNorm-backward sums of the stored values: partial row = [sum g | sum g * xhat]
-  const char* bn_y;        // [N][H][W][64]
-  const float* bn_coef;    // [mean | invstd | scale | shift] (4 * 64)
 };
 
 #define C3_ROWS 4
 #define C3_PPOS 144     /* bytes per halo position */
 #define C3_MAXW 56
 
-template <typename T, bool XF = false, bool BNB = false>
+template <typename T, bool XF = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C3Params p) {
   static_assert(sizeof(T) == 2, "16-bit storage");
   constexpr int HR = C3_ROWS + 2;
@@ -78,8 +73,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C3Params p) {
   if constexpr (XF) {
     if (tid < 128) s_xf[tid] = p.xf[tid];
   }
-  __shared__ float s_bn[BNB ? 256 : 1];   // [mean | invstd | scale | shift]
-  if constexpr (BNB) s_bn[tid] = p.bn_coef[tid];
   const int nchunks = HR * W * 8;
   auto stage_halo = [&](int work) {   // global -> LDS, a batch of four 16-byte chunks per thread in flight
     const int band = work % p.nbands, n = work / p.nbands;
@@ -159,18 +152,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C3Params p) {
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      u32x4 ybn[BNB ? 2 : 1];
-      if constexpr (BNB) {   // the BatchNorm inputs of this lane's two epilogue chunks, requested ahead of the MFMAs
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const int pxo = tile * 32 + k * 16 + erow;
-          const int oyo = (int)cn_fastdiv((unsigned)(pxo < npx ? pxo : 0), p.div_w);
-          const int oxo = pxo - oyo * W;
-          const bool ok = pxo < npx && oy0 + oyo < H;
-          ybn[k] = ok ? cn_ld16(p.bn_y + ((((size_t)n * H + (size_t)(oy0 + oyo)) * W + (size_t)oxo) * 64 + (size_t)(ct * 32 + ech * 8)) * 2)
-                      : cn_zero16();
-        }
-      }
       auto tap_off = [&](int tap) {
         const int tr = tap / 3, ts = tap - tr * 3;
         const int dr = p.flip ? 2 - tr : tr, ds = p.flip ? 2 - ts : ts;
@@ -211,27 +192,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C3Params p) {
         const int oyo = (int)cn_fastdiv((unsigned)(pxo < npx ? pxo : 0), p.div_w);
         const int oxo = pxo - oyo * W;
         if (pxo < npx && oy0 + oyo < H) {
-          if constexpr (BNB) {
-            float f[8], yv[8];
+          if (p.partial != nullptr) {
+            float f[8];
             Chunk<T>::unpack(v, f);
-            Chunk<T>::unpack(ybn[k], yv);
-            const float* cf = s_bn + (ct * 32 + ech * 8);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = fmaf(yv[e], cf[128 + e], cf[192 + e]) > 0.f ? f[e] : 0.f;
-            const u32x4 g = Chunk<T>::pack(f);
-            Chunk<T>::unpack(g, f);     // sums of the values as stored
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { ssum[e] += f[e]; ssq[e] = fmaf(f[e], yv[e], ssq[e]); }
-            cn_st16(p.y + ((((size_t)n * H + (size_t)(oy0 + oyo)) * W + (size_t)oxo) * 64 + (size_t)(ct * 32 + ech * 8)) * 2, g);
-          } else {
-            if (p.partial != nullptr) {
-              float f[8];
-              Chunk<T>::unpack(v, f);
-#pragma unroll
-              for (int e = 0; e < 8; ++e) { ssum[e] += f[e]; ssq[e] = fmaf(f[e], f[e], ssq[e]); }
-            }
-            cn_st16(p.y + ((((size_t)n * H + (size_t)(oy0 + oyo)) * W + (size_t)oxo) * 64 + (size_t)(ct * 32 + ech * 8)) * 2, v);
+            for (int e = 0; e < 8; ++e) { ssum[e] += f[e]; ssq[e] = fmaf(f[e], f[e], ssq[e]); }
           }
+          cn_st16(p.y + ((((size_t)n * H + (size_t)(oy0 + oyo)) * W + (size_t)oxo) * 64 + (size_t)(ct * 32 + ech * 8)) * 2, v);
         }
       }
       cn_wave_sync();
@@ -264,7 +231,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C3Params p) {
         b += red[((g * 2 + ctile) * 32 + cc) * 2 + 1];
       }
       float* dst = p.partial + (size_t)blockIdx.x * 128;
-      if constexpr (BNB) b = s_bn[64 + c] * (b - s_bn[c] * a);   // sum g*y -> sum g*xhat (jdgrad_kernel's form)
       dst[c] = a;
       dst[64 + c] = b;
     }
@@ -286,8 +252,7 @@ extern "C" int cn_conv3x3_c64_rows(int N, int H) { return c3_wgs(N * ((H + C3_RO
 // forward): cn_conv3x3_c64_rows(N, H) rows of 128 floats [sum | sum of squares] of the stored outputs for
 // cn_bn_fwd_train_partials.  Same output bits as cn_conv2d_fwd / cn_conv2d_dgrad.
 static int c3_impl(const char* who, const void* x, const float* xf, int relu, void* a_out, const void* w, void* y, int N,
-                   int H, int W, int dtype, int flip, float* partial, int partial_rows, void* stream,
-                   const void* bn_y = nullptr, const float* bn_coef = nullptr) {
+                   int H, int W, int dtype, int flip, float* partial, int partial_rows, void* stream) {
   if (x == nullptr || w == nullptr || y == nullptr) { cn_set_error("%s: null operand", who); return CN_EINVAL; }
   if (!cn_conv3x3_c64_ok(H, W, 64, 64, dtype) || N <= 0) { cn_set_error("%s: unsupported shape", who); return CN_ESHAPE; }
   C3Params p;
@@ -298,15 +263,11 @@ static int c3_impl(const char* who, const void* x, const float* xf, int relu, vo
   p.nwork = N * p.nbands;
   p.div_w = cn_make_fastdiv((unsigned)W);
   p.xf = xf; p.a_out = (char*)a_out; p.relu = relu;
-  p.bn_y = (const char*)bn_y; p.bn_coef = bn_coef;
   const int nwg = c3_wgs(p.nwork);
   if (partial != nullptr && partial_rows < nwg) { cn_set_error("%s: partial buffer of %d rows < %d", who, partial_rows, nwg); return CN_EWORKSPACE; }
   cn_set_last_kernel("conv3x3_c64_kernel<%s%s>%s", dtype == CN_F16 ? "f16_t" : "bf16_t",
-                     xf != nullptr ? ", true" : (bn_y != nullptr ? ", false, true" : ""), flip ? " [dgrad]" : "");
-  if (bn_y != nullptr) {
-    if (dtype == CN_F16) CN_LAUNCH((conv3x3_c64_kernel<f16_t, false, true>), dim3((unsigned)nwg), dim3(256), (hipStream_t)stream, p);
-    else CN_LAUNCH((conv3x3_c64_kernel<bf16_t, false, true>), dim3((unsigned)nwg), dim3(256), (hipStream_t)stream, p);
-  } else if (xf != nullptr) {
+                     xf != nullptr ? ", true" : "", flip ? " [dgrad]" : "");
+  if (xf != nullptr) {
     if (dtype == CN_F16) CN_LAUNCH((conv3x3_c64_kernel<f16_t, true>), dim3((unsigned)nwg), dim3(256), (hipStream_t)stream, p);
     else CN_LAUNCH((conv3x3_c64_kernel<bf16_t, true>), dim3((unsigned)nwg), dim3(256), (hipStream_t)stream, p);
   } else {
@@ -327,17 +288,4 @@ extern "C" int cn_conv3x3_c64_lazya(const void* bn_y, const float* stats, int re
                                     int N, int H, int W, int dtype, float* partial, int partial_rows, void* stream) {
   if (stats == nullptr || a_out == nullptr) { cn_set_error("conv3x3_c64_lazya: null operand"); return CN_EINVAL; }
   return c3_impl("conv3x3_c64_lazya", bn_y, stats + 2 * 64, relu, a_out, w, y, N, H, W, dtype, 0, partial, partial_rows, stream);
-}
-
-// Data gradient (cn_conv3x3_c64 with flip = 1) whose output is the gradient of a BatchNorm + ReLU output (bn1 in front
-// of the first stage's conv2): the epilogue masks it with that ReLU (recomputed from bn_y and stats = [mean | invstd |
-// scale | shift], 64 channels), stores g = dx * mask and emits the partial rows [sum g | sum g * xhat] (one per
-// workgroup, cn_conv3x3_c64_rows) for cn_bn_bwd_partials: cn_conv2d_dgrad_bnbwd_sa's contract (bn_mask = NULL, relu = 1,
-// no addend) on the halo kernel; g has its bits.
-extern "C" int cn_conv3x3_c64_dgrad_bnbwd(const void* dy, const void* w_crsk, void* g, int N, int H, int W, int dtype,
-                                          const void* bn_y, const float* bn_stats, float* partial, int partial_rows,
-                                          void* stream) {
-  if (bn_y == nullptr || bn_stats == nullptr || partial == nullptr) { cn_set_error("conv3x3_c64_dgrad_bnbwd: null operand"); return CN_EINVAL; }
-  return c3_impl("conv3x3_c64_dgrad_bnbwd", dy, nullptr, 0, nullptr, w_crsk, g, N, H, W, dtype, 1, partial, partial_rows, stream,
-                 bn_y, bn_stats);
 }

@@ -53,8 +53,8 @@ struct IgemmParams {
   unsigned int x_bytes, w_bytes;   // extents of the gather source / filter tensors (buffer descriptors)
   int simple;                      // 1: no tap of a valid row ever leaves the image (skip bounds tests)
   int x_nt;                        // 1: every gathered element is read by one workgroup only -> non-temporal loads
-  const float* xf;                 // optional [scale(Ci) | shift(Ci)]: the gathered operand is act(x*scale+shift), applied on load (XF)
-  int xf_relu;
+  const float* xf;                 // optional per-channel fp32 tables of an operand transform applied on load (XF; modes below)
+  int xf_relu;                     // (mode 3: the junction has a ReLU)
   // XF mode 2 ("lazy dy", round 3): the gathered operand is the BatchNorm-backward result c1[c]*x + c2[c]*x2 + c3[c]
   // (x = masked upstream gradient g, x2 = BatchNorm input y, xf = [c1 | c2 | c3] of the Ci channels), rounded to T
   // exactly as bn_bwd_apply_kernel stores it - so that apply pass (read g, read y, write dy) never runs
@@ -116,10 +116,10 @@ __device__ __forceinline__ int ig_slot(int row, int chunk) {
 //       variant spends ~416 LDS cycles per K tile on ds_write_b128 against 512 MFMA cycles).
 //       STAGES = 4 with GLDS: a 4-deep DMA ring (3 K tiles in flight across raw barriers, counted
 //       vmcnt waits) for long reductions, one workgroup per CU.
-// XF: the pixel operand is a BatchNorm input y whose normalisation + ReLU, z = act(y*scale[c] + shift[c]) rounded to T
-//     exactly as bn_apply stores it, is applied between the global load and the LDS store (register-staged variants
-//     only), so the inner BatchNorm's apply pass - one read and one write of the activation - disappears.  Padded taps
-//     stay zero (they are zeros of z, not of y).
+// XF: the pixel operand is transformed between the global load and the LDS store (register-staged variants only), with
+//     the arithmetic and rounding of the streaming pass it replaces: XF = 1 "lazy dy" (IgemmParams::xf_mode 2), XF = 3
+//     "lazy z" (mode 3).  (A plain BatchNorm apply folded in the same way was built in round 2, measured slower than
+//     apply + convolution on the tiled kernels and removed in round 4: profiles/r02e_bn_apply_folded_into_conv_operand_load.txt.)
 #define IG_XF_MAX 512
 #define IG_XF_TAB_BYTES (IG_XF_MAX * 16)   /* up to four per-channel fp32 tables */
 // ILV (round 3, LDS-DMA double buffer only): the DMA instructions of K tile kt+1 are issued BETWEEN the MFMAs of tile kt
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(WC * WP * 64, (XF != 0 && WC * WP == 8) ? 4 : 1) vo
     if (EPI) s_addpix[tid] = apix;
   }
   if (XF) {
-    const int ntab = (p.xf_mode == 2 ? 3 : 2) * p.Ci;
+    const int ntab = (XF == 3 ? 2 : 3) * p.Ci;   // lazy z: [scale | shift]; lazy dy: [c1 | c2 | c3]
     for (int c = tid; c < ntab; c += NT) s_xf[c] = p.xf[c];
     if (XF == 3 && p.xf2 != nullptr)
       for (int c = tid; c < 2 * p.Ci; c += NT) s_xf[2 * p.Ci + c] = p.xf2[c];
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(WC * WP * 64, (XF != 0 && WC * WP == 8) ? 4 : 1) vo
     if (GLDS) cn_buf_ld16_lds(xbuf, o, dp_ + i * RS * 128);
     else preg[i] = (!ILV && simple && p.x_nt) ? cn_buf_ld16_nt(xbuf, o) : cn_buf_ld16(xbuf, o);
     if (XF == 3) preg2[i] = cn_buf_ld16(x2buf, o);
-    else if (XF) { if (p.xf_mode == 2) preg2[i] = cn_buf_ld16(x2buf, o); }
+    else if (XF) preg2[i] = cn_buf_ld16(x2buf, o);
   };
   auto issue_w = [&](int i, int buf) {   // filter row r0 + RS*i of the tile
     char* dw_ = lds + buf * STAGE + (8 * wave) * 128;             // this wave's KiB of filter rows
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(WC * WP * 64, (XF != 0 && WC * WP == 8) ? 4 : 1) vo
       }
     } else if (XF) {
       constexpr int CH = ElemTraits<T>::kChunk;
-      if (p.xf_mode == 2) {   // dy = c1*g + c2*y + c3, the operation order of bn_bwd_apply_kernel (bit-identical operand)
+      {   // XF = 1 is mode 2: dy = c1*g + c2*y + c3, the operation order of bn_bwd_apply_kernel (bit-identical operand)
         float c1[CH], c2[CH], c3[CH];
 #pragma unroll
         for (int e = 0; e < CH; ++e) {
@@ -416,22 +416,6 @@ __global__ __launch_bounds__(WC * WP * 64, (XF != 0 && WC * WP == 8) ? 4 : 1) vo
           for (int e = 0; e < CH; ++e) g[e] = fmaf(c1[e], g[e], fmaf(c2[e], v[e], c3[e]));
           const u32x4 o = Chunk<T>::pack(g);
           preg[i] = ((xf_ok >> i) & 1u) ? o : cn_zero16();
-        }
-      } else {
-        float sc[CH], sh[CH];
-#pragma unroll
-        for (int e = 0; e < CH; ++e) { sc[e] = s_xf[xf_chunk * CH + e]; sh[e] = s_xf[p.Ci + xf_chunk * CH + e]; }
-#pragma unroll
-        for (int i = 0; i < NPR; ++i) {
-          float f[CH];
-          Chunk<T>::unpack(preg[i], f);
-#pragma unroll
-          for (int e = 0; e < CH; ++e) {
-            f[e] = fmaf(f[e], sc[e], sh[e]);
-            if (p.xf_relu) f[e] = f[e] > 0.f ? f[e] : 0.f;
-          }
-          const u32x4 v = Chunk<T>::pack(f);
-          preg[i] = ((xf_ok >> i) & 1u) ? v : cn_zero16();
         }
       }
     }
@@ -900,18 +884,11 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
   }
   if (p.xf != nullptr) {   // operand transform: register-staged single buffer only
     if (epi || p.Ci > IG_XF_MAX) { cn_set_error("igemm: operand transform with an epilogue operand / more than %d channels", IG_XF_MAX); return CN_EINVAL; }
-    // 128-channel outputs, 16-bit storage: the tile on eight waves held to 128 VGPRs (two workgroups = four waves per
-    // SIMD; the four-wave form needs 204 = two waves per SIMD).  Same tile, same accumulation order: same outputs.
-    // Knob "igemm_xf_8w" (A/B; whole step +0.15 % SLOWER with it, gpurun r3e: off by default).
-    bool w8 = false;
-    if constexpr (sizeof(T) == 2 && !OUTF32) w8 = p.Co > 64 && p.stats == nullptr && cn_get_option("igemm_xf_8w", 0) != 0;
+    if (p.xf_mode != 2) { cn_set_error("igemm: unknown operand transform %d", p.xf_mode); return CN_EINVAL; }
     cn_set_last_kernel("igemm_kernel<%s, %s, 1, %s, false, false, false, true, false>", tname,
-                       p.Co <= 64 ? "1, 4, 2, 1" : (w8 ? "2, 4, 2, 1" : "2, 2, 2, 2"), OUTF32 ? "true" : "false");
+                       p.Co <= 64 ? "1, 4, 2, 1" : "2, 2, 2, 2", OUTF32 ? "true" : "false");
     if (p.Co <= 64) CN_LAUNCH((igemm_kernel<T, 1, 4, 2, 1, 1, OUTF32, false, false, false, 1>), grid, dim3(256), stream, p);
-    else if (w8) {
-      if constexpr (sizeof(T) == 2 && !OUTF32)
-        CN_LAUNCH((igemm_kernel<T, 2, 4, 2, 1, 1, false, false, false, false, 1>), grid, dim3(512), stream, p);
-    } else CN_LAUNCH((igemm_kernel<T, 2, 2, 2, 2, 1, OUTF32, false, false, false, 1>), grid, dim3(256), stream, p);
+    else CN_LAUNCH((igemm_kernel<T, 2, 2, 2, 2, 1, OUTF32, false, false, false, 1>), grid, dim3(256), stream, p);
     return cn_check_launch("igemm");
   }
   if constexpr (sizeof(T) == 2 && !OUTF32) {
@@ -1119,22 +1096,6 @@ extern "C" int cn_conv2d_fwd_bnstats_centered(const void* x, const void* w_krsc,
   }
   return ig_conv_fwd(x, w_krsc, y, bias, partial, N, H, W, C, K, R, S, stride_h, stride_w, pad_h, pad_w, dtype,
                      0, relu, stream, nullptr, 0, pivot);
-}
-
-// Convolution forward whose input is a BatchNorm *input*: x_op = act(x*scale[c] + shift[c]) (xf = [scale | shift],
-// 2*C floats, e.g. stats_out + 2C of cn_bn_fwd_train*), applied on the operand load, so the BatchNorm between two
-// convolutions needs no apply pass of its own.  partial (optional): the statistics epilogue of cn_conv2d_fwd_bnstats.
-extern "C" int cn_conv2d_fwd_xf(const void* x, const float* xf, int xf_relu, const void* w_krsc, void* y, int N, int H,
-                                int W, int C, int K, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w,
-                                int dtype, float* partial, int partial_rows, void* stream) {
-  if (xf == nullptr) { cn_set_error("conv2d_fwd_xf: no transform table"); return CN_EINVAL; }
-  const long long P = (H + 2 * pad_h - R) / stride_h + 1, Q = (W + 2 * pad_w - S) / stride_w + 1;
-  if (partial != nullptr && partial_rows < cn_conv2d_bnstats_rows((long long)N * P * Q)) {
-    cn_set_error("conv2d_fwd_xf: partial buffer of %d rows is too small", partial_rows);
-    return CN_EWORKSPACE;
-  }
-  return ig_conv_fwd(x, w_krsc, y, nullptr, partial, N, H, W, C, K, R, S, stride_h, stride_w, pad_h, pad_w, dtype, 0, 0,
-                     stream, xf, xf_relu);
 }
 
 // "Lazy z" forward (round 3): the convolution's input is the output of a residual junction that has not been applied

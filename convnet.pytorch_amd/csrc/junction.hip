@@ -43,10 +43,9 @@ struct JdParams {
   unsigned int dy_bytes, out_bytes, add_bytes, mask_bytes;
 };
 
-// PF: the epilogue operands of stage s + 1 are requested before stage s is processed (72 more registers); PF = false
-// (the 256-channel reductions, whose filter fragments take 128 registers): they are requested at the start of their own
-// stage, ahead of its MFMAs.  A workgroup computes the CO channels from blockIdx.y * CO on of p.co_total.
-template <typename T, int KD, int CO, bool PF = true>
+// The epilogue operands of stage s + 1 are requested before stage s is processed (72 registers).  A workgroup computes
+// the CO channels from blockIdx.y * CO on of p.co_total.
+template <typename T, int KD, int CO>
 __global__ __launch_bounds__(512) void jdgrad_kernel(JdParams p) {
   static_assert(sizeof(T) == 2, "16-bit storage");
   constexpr int NCW = CO / 64;          // wave columns of 64 channels
@@ -203,16 +202,15 @@ __global__ __launch_bounds__(512) void jdgrad_kernel(JdParams p) {
   if (m_begin < m_end) {
     Epi cur, nxt;
     load_dy(m_begin);
-    if (PF) load_epi(m_begin, cur);
+    load_epi(m_begin, cur);
     int buf = 0;
     for (int mb = m_begin; mb < m_end; mb += BM) {
       store_dy(buf);
       __syncthreads();    // (two dy tiles: the tile of stage s + 1 is written while stage s is still being read: one barrier per stage)
       const bool more = mb + BM < m_end;
-      if (!PF) load_epi(mb, cur);
-      if (more) { load_dy(mb + BM); if (PF) load_epi(mb + BM, nxt); }
+      if (more) { load_dy(mb + BM); load_epi(mb + BM, nxt); }
       compute(mb, buf, cur);
-      if (PF && more) cur = nxt;
+      if (more) cur = nxt;
       buf ^= 1;
     }
   }
@@ -257,7 +255,7 @@ __global__ __launch_bounds__(512) void jdgrad_kernel(JdParams p) {
 
 // The 256-channel reductions (the 28x28 -> 14x14 and the 14x14 junctions: K = 256 gradient channels, C = 512 / 1024) with
 // a wave owning 32 channels instead of 64: the filter fragments of a wave are 64 registers instead of 128, so the
-// stage-ahead prefetch of the epilogue operands fits without spills (the 64-channel form above needs PF = false and
+// stage-ahead prefetch of the epilogue operands fits without spills (the 64-channel-wave form needs 128 filter registers and
 // still spills 20 registers).  A workgroup owns a pixel range and a 256-channel slice (blockIdx.y) - eight waves of 32
 // channels, all 32 pixels of a stage each -; the dy tile (16 KB per stage) is read once per slice (C / 256 times, from
 // L2 after the first).  Epilogue accesses are 64 contiguous bytes per pixel row and wave.  Same g bits.
@@ -442,7 +440,6 @@ static int jd_splits(long long M, int BM) {
   return ns;
 }
 static int jd_bm(int C) { return C == 256 ? 64 : 32; }   // (C >= 512: 512-channel slices of 32-pixel stages)
-static int jd_k256_mode() { return cn_get_option("jdgrad_k256", 2); }   // 0 tiled kernel, 1 64-channel waves, 2 32-channel waves
 // pixel ranges: whole stages per workgroup; returns the number of ranges (= partial rows) and their length
 static int jd_plan(long long M, int BM, long long* mps_out, int slices = 1) {
   int ns0 = jd_splits(M, BM);
@@ -456,13 +453,11 @@ static int jd_plan(long long M, int BM, long long* mps_out, int slices = 1) {
 // Shapes the streaming junction kernel is instantiated for: K channels of dy (conv1's outputs), C channels of g.
 extern "C" int cn_conv2d_dgrad_junction_ok(int C, int K, int dtype) {
   if (dtype != CN_BF16 && dtype != CN_F16) return 0;
-  // 256-channel reductions (the 28x28 -> 14x14 and 14x14 junctions) in 512-channel slices without the stage-ahead
-  // epilogue prefetch: 128 filter registers + the epilogue operands spill (20 VGPRs) and the step does not move
-  // (17.75 vs 17.76 ms): built and tested, OFF by default (knob "jdgrad_k256")
-  if ((C == 512 || C == 1024) && K == 256) return jd_k256_mode() != 0 ? 1 : 0;   // (mode 2: jdgrad_w32_kernel)
-  // 512-channel reductions (the last stage's junctions) on the same kernel: 128 filter registers, 28 spilled - the step
-  // is 0.3 % SLOWER with it (17.62 vs 17.55 ms): built, tested, OFF (knob "jdgrad_k512")
-  if ((C == 1024 || C == 2048) && K == 512) return (jd_k256_mode() == 2 && cn_get_option("jdgrad_k512", 0) != 0) ? 1 : 0;
+  // 256-channel reductions (the 28x28 -> 14x14 and 14x14 junctions): jdgrad_w32_kernel, a wave owns 32 channels.  (Measured
+  // and not kept: the same reductions on 64-channel waves - 128 filter registers, 20 spilled, step neutral - and the
+  // last stage's 512-channel reductions on 32-channel waves - 28 spilled, step +0.3 %: they stay on the tiled kernel;
+  // profiles/r03_ab_second_session_whole_step.txt.)
+  if ((C == 512 || C == 1024) && K == 256) return 1;
   return ((C == 256 && (K == 64 || K == 128)) || (C == 512 && K == 128)) ? 1 : 0;
 }
 extern "C" int cn_conv2d_dgrad_junction_rows(int N, int H, int W, int C) {   // (the K <= 128 forms)
@@ -470,7 +465,7 @@ extern "C" int cn_conv2d_dgrad_junction_rows(int N, int H, int W, int C) {   // 
 }
 // partial rows cn_conv2d_dgrad_junction writes for K -> C channels (the 256-channel reductions plan per channel slice)
 extern "C" int cn_conv2d_dgrad_junction_rows_k(int N, int H, int W, int C, int K) {
-  return jd_plan((long long)N * H * W, jd_bm(C), nullptr, (K >= 256 && jd_k256_mode() == 2) ? C / 256 : 1);
+  return jd_plan((long long)N * H * W, jd_bm(C), nullptr, K >= 256 ? C / 256 : 1);
 }
 
 // cn_conv2d_dgrad_bnbwd_sa for a 1x1 / stride-1 / unpadded convolution with K -> C channels of an instantiated shape,
@@ -492,7 +487,7 @@ extern "C" int cn_conv2d_dgrad_junction(const void* dy, const void* w_crsk, void
   const long long ab = addend_sub == 2 ? (long long)N * aH * aW * C * 2 : ob;
   if (ob >= (1ll << 31) || db >= (1ll << 31)) { cn_set_error("conv2d_dgrad_junction: operand exceeds the 2 GiB buffer-descriptor window"); return CN_ESHAPE; }
   const int BM = jd_bm(C);
-  const bool w32 = K >= 256 && jd_k256_mode() == 2;
+  const bool w32 = K >= 256;
   long long mps = 0;
   const int nsplit = jd_plan(M, BM, &mps, w32 ? C / 256 : 1);
   if (partial_rows < nsplit) { cn_set_error("conv2d_dgrad_junction: partial buffer of %d rows < %d", partial_rows, nsplit); return CN_EWORKSPACE; }
@@ -510,26 +505,20 @@ extern "C" int cn_conv2d_dgrad_junction(const void* dy, const void* w_crsk, void
   if (w32) {
     cn_set_last_kernel("jdgrad_w32_kernel<%s, %d> [%d channels]", tn, K, C);
     dim3 g32((unsigned)nsplit, (unsigned)(C / 256));
-    if (K == 256) {
-      if (dtype == CN_F16) CN_LAUNCH((jdgrad_w32_kernel<f16_t, 256>), g32, dim3(512), st, p);
-      else CN_LAUNCH((jdgrad_w32_kernel<bf16_t, 256>), g32, dim3(512), st, p);
-    } else {
-      if (dtype == CN_F16) CN_LAUNCH((jdgrad_w32_kernel<f16_t, 512>), g32, dim3(512), st, p);
-      else CN_LAUNCH((jdgrad_w32_kernel<bf16_t, 512>), g32, dim3(512), st, p);
-    }
+    if (dtype == CN_F16) CN_LAUNCH((jdgrad_w32_kernel<f16_t, 256>), g32, dim3(512), st, p);
+    else CN_LAUNCH((jdgrad_w32_kernel<bf16_t, 256>), g32, dim3(512), st, p);
     return cn_check_launch("jdgrad_w32");
   }
   cn_set_last_kernel("jdgrad_kernel<%s, %d, %d>", tn, K, C);
   dim3 grid((unsigned)nsplit, (unsigned)(C > 512 ? C / 512 : 1));
-#define JD_GO(KD, CO, PF)                                                                           \
-  do {                                                                                              \
-    if (dtype == CN_F16) CN_LAUNCH((jdgrad_kernel<f16_t, KD, CO, PF>), grid, dim3(512), st, p);      \
-    else CN_LAUNCH((jdgrad_kernel<bf16_t, KD, CO, PF>), grid, dim3(512), st, p);                     \
+#define JD_GO(KD, CO)                                                                           \
+  do {                                                                                          \
+    if (dtype == CN_F16) CN_LAUNCH((jdgrad_kernel<f16_t, KD, CO>), grid, dim3(512), st, p);      \
+    else CN_LAUNCH((jdgrad_kernel<bf16_t, KD, CO>), grid, dim3(512), st, p);                     \
   } while (0)
-  if (C == 256 && K == 64) JD_GO(64, 256, true);
-  else if (C == 256 && K == 128) JD_GO(128, 256, true);
-  else if (K == 128) JD_GO(128, 512, true);
-  else JD_GO(256, 512, false);
+  if (C == 256 && K == 64) JD_GO(64, 256);
+  else if (C == 256 && K == 128) JD_GO(128, 256);
+  else JD_GO(128, 512);
 #undef JD_GO
   return cn_check_launch("jdgrad");
 }

@@ -215,8 +215,8 @@ struct StemWgParams {
   FastDiv div_q;
 };
 
-__global__ void wgrad_reduce_kernel(const float* part, float* dw, int nsplit, int Co, int ntaps, int Ci, int Creal,
-                                    float beta, float scale);   // wgrad.hip
+int wg_launch_reduce(hipStream_t stream, const float* part, float* dw, int nsplit, int Co, int ntaps, int Ci, int Creal,
+                     float beta, float scale);   // wgrad.hip
 
 template <typename T>
 __global__ __launch_bounds__(512, 4) void stem_wgrad_kernel(StemWgParams p) {
@@ -361,8 +361,5 @@ extern "C" int cn_stem_wgrad(const void* xp, const void* dy, float* dwp, int N, 
     if (rc) return rc;
   }
   if (phase == 1) return CN_OK;
-  const long long total = 64ll * STEM_R * STEM_S2 * 8;
-  CN_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), st, (const float*)workspace, dwp, nwg,
-            64, STEM_R * STEM_S2, 8, 8, beta, scale);
-  return cn_check_launch("wgrad_reduce");
+  return wg_launch_reduce(st, (const float*)workspace, dwp, nwg, 64, STEM_R * STEM_S2, 8, 8, beta, scale);
 }

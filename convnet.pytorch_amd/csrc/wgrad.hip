@@ -439,160 +439,6 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(WgradParams p) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// 256 (co) x 256 (columns) tile, 8 waves of 128 x 64, LDS-DMA double buffer, one workgroup per CU: half the
-// L2 -> LDS bytes per flop of the 128 x 128 tile (the same lever as igemm's 256 x 256 tile; these launches are
-// L2-feed bound).  A stage holds four [64 pixel rows][256 bytes] sub-tile images
-// (dY co 0-127 | dY co 128-255 | X columns 0-127 | X columns 128-255), each with the 128-wide kernel's layout and
-// source-side XOR swizzle, so the conflict-free transpose reads carry over unchanged.
-__global__ __launch_bounds__(512) void wgrad_dma256_kernel(WgradParams p) {
-  constexpr int BKP = 64, RB = 256, SUB = BKP * RB, STAGE = 4 * SUB;
-  constexpr int TI = 4, TJ = 2;
-  __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = cn_uniform(tid >> 6);   // 0..7 (wave-uniform: LDS-DMA bases stay in SGPRs)
-  const int wi = wave & 1, wj = wave >> 1;
-
-  unsigned int tile = cn_xcd_remap(blockIdx.x, gridDim.x);
-  const int jt = tile % p.n_jtiles;
-  tile /= p.n_jtiles;
-  const int it = tile % p.n_itiles;
-  const int split = tile / p.n_itiles;
-  const int i0 = it * 256, j0 = jt * 256;
-  const int m_begin = split * p.m_per_split;
-  int m_end = m_begin + p.m_per_split;
-  if (m_end > p.M) m_end = p.M;
-  const int HoWo = p.Ho * p.Wo;
-
-  const cn_buf_t xbuf = cn_make_buf(p.x, p.x_bytes);
-  const cn_buf_t dybuf = cn_make_buf(p.dy, p.dy_bytes);
-  const unsigned int rowI_pitch = (unsigned int)(p.Co * 2), rowJ_pitch = (unsigned int)(p.Ci * 2);
-
-  // DMA coordinates: a stage is 64 KiB-blocks; instruction i of wave w fills block i*8 + w, i.e. sub-tile i>>1,
-  // rows ((i&1)*8 + w)*4 + r of it.  Row & 3 = r for every block, so the fetched chunk column is fixed per thread.
-  const int r = lane >> 4, sl = lane & 15;
-  const int cch = sl ^ (r << 2);      // chunk (8 elements) of the 128-wide sub-tile this lane fetches
-  unsigned int colI_b[2], colJ_b[2];
-  int dhs[2], dws[2];
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int co = i0 + s * 128 + cch * 8;
-    colI_b[s] = co < p.Co ? (unsigned int)(co * 2) : CN_OOB;
-    const int jc = (j0 + s * 128) / 8 + cch;
-    const bool validJ = jc < p.ntaps * p.cpt;
-    int tap = 0, cchunk = jc;
-    if (p.ntaps > 1) {
-      tap = validJ ? (int)cn_fastdiv((unsigned)jc, p.div_cpt) : 0;
-      cchunk = validJ ? jc - tap * p.cpt : 0;
-    }
-    const int dhdw = p.tap_dhdw[tap];
-    dhs[s] = (int)(short)(dhdw & 0xffff);
-    dws[s] = dhdw >> 16;
-    colJ_b[s] = validJ ? (unsigned int)(cchunk * 16) : CN_OOB;
-  }
-
-  auto load_stage = [&](int mb, int buf) {
-    char* base = lds + buf * STAGE;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int sub = i >> 1;                       // 0, 1: dY halves; 2, 3: X halves
-      const int kb = (i & 1) * 8 + wave;            // KiB block inside the sub-tile
-      const int m = mb + kb * 4 + r;
-      char* dst = base + sub * SUB + kb * 1024;
-      if (sub < 2) {
-        const bool ok = m < m_end && colI_b[sub] < CN_OOB;
-        cn_buf_ld16_lds(dybuf, ok ? (unsigned int)m * rowI_pitch + colI_b[sub] : CN_OOB, dst);
-      } else {
-        const int s = sub - 2;
-        bool ok = m < m_end && colJ_b[s] < CN_OOB;
-        unsigned int off;
-        if (p.simple) {
-          off = (unsigned int)m * rowJ_pitch + colJ_b[s];
-        } else {
-          const int mm = ok ? m : 0;
-          const int n = (int)cn_fastdiv((unsigned)mm, p.div_hw);
-          const int rem = mm - n * HoWo;
-          const int ho = (int)cn_fastdiv((unsigned)rem, p.div_w);
-          const int wo = rem - ho * p.Wo;
-          const int hi = ho * p.stride_h + dhs[s], wq = wo * p.stride_w + dws[s];
-          ok = ok && (unsigned)hi < (unsigned)p.Hi && (unsigned)wq < (unsigned)p.Wi;
-          off = (unsigned int)((n * p.Hi + hi) * p.Wi + wq) * rowJ_pitch + colJ_b[s];
-        }
-        cn_buf_ld16_lds(xbuf, ok ? off : CN_OOB, dst);
-      }
-    }
-  };
-
-  f32x16 acc[TI][TJ];
-#pragma unroll
-  for (int a = 0; a < TI; ++a)
-#pragma unroll
-    for (int b = 0; b < TJ; ++b)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
-
-  const int L = lane & 15, g1 = (lane >> 4) & 1, h = lane >> 5;
-  const int rlo = h * 8 + (L >> 2);
-  const int inner = g1 * 32 + (L & 3) * 8;
-  int offI[TI], offJ[TJ];
-#pragma unroll
-  for (int a = 0; a < TI; ++a) offI[a] = wi * SUB + rlo * RB + ((a ^ (rlo & 3)) << 6) + inner;
-#pragma unroll
-  for (int b = 0; b < TJ; ++b)
-    offJ[b] = (2 + (wj >> 1)) * SUB + rlo * RB + ((((wj & 1) * 2 + b) ^ (rlo & 3)) << 6) + inner;
-
-  auto compute = [&](int buf) {
-    const char* t = lds + buf * STAGE;
-#pragma unroll
-    for (int kk = 0; kk < BKP / 16; ++kk) {
-      s16x8 af[TI], bfr[TJ];
-#pragma unroll
-      for (int a = 0; a < TI; ++a) {
-        const char* q = t + kk * 16 * RB + offI[a];
-        s16x4 lo = cn_lds_read_tr16_b64(q);
-        s16x4 hi = cn_lds_read_tr16_b64(q + 4 * RB);
-        af[a] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-      }
-#pragma unroll
-      for (int b = 0; b < TJ; ++b) {
-        const char* q = t + kk * 16 * RB + offJ[b];
-        s16x4 lo = cn_lds_read_tr16_b64(q);
-        s16x4 hi = cn_lds_read_tr16_b64(q + 4 * RB);
-        bfr[b] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-      }
-#pragma unroll
-      for (int a = 0; a < TI; ++a)
-#pragma unroll
-        for (int b = 0; b < TJ; ++b) acc[a][b] = cn_mfma_32x32x16_bf16(af[a], bfr[b], acc[a][b]);
-    }
-  };
-
-  if (m_begin < m_end) {
-    load_stage(m_begin, 0);
-    int buf = 0;
-    for (int mb = m_begin; mb < m_end; mb += BKP, buf ^= 1) {
-      __syncthreads();
-      if (mb + BKP < m_end) load_stage(mb + BKP, buf ^ 1);
-      compute(buf);
-    }
-  }
-
-  float* out = p.part + (size_t)split * (size_t)p.Co * (size_t)p.ncols;
-#pragma unroll
-  for (int a = 0; a < TI; ++a)
-#pragma unroll
-    for (int b = 0; b < TJ; ++b) {
-      const int col = j0 + (wj >> 1) * 128 + ((wj & 1) * 2 + b) * 32 + (lane & 31);
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int co = i0 + wi * 128 + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-        if (co < p.Co && col < p.ncols) out[(size_t)co * p.ncols + col] = acc[a][b][q];
-      }
-    }
-}
-
 // Fixed-order reduction of the split partials into the KRSC fp32 gradient (C_real <= Ci channels
 // kept per tap: the stem's input is channel-padded).  beta = 1 accumulates (chunked batches).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, float* dw, int nsplit, int Co,
@@ -630,6 +476,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, fl
     float s = ((s0 + s1) + (s2 + s3)) * scale;
     dw[idx] = beta != 0.f ? beta * dw[idx] + s : s;
   }
+}
+
+// Second stage of every split weight gradient (the tile kernels, the band kernel, the junction pair, the stem).  One thread
+// per output on purpose: spreading the split dimension over more lanes makes the launch itself 2x faster and the STEP
+// 1 % slower - it puts 4-8x the workgroups beside the backward chain (profiles/r04_ab_wgrad_reduce_lanes_and_side_streams_rejected.txt).
+int wg_launch_reduce(hipStream_t stream, const float* part, float* dw, int nsplit, int Co, int ntaps, int Ci,
+                     int Creal, float beta, float scale) {
+  const long long total = (long long)Co * ntaps * Creal;
+  unsigned nb = (unsigned)((total + 255) / 256);
+  if (nb > 8192) nb = 8192;
+  CN_LAUNCH(wgrad_reduce_kernel, dim3(nb), dim3(256), stream, part, dw, nsplit, Co, ntaps, Ci, Creal, beta, scale);
+  return cn_check_launch("wgrad_reduce");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1075,23 +933,12 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(Wg3Params p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// (A 256 x 256 tile on eight waves - half the L2 -> LDS bytes per flop - was built in round 2: faster alone on the gathering
+// layers, slower in the step, where a 512-thread workgroup with 128 KiB of LDS evicts the chain's kernels; removed in
+// round 4: profiles/r02d_ab_wgrad_256sq_whole_step.txt.)
 struct WgradPlan {
   int BI, BJ, BKP, n_itiles, n_jtiles, nsplit, m_per_split, ncols;
 };
-
-// The 256 x 256 tile (wgrad_dma256_kernel): bf16, >= 256 output channels and columns.  Per layer, alone on the
-// GPU, it wins on the gathering layers with long pixel reductions (3x3 and strided 1x1 at 14x14 / 28x28:
-// 490 -> 690 TFLOP/s, profiles/r02d_conv_layers_wgrad_256sq.txt) and loses on the identity-gather 1x1 layers and the
-// 7x7 maps.  In the real step the weight gradients run on the side stream BESIDE the dgrad / BatchNorm chain, and a
-// 512-thread workgroup that owns 128 KiB of LDS evicts that co-residency: whole step 20.61 ms without it vs 20.67 ms
-// with it (3 A/B pairs, profiles/README.md).  So it is off by default; knob "wgrad_256sq": 1 = wherever the shape
-// allows, 2 = the per-layer heuristic (gathering layers, M >= "wgrad_256sq_min_m").
-static bool wg_use_256(int M, int Co, int ncols, int dtype, bool simple) {
-  const int knob = cn_get_option("wgrad_256sq", 0);
-  if (knob <= 0 || dtype != CN_BF16 || Co < 256 || Co % 128 != 0 || ncols < 256) return false;
-  if (knob == 1) return true;
-  return !simple && M >= cn_get_option("wgrad_256sq_min_m", 32768);
-}
 
 // Plan of the band kernel (wgrad3x3_kernel); ok = false: the shape is served by the tile kernels
 struct Wg3Plan {
@@ -1127,25 +974,9 @@ static Wg3Plan wg3_plan(int N, int H, int W, int C, int K, int R, int S, int str
   return pl;
 }
 
-static WgradPlan wg_plan(int M, int Co, int ntaps, int Ci, int dtype, bool simple, bool lazy = false) {
+static WgradPlan wg_plan(int M, int Co, int ntaps, int Ci, int dtype, bool simple) {
   WgradPlan pl;
   pl.ncols = ntaps * Ci;
-  if (!lazy && wg_use_256(M, Co, pl.ncols, dtype, simple)) {   // (lazy dy: register-staged tiles only)
-    pl.BI = 256; pl.BJ = 256; pl.BKP = 64;
-    pl.n_itiles = (Co + 255) / 256;
-    pl.n_jtiles = (pl.ncols + 255) / 256;
-    const int tiles = pl.n_itiles * pl.n_jtiles;
-    const int stages = (M + 63) / 64;
-    int want = (cn_get_option("wgrad_256sq_wgs", 256) + tiles - 1) / tiles;
-    int max_split = (stages + 7) / 8;
-    if (max_split < 1) max_split = 1;
-    int nsplit = want < max_split ? want : max_split;
-    if (nsplit < 1) nsplit = 1;
-    const int sps = (stages + nsplit - 1) / nsplit;
-    pl.m_per_split = sps * 64;
-    pl.nsplit = (M + pl.m_per_split - 1) / pl.m_per_split;
-    return pl;
-  }
   pl.BI = Co <= 64 ? 64 : 128;
   pl.BJ = 128;
   pl.BKP = dtype == CN_F32 ? 32 : 64;
@@ -1194,13 +1025,6 @@ static void wg_launch(const WgradParams& p, const WgradPlan& pl, hipStream_t str
   // at 2 (profiles/README.md).  Tuning knob "wgrad_variant": 0 = this heuristic, 1 = register-staged,
   // 2 = LDS-DMA everywhere.
   const int wv = p.dy2 != nullptr ? 1 : cn_get_option("wgrad_variant", 0);   // lazy dy: register-staged only
-  if (pl.BI == 256) {
-    if constexpr (std::is_same<T, bf16_t>::value) {
-      cn_set_last_kernel("wgrad_dma256_kernel");
-      CN_LAUNCH(wgrad_dma256_kernel, grid, dim3(512), stream, p);
-    }
-    return;
-  }
   if (std::is_same<T, bf16_t>::value && (wv == 2 || (wv == 0 && p.simple))) {   // (the LDS-DMA kernels are bf16 instantiations)
     cn_set_last_kernel("wgrad_dma_kernel<%d>", pl.BI == 64 ? 64 : 128);
     if (pl.BI == 64) CN_LAUNCH((wgrad_dma_kernel<64>), grid, dim3(256), stream, p);
@@ -1300,15 +1124,9 @@ static int wg_conv2d_wgrad(const void* x, const void* dy, float* dw_krsc, int C_
       if (rc3) return rc3;
     }
     if (phase3 == 1) return CN_OK;
-    long long total3 = (long long)K * 9 * C_real;
-    unsigned nb3 = (unsigned)((total3 + 255) / 256);
-    if (nb3 > 8192) nb3 = 8192;
-    CN_LAUNCH(wgrad_reduce_kernel, dim3(nb3), dim3(256), (hipStream_t)stream, (const float*)workspace, dw_krsc,
-              p3.nsplit, K, 9, C, C_real, beta, scale);
-    return cn_check_launch("wgrad_reduce");
+    return wg_launch_reduce((hipStream_t)stream, (const float*)workspace, dw_krsc, p3.nsplit, K, 9, C, C_real, beta, scale);
   }
-  WgradPlan pl = wg_plan(N * P * Q, K, R * S, C, dtype, simple_gather, lazy_y != nullptr);
-  if (lazy_y != nullptr && pl.BI == 256) { cn_set_error("conv2d_wgrad_lazy: not with the 256 x 256 tile (knob wgrad_256sq)"); return CN_EINVAL; }
+  WgradPlan pl = wg_plan(N * P * Q, K, R * S, C, dtype, simple_gather);
   size_t need = (size_t)pl.nsplit * (size_t)K * (size_t)pl.ncols * sizeof(float);
   if (ws_bytes < need || workspace == nullptr) {
     cn_set_error("conv2d_wgrad: workspace %zu < %zu bytes", ws_bytes, need);
@@ -1348,12 +1166,7 @@ static int wg_conv2d_wgrad(const void* x, const void* dy, float* dw_krsc, int C_
     if (rc) return rc;
   }
   if (phase == 1) return CN_OK;
-  long long total = (long long)K * R * S * C_real;
-  unsigned nb = (unsigned)((total + 255) / 256);
-  if (nb > 8192) nb = 8192;
-  CN_LAUNCH(wgrad_reduce_kernel, dim3(nb), dim3(256), (hipStream_t)stream, (const float*)workspace, dw_krsc,
-            pl.nsplit, K, R * S, C, C_real, beta, scale);
-  return cn_check_launch("wgrad_reduce");
+  return wg_launch_reduce((hipStream_t)stream, (const float*)workspace, dw_krsc, pl.nsplit, K, R * S, C, C_real, beta, scale);
 }
 
 // Junction pair entry point (see jbwd_kernel): shapes it is instantiated for.
@@ -1406,9 +1219,5 @@ extern "C" int cn_conv2d_bwd1x1_lazy(const void* x, const void* g, const void* b
     if (rc) return rc;
   }
   if (phase == 1) return CN_OK;
-  long long total = (long long)K * C;
-  unsigned nb = (unsigned)((total + 255) / 256);
-  CN_LAUNCH(wgrad_reduce_kernel, dim3(nb), dim3(256), st, (const float*)workspace, dw_krsc, nsplit, K, 1, C, C, beta,
-            scale);
-  return cn_check_launch("wgrad_reduce");
+  return wg_launch_reduce(st, (const float*)workspace, dw_krsc, nsplit, K, 1, C, C, beta, scale);
 }

@@ -422,28 +422,6 @@ def conv2d_fwd(x, w_krsc, bias, K, R, S, stride, pad, out_f32=False, relu=False,
     return y
 
 
-def conv2d_fwd_xf(x, xf, xf_relu, w_krsc, K, R, S, stride, pad, bn_stats=False):
-    """conv(act(x*scale + shift)) with the BatchNorm apply folded into the operand load (cn_conv2d_fwd_xf).
-    xf: fp32 [scale | shift] of the C input channels."""
-    N, H, W, C = x.shape
-    P, Q = conv_out_hw(H, W, R, S, stride, pad)
-    y = torch.empty((N, P, Q, K), dtype=x.dtype, device=x.device)
-    L = _L()
-    partial, rows = None, 0
-    if bn_stats:
-        rows = L.cn_conv2d_bnstats_rows(N * P * Q)
-        partial = torch.empty((rows, 2 * K), dtype=torch.float32, device=x.device)
-    PROFILER.run(_last_kernel(), 1, 2.0 * N * P * Q * K * C * R * S,
-                 x.numel() * _esize(x) + y.numel() * _esize(y) + K * R * S * C * _esize(x),
-                 lambda: check(L.cn_conv2d_fwd_xf(ptr(x), ptr(xf), int(xf_relu), ptr(w_krsc), ptr(y), N, H, W, C, K, R, S,
-                                                  stride[0], stride[1], pad[0], pad[1], dtype_code(x.dtype), ptr(partial),
-                                                  rows, stream_of(x)), 'cn_conv2d_fwd_xf'),
-                 x.device, detail=_conv_detail('fwd-xf', C, H, K, R, stride))
-    if bn_stats:
-        _park_stats(y, partial, rows)
-    return y
-
-
 def conv2d_fwd_lazyz(lz, w_krsc, K, bn_stats=False, pivot=None):
     """conv1x1(z) with z = relu(bn(y) + residual) formed on the operand load and stored by the kernel
     (cn_conv2d_fwd_lazyz).  lz: the junction's parked state (BatchNormActFunction.forward)."""
@@ -534,19 +512,6 @@ def lazy_z_consumer_ok(conv):
             and not getattr(conv, 'out_f32', False))
 
 
-# The first stage's conv2 data gradient on the halo kernel can also reduce for bn1 (cn_conv3x3_c64_dgrad_bnbwd).  Built,
-# tested (g bit-identical) and measured: the step is 0.2 % SLOWER with it (17.70 vs 17.66 ms, three interleaved rounds,
-# profiles/r03_ab_second_session_whole_step.txt) - like the tiled kernel's epilogue (FUSE_BN_BWD_INNER_MB), the extra
-# operand stream costs the chain's MFMA-bound kernel more than the separate pass costs beside the side stream.  OFF;
-# CONVNET_AMD_HALO_DGRAD_BN=1 enables it (A/B).
-HALO_DGRAD_BN = os.environ.get('CONVNET_AMD_HALO_DGRAD_BN', '0') == '1'
-
-
-def halo_dgrad_bn_ok(dy, x_shape, K, R, S, stride, pad):
-    N, H, W, C = x_shape
-    return (HALO_DGRAD_BN and FUSE_BN_BWD and _halo3x3_ok(dy, K, C, R, S, stride, pad) and tuple(dy.shape[1:3]) == (H, W))
-
-
 def conv2d_dgrad(dy, w_crsk, x_shape, K, R, S, stride, pad, addend=None, bn=None, addend_sub=1):
     """dx (NHWC).  With bn = (bn_y, bn_mask_or_None, bn_stats[4C], relu) the epilogue also does the
     reduction half of that BatchNorm's backward: returns (g = dx*relu_mask, partial, rows).
@@ -575,16 +540,6 @@ def conv2d_dgrad(dy, w_crsk, x_shape, K, R, S, stride, pad, addend=None, bn=None
         return dx
     bn_y, bn_mask, bn_stats, bn_relu = bn
     L = _L()
-    if addend is None and bn_mask is None and bn_relu and halo_dgrad_bn_ok(dy, x_shape, K, R, S, stride, pad):
-        rows = L.cn_conv3x3_c64_rows(N, H)
-        partial = torch.empty((rows, 2 * C), dtype=torch.float32, device=dy.device)
-        PROFILER.run(_last_kernel(), 1, flops, nbytes + dx.numel() * _esize(dx) + partial.numel() * 4,
-                     lambda: check(L.cn_conv3x3_c64_dgrad_bnbwd(ptr(dy), ptr(w_crsk), ptr(dx), N, H, W, dtype_code(dy.dtype),
-                                                                ptr(bn_y), ptr(bn_stats), ptr(partial), rows, stream_of(dy)),
-                                   'cn_conv3x3_c64_dgrad_bnbwd'),
-                     dy.device, detail=detail)
-        COUNTERS['halo_dgrad_bn'] = COUNTERS.get('halo_dgrad_bn', 0) + 1
-        return dx, partial, rows
     if JDGRAD and (R, S) == (1, 1) and tuple(stride) == (1, 1) and tuple(pad) == (0, 0) and bn_mask is not None \
             and addend is not None and L.cn_conv2d_dgrad_junction_ok(C, K, dtype_code(dy.dtype)):
         rows = L.cn_conv2d_dgrad_junction_rows_k(N, H, W, C, K)
@@ -959,9 +914,7 @@ class Conv2dFunction(Function):
             final = holder is None or addend is not None
             bn_args = _input_bn_state(mod, x) if (final and FUSE_BN_BWD) else None
             if bn_args is not None and holder is None and x.numel() * _esize(x) > FUSE_BN_BWD_INNER_MB * 2 ** 20 \
-                    and not (FUSE_BN_BWD_INNER_1X1 and (R, S) == (1, 1)) \
-                    and not (bn_args[2] is None and bn_args[4]
-                             and halo_dgrad_bn_ok(dy, x.shape, mod.out_channels, R, S, mod.stride, mod.padding)):
+                    and not (FUSE_BN_BWD_INNER_1X1 and (R, S) == (1, 1)):
                 bn_args = None
             if bn_args is not None and holder is not None and x.numel() * _esize(x) < FUSE_BN_BWD_JUNC_MIN_MB * 2 ** 20:
                 bn_args = None

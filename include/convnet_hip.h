@@ -106,10 +106,6 @@ int cn_conv3x3_c64(const void* x, const void* w, void* y, int N, int H, int W, i
  * the bn1 -> relu -> conv2 sequence of /root/reference models/resnet.py:122-128 in the first stage. */
 int cn_conv3x3_c64_lazya(const void* bn_y, const float* stats, int relu, void* a_out, const void* w, void* y, int N, int H,
                          int W, int dtype, float* partial, int partial_rows, void* stream);
-/* cn_conv2d_dgrad_bnbwd_sa's contract (no addend, ReLU recomputed from bn_y: bn_mask = NULL, relu = 1) on the halo kernel:
- * g = dx * relu_mask and cn_conv3x3_c64_rows partial rows [sum g | sum g * xhat] for cn_bn_bwd_partials. */
-int cn_conv3x3_c64_dgrad_bnbwd(const void* dy, const void* w_crsk, void* g, int N, int H, int W, int dtype, const void* bn_y,
-                               const float* bn_stats, float* partial, int partial_rows, void* stream);
 /* The 7x7 / stride-2 stem (/root/reference models/resnet.py:226) on the pixel-pair image of cn_nchw_to_pairs as a halo
  * kernel (csrc/stem.hip): y[n][oy][ox][k] = sum_{r<7, s2<4, e<8} xp[n][2*oy + r][ox + s2][e] * wp[k][r][s2][e], i.e.
  * cn_conv2d_fwd_bnstats on the pair image (R = 7, S = 4, stride (2, 1), no padding) with 64 output channels; the input
@@ -140,13 +136,6 @@ int cn_stem_wgrad(const void* xp, const void* dy, float* dwp, int N, int Hp, int
 int cn_conv2d_fwd_lazyz(const void* bn_y, const void* res, const float* stats, const float* res_stats, int relu, void* z,
                         unsigned char* z_mask, const void* w_krsc, void* y, int N, int H, int W, int C, int K, int dtype,
                         float* partial, int partial_rows, const float* pivot, void* stream);
-/* conv forward on a BatchNorm INPUT: the operand is act(x*scale[c] + shift[c]) (xf = [scale | shift], 2*C floats =
- * stats_out + 2C of cn_bn_fwd_train*), rounded to dtype like cn_bn_fwd_train's z and applied on the operand load, so
- * an inner BatchNorm (models/resnet.py:143-152: bn -> relu -> next conv) needs no apply pass; C <= 512; partial
- * (optional) as in cn_conv2d_fwd_bnstats */
-int cn_conv2d_fwd_xf(const void* x, const float* xf, int xf_relu, const void* w_krsc, void* y, int N, int H, int W,
-                     int C, int K, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w, int dtype,
-                     float* partial, int partial_rows, void* stream);
 int cn_conv2d_dgrad(const void* dy, const void* w_crsk, void* dx, const void* addend /*optional: dx += addend,
                     the residual-branch gradient of models/resnet.py:162 folded into the epilogue*/, int N, int H,
                     int W, int C, int K, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w,

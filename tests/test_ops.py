@@ -877,42 +877,6 @@ def test_igemm_interleaved_dma_issue_is_bit_identical(mode):
 
 
 @pytest.mark.parametrize('mode', MODES)
-def test_wgrad_256x256_tile_matches_128_tile_and_cpu(mode):
-    """wgrad_dma256_kernel (8 waves, 256 x 256 tile; forced with the wgrad_256sq knob) against the 128-wide
-    kernels and the CPU weight gradient: identity gather (1x1), 3x3 with padding, a strided 3x3, ragged Co."""
-    dev = _dev(mode)
-    import convnet_amd as ca
-    ops, L = ca.ops, ca._lib.load()
-    dtype = torch.bfloat16
-    cfgs = [(2, 9, 10, 256, 256, 1, 1, 0), (1, 10, 9, 32, 384, 3, 1, 1)] if mode == 'emul' else \
-        [(8, 14, 14, 1024, 256, 1, 1, 0), (8, 14, 14, 256, 256, 3, 1, 1), (4, 28, 28, 256, 384, 3, 2, 1),
-         (6, 7, 7, 512, 512, 3, 1, 1)]
-    try:
-        L.cn_set_option(b'wgrad_3x3', 0)      # the tile kernels under test (3x3 / stride 1 normally takes the band kernel)
-        for (N, H, W, C, K, R, st, pad) in cfgs:
-            g = torch.Generator().manual_seed(K + H + R)
-            P, Q = (H + 2 * pad - R) // st + 1, (W + 2 * pad - R) // st + 1
-            x = torch.randn(N, C, H, W, generator=g)
-            dy = torch.randn(N, K, P, Q, generator=g)
-            xh, dyh = _nhwc(x, dtype, dev), _nhwc(dy, dtype, dev)
-            ref = torch.nn.grad.conv2d_weight(xh.float().cpu().permute(0, 3, 1, 2), (K, C, R, R),
-                                              dyh.float().cpu().permute(0, 3, 1, 2), st, pad)
-            outs = {}
-            for big in (0, 1):
-                L.cn_set_option(b'wgrad_256sq', big)
-                dw = torch.zeros(K, R, R, C, device=dev)
-                ops.conv2d_wgrad(xh, dyh, dw, C, K, R, R, (st, st), (pad, pad), beta=0.0)
-                name = L.cn_last_kernel_name().decode()
-                assert ('dma256' in name) == bool(big), name
-                outs[big] = dw.cpu().permute(0, 3, 1, 2)
-            assert rel_l2(outs[1], ref) < 2e-5 and rel_l2(outs[0], ref) < 2e-5
-            assert rel_l2(outs[1], outs[0]) < 1e-5
-    finally:
-        L.cn_set_option(b'wgrad_256sq', 0)
-        L.cn_set_option(b'wgrad_3x3', 1)
-
-
-@pytest.mark.parametrize('mode', MODES)
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 def test_wgrad_3x3_band_kernel(mode, dtype):
     """wgrad3x3_kernel (round 3): 3x3 / stride 1 / pad 1 weight gradients with the activation staged once per band of
@@ -960,65 +924,6 @@ def test_wgrad_3x3_band_kernel(mode, dtype):
         dw2 = torch.full((K, 3, 3, C), 0.5, device=dev)
         ops.conv2d_wgrad(xh, dyh, dw2, C, K, 3, 3, (1, 1), (1, 1), beta=1.0, scale=0.25)
         assert rel_l2(dw2.cpu().permute(0, 3, 1, 2), 0.5 + 0.25 * outs[1]) < 2e-5
-
-
-@pytest.mark.parametrize('mode', MODES)
-@pytest.mark.parametrize('dtype', DTYPES)
-def test_conv_with_batchnorm_apply_folded_into_the_operand_load(mode, dtype):
-    """cn_conv2d_fwd_xf(y, [scale | shift]) == conv(relu(bn_apply(y))) bit for bit (the transform rounds to the
-    compute dtype exactly like bn_apply stores z; padded taps stay zero), with and without the statistics epilogue."""
-    _f16_emul_subset(mode, dtype)
-    dev = _dev(mode)
-    import convnet_amd as ca
-    ops, L = ca.ops, ca._lib.load()
-    cfgs = [(2, 9, 8, 16, 64, 3, 1, 1), (2, 7, 6, 32, 136, 1, 1, 0), (1, 12, 11, 16, 72, 3, 2, 1)] if mode == 'emul' else \
-        [(8, 56, 56, 64, 64, 3, 1, 1), (8, 56, 56, 64, 256, 1, 1, 0), (4, 56, 56, 128, 128, 3, 2, 1),
-         (8, 14, 14, 256, 1024, 1, 1, 0), (4, 7, 7, 512, 2048, 1, 1, 0), (3, 17, 13, 64, 72, 3, 2, 1)]
-    for (N, H, W, C, K, R, st, pad) in cfgs:
-        if dtype != torch.float32 and C % 8:
-            continue
-        g = torch.Generator().manual_seed(K + H)
-        yh = _nhwc(torch.randn(N, C, H, W, generator=g) * 1.5 + 0.3, dtype, dev)
-        wk = (torch.randn(K, R, R, C, generator=g) * (2.0 / (C * R * R)) ** 0.5).to(dtype).to(dev)
-        bn = ca.nn.BatchNorm2d(C)
-        with torch.no_grad():
-            bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
-            bn.bias.copy_(torch.randn(C, generator=g) * 0.2)
-        ca.engine.prepare(torch.nn.Sequential(bn), dev, dtype)
-        bn.train()
-        with torch.no_grad():
-            fn = ops.BatchNormActFunction
-            z = fn.apply(yh, bn.weight, bn.bias, None, bn, True)
-        stats = bn._last_stats if hasattr(bn, '_last_stats') else None
-        # scale / shift of the batch statistics, as cn_bn_fwd_train wrote them (stats_out + 2C)
-        M = N * H * W
-        st4 = torch.empty(4 * C, dtype=torch.float32, device=dev)
-        z2 = torch.empty_like(yh)
-        ws = ops.workspace(L.cn_bn_workspace(M, C, ca._lib.dtype_code(dtype)), dev)
-        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
-        ca._lib.check(L.cn_bn_fwd_train(yh.data_ptr(), None, z2.data_ptr(), None, bn.weight.data_ptr(), bn.bias.data_ptr(),
-                                        rm.data_ptr(), rv.data_ptr(), None, 0.1, bn.eps, st4.data_ptr(), M, C, 1,
-                                        ca._lib.dtype_code(dtype), ws.data_ptr(), ws.numel() * 4, ca._lib.stream_of(yh)))
-        assert torch.equal(z2.cpu(), z.cpu())
-        xf = st4[2 * C:]
-        L.cn_set_option(b'igemm_variant', 1)
-        try:
-            ref = ops.conv2d_fwd(z2, wk, None, K, R, R, (st, st), (pad, pad))
-            got = ops.conv2d_fwd_xf(yh, xf, True, wk, K, R, R, (st, st), (pad, pad))
-            assert torch.equal(got.cpu(), ref.cpu()), (N, H, W, C, K, R, st, pad)
-            ref_s = ops.conv2d_fwd(z2, wk, None, K, R, R, (st, st), (pad, pad), bn_stats=True)
-            pr = ops.take_pending_stats(ref_s)
-            got_s = ops.conv2d_fwd_xf(yh, xf, True, wk, K, R, R, (st, st), (pad, pad), bn_stats=True)
-            pg = ops.take_pending_stats(got_s)
-            # the stored outputs are the same bits; the plain convolution may run the eight-wave form of the tile
-            # (igemm_8w), which associates the per-tile statistics over 512 instead of 256 threads
-            assert torch.equal(got_s.cpu(), ref_s.cpu())
-            if pg.partial.shape == pr.partial.shape:
-                assert torch.allclose(pg.partial.cpu(), pr.partial.cpu(), rtol=1e-5, atol=1e-4)
-            else:   # (the 64-channel 3x3 layers run on the halo kernel: one partial row per workgroup, not per 128 pixels)
-                assert rel_l2(pg.partial.double().sum(0).cpu(), pr.partial.double().sum(0).cpu()) < 1e-5
-        finally:
-            L.cn_set_option(b'igemm_variant', 0)
 
 
 @pytest.mark.parametrize('mode', MODES)
@@ -1253,11 +1158,13 @@ def test_streaming_junction_dgrad_equals_tiled_epilogue_kernel(mode, dtype):
     ops, L = ca.ops, ca._lib.load()
     if mode == 'emul':
         cases = [(1, 6, 10, 256, 64, 1, 3), (2, 6, 6, 256, 128, 2, 2), (1, 5, 9, 512, 128, 1, 5), (1, 4, 6, 512, 256, 2, 2),
-                 (1, 3, 5, 1024, 256, 1, 3), (1, 3, 3, 1024, 512, 2, 2)]
+                 (1, 3, 5, 1024, 256, 1, 3)]
     else:
+        # (the last three: the bench's own sizes, N = 256)
         cases = [(8, 56, 56, 256, 64, 1, 256), (8, 56, 56, 256, 128, 2, 256), (16, 28, 28, 512, 128, 1, 256),
                  (3, 17, 13, 256, 64, 2, 7), (2, 9, 11, 512, 128, 1, 256), (16, 28, 28, 512, 256, 2, 256),
-                 (32, 14, 14, 1024, 256, 1, 256), (32, 7, 7, 2048, 512, 1, 256), (8, 14, 14, 1024, 512, 2, 256)]
+                 (32, 14, 14, 1024, 256, 1, 256), (256, 56, 56, 256, 64, 1, 256), (256, 28, 28, 512, 128, 1, 256),
+                 (256, 14, 14, 1024, 256, 1, 256)]
     for (N, H, W, C, K, sub, splits) in cases:
         g_ = torch.Generator().manual_seed(C + K + H)
         M = N * H * W
@@ -1285,23 +1192,13 @@ def test_streaming_junction_dgrad_equals_tiled_epilogue_kernel(mode, dtype):
             assert 'igemm_kernel' in L.cn_last_kernel_name().decode()
             ops.JDGRAD = True
             L.cn_set_option(b'jdgrad_splits', splits)
-            L.cn_set_option(b'jdgrad_k512', 1)      # (the 512-channel-reduction form is off by default)
             g1, p1, r1 = ops.conv2d_dgrad(dyh, wc, (N, H, W, C), K, 1, 1, (1, 1), (0, 0), addend=addend,
                                           bn=(bn_y, bits, stats, True), addend_sub=sub)
             assert ('jdgrad_w32_kernel' if K >= 256 else 'jdgrad_kernel') in L.cn_last_kernel_name().decode()
             assert r1 == L.cn_conv2d_dgrad_junction_rows_k(N, H, W, C, K)
-            if K == 256:      # the 64-channel-wave form of the 256-channel reductions (knob jdgrad_k256 = 1): same bits
-                L.cn_set_option(b'jdgrad_k256', 1)
-                g2, p2, r2 = ops.conv2d_dgrad(dyh, wc, (N, H, W, C), K, 1, 1, (1, 1), (0, 0), addend=addend,
-                                              bn=(bn_y, bits, stats, True), addend_sub=sub)
-                assert 'jdgrad_kernel' in L.cn_last_kernel_name().decode()
-                assert torch.equal(g2.cpu(), g0.cpu()), (N, H, W, C, K, sub)
-                assert rel_l2(p2.double().sum(0).cpu(), p1.double().sum(0).cpu()) < 5e-5
         finally:
             ops.JDGRAD = saved
             L.cn_set_option(b'jdgrad_splits', 256)
-            L.cn_set_option(b'jdgrad_k256', 2)
-            L.cn_set_option(b'jdgrad_k512', 0)
         assert tuple(p1.shape) == (r1, 2 * C) and r1 <= max(splits, 1)
         assert torch.equal(g1.cpu(), g0.cpu()), (N, H, W, C, K, sub)
         s0, s1 = p0.double().sum(0), p1.double().sum(0)
@@ -1470,6 +1367,12 @@ def test_streaming_conv1x1_forward_equals_tiled_kernel(mode, dtype):
             ops.CONV1X1_STREAM = saved
         assert torch.equal(y1.cpu(), y0.cpu()) and torch.equal(y2.cpu(), y0.cpu()), (N, H, W, C, K)
         assert rel_l2(p1.partial.double().sum(0).cpu(), p0.partial.double().sum(0).cpu()) < 1e-5
+        # ... and against the definition on the CPU (fp32 product of the same 16-bit operands; sums of the stored values)
+        y_cpu = x.float().cpu().reshape(-1, C) @ w.float().cpu().reshape(K, C).t()
+        assert rel_l2(y1.float().cpu().reshape(-1, K), y_cpu) < _tol(dtype), (N, H, W, C, K)
+        yd = y1.double().cpu().reshape(-1, K)
+        ps = p1.partial.double().sum(0).cpu()
+        assert rel_l2(ps[:K], yd.sum(0)) < 1e-5 and rel_l2(ps[K:], (yd * yd).sum(0)) < 1e-5, (N, H, W, C, K)
 
 
 @pytest.mark.parametrize('mode', MODES)
@@ -1511,39 +1414,14 @@ def test_lazy_a_conv_equals_apply_then_conv(mode, dtype):
             assert torch.equal(out1.cpu(), out0.cpu()), (N, H, W, C, K, relu)
             if p0 is not None or p1 is not None:
                 assert p0.rows == p1.rows and torch.equal(p1.partial.cpu(), p0.partial.cpu())
-
-
-@pytest.mark.parametrize('mode', MODES)
-@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
-def test_conv3x3_halo_dgrad_with_bn_backward_reduction_equals_tiled_kernel(mode, dtype):
-    """cn_conv3x3_c64_dgrad_bnbwd (the halo data gradient masking with the ReLU of the BatchNorm in front of the
-    convolution and reducing for its backward) against the tiled cn_conv2d_dgrad_bnbwd_sa: g bit for bit, the partial
-    column sums to fp32 association."""
-    _f16_emul_subset(mode, dtype, keep=True)
-    dev = _dev(mode)
-    import convnet_amd as ca
-    ops, L = ca.ops, ca._lib.load()
-    C = K = 64
-    for (N, H, W) in ([(1, 6, 7), (2, 5, 4)] if mode == 'emul' else [(8, 56, 56), (3, 17, 13), (2, 9, 56)]):
-        g_ = torch.Generator().manual_seed(N * H + W)
-        dy = torch.randn(N, H, W, K, generator=g_).to(dtype).to(dev)
-        wc = (torch.randn(C, 3, 3, K, generator=g_) * (2.0 / (9 * K)) ** 0.5).to(dtype).to(dev)
-        bn_y = (torch.randn(N, H, W, C, generator=g_) * 1.5 + 0.2).to(dtype).to(dev)
-        stats = torch.cat([torch.randn(C, generator=g_) * 0.3, torch.rand(C, generator=g_) + 0.5,
-                           torch.rand(C, generator=g_) + 0.5, torch.randn(C, generator=g_) * 0.4]).to(dev)
-        saved = ops.HALO_DGRAD_BN
-        try:
-            ops.HALO_DGRAD_BN = False
-            g0, p0, r0 = ops.conv2d_dgrad(dy, wc, (N, H, W, C), K, 3, 3, (1, 1), (1, 1), bn=(bn_y, None, stats, True))
-            assert 'igemm_kernel' in L.cn_last_kernel_name().decode()
-            ops.HALO_DGRAD_BN = True
-            g1, p1, r1 = ops.conv2d_dgrad(dy, wc, (N, H, W, C), K, 3, 3, (1, 1), (1, 1), bn=(bn_y, None, stats, True))
-            assert 'conv3x3_c64_kernel' in L.cn_last_kernel_name().decode() and 'false, true' in L.cn_last_kernel_name().decode()
-        finally:
-            ops.HALO_DGRAD_BN = saved
-        assert torch.equal(g1.cpu(), g0.cpu()), (N, H, W)
-        s0, s1 = p0[:r0].double().sum(0).cpu(), p1[:r1].double().sum(0).cpu()
-        assert rel_l2(s1[:C], s0[:C]) < 1e-5 and rel_l2(s1[C:], s0[C:]) < 1e-4, (N, H, W)
+            # ... and against the definition on the CPU: batch statistics of y2, a = relu?(bn(y2)), out = conv1x1(a)
+            yc = y2.float().cpu().reshape(-1, C)
+            mean, var = yc.double().mean(0), yc.double().var(0, unbiased=False)
+            a_cpu = ((yc.double() - mean) / (var + 1e-5).sqrt() * gamma.double().cpu() + beta.double().cpu()).float()
+            a_cpu = a_cpu.clamp_min(0) if relu else a_cpu
+            assert rel_l2(a1.float().cpu().reshape(-1, C), a_cpu) < _tol(dtype), (N, H, W, C, K, relu)
+            out_cpu = a1.float().cpu().reshape(-1, C) @ w.float().cpu().reshape(K, C).t()
+            assert rel_l2(out1.float().cpu().reshape(-1, K), out_cpu) < _tol(dtype), (N, H, W, C, K, relu)
 
 
 @pytest.mark.parametrize('mode', MODES)
@@ -1584,6 +1462,14 @@ def test_lazy_a_conv3x3_halo_equals_apply_then_conv(mode, dtype):
             assert torch.equal(out1.cpu(), out0.cpu()), (N, H, W, relu)
             if p0 is not None or p1 is not None:
                 assert p0.rows == p1.rows and torch.equal(p1.partial.cpu(), p0.partial.cpu())
+            # ... and against the definition on the CPU: a = relu?(bn(y1)) with batch statistics, out = conv3x3(a), pad 1
+            yc = y1.float().cpu().reshape(-1, C)
+            mean, var = yc.double().mean(0), yc.double().var(0, unbiased=False)
+            a_cpu = ((yc.double() - mean) / (var + 1e-5).sqrt() * gamma.double().cpu() + beta.double().cpu()).float()
+            a_cpu = a_cpu.clamp_min(0) if relu else a_cpu
+            assert rel_l2(a1.float().cpu().reshape(-1, C), a_cpu) < _tol(dtype), (N, H, W, relu)
+            out_cpu = F.conv2d(a1.float().cpu().permute(0, 3, 1, 2), w.float().cpu().permute(0, 3, 1, 2), padding=1)
+            assert rel_l2(out1.float().cpu().permute(0, 3, 1, 2), out_cpu) < _tol(dtype), (N, H, W, relu)
 
 
 @pytest.mark.parametrize('mode', MODES)

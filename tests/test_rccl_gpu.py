@@ -118,6 +118,39 @@ def test_bench_self_launches_its_ranks(tmp_path):
     assert r2.returncode != 0 and 'WORLD_SIZE' in (r2.stdout + r2.stderr)
 
 
+def test_bench_eight_rank_protocol_under_the_drivers_launcher(tmp_path):
+    """the 8-GPU run is the driver's, on a node this build never sees - so its PROTOCOL is exercised
+    here with eight ranks sharing the one device (BENCH_SHARE_GPU=1: gloo collectives, RCCL refuses two ranks per device),
+    launched exactly as the driver launches it (`python -m torch.distributed.run --nnodes=1 --nproc-per-node 8
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 --steps K --warmup W`): rendezvous, WORLD_SIZE / RANK /
+    LOCAL_RANK handling, the barrier-bracketed timed region with the MAX over ranks, and ONE contract line, from rank 0
+    only, that says n_gpus = 8, global batch = 8 x per-GPU batch, weak scaling, `transport_fallback` false (gloo here is
+    asked for, not a recovery) and which device every rank used.  Reference: /root/reference/main.py:145-156,
+    trainer.py:79-82."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, BENCH_SHARE_GPU='1', CONVNET_AMD_EMULATE='0')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '3',
+           '--warmup', '2', '--batch', '4', '--no-cpu-baseline', '--no-kernel-profile']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.split('\n') if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]          # rank 0 only
+    assert [l for l in r.stdout.split('\n') if l.strip()][-1] == lines[0]
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 8 and rec['steps'] == 3 and rec['warmup'] == 2 and rec['scaling'] == 'weak'
+    assert rec['config']['global_batch'] == 32 and rec['config']['parallelism'] == 'dp8'
+    assert rec['config']['rank_devices'] == [0] * 8          # (a full node: [0, 1, ..., 7])
+    assert 'gloo' in rec['config']['transport'] and rec['transport_fallback'] is False
+    assert abs(rec['value'] - 32 * 1e3 / rec['ms_per_step']) / rec['value'] < 1e-3
+    assert len(lines[0]) < 8192
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # >= 2 devices: the direct-RCCL transport with more than one rank (VERDICT r2 item 4)
 NDEV = torch.cuda.device_count() if torch.cuda.is_available() else 0

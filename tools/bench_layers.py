@@ -84,17 +84,11 @@ def main():
             tot[('dgrad', v)] += ms * cnt
             cols_d.append('%8.3f %6.0f' % (ms, gf / ms))
         L.cn_set_option(b'igemm_variant', 0)
-        L.cn_set_option(b'wgrad_256sq', 0)
         msw = timeit(lambda: ca.ops.conv2d_wgrad(x, dy, dw, C, K, R, R, (st, st), (pad, pad), beta=0.0), args.iters)
-        L.cn_set_option(b'wgrad_256sq', 1)
-        msw2 = timeit(lambda: ca.ops.conv2d_wgrad(x, dy, dw, C, K, R, R, (st, st), (pad, pad), beta=0.0), args.iters)
-        used256 = 'dma256' in L.cn_last_kernel_name().decode()
-        L.cn_set_option(b'wgrad_256sq', 0)
         tot['wgrad'] += msw * cnt
-        tot['wgrad256'] = tot.get('wgrad256', 0.0) + (msw2 if used256 else msw) * cnt
-        print('%dx %4d,%3d -> %4d, %dx%d/%d %12s %5.0f | %s | %s | %8.3f %6.0f %5.0f | 256sq %s' % (
+        print('%dx %4d,%3d -> %4d, %dx%d/%d %12s %5.0f | %s | %s | %8.3f %6.0f %5.0f' % (
             cnt, C, H, K, R, R, st, '', gf, ' '.join(cols), ' '.join(cols_d), msw, gf / msw,
-            (x.numel() + dy.numel()) * 2 / 1e9 / msw * 1e3, ('%8.3f %6.0f' % (msw2, gf / msw2)) if used256 else '       -'))
+            (x.numel() + dy.numel()) * 2 / 1e9 / msw * 1e3))
         del x, w, wc, dy, dw
     print('TOTAL per step (ms): ' + '  '.join('%s=%.2f' % (str(k), v) for k, v in tot.items()))
 
