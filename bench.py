@@ -81,7 +81,7 @@ def run_pmc_passes(args):
     if shutil.which('rocprofv3') is None:
         return None
     tmp = tempfile.mkdtemp(prefix='bench_pmc_', dir='/tmp')
-    env = dict(os.environ, TMPDIR='/tmp', CONVNET_AMD_GRAPH='0')
+    env = dict(os.environ, TMPDIR='/tmp', CONVNET_AMD_FLAGS=','.join(filter(None, [os.environ.get('CONVNET_AMD_FLAGS', ''), 'graph=0'])))
     cmd = [sys.executable, os.path.abspath(__file__), '--steps', '2', '--warmup', '1', '--no-cpu-baseline',
            '--no-kernel-profile', '--batch', str(args.batch), '--depth', str(args.depth), '--dtype', args.dtype] + \
         (['--quantize'] if args.quantize else [])

@@ -34,8 +34,6 @@ _SIGNATURES = {
     'cn_build_info': (ctypes.c_char_p, []),
     'cn_last_kernel_name': (ctypes.c_char_p, []),
     'cn_kernel_log': (ctypes.c_char_p, [c_i]),
-    'cn_stream_create_masked': (c_i, [c_i, c_i, c_p]),
-    'cn_stream_destroy': (c_i, [c_p]),
     'cn_is_emulator': (c_i, []),
     'cn_set_option': (c_i, [ctypes.c_char_p, c_i]),
     'cn_stream_fork': (c_i, [c_p, c_p]),

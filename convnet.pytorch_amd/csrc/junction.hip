@@ -906,11 +906,9 @@ __global__ __launch_bounds__(512) void jdlazy_kernel(JlParams p) {
 }
 
 extern "C" int cn_conv2d_dgrad_lazy_stream_ok(int C, int K, int dtype) {   // K gradient channels -> C input channels
-  // 0 off, 1 both shapes, 2 only 512 -> 128 (default: the 512 -> 256 launch - the second stage's projection, once per
-  // step - goes from ~276 to ~130 us on this kernel and the step does not move, 17.56 vs 17.57 ms: by then the side
-  // stream's weight gradients are what the step waits for; profiles/r03_ab_second_session_whole_step.txt)
-  const int mode = cn_get_option("jdlazy", 2);
-  return (dtype == CN_BF16 || dtype == CN_F16) && K == 512 && (C == 128 || (C == 256 && mode == 1)) && mode != 0 ? 1 : 0;
+  // 512 -> 128 (conv3 of the second stage) and 512 -> 256 (that stage's stride-2 projection on its coarse grid: once per
+  // step, ~276 -> ~130 us on this kernel; the step does not move either way, round 3 and round 4 A/Bs)
+  return (dtype == CN_BF16 || dtype == CN_F16) && K == 512 && (C == 128 || C == 256) ? 1 : 0;
 }
 // cn_conv2d_dgrad_lazy for a 1x1 / stride-1 convolution of an instantiated shape (512 -> 128 or 256 channels) as a
 // persistent streaming kernel.  Same bits.

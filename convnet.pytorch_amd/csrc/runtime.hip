@@ -158,38 +158,6 @@ extern "C" int cn_stream_wait_mark(int handle, void* to_stream) {
 #endif
 }
 
-// A stream restricted to a share of the compute units (hipExtStreamCreateWithCUMask): `eighths` of every group of
-// eight consecutive CU-mask bits are enabled (1..8), so the share is spread evenly whatever the bit -> XCD mapping is.
-// Used for the weight-gradient side stream: on a step that is HBM-bound a side stream that owns every CU takes
-// bandwidth from the critical chain it is meant to fill gaps of.  The caller owns the stream (cn_stream_destroy).
-extern "C" int cn_stream_create_masked(int eighths, int priority, void** out) {
-#ifdef CN_EMULATE
-  (void)eighths; (void)priority;
-  if (out) *out = nullptr;
-  cn_set_error("stream_create_masked: not available in the emulator build");
-  return CN_EHIP;
-#else
-  if (out == nullptr || eighths < 1 || eighths > 8) { cn_set_error("stream_create_masked: eighths must be 1..8"); return CN_EINVAL; }
-  const unsigned int byte = (unsigned int)((1u << eighths) - 1u);
-  uint32_t mask[8];
-  for (int i = 0; i < 8; ++i) mask[i] = byte * 0x01010101u;
-  hipStream_t st = nullptr;
-  (void)priority;
-  hipError_t e = hipExtStreamCreateWithCUMask(&st, 8, mask);
-  if (e != hipSuccess) { cn_set_error("stream_create_masked: %s", hipGetErrorString(e)); return CN_EHIP; }
-  *out = (void*)st;
-  return CN_OK;
-#endif
-}
-extern "C" int cn_stream_destroy(void* stream) {
-#ifndef CN_EMULATE
-  if (stream != nullptr && hipStreamDestroy((hipStream_t)stream) != hipSuccess) { cn_set_error("stream_destroy failed"); return CN_EHIP; }
-#else
-  (void)stream;
-#endif
-  return CN_OK;
-}
-
 extern "C" int cn_is_emulator(void) {
 #ifdef CN_EMULATE
   return 1;

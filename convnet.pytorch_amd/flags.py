@@ -32,6 +32,7 @@ _DEFAULTS = {
     'subsampled_shortcut_grad': 1,   # stride-2 projection's input gradient kept on its coarse grid
     'dual_bn': 1,              # projection shortcut's BatchNorm applied inside the junction's apply pass
     'lazy_dy': 1,              # junction BatchNorm-backward apply left to conv3's / the projection's dgrad + wgrad
+    'lazy_min_mb': LAZY_MIN_BYTES / 2 ** 20,   # lazy dy / lazy z for junction tensors of at least this size
     'lazy_z': 1,               # junction apply left to the next block's conv1
     'lazy_a': '1',             # inner BatchNorm apply left to its streaming / halo consumer ('1x1': 1x1 consumers only)
     'jpair': 1,                # dgrad + wgrad of a lazy-dy 64 -> 256 convolution in one pass (fp32 summation order differs)

@@ -15,7 +15,7 @@ import torch
 import torch.distributed as dist
 from torch.autograd import Function
 
-from . import _lib
+from . import _lib, flags
 from ._lib import check, dtype_code, ptr, stream_of
 
 # ---------------------------------------------------------------------------------------------
@@ -105,64 +105,40 @@ class KernelProfiler(object):
 
 
 PROFILER = KernelProfiler()
-# CONVNET_AMD_SUBSAMPLED_SHORTCUT_GRAD=0: the stride-2 projection shortcut's input gradient as a dense tensor (A/B knob)
-SUBSAMPLED_SHORTCUT_GRAD = os.environ.get('CONVNET_AMD_SUBSAMPLED_SHORTCUT_GRAD', '1') == '1'
-# CONVNET_AMD_STEM_XMAX=0: the fused stem's BatchNorm-backward sums over the input map with the pool gather (A/B knob)
-STEM_XMAX = os.environ.get('CONVNET_AMD_STEM_XMAX', '1') == '1'
-# CONVNET_AMD_CENTERED_STATS=0: plain sum / sum-of-squares statistics partials (A/B knob)
-_cs = os.environ.get('CONVNET_AMD_CENTERED_STATS', '1')   # 0 = never, 1 = fp32 models, all = every dtype
-CENTERED_STATS = 'all' if _cs == 'all' else (_cs == '1')
+# The switches below mirror flags.py (ONE table: defaults, meaning, how to override for an A/B); tests flip these module
+# attributes to compare a fused path with the one it replaces.
+# 0: the stride-2 projection shortcut's input gradient as a dense tensor
+SUBSAMPLED_SHORTCUT_GRAD = flags.on('subsampled_shortcut_grad')
+# 0: the fused stem's BatchNorm-backward sums over the input map with the pool gather
+STEM_XMAX = flags.on('stem_xmax')
+# 0: plain sum / sum-of-squares statistics partials; 1: centred on the running mean for fp32 models; all: every dtype
+CENTERED_STATS = 'all' if flags.text('centered_stats') == 'all' else flags.on('centered_stats')
 
 
 class SideStream(object):
     """Optional second HIP stream for the weight-gradient kernels: wgrad(x, dy) and dgrad(dy, w) of a
     layer are independent, and the late layers' launches are too small to fill 256 CUs on their
     own, so running wgrad beside the main backward stream packs the machine better.
-    Measured +5.2 % on ResNet-50 b=256 (10.04k -> 10.56k img/s).  On by default; CONVNET_AMD_WGRAD_STREAM=0
-    disables it.  Trainer / BucketReducer join the stream before the gradient all-reduce and the
-    optimizer step; while the KernelProfiler is recording everything stays on one stream."""
+    Measured +5.2 % on ResNet-50 b=256 (10.04k -> 10.56k img/s).  On by default (flag wgrad_stream).  Trainer /
+    BucketReducer join the stream before the gradient all-reduce and the optimizer step; while the KernelProfiler is
+    recording in "alone" mode everything stays on one stream.  ONE side stream at the runtime's default priority, all
+    CUs: two or three streams, a high-priority side stream and CU masks were measured slower or neutral
+    (profiles/r03_ab_whole_step_knobs.txt, profiles/r04_ab_wgrad_reduce_lanes_and_side_streams_rejected.txt)."""
 
     def __init__(self):
-        self.enabled = os.environ.get('CONVNET_AMD_WGRAD_STREAM', '1') == '1'
-        # CONVNET_AMD_WGRAD_STREAMS: number of side streams the weight-gradient launches rotate over (A/B knob)
-        self.nstreams = max(1, int(os.environ.get('CONVNET_AMD_WGRAD_STREAMS', '1')))
+        self.enabled = flags.on('wgrad_stream')
         self._streams = {}
-        self._rr = 0
         self.used = False
-        # CONVNET_AMD_MARKS=0: always hand off with an event record (A/B knob)
-        self.marks = os.environ.get('CONVNET_AMD_MARKS', '1') == '1'
+        self.marks = flags.on('marks')     # 0: always hand off with an event record
         self.capturing = False      # set by Trainer around HIP-graph capture
         self._mark = None
 
-    def _all(self, device):
-        ss = self._streams.get(device)
-        if ss is None:
-            # CONVNET_AMD_WGRAD_STREAM_PRIO: HIP stream priority of the side stream (A/B knob; default = the
-            # runtime's default priority)
-            prio = os.environ.get('CONVNET_AMD_WGRAD_STREAM_PRIO')
-            # CONVNET_AMD_WGRAD_CUS = 1..7: the side stream owns that many eighths of the compute units (A/B knob)
-            share = int(os.environ.get('CONVNET_AMD_WGRAD_CUS', '8'))
-            if 1 <= share <= 7:
-                import ctypes
-                ss = []
-                for _ in range(self.nstreams):
-                    h = ctypes.c_void_p()
-                    with torch.cuda.device(device):
-                        check(_L().cn_stream_create_masked(share, 0, ctypes.byref(h)), 'cn_stream_create_masked')
-                    ss.append(torch.cuda.ExternalStream(h.value, device=device))
-            else:
-                ss = [torch.cuda.Stream(device, priority=int(prio)) if prio is not None else torch.cuda.Stream(device)
-                      for _ in range(self.nstreams)]
-            self._streams[device] = ss
-        return ss
-
     def get(self, device):
-        """The side stream the next weight-gradient launch goes to (stream 0 when there is only one)."""
-        ss = self._all(device)
-        if len(ss) == 1:
-            return ss[0]
-        self._rr = (self._rr + 1) % len(ss)
-        return ss[self._rr]
+        """The side stream the weight-gradient launches go to."""
+        st = self._streams.get(device)
+        if st is None:
+            st = self._streams[device] = torch.cuda.Stream(device)
+        return st
 
     @contextlib.contextmanager
     def mark(self, dy):
@@ -198,12 +174,8 @@ class SideStream(object):
         notify()
 
     def gather(self, device):
-        """Stream 0 after it has been made to wait for the other side streams: the one stream a collective
-        (or a join) has to order itself behind."""
-        ss = self._all(device)
-        for s in ss[1:]:
-            ss[0].wait_stream(s)
-        return ss[0]
+        """The stream a collective (or a join) has to order itself behind."""
+        return self.get(device)
 
     def active(self, t):
         # not while a HIP graph is being captured: a replayed graph runs faster as one chain (b=8 +4 %, b=32 +3 %,
@@ -254,65 +226,54 @@ def conv_out_hw(H, W, R, S, stride, pad):
 # ---------------------------------------------------------------------------------------------
 # raw (non-autograd) kernel calls
 
-# A/B switch: 0 = every BatchNorm re-reads its input for the statistics (bn_stats_kernel)
-FUSE_BN_STATS = os.environ.get('CONVNET_AMD_FUSE_BN_STATS', '1') != '0'
-# statistics epilogue only for conv outputs of at least this many MB (A/B knob; 0 = always)
-FUSE_BN_STATS_MIN_MB = float(os.environ.get('CONVNET_AMD_FUSE_BN_STATS_MIN_MB', '0'))
-# A/B switch: 0 = the stem runs as a 49-tap conv on a 3->8 channel padded image instead of the pixel-pair form
-STEM_PAIRS = os.environ.get('CONVNET_AMD_STEM_PAIRS', '1') != '0'
-# A/B switch: 0 = the pixel-pair stem runs through the tiled implicit-GEMM kernel instead of the halo kernel (csrc/stem.hip)
-STEM_HALO = os.environ.get('CONVNET_AMD_STEM_HALO', '1') != '0'
-# A/B switch: 0 = the 64 -> 64 channel 3x3 convolutions run through the tiled implicit-GEMM kernel instead of the halo
-# kernel (csrc/conv3x3.hip)
-CONV3X3_HALO = os.environ.get('CONVNET_AMD_CONV3X3_HALO', '1') != '0'
-# A/B switch: 0 = conv3 / the stride-1 projection forward through the tiled kernel instead of the streaming kernel
-CONV1X1_STREAM = os.environ.get('CONVNET_AMD_CONV1X1_STREAM', '1') != '0'
-CONV1X1_STREAM_MAXK = int(os.environ.get('CONVNET_AMD_CONV1X1_STREAM_MAXK', '1024'))   # (A/B: 512 = without the 256 -> 1024 form)
-# A/B switch: 0 = the stem's bn1 -> relu -> maxpool runs as separate BatchNorm and max-pool passes
-FUSE_STEM_POOL = os.environ.get('CONVNET_AMD_FUSE_STEM_POOL', '1') != '0'
-# A/B switch: 0 = BatchNorm backward always runs its own reduction pass over (dz, y)
-FUSE_BN_BWD = os.environ.get('CONVNET_AMD_FUSE_BN_BWD', '1') != '0'
-# The fusion always pays at the residual junctions (the epilogue adds the other branch's gradient anyway and
-# no dres tensor is written).  For the BNs inside a block it only pays while the activation is small:
-# measured per layer (profiles/r01_epilogue_fusions_per_layer.txt) the epilogue costs more than the
-# standalone reduction pass it removes on the 56x56 / 28x28 maps and is a wash on the small ones; whole-step
-# A/B: junctions only 21.34 ms vs everywhere 21.71 ms.  Threshold in MB of the BN input (0 = junctions only).
-FUSE_BN_BWD_INNER_MB = float(os.environ.get('CONVNET_AMD_FUSE_BN_BWD_INNER_MB', '0'))
-# A/B knob: 1 = the BNs inside a block whose upstream gradient comes out of a 1x1 dgrad (bn2 of a bottleneck, behind
-# conv3) take the fused reduction too (a bandwidth-bound producer: the epilogue's extra read replaces a two-tensor pass)
-FUSE_BN_BWD_INNER_1X1 = os.environ.get('CONVNET_AMD_FUSE_BN_BWD_INNER_1X1', '0') == '1'
+# 0 = every BatchNorm re-reads its input for the statistics (bn_stats_kernel)
+FUSE_BN_STATS = flags.on('fuse_bn_stats')
+# 0 = the stem runs as a 49-tap conv on a 3->8 channel padded image instead of the pixel-pair form
+STEM_PAIRS = flags.on('stem_pairs')
+# 0 = the pixel-pair stem runs through the tiled implicit-GEMM kernel instead of the halo kernel (csrc/stem.hip)
+STEM_HALO = flags.on('stem_halo')
+# 0 = the 64 -> 64 channel 3x3 convolutions run through the tiled implicit-GEMM kernel instead of the halo kernel
+# (csrc/conv3x3.hip)
+CONV3X3_HALO = flags.on('conv3x3_halo')
+# 0 = conv3 / the stride-1 projection forward through the tiled kernel instead of the streaming kernel
+CONV1X1_STREAM = flags.on('conv1x1_stream')
+# 0 = the stem's bn1 -> relu -> maxpool runs as separate BatchNorm and max-pool passes
+FUSE_STEM_POOL = flags.on('fuse_stem_pool')
+# 0 = BatchNorm backward always runs its own reduction pass over (dz, y).  The fusion is used at the residual JUNCTIONS
+# only (the block-input dgrad's epilogue adds the other branch's gradient anyway and no dres tensor is written); at the
+# BatchNorms inside a block the epilogue's extra operand stream costs the producing kernel more than the separate pass
+# costs (profiles/r01_epilogue_fusions_per_layer.txt; whole step: junctions only 21.34 ms vs everywhere 21.71 ms).
+FUSE_BN_BWD = flags.on('fuse_bn_bwd')
 # "Lazy dy" (round 3): at a residual junction whose BatchNorm follows a 1x1 convolution (bn3(conv3(.)), the projection
 # shortcut's BatchNorm) the backward apply pass  dy = c1*g + c2*y + c3  is not run: the convolution's dgrad and wgrad
 # form dy on their operand loads (cn_conv2d_dgrad_lazy / cn_conv2d_wgrad_lazy) - one write and one read of the
-# largest tensors of the step less on the critical chain.  For BN inputs of at least LAZY_DY_MIN_MB (bandwidth-bound
-# layers; the small maps keep the LDS-DMA weight-gradient kernels).  CONVNET_AMD_LAZY_DY=0 disables it (A/B).
-LAZY_DY = os.environ.get('CONVNET_AMD_LAZY_DY', '1') == '1'
-LAZY_DY_MIN_MB = float(os.environ.get('CONVNET_AMD_LAZY_DY_MIN_MB', '150'))
+# largest tensors of the step less on the critical chain.  For BN inputs that every pass streams from HBM
+# (flags.LAZY_MIN_BYTES: 0.6 of the Infinity Cache; the smaller maps keep the LDS-DMA weight-gradient kernels).
+LAZY_DY = flags.on('lazy_dy')
+LAZY_DY_MIN_MB = float(flags.get('lazy_min_mb'))
 # Junction behind a projection shortcut (round 3): the shortcut BatchNorm only finalises its statistics; its apply runs
 # inside the junction BatchNorm's apply pass (cn_bn_apply_dual), so the normalised shortcut tensor is neither written nor
-# re-read.  Bit-identical; CONVNET_AMD_DUAL_BN=0 restores the two apply passes (A/B).
-DUAL_BN = os.environ.get('CONVNET_AMD_DUAL_BN', '1') == '1'
+# re-read.  Bit-identical.
+DUAL_BN = flags.on('dual_bn')
 # "Lazy z" (round 3): a residual junction whose output feeds a 1x1 / stride-1 convolution of at most 128 output channels
 # (the next bottleneck's conv1) is finalised but not applied; that convolution forms z = relu(bn(y) + residual) on its
 # operand load and stores it (cn_conv2d_fwd_lazyz): the junction's apply pass (read y, read residual, write z) and the
 # convolution's re-read of z become one read of y and the residual and one write of z.  Bit-identical.  Only inside a
 # model forward that guarantees the convolution runs next (LAZY_Z_SCOPE, set by ResNetImagenet.features) and for
-# junction tensors of at least LAZY_Z_MIN_MB (bandwidth-bound layers).  CONVNET_AMD_LAZY_Z=0 disables it (A/B).
-LAZY_Z = os.environ.get('CONVNET_AMD_LAZY_Z', '1') == '1'
-LAZY_Z_MIN_MB = float(os.environ.get('CONVNET_AMD_LAZY_Z_MIN_MB', '150'))
+# junction tensors of at least LAZY_Z_MIN_MB (same size rule as lazy dy).
+LAZY_Z = flags.on('lazy_z')
+LAZY_Z_MIN_MB = float(flags.get('lazy_min_mb'))
 LAZY_Z_SCOPE = [0]
 # Junction pair (round 3): where lazy dy applies and the convolution has an instantiated shape (64 -> 256 channels: conv3
 # and the projection of ResNet-50's first stage), its data gradient and weight gradient run as ONE kernel on the backward
 # chain (cn_conv2d_bwd1x1_lazy): g and y are read once instead of twice.  dx bit-identical, dW differs by fp32
-# summation order.  CONVNET_AMD_JPAIR=0: the two lazy kernels (A/B).
-JPAIR = os.environ.get('CONVNET_AMD_JPAIR', '1') == '1'
+# summation order.
+JPAIR = flags.on('jpair')
 # Streaming junction kernel (round 3): the fused junction data gradient (conv1's dgrad + shortcut gradient + ReLU mask +
 # BatchNorm-backward sums) of the instantiated large shapes runs as one persistent streaming kernel
 # (cn_conv2d_dgrad_junction, csrc/junction.hip) instead of the tiled GEMM kernel's epilogue.  g bit-identical, the
-# partial sums in another fp32 association.  CONVNET_AMD_JDGRAD=0: the tiled kernel everywhere (A/B).
-JDGRAD = os.environ.get('CONVNET_AMD_JDGRAD', '1') == '1'
-# junction fusion only for BN inputs of at least this many MB (A/B knob; 0 = every junction)
-FUSE_BN_BWD_JUNC_MIN_MB = float(os.environ.get('CONVNET_AMD_FUSE_BN_BWD_JUNC_MIN_MB', '0'))
+# partial sums in another fp32 association.
+JDGRAD = flags.on('jdgrad')
 
 
 # how often each BatchNorm path ran (tests assert that the fused paths really are the ones in use)
@@ -366,10 +327,10 @@ def conv2d_fwd(x, w_krsc, bias, K, R, S, stride, pad, out_f32=False, relu=False,
     P, Q = conv_out_hw(H, W, R, S, stride, pad)
     y = torch.empty((N, P, Q, K), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
     if CONV1X1_STREAM and bias is None and not out_f32 and not relu and pivot is None and (R, S) == (1, 1) \
-            and tuple(stride) == (1, 1) and tuple(pad) == (0, 0) and K <= CONV1X1_STREAM_MAXK \
+            and tuple(stride) == (1, 1) and tuple(pad) == (0, 0) \
             and _L().cn_conv1x1_stream_fwd_ok(C, K, dtype_code(x.dtype)):
         L = _L()
-        want = bn_stats and y.numel() * _esize(y) >= FUSE_BN_STATS_MIN_MB * 2 ** 20
+        want = bn_stats
         rows = L.cn_conv1x1_stream_fwd_rows(N, H, W, K) if want else 0
         partial = torch.empty((rows, 2 * K), dtype=torch.float32, device=x.device) if want else None
         PROFILER.run(_last_kernel(), 1, 2.0 * N * P * Q * K * C,
@@ -382,7 +343,7 @@ def conv2d_fwd(x, w_krsc, bias, K, R, S, stride, pad, out_f32=False, relu=False,
         return y
     if bias is None and not out_f32 and not relu and pivot is None and _halo3x3_ok(x, C, K, R, S, stride, pad):
         L = _L()
-        want = bn_stats and y.numel() * _esize(y) >= FUSE_BN_STATS_MIN_MB * 2 ** 20
+        want = bn_stats
         rows = L.cn_conv3x3_c64_rows(N, H) if want else 0
         partial = torch.empty((rows, 2 * K), dtype=torch.float32, device=x.device) if want else None
         PROFILER.run(_last_kernel(), 1, 2.0 * N * P * Q * K * C * R * S,
@@ -393,7 +354,7 @@ def conv2d_fwd(x, w_krsc, bias, K, R, S, stride, pad, out_f32=False, relu=False,
         if want:
             _park_stats(y, partial, rows, None)
         return y
-    if bn_stats and not out_f32 and y.numel() * _esize(y) >= FUSE_BN_STATS_MIN_MB * 2 ** 20:
+    if bn_stats and not out_f32:
         L = _L()
         rows = L.cn_conv2d_bnstats_rows(N * P * Q)
         partial = torch.empty((rows, 2 * K), dtype=torch.float32, device=x.device)
@@ -450,9 +411,9 @@ def conv2d_fwd_lazyz(lz, w_krsc, K, bn_stats=False, pivot=None):
 # streaming forward kernel only finalises its statistics; the convolution forms a = relu(y * scale + shift) on its
 # operand path and writes it as a side output (cn_conv1x1_stream_fwd_lazya): the apply pass - one read of y, one write
 # of a - and the convolution's read of a become one read of y and one write of a.  Same scope rule as lazy z (the
-# consumer runs next by construction of the block's forward).  CONVNET_AMD_LAZY_A=0 disables it (A/B).
-LAZY_A = os.environ.get('CONVNET_AMD_LAZY_A', '1') != '0'
-LAZY_A_3X3 = os.environ.get('CONVNET_AMD_LAZY_A', '1') != '1x1'      # ('1x1': the streaming 1x1 consumers only, A/B)
+# consumer runs next by construction of the block's forward).
+LAZY_A = flags.on('lazy_a')
+LAZY_A_3X3 = flags.text('lazy_a') != '1x1'      # ('1x1': the streaming 1x1 consumers only)
 
 
 def lazy_a_consumer_ok(conv, y):
@@ -464,7 +425,7 @@ def lazy_a_consumer_ok(conv, y):
             or getattr(conv, 'stride', None) != (1, 1):
         return False
     if getattr(conv, 'kernel_size', None) == (1, 1) and conv.padding == (0, 0):
-        return (CONV1X1_STREAM and conv.out_channels <= CONV1X1_STREAM_MAXK
+        return (CONV1X1_STREAM
                 and bool(_L().cn_conv1x1_stream_fwd_ok(C, conv.out_channels, dtype_code(dtype))))
     if getattr(conv, 'kernel_size', None) == (3, 3) and conv.padding == (1, 1):
         return (CONV3X3_HALO and LAZY_A_3X3 and bool(_L().cn_conv3x3_c64_ok(y.shape[1], y.shape[2], C, conv.out_channels, dtype_code(dtype))))
@@ -478,7 +439,7 @@ def conv2d_fwd_lazya(la, w_krsc, K, bn_stats=False, kernel=(1, 1)):
     N, H, W, C = bn_y.shape
     L = _L()
     y = torch.empty((N, H, W, K), dtype=bn_y.dtype, device=bn_y.device)
-    want = bn_stats and y.numel() * _esize(y) >= FUSE_BN_STATS_MIN_MB * 2 ** 20
+    want = bn_stats
     if tuple(kernel) == (3, 3):
         rows = L.cn_conv3x3_c64_rows(N, H) if want else 0
         partial = torch.empty((rows, 2 * K), dtype=torch.float32, device=bn_y.device) if want else None
@@ -564,14 +525,8 @@ def conv2d_dgrad(dy, w_crsk, x_shape, K, R, S, stride, pad, addend=None, bn=None
     return dx, partial, rows
 
 
-# measurement only (wrong results): weight gradients not computed at all - how much of the step the side stream costs
-_SKIP_WGRAD = os.environ.get('CONVNET_AMD_DEBUG_SKIP_WGRAD', '0') == '1'
-
-
 def conv2d_wgrad(x, dy, dw_krsc, c_real, K, R, S, stride, pad, beta=1.0, scale=1.0, tag='main'):
     """dw_krsc (fp32, [K][R][S][c_real] memory order) = beta*dw + scale*wgrad."""
-    if _SKIP_WGRAD:
-        return
     N, H, W, C = x.shape
     code = dtype_code(x.dtype)
     L = _L()
@@ -623,8 +578,6 @@ def conv2d_dgrad_lazy(g, bn_y, coef, w_crsk, x_shape, K, R, S, stride, pad):
 
 def conv2d_wgrad_lazy(x, g, bn_y, coef, dw_krsc, c_real, K, R, S, stride, pad, beta=1.0, scale=1.0, tag='main'):
     """wgrad whose dy operand is formed on load from (g, bn_y, coef) (cn_conv2d_wgrad_lazy)."""
-    if _SKIP_WGRAD:
-        return
     N, H, W, C = x.shape
     code = dtype_code(x.dtype)
     L = _L()
@@ -913,11 +866,8 @@ class Conv2dFunction(Function):
             # (inner convs) or when the other branch's gradient is being added right here
             final = holder is None or addend is not None
             bn_args = _input_bn_state(mod, x) if (final and FUSE_BN_BWD) else None
-            if bn_args is not None and holder is None and x.numel() * _esize(x) > FUSE_BN_BWD_INNER_MB * 2 ** 20 \
-                    and not (FUSE_BN_BWD_INNER_1X1 and (R, S) == (1, 1)):
-                bn_args = None
-            if bn_args is not None and holder is not None and x.numel() * _esize(x) < FUSE_BN_BWD_JUNC_MIN_MB * 2 ** 20:
-                bn_args = None
+            if bn_args is not None and holder is None:
+                bn_args = None      # junctions only (see FUSE_BN_BWD)
             if bn_args is not None:
                 bn_mod, bn_y, bn_mask, bn_stats, bn_relu = bn_args
                 dx, partial, rows = conv2d_dgrad(dy, mod.w_crsk, x.shape, mod.out_channels, R, S, mod.stride,
@@ -1039,7 +989,7 @@ class StemPairConvFunction(Function):
 def _lazy_dy_ok(bn_mod, y):
     """This junction BatchNorm's backward apply can be left to the convolution that produced its input."""
     conv = getattr(bn_mod, 'producer_conv', None)
-    if not LAZY_DY or conv is None or FUSE_BN_BWD_INNER_MB > 0 or FUSE_BN_BWD_INNER_1X1:
+    if not LAZY_DY or conv is None:
         return False
     if getattr(conv, 'junction_conv1', False):
         return False    # conv1 of a block: its data gradient is the junction kernel (addend + reduction), not a lazy consumer

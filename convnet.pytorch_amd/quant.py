@@ -29,15 +29,15 @@ import torch
 import torch.nn as tnn
 from torch.autograd import Function
 
-from . import _lib, nn as cnn, ops
+from . import _lib, flags, nn as cnn, ops
 from ._lib import check, dtype_code, ptr, stream_of
 
 # RangeBN's input quantiser folded into its kernels (cn_rangebn_fwd_q / cn_rangebn_bwd_q: the quantised copy of every
 # convolution output is neither written nor re-read).  Same results, bit for bit - and measured SLOWER on the whole step
 # (ResNet-50 bf16 b=256: 50.1 vs 49.5 ms): the three kernels that now snap on load (statistics with their per-element
 # arg-max bookkeeping, apply, backward reduce) pay the quantiser's division three times and turn VALU-bound.  Off by
-# default; CONVNET_AMD_QUANT_FUSE_RBN=1 switches it on (A/B).
-FUSE_RBN_QUANT = os.environ.get('CONVNET_AMD_QUANT_FUSE_RBN', '0') == '1'
+# default (flag quant_fuse_rbn).
+FUSE_RBN_QUANT = flags.on('quant_fuse_rbn')
 _NOISE_SOURCE = None
 _SEED = [0x5EED5EED]
 
@@ -191,10 +191,10 @@ def _quantize_filters(mod, num_bits):
 
 
 # ---- true int8 MFMA forward (csrc/qconv_i8.hip) ------------------------------------------------------------
-# CONVNET_AMD_QUANT_INT8=1 (or QConv2d.int8_forward = True): the forward product of every eligible QConv2d
+# flag quant_int8 (or QConv2d.int8_forward = True): the forward product of every eligible QConv2d
 # (input channels a multiple of 16: everything but the 3-channel stem) runs on v_mfma_i32_32x32x32_i8 instead
 # of the float kernels on dequantised operands.  Same result up to fp32 rounding; backward unchanged.
-INT8_FORWARD = os.environ.get('CONVNET_AMD_QUANT_INT8', '0') == '1'
+INT8_FORWARD = flags.on('quant_int8')
 _I8_GEOM = {}
 
 

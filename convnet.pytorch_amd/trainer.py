@@ -22,7 +22,7 @@ import time
 import torch
 import torch.distributed as dist
 
-from . import _lib, engine, ops
+from . import _lib, engine, flags, ops
 from ._lib import check, ptr, stream_of
 from .cross_entropy import CrossEntropyLoss
 from .meters import AverageMeter, accuracy
@@ -111,10 +111,10 @@ class Trainer(object):
         self.arena = engine.prepare(model, self.device, dtype, bucket_mb=bucket_mb)
         self.reducer = None
         self._main_stream = None   # high-priority HIP stream of the step loop (created lazily on a GPU)
-        # CONVNET_AMD_GRAPH: 'auto' (default) captures only when the eager step is host-bound, 1 = always, 0 = never
-        self._graph_mode = os.environ.get('CONVNET_AMD_GRAPH', 'auto')
+        # flag graph: 'auto' (default) captures only when the eager step is host-bound, 1 = always, 0 = never
+        self._graph_mode = flags.text('graph')
         self._use_graph = self._graph_mode != '0'
-        self._graph_dp = os.environ.get('CONVNET_AMD_GRAPH_DP', '0') == '1'   # capture RCCL buckets too (opt-in)
+        self._graph_dp = flags.on('graph_dp')   # capture RCCL buckets too (opt-in)
         self._gstates = {}               # per (shapes, step options) key: {'seen': warm-up / timing bookkeeping, 'graph': capture}
         self._graph_eager_for = set()    # (shapes, chunking) for which auto mode settled on eager launches
         from . import nn as cnn
@@ -232,7 +232,7 @@ class Trainer(object):
     # values - meters, the clip coefficient and (lr, momentum) live in device memory, workspaces are
     # caller-owned - so after two eager warm-up steps of a given shape the whole device side of the step
     # (layout cast, forward, loss + meters, backward on both streams, bucket all-reduces, clip, SGD) is
-    # captured once and replayed: one graph launch per step.  CONVNET_AMD_GRAPH=0 keeps the eager path.
+    # captured once and replayed: one graph launch per step.  Flag graph = 0 keeps the eager path.
     def _graph_ok(self, inputs, target):
         if not self._use_graph or self.device.type != 'cuda' or ops.PROFILER.enabled:
             return False
@@ -348,13 +348,13 @@ class Trainer(object):
     def forward(self, data_loader, num_steps=None, training=False, average_output=False, chunk_batch=1):
         """The per-batch loop of trainer.py:179-263.  On a GPU the whole loop runs on a high-priority HIP
         stream: the forward / dgrad / BatchNorm chain is the critical path, the weight-gradient kernels on
-        the (normal-priority) side stream only have to fill its gaps (+0.6 % on ResNet-50;
-        CONVNET_AMD_MAIN_STREAM_PRIO=off keeps everything on the caller's stream)."""
+        the (normal-priority) side stream only have to fill its gaps (+0.6 % on ResNet-50; flag main_stream_prio =
+        off keeps everything on the caller's stream)."""
         dev = torch.device(self.device)
-        if dev.type != 'cuda' or os.environ.get('CONVNET_AMD_MAIN_STREAM_PRIO', '-1') == 'off':
+        if dev.type != 'cuda' or flags.text('main_stream_prio') == 'off':
             return self._forward(data_loader, num_steps, training, average_output, chunk_batch)
         if self._main_stream is None:
-            self._main_stream = torch.cuda.Stream(dev, priority=int(os.environ.get('CONVNET_AMD_MAIN_STREAM_PRIO', '-1')))
+            self._main_stream = torch.cuda.Stream(dev, priority=int(flags.text('main_stream_prio')))
         caller = torch.cuda.current_stream(dev)
         self._main_stream.wait_stream(caller)          # everything the caller queued (inputs, weights) is visible
         try:

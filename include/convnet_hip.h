@@ -52,10 +52,6 @@ const char* cn_last_kernel_name(void);
  * entry point may launch several instantiations: a strided dgrad dispatches each output-parity class on its own
  * reduction length).  clear != 0 empties the log.  Lets measurement code count launches per kernel as rocprofv3 does. */
 const char* cn_kernel_log(int clear);
-/* a HIP stream restricted to `eighths`/8 of the compute units, spread evenly over the XCDs (hipExtStreamCreateWithCUMask);
- * the caller owns it.  For the weight-gradient side stream of a bandwidth-bound step. */
-int cn_stream_create_masked(int eighths, int priority, void** stream /* HOST */);
-int cn_stream_destroy(void* stream);
 int cn_is_emulator(void); /* 1 only in the TEST-ONLY CPU emulator build */
 /* kernel-variant tuning knobs for A/B measurement (e.g. "igemm_stages" = 1|2); results never change */
 int cn_set_option(const char* name, int value);

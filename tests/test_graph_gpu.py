@@ -77,10 +77,10 @@ def test_graph_replay_is_bit_identical_to_eager(tmp_path):
 
 
 def test_graph_with_world1_rccl_buckets_inside(tmp_path):
-    assert 'GRAPH_OK dist' in _run(tmp_path, {'TEST_DIST': '1', 'CONVNET_AMD_GRAPH_DP': '1'}, 29553)
+    assert 'GRAPH_OK dist' in _run(tmp_path, {'TEST_DIST': '1', 'CONVNET_AMD_FLAGS': 'graph_dp=1'}, 29553)
 
 
 def test_graph_replay_with_lazy_dy_is_bit_identical_to_eager(tmp_path):
     """The same with the junction BatchNorms' backward apply left to the consumers (ops.LAZY_DY forced on for this
     small model): the placeholder gradients and the finalize-only BatchNorm calls are capture-safe."""
-    assert 'GRAPH_OK single' in _run(tmp_path, {'CONVNET_AMD_LAZY_DY_MIN_MB': '0'}, 29555)
+    assert 'GRAPH_OK single' in _run(tmp_path, {'CONVNET_AMD_FLAGS': 'lazy_min_mb=0'}, 29555)

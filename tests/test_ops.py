@@ -1491,15 +1491,14 @@ def test_streaming_lazy_dgrad_equals_tiled_kernel(mode, dtype):
         coef = torch.cat([torch.rand(K, generator=g_) + 0.5, torch.randn(K, generator=g_) * 0.05,
                           torch.randn(K, generator=g_) * 0.01]).to(dev)
         wc = (torch.randn(C, 1, 1, K, generator=g_) * (2.0 / K) ** 0.5).to(dtype).to(dev)
-        L.cn_set_option(b'jdlazy', 0)
-        try:
-            d0 = ops.conv2d_dgrad_lazy(gq, yq, coef, wc, (N, H, W, C), K, 1, 1, (1, 1), (0, 0))
-            assert 'igemm_kernel' in L.cn_last_kernel_name().decode()
-            L.cn_set_option(b'jdlazy', 1)      # (1: both shapes; the default, 2, keeps 512 -> 256 on the tiled kernel)
-            d1 = ops.conv2d_dgrad_lazy(gq, yq, coef, wc, (N, H, W, C), K, 1, 1, (1, 1), (0, 0))
-            assert 'jdlazy_kernel' in L.cn_last_kernel_name().decode()
-        finally:
-            L.cn_set_option(b'jdlazy', 2)
+        # the tiled kernel through its own entry point, the streaming kernel through the dispatching wrapper
+        d0 = torch.empty((N, H, W, C), dtype=dtype, device=dev)
+        P = ca._lib.ptr
+        ca._lib.check(L.cn_conv2d_dgrad_lazy(P(gq), P(yq), P(coef), P(wc), P(d0), N, H, W, C, K, 1, 1, 1, 1, 0, 0,
+                                             ca._lib.dtype_code(dtype), ca._lib.stream_of(gq)), 'cn_conv2d_dgrad_lazy')
+        assert 'igemm_kernel' in L.cn_last_kernel_name().decode()
+        d1 = ops.conv2d_dgrad_lazy(gq, yq, coef, wc, (N, H, W, C), K, 1, 1, (1, 1), (0, 0))
+        assert 'jdlazy_kernel' in L.cn_last_kernel_name().decode()
         if dtype == torch.bfloat16 or mode == 'emul':
             assert torch.equal(d1.cpu(), d0.cpu()), (N, H, W, C)
         else:

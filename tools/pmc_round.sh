@@ -8,7 +8,7 @@ mkdir -p $OUT
 LAYERS="2,3,10,13,15,16,19,22"
 run() { # name counters... -- cmd
   name=$1; shift; ctrs=$1; shift
-  CONVNET_AMD_GRAPH=0 timeout 600 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $OUT/$name -o $name -- "$@" > $OUT/$name.log 2>&1
+  CONVNET_AMD_FLAGS=graph=0 timeout 600 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $OUT/$name -o $name -- "$@" > $OUT/$name.log 2>&1
   echo "$name rc=$?"; ls $OUT/$name | head -5
 }
 run sq1 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA" python tools/bench_layers.py --iters 2 --variants 0 --only $LAYERS
