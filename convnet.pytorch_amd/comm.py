@@ -53,26 +53,32 @@ class RcclCommunicator(object):
         self.world = dist.get_world_size(process_group)
         self.device = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
         self._h = ctypes.c_void_p()
-        # phase 1
-        rc = L.cn_comm_load()
-        _agree(rc == 0, 'load librccl', _lib.last_error() if rc != 0 else None, process_group, self.device)
-        # phase 2
-        buf = ctypes.create_string_buffer(128)
-        err = None
-        if self.rank == 0 and L.cn_comm_unique_id(buf) != 0:
-            err = _lib.last_error()
-        box = [(buf.raw if err is None else b'') if self.rank == 0 else None]
-        if self.world > 1:
-            src = dist.get_global_rank(process_group, 0) if process_group is not None else 0
-            dist.broadcast_object_list(box, src=src, group=process_group)
-        _agree(len(box[0]) == 128, 'unique id', err, process_group, self.device)
-        # phase 3
-        with torch.cuda.device(self.device):
-            rc = L.cn_comm_init(ctypes.byref(self._h), box[0], self.rank, self.world)
-        _agree(rc == 0, 'ncclCommInitRank', _lib.last_error() if rc != 0 else None, process_group, self.device)
-        ver = ctypes.c_int(0)
-        check(L.cn_comm_info(self._h, None, None, ctypes.byref(ver)), 'cn_comm_info')
-        self.rccl_version = ver.value
+        try:
+            # phase 1
+            rc = L.cn_comm_load()
+            _agree(rc == 0, 'load librccl', _lib.last_error() if rc != 0 else None, process_group, self.device)
+            # phase 2
+            buf = ctypes.create_string_buffer(128)
+            err = None
+            if self.rank == 0 and L.cn_comm_unique_id(buf) != 0:
+                err = _lib.last_error()
+            box = [(buf.raw if err is None else b'') if self.rank == 0 else None]
+            if self.world > 1:
+                src = dist.get_global_rank(process_group, 0) if process_group is not None else 0
+                dist.broadcast_object_list(box, src=src, group=process_group)
+            _agree(len(box[0]) == 128, 'unique id', err, process_group, self.device)
+            # phase 3
+            with torch.cuda.device(self.device):
+                rc = L.cn_comm_init(ctypes.byref(self._h), box[0], self.rank, self.world)
+            _agree(rc == 0, 'ncclCommInitRank', _lib.last_error() if rc != 0 else None, process_group, self.device)
+            ver = ctypes.c_int(0)
+            check(L.cn_comm_info(self._h, None, None, ctypes.byref(ver)), 'cn_comm_info')
+            self.rccl_version = ver.value
+        except Exception:
+            # a rank whose own cn_comm_init succeeded still gets here when a PEER failed (the agreement step raises on
+            # every rank): its communicator, stream and events must not outlive the failed set-up
+            self.destroy()
+            raise
 
     # -- collectives ---------------------------------------------------------------------------
     def allreduce_bucket(self, view, streams):

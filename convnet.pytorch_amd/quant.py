@@ -299,6 +299,8 @@ class QConv2dFunction(Function):
                 qparams(st[3], x.shape[0], 0, qm.running_zero_point, qm.running_range, qm.momentum)
                 qx = st[4]
             elif qm.training and getattr(mod, 'share_q_out', False):
+                # (QuantMeasure exists in ONE configuration - its constructor refuses stochastic / non-dequantising /
+                # other flatten_dims - so the shared copy depends on num_bits only, which the stash records and matches)
                 mm = minmax_rows(x, x.shape[0])
                 qp = qparams(mm, x.shape[0], 0, qm.running_zero_point, qm.running_range, qm.momentum)
                 qx = quantize(x, qp[0:1], qp[1:2], qm.num_bits)

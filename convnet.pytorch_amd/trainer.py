@@ -119,8 +119,12 @@ class Trainer(object):
         self._graph_eager_for = set()    # (shapes, chunking) for which auto mode settled on eager launches
         from . import nn as cnn
         # a captured step replays the SAME kernels: host-drawn Dropout masks (models/mnist.py) rule it out
-        self._graph_model_ok = not any((isinstance(m, cnn.Dropout) and m.p > 0) or getattr(m, 'no_graph', False)
-                                       for m in model.modules())
+        # modules whose capturability can change at run time (quant.QuantMeasure.no_graph follows the noise source) are
+        # asked at every step (_graph_ok), the others once
+        self._graph_dynamic = [m for m in model.modules() if isinstance(getattr(type(m), 'no_graph', None), property)]
+        self._graph_model_ok = not any((isinstance(m, cnn.Dropout) and m.p > 0)
+                                       or (not isinstance(getattr(type(m), 'no_graph', None), property)
+                                           and getattr(m, 'no_graph', False)) for m in model.modules())
         self.world_size = 1
         if distributed:
             if not dist.is_initialized():
@@ -154,9 +158,9 @@ class Trainer(object):
             # host side of trainer.py:111-112 (the regime moves lr / momentum; nothing here touches the device
             # except a tiny H2D copy when the schedule changes)
             self.optimizer.update(self.epoch, self.training_steps)
-            # (shape, chunking) for which auto mode already settled on eager launches: straight to the eager body (the
-            # bookkeeping of _graph_step costs a nearly host-bound step 1 %)
-            if (inputs_batch.shape, target_batch.shape, chunk_batch) not in self._graph_eager_for \
+            # configurations for which auto mode already settled on eager launches go straight to the eager body (the
+            # bookkeeping of _graph_step costs a nearly host-bound step 1 %); the verdict is keyed like the graphs are
+            if self._graph_key(inputs_batch, target_batch, chunk_batch) not in self._graph_eager_for \
                     and self._graph_ok(inputs_batch, target_batch):
                 return self._graph_step(inputs_batch, target_batch, chunk_batch)
         return self._body(inputs_batch, target_batch, training, chunk_batch)
@@ -240,9 +244,16 @@ class Trainer(object):
             return False
         if not isinstance(self.criterion, CrossEntropyLoss) or not self._graph_model_ok:
             return False
+        if self._graph_dynamic and any(getattr(m, 'no_graph', False) for m in self._graph_dynamic):
+            return False     # (a host-side noise source was installed after construction: quant.set_noise_source)
         if self.reducer is not None and (self.reducer.comm is None or not self._graph_dp):
             return False
         return True
+
+    def _graph_key(self, inputs, target, chunk_batch):
+        """Everything a captured step bakes in besides the tensors' contents."""
+        return (tuple(inputs.shape), tuple(target.shape), chunk_batch, float(self.grad_clip), self.loss_scale,
+                self.grad_scale, self.optimizer.runs_signature(), getattr(self.criterion, 'smooth_eps', None), self.world_size)
 
     def _graph_step(self, inputs, target, chunk_batch):
         """State is kept PER KEY (batch shapes + step options): the odd-shaped last batch of an epoch warms up /
@@ -252,16 +263,16 @@ class Trainer(object):
         into the device meters right away, other callers must clone what they keep."""
         opt = self.optimizer
         opt.push_hyper()
-        key = (tuple(inputs.shape), tuple(target.shape), chunk_batch, float(self.grad_clip), self.loss_scale,
-               self.grad_scale, opt.runs_signature(), self.criterion.smooth_eps, self.world_size)
-        gs = self._gstates.get(key)
+        key = self._graph_key(inputs, target, chunk_batch)
+        gs = self._gstates.pop(key, None)
         if gs is None:
-            if len(self._gstates) >= 4:      # bounded: drop the oldest key (dicts keep insertion order)
-                self._gstates.pop(next(iter(self._gstates)))
-            gs = self._gstates[key] = {'seen': {'n': 0}, 'graph': None}
+            if len(self._gstates) >= 4:      # bounded, least recently USED out (a hit re-inserts its key at the end, so
+                self._gstates.pop(next(iter(self._gstates)))   # the hot full-batch graph is never the one evicted)
+            gs = {'seen': {'n': 0}, 'graph': None}
+        self._gstates[key] = gs
         seen = gs['seen']
         st = gs['graph']
-        eager_key = (inputs.shape, target.shape, chunk_batch)
+        eager_key = key      # an 'eager' verdict holds for exactly the configuration it was measured on
         if st is None:
             warm = 4 if self._graph_mode == 'auto' else 2
             if seen['n'] < warm:       # eager warm-up (lazy workspace growth, allocator warm)
