@@ -124,8 +124,10 @@ _SIGNATURES = {
     'cn_quantize_rows': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
     'cn_rangebn_workspace': (c_sz, [c_i, c_i, c_i]),
     'cn_rangebn_fwd': (c_i, [c_p] * 7 + [c_f, c_f, c_i, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
-    'cn_rangebn_fwd_q': (c_i, [c_p, c_p, c_i] + [c_p] * 6 + [c_f, c_f, c_i, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
-    'cn_rangebn_bwd_q': (c_i, [c_p, c_p, c_p, c_i] + [c_p] * 6 + [c_i, c_i, c_i, c_f, c_i, c_p, c_sz, c_p]),
+    'cn_rangebn_fwd_q': (c_i, [c_p, c_p, c_i] + [c_p] * 7 + [c_f, c_f, c_i, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_sz, c_p]),
+    'cn_rangebn_bwd_mm': (c_i, [c_p] * 8 + [c_i, c_i, c_i, c_f, c_i, c_i, c_p, c_p, c_sz, c_p]),
+    'cn_eltwise_mm_workspace': (c_sz, [c_ll, c_i, c_i]),
+    'cn_eltwise_mm': (c_i, [c_i, c_p, c_p, c_p, c_ll, c_i, c_i, c_p, c_p, c_sz, c_p]),
     'cn_rangebn_bwd': (c_i, [c_p] * 8 + [c_i, c_i, c_i, c_f, c_i, c_p, c_sz, c_p]),
     'cn_i8_prepare_activation': (c_i, [c_p] * 5 + [c_i] * 11 + [c_p, c_p, c_p, c_p, c_i, c_p]),
     'cn_i8_prepare_weight': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),

@@ -32,6 +32,9 @@ __device__ __forceinline__ void q_block_minmax(float& mn, float& mx, float* red 
   mx = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
 }
 
+// v as a T stores it (round to nearest even for the 16-bit types)
+template <typename T> __device__ __forceinline__ float q_round_to(float v) { T t; cn_store_elem<T>(&t, v); return cn_load_elem<T>(&t); }
+
 // Stage 1: block (split s, row r) scans its slice of row r.  partial[(r*splits + s)*2] = {min, max}.
 template <typename T>
 __global__ __launch_bounds__(Q_NT) void minmax_partial_kernel(const T* x, long long row_len, int splits, int vec,
@@ -315,11 +318,13 @@ extern "C" int cn_quantize_rows(const float* x, float* y, int rows, int row_len,
   return cn_check_launch("quantize_rows");
 }
 
-// Input quantiser folded into the RangeBN kernels (round 3): RangeBN's QuantMeasure (quantize.py:270,308) snaps its input
-// to the 8-bit grid before anything else; with xqp = [zero_point, range] (cn_qparams' output) the kernels below read the
-// RAW convolution output and snap each element on load - quantize_kernel's arithmetic, rounded to T as it would have
-// been stored - so the quantised copy is never written or re-read (one write + one read of every RangeBN input less,
-// in forward; the backward kernels re-snap the saved raw tensor).  xqp == nullptr: x is already quantised.
+// Input quantiser folded into RangeBN's STATISTICS pass (round 4): RangeBN's QuantMeasure (quantize.py:270,308) snaps its
+// input to the 8-bit grid before anything else; with xqp = [zero_point, range] (cn_qparams' output) rangebn_stats_kernel
+// reads the RAW convolution output, snaps each element on load - quantize_kernel's arithmetic, rounded to T - takes its
+// statistics of the snapped values and STORES them (qx_out): the separate quantiser pass (one read of every RangeBN input)
+// disappears, the apply pass and the backward kernels read qx_out.  (Round 3 snapped on load in all three kernels and
+// never stored: the division three times per element made them VALU-bound and the step slower.)  xqp == nullptr: x is
+// already quantised.
 struct RbnSnap {
   float zp, scale, qmax;
   int on;
@@ -354,7 +359,7 @@ struct RbnPartial {   // one per (chunk, slice, channel)
 
 template <typename T>
 __global__ __launch_bounds__(Q_NT) void rangebn_stats_kernel(const T* x, int M, int C, int chunks, int sub, int cols,
-                                                            RbnPartial* part, const float* xqp, float qmax) {
+                                                            RbnPartial* part, const float* xqp, float qmax, T* qx_out) {
   constexpr int CH = ElemTraits<T>::kChunk;
   __shared__ float s_mx[Q_NT * CH], s_mn[Q_NT * CH], s_sum[Q_NT * CH];
   __shared__ int s_imx[Q_NT * CH], s_imn[Q_NT * CH];
@@ -380,6 +385,7 @@ __global__ __launch_bounds__(Q_NT) void rangebn_stats_kernel(const T* x, int M, 
       float f[CH];
       Chunk<T>::unpack(v, f);
       rbn_snap_chunk<T>(snap, f);
+      if (qx_out != nullptr) cn_st16((char*)qx_out + ((size_t)p * CC + cc) * 16, Chunk<T>::pack(f));   // (every element is visited once)
 #pragma unroll
       for (int e = 0; e < CH; ++e) {
         if (f[e] > mx[e]) { mx[e] = f[e]; imx[e] = p; }
@@ -533,19 +539,25 @@ __global__ __launch_bounds__(Q_NT) void rangebn_infer_stats_kernel(const float* 
 }
 
 // z = act(((x - mean) / (scale + eps)) * w + b [+ residual])   (quantize.py:312-325, then the block's add / ReLU)
+// Grid (blocks per row, rows): `rows` consecutive equal parts of the nch chunks (the samples of the batch; 1 = the whole
+// tensor).  mm_partial (optional): [rows][gridDim.x][2] = {min, max} of the values AS STORED per block - the per-sample
+// extremes the next activation quantiser needs (QuantMeasure, quantize.py:158-182), so its min / max pass over z disappears.
 template <typename T>
 __global__ __launch_bounds__(Q_NT) void rangebn_apply_kernel(const T* x, const T* residual, T* z, const float* stats,
                                                             const float* weight, const float* bias, long long nch,
-                                                            int C, int relu, const float* xqp, float qmax) {
+                                                            int C, int relu, float* mm_partial) {
   constexpr int CH = ElemTraits<T>::kChunk;
+  __shared__ float red[8];
   const int CC = C / CH;
-  const RbnSnap snap = rbn_snap_make(xqp, qmax);
+  const long long rch = nch / gridDim.y;                       // chunks per row (a multiple of CC)
+  const long long row0 = (long long)blockIdx.y * rch, row1 = row0 + rch;
   const long long stride = (long long)gridDim.x * Q_NT;
   // the grid stride is a multiple of the chunk columns in every launch the host makes (q_grid_cols): a thread stays on
   // one chunk column, so its 4 x CH coefficients are loaded once (they were re-read from L1 for every chunk: 32 loads
   // beside the one 16-byte load that carries the data)
   const bool fixed_col = stride % CC == 0;
   float mean[CH], den[CH], w[CH], b[CH];
+  float mn = INFINITY, mx = -INFINITY;
   auto load_coef = [&](long long id) {
     const int c0 = (int)(id % CC) * CH;
 #pragma unroll
@@ -554,7 +566,6 @@ __global__ __launch_bounds__(Q_NT) void rangebn_apply_kernel(const T* x, const T
   auto apply = [&](const u32x4& vx, const u32x4& vr, long long id) {
     float f[CH], r[CH];
     Chunk<T>::unpack(vx, f);
-    rbn_snap_chunk<T>(snap, f);
     if (residual != nullptr) Chunk<T>::unpack(vr, r);
 #pragma unroll
     for (int e = 0; e < CH; ++e) {
@@ -566,11 +577,15 @@ __global__ __launch_bounds__(Q_NT) void rangebn_apply_kernel(const T* x, const T
       f[e] = v;
     }
     cn_st16((char*)z + id * 16, Chunk<T>::pack(f));
+    if (mm_partial != nullptr) {   // (of the fp32 values: rounding to T is monotonic, so the extremes are rounded once at the end)
+#pragma unroll
+      for (int e = 0; e < CH; ++e) { mn = fminf(mn, f[e]); mx = fmaxf(mx, f[e]); }
+    }
   };
-  long long id = (long long)blockIdx.x * Q_NT + threadIdx.x;
-  if (id < nch) load_coef(id);
+  long long id = row0 + (long long)blockIdx.x * Q_NT + threadIdx.x;
+  if (id < row1) load_coef(id);
   if (fixed_col) {
-    for (; id + stride < nch; id += 2 * stride) {   // two (four with a residual) loads in flight
+    for (; id + stride < row1; id += 2 * stride) {   // two (four with a residual) loads in flight
       const u32x4 v0 = cn_ld16((const char*)x + id * 16), v1 = cn_ld16((const char*)x + (id + stride) * 16);
       u32x4 r0 = cn_zero16(), r1 = cn_zero16();
       if (residual != nullptr) { r0 = cn_ld16((const char*)residual + id * 16); r1 = cn_ld16((const char*)residual + (id + stride) * 16); }
@@ -578,10 +593,30 @@ __global__ __launch_bounds__(Q_NT) void rangebn_apply_kernel(const T* x, const T
       apply(v1, r1, id + stride);
     }
   }
-  for (; id < nch; id += stride) {
+  for (; id < row1; id += stride) {
     if (!fixed_col) load_coef(id);
     apply(cn_ld16((const char*)x + id * 16), residual != nullptr ? cn_ld16((const char*)residual + id * 16) : cn_zero16(), id);
   }
+  if (mm_partial != nullptr) {
+    q_block_minmax(mn, mx, red);
+    if (threadIdx.x == 0) {
+      mm_partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2] = q_round_to<T>(mn);
+      mm_partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + 1] = q_round_to<T>(mx);
+    }
+  }
+}
+
+// Grid of a per-row elementwise pass: blocks per row (their stride a multiple of `cols` chunk columns), <= 8192 blocks in all
+static unsigned q_grid_rows(long long nch, int rows, int cols) {
+  if (rows < 1) rows = 1;
+  // >= 8 chunks per thread where the row is long enough: a thread's set-up (its chunk column's coefficients, the routing
+  // table entries) is 24-40 loads, as much as the data of several chunks
+  long long bpr = (nch / rows + 8 * Q_NT - 1) / (8 * Q_NT);
+  const long long cap = 8192 / rows > 1 ? 8192 / rows : 1;
+  if (bpr > cap) bpr = cap;
+  if (bpr < 1) bpr = 1;
+  if (cols > Q_NT && cols % Q_NT == 0) { const long long m = cols / Q_NT; bpr = (bpr + m - 1) / m * m; }
+  return (unsigned)bpr;
 }
 
 extern "C" size_t cn_rangebn_workspace(int M, int C, int chunks) {
@@ -608,16 +643,21 @@ static int rbn_cols(int CC) {
 // `chunks` chunk-wise max - min, M % chunks == 0 as the reference's view() requires), running statistics
 // updated, stats[2C] = {mean | scale + eps} and arg[C][2*chunks] saved for the backward pass.  training == 0:
 // running statistics.  z = act(affine(normalised x) [+ residual]).
+// xqp / qx_out (training): x is the RAW input, snapped by the statistics pass and stored to qx_out (see RbnSnap).
+// mm_rows / z_minmax: per-row {min, max} of the stored z over mm_rows equal row groups of the M pixels (the batch samples).
 static int rangebn_fwd_impl(const void* x, const void* residual, void* z, const float* weight, const float* bias,
                               float* running_mean, float* running_var, float momentum, float eps, int chunks,
                               float scale_fix, float* stats, int* arg, int M, int C, int relu, int training, int dtype,
-                              float* ws, size_t ws_bytes, void* stream_, const float* xqp, int x_bits) {
+                              float* ws, size_t ws_bytes, void* stream_, const float* xqp, int x_bits, void* qx_out,
+                              int mm_rows, float* z_minmax) {
   const float qmax = (float)((1 << (x_bits > 0 ? x_bits : 8)) - 1);
   hipStream_t stream = (hipStream_t)stream_;
   const int CH = dtype == CN_BF16 ? 8 : 4;
   if (dtype != CN_BF16 && dtype != CN_F32) { cn_set_error("rangebn_fwd: bad dtype"); return CN_EINVAL; }
   if (M <= 0 || C <= 0 || C % CH != 0) { cn_set_error("rangebn_fwd: M=%d C=%d (C must be a multiple of %d)", M, C, CH); return CN_ESHAPE; }
   if (x == nullptr || z == nullptr || weight == nullptr || bias == nullptr || stats == nullptr) { cn_set_error("rangebn_fwd: null operand"); return CN_EINVAL; }
+  if (xqp != nullptr && (!training || qx_out == nullptr)) { cn_set_error("rangebn_fwd: the folded input quantiser needs training statistics and qx_out"); return CN_EINVAL; }
+  if (z_minmax != nullptr && (mm_rows < 1 || M % mm_rows != 0 || mm_rows > 8192)) { cn_set_error("rangebn_fwd: %d pixels do not split into %d rows", M, mm_rows); return CN_ESHAPE; }
   const int CC = C / CH;
   if (training) {
     if (chunks <= 0 || M % chunks != 0) { cn_set_error("rangebn_fwd: %d values per channel do not split into %d chunks", M, chunks); return CN_ESHAPE; }
@@ -626,9 +666,9 @@ static int rangebn_fwd_impl(const void* x, const void* residual, void* z, const 
     const int sub = rbn_sub(M, chunks), cols = rbn_cols(CC);
     dim3 grid((unsigned)((CC + cols - 1) / cols), (unsigned)(chunks * sub));
     if (dtype == CN_BF16)
-      CN_LAUNCH(rangebn_stats_kernel<bf16_t>, grid, dim3(Q_NT), stream, (const bf16_t*)x, M, C, chunks, sub, cols, (RbnPartial*)ws, xqp, qmax);
+      CN_LAUNCH(rangebn_stats_kernel<bf16_t>, grid, dim3(Q_NT), stream, (const bf16_t*)x, M, C, chunks, sub, cols, (RbnPartial*)ws, xqp, qmax, (bf16_t*)qx_out);
     else
-      CN_LAUNCH(rangebn_stats_kernel<float>, grid, dim3(Q_NT), stream, (const float*)x, M, C, chunks, sub, cols, (RbnPartial*)ws, xqp, qmax);
+      CN_LAUNCH(rangebn_stats_kernel<float>, grid, dim3(Q_NT), stream, (const float*)x, M, C, chunks, sub, cols, (RbnPartial*)ws, xqp, qmax, (float*)qx_out);
     if (2 * chunks <= RF_T)
       CN_LAUNCH(rangebn_finalize_par_kernel, dim3((unsigned)((C + RF_C - 1) / RF_C)), dim3(RF_C * RF_T), stream, (const RbnPartial*)ws, M,
               C, chunks, sub, scale_fix, eps, momentum, running_mean, running_var, stats, arg);
@@ -641,12 +681,22 @@ static int rangebn_fwd_impl(const void* x, const void* residual, void* z, const 
               (const float*)running_mean, (const float*)running_var, eps, C, stats);
   }
   const long long nch = (long long)M * CC;
+  const void* xa = xqp != nullptr ? qx_out : x;       // the apply pass reads the snapped copy the statistics pass stored
+  const int rows = z_minmax != nullptr ? mm_rows : 1;
+  const unsigned bpr = z_minmax != nullptr ? q_grid_rows(nch, rows, CC) : q_grid_cols(nch, CC);
+  float* mmp = nullptr;
+  if (z_minmax != nullptr) {     // (the statistics partials in ws are dead once finalize has run, in stream order)
+    if (ws == nullptr || ws_bytes < (size_t)rows * bpr * 2 * sizeof(float)) { cn_set_error("rangebn_fwd: workspace too small for the min / max partials"); return CN_EWORKSPACE; }
+    mmp = ws;
+  }
   if (dtype == CN_BF16)
-    CN_LAUNCH(rangebn_apply_kernel<bf16_t>, dim3(q_grid_cols(nch, C / 8)), dim3(Q_NT), stream, (const bf16_t*)x, (const bf16_t*)residual,
-              (bf16_t*)z, (const float*)stats, weight, bias, nch, C, relu, xqp, qmax);
+    CN_LAUNCH(rangebn_apply_kernel<bf16_t>, dim3(bpr, (unsigned)rows), dim3(Q_NT), stream, (const bf16_t*)xa, (const bf16_t*)residual,
+              (bf16_t*)z, (const float*)stats, weight, bias, nch, C, relu, mmp);
   else
-    CN_LAUNCH(rangebn_apply_kernel<float>, dim3(q_grid_cols(nch, C / 4)), dim3(Q_NT), stream, (const float*)x, (const float*)residual,
-              (float*)z, (const float*)stats, weight, bias, nch, C, relu, xqp, qmax);
+    CN_LAUNCH(rangebn_apply_kernel<float>, dim3(bpr, (unsigned)rows), dim3(Q_NT), stream, (const float*)xa, (const float*)residual,
+              (float*)z, (const float*)stats, weight, bias, nch, C, relu, mmp);
+  if (z_minmax != nullptr)
+    CN_LAUNCH(minmax_final_kernel, dim3((unsigned)((rows + Q_NT - 1) / Q_NT)), dim3(Q_NT), stream, (const float*)mmp, rows, (int)bpr, z_minmax);
   return cn_check_launch("rangebn_fwd");
 }
 
@@ -655,17 +705,21 @@ extern "C" int cn_rangebn_fwd(const void* x, const void* residual, void* z, cons
                               float scale_fix, float* stats, int* arg, int M, int C, int relu, int training, int dtype,
                               float* ws, size_t ws_bytes, void* stream_) {
   return rangebn_fwd_impl(x, residual, z, weight, bias, running_mean, running_var, momentum, eps, chunks, scale_fix, stats,
-                          arg, M, C, relu, training, dtype, ws, ws_bytes, stream_, nullptr, 8);
+                          arg, M, C, relu, training, dtype, ws, ws_bytes, stream_, nullptr, 8, nullptr, 0, nullptr);
 }
-// cn_rangebn_fwd on the RAW input: x_qparams = [zero_point, range] of its x_bits-bit activation quantiser (cn_qparams);
-// every element is snapped on load (see RbnSnap).  Same results as cn_quantize followed by cn_rangebn_fwd.
-extern "C" int cn_rangebn_fwd_q(const void* x, const float* x_qparams, int x_bits, const void* residual, void* z,
+// Training forward on the RAW input with the producer-side fusions of round 4:
+//   x_qparams = [zero_point, range] of the x_bits-bit input quantiser (cn_qparams): the statistics pass snaps every element
+//     on load and stores the snapped tensor to qx_out (what cn_quantize would have written; the backward pass takes it);
+//   z_minmax (optional, mm_rows rows = batch samples): per-sample {min, max} of the stored z for the next quantiser.
+// Same qx, z, stats, arg bits as cn_quantize followed by cn_rangebn_fwd; z_minmax = cn_minmax_rows(z, mm_rows).
+extern "C" int cn_rangebn_fwd_q(const void* x, const float* x_qparams, int x_bits, void* qx_out, const void* residual, void* z,
                                 const float* weight, const float* bias, float* running_mean, float* running_var,
-                                float momentum, float eps, int chunks, float scale_fix, float* stats, int* arg, int M, int C,
-                                int relu, int training, int dtype, float* ws, size_t ws_bytes, void* stream_) {
-  if (x_qparams == nullptr || x_bits < 1 || x_bits > 23) { cn_set_error("rangebn_fwd_q: needs the input quantiser's parameters"); return CN_EINVAL; }
+                                float momentum, float eps, int chunks, float scale_fix, float* stats, int* arg, int M,
+                                int C, int relu, int dtype, int mm_rows, float* z_minmax, float* ws, size_t ws_bytes,
+                                void* stream_) {
+  if (x_qparams == nullptr || x_bits < 1 || x_bits > 23 || qx_out == nullptr) { cn_set_error("rangebn_fwd_q: needs the input quantiser's parameters and qx_out"); return CN_EINVAL; }
   return rangebn_fwd_impl(x, residual, z, weight, bias, running_mean, running_var, momentum, eps, chunks, scale_fix, stats,
-                          arg, M, C, relu, training, dtype, ws, ws_bytes, stream_, x_qparams, x_bits);
+                          arg, M, C, relu, 1, dtype, ws, ws_bytes, stream_, x_qparams, x_bits, qx_out, mm_rows, z_minmax);
 }
 
 // ---- backward.  g = the (already quantised) gradient of the RangeBN output, x = its quantised input.
@@ -675,8 +729,7 @@ extern "C" int cn_rangebn_fwd_q(const void* x, const float* x_qparams, int x_bit
 //   => dx[first argmax of chunk j] += dL/dscale * fix / chunks,  dx[first argmin of chunk j] -= the same.
 template <typename T>
 __global__ __launch_bounds__(Q_NT) void rangebn_bwd_reduce_kernel(const T* g, const T* x, const float* stats, int M, int C,
-                                                                 int rows_per, int cols, float* partial, const float* xqp,
-                                                                 float qmax) {
+                                                                 int rows_per, int cols, float* partial) {
   constexpr int CH = ElemTraits<T>::kChunk;
   __shared__ float s1[Q_NT * CH], s2[Q_NT * CH];
   const int tid = threadIdx.x, CC = C / CH;
@@ -687,13 +740,11 @@ __global__ __launch_bounds__(Q_NT) void rangebn_bwd_reduce_kernel(const T* g, co
   float a1[CH], a2[CH], mean[CH];
 #pragma unroll
   for (int e = 0; e < CH; ++e) { a1[e] = 0.f; a2[e] = 0.f; mean[e] = cc < CC ? stats[cc * CH + e] : 0.f; }
-  const RbnSnap snap = rbn_snap_make(xqp, qmax);
   if (cc < CC) {
     auto visit = [&](const u32x4& vg, const u32x4& vx) {
       float fg[CH], fx[CH];
       Chunk<T>::unpack(vg, fg);
       Chunk<T>::unpack(vx, fx);
-      rbn_snap_chunk<T>(snap, fx);
 #pragma unroll
       for (int e = 0; e < CH; ++e) { a1[e] += fg[e]; a2[e] += fg[e] * (fx[e] - mean[e]); }
     };
@@ -766,42 +817,107 @@ __global__ __launch_bounds__(RF_C * RF_T) void rangebn_bwd_finalize_kernel(const
   coef[2 * C + c] = (-w * r * r * s2) * route;
 }
 
+// dx = g * a[c] + b[c], rounded to T, then the routing of dL/dscale: the chunk's first maximum gets +d[c], its first minimum
+// -d[c] (each a separate rounded update, +d first: what a routing pass over the stored dx does - distinct chunks and
+// distinct channels never share an element; maximum == minimum only in a constant chunk, where the two cancel).
+// arg == nullptr: no routing here (rangebn_bwd_route_kernel follows).  Grid (blocks per row, rows) and mm_partial as
+// rangebn_apply_kernel: per-sample {min, max} of the FINAL dx for the gradient quantiser of the convolution in front
+// (UniformQuantizeGrad, quantize.py:101-112), so its min / max pass over dx disappears.
 template <typename T>
-__global__ __launch_bounds__(Q_NT) void rangebn_bwd_apply_kernel(const T* g, T* dx, const float* coef, long long nch, int C) {
+__global__ __launch_bounds__(Q_NT) void rangebn_bwd_apply_kernel(const T* g, T* dx, const float* coef, long long nch, int C,
+                                                                const int* arg, int chunks, int L, float* mm_partial) {
   constexpr int CH = ElemTraits<T>::kChunk;
+  __shared__ float red[8];
   const int CC = C / CH;
+  const long long rch = nch / gridDim.y;
+  const long long row0 = (long long)blockIdx.y * rch, row1 = row0 + rch;
   const long long stride = (long long)gridDim.x * Q_NT;
   const bool fixed_col = stride % CC == 0;   // see rangebn_apply_kernel
-  float a[CH], b[CH];
+  const int dm = (int)(stride / CC);         // pixels a thread advances per step (fixed_col)
+  float a[CH], b[CH], d[CH];
+  int imx[CH], imn[CH];
+  int c0 = 0, jend = 0, jcur = -1;           // the thread's channels; end pixel / index of the statistics chunk in `imx / imn`
+  float mn = INFINITY, mx = -INFINITY, mnr = INFINITY, mxr = -INFINITY;
   auto load_coef = [&](long long id) {
-    const int c0 = (int)(id % CC) * CH;
+    c0 = (int)(id % CC) * CH;
+    jcur = -1;
+    jend = 0;
 #pragma unroll
-    for (int e = 0; e < CH; ++e) { a[e] = coef[c0 + e]; b[e] = coef[C + c0 + e]; }
+    for (int e = 0; e < CH; ++e) { a[e] = coef[c0 + e]; b[e] = coef[C + c0 + e]; d[e] = arg != nullptr ? coef[2 * C + c0 + e] : 0.f; }
   };
-  auto apply = [&](const u32x4& v, long long id) {
+  // (m = pixel of chunk `id`, carried by the caller: no 64-bit division per element)
+  auto apply = [&](const u32x4& v, long long id, int m) {
     float f[CH];
     Chunk<T>::unpack(v, f);
 #pragma unroll
     for (int e = 0; e < CH; ++e) f[e] = f[e] * a[e] + b[e];
-    cn_st16((char*)dx + id * 16, Chunk<T>::pack(f));
+    u32x4 o = Chunk<T>::pack(f);
+    bool routed = false;
+    if (arg != nullptr) {
+      if (m >= jend || jcur < 0) {             // entered another statistics chunk (a thread's pixels only increase)
+        jcur = m / L;
+        jend = (jcur + 1) * L;
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+          imx[e] = arg[(size_t)(c0 + e) * 2 * chunks + jcur];
+          imn[e] = arg[(size_t)(c0 + e) * 2 * chunks + chunks + jcur];
+        }
+      }
+      int hit = 0;
+#pragma unroll
+      for (int e = 0; e < CH; ++e) hit |= (int)(m == imx[e]) | (int)(m == imn[e]);
+      if (hit) {
+        routed = true;
+        Chunk<T>::unpack(o, f);                // the stored value, then +d and -d each rounded to T
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+          if (m == imx[e]) f[e] = q_round_to<T>(f[e] + d[e]);
+          if (m == imn[e]) f[e] = q_round_to<T>(f[e] - d[e]);
+        }
+        o = Chunk<T>::pack(f);
+      }
+    }
+    cn_st16((char*)dx + id * 16, o);
+    if (mm_partial != nullptr) {
+      // plain chunks: the fp32 values (rounding to T is monotonic, the extremes are rounded once at the end); a chunk with a
+      // routed element: its values as stored (f holds them)
+      if (routed) {
+#pragma unroll
+        for (int e = 0; e < CH; ++e) { mnr = fminf(mnr, f[e]); mxr = fmaxf(mxr, f[e]); }
+      } else {
+#pragma unroll
+        for (int e = 0; e < CH; ++e) { mn = fminf(mn, f[e]); mx = fmaxf(mx, f[e]); }
+      }
+    }
   };
-  long long id = (long long)blockIdx.x * Q_NT + threadIdx.x;
-  if (id < nch) load_coef(id);
+  long long id = row0 + (long long)blockIdx.x * Q_NT + threadIdx.x;
+  int m = 0;
+  if (id < row1) { load_coef(id); m = (int)(id / CC); }
   if (fixed_col) {
-    for (; id + stride < nch; id += 2 * stride) {
+    for (; id + stride < row1; id += 2 * stride, m += 2 * dm) {
       const u32x4 v0 = cn_ld16((const char*)g + id * 16), v1 = cn_ld16((const char*)g + (id + stride) * 16);
-      apply(v0, id);
-      apply(v1, id + stride);
+      apply(v0, id, m);
+      apply(v1, id + stride, m + dm);
+    }
+    for (; id < row1; id += stride, m += dm) apply(cn_ld16((const char*)g + id * 16), id, m);
+  } else {
+    for (; id < row1; id += stride) {
+      load_coef(id);
+      apply(cn_ld16((const char*)g + id * 16), id, (int)(id / CC));
     }
   }
-  for (; id < nch; id += stride) {
-    if (!fixed_col) load_coef(id);
-    apply(cn_ld16((const char*)g + id * 16), id);
+  if (mm_partial != nullptr) {
+    mn = fminf(q_round_to<T>(mn), mnr);
+    mx = fmaxf(q_round_to<T>(mx), mxr);
+    q_block_minmax(mn, mx, red);
+    if (threadIdx.x == 0) {
+      mm_partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2] = mn;
+      mm_partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + 1] = mx;
+    }
   }
 }
 
-// one thread per (channel, chunk): the chunk's first maximum gets +d, its first minimum -d (distinct chunks and
-// distinct channels never share an element; maximum == minimum only in a constant chunk, where the two cancel)
+// one thread per (channel, chunk): the chunk's first maximum gets +d, its first minimum -d (the unfused form of the routing)
 template <typename T>
 __global__ __launch_bounds__(Q_NT) void rangebn_bwd_route_kernel(T* dx, const float* coef, const int* arg, int C, int chunks) {
   const int id = blockIdx.x * Q_NT + threadIdx.x;
@@ -821,17 +937,20 @@ __global__ __launch_bounds__(Q_NT) void rangebn_bwd_route_kernel(T* dx, const fl
   }
 }
 
+// mm_rows / dx_minmax given: the routing is folded into the apply pass and the per-row extremes of the final dx come out
+// of it (3 launches); else apply + routing pass (4 launches).  Same dx bits.
 static int rangebn_bwd_impl(const void* g, const void* x, const float* weight, const float* stats, const int* arg,
                               void* dx, float* dweight, float* dbias, int M, int C, int chunks, float scale_fix,
-                              int dtype, float* ws, size_t ws_bytes, void* stream_, const float* xqp, int x_bits) {
-  const float qmax = (float)((1 << (x_bits > 0 ? x_bits : 8)) - 1);
+                              int dtype, float* ws, size_t ws_bytes, void* stream_, int mm_rows, float* dx_minmax) {
   hipStream_t stream = (hipStream_t)stream_;
   const int CH = dtype == CN_BF16 ? 8 : 4;
   if (dtype != CN_BF16 && dtype != CN_F32) { cn_set_error("rangebn_bwd: bad dtype"); return CN_EINVAL; }
-  if (M <= 0 || C <= 0 || C % CH != 0 || chunks <= 0) { cn_set_error("rangebn_bwd: bad shape"); return CN_ESHAPE; }
+  if (M <= 0 || C <= 0 || C % CH != 0 || chunks <= 0 || M % chunks != 0) { cn_set_error("rangebn_bwd: bad shape"); return CN_ESHAPE; }
   if (g == nullptr || x == nullptr || weight == nullptr || stats == nullptr || arg == nullptr || dx == nullptr ||
       dweight == nullptr || dbias == nullptr) { cn_set_error("rangebn_bwd: null operand"); return CN_EINVAL; }
   if (ws == nullptr || ws_bytes < cn_rangebn_workspace(M, C, chunks)) { cn_set_error("rangebn_bwd: workspace too small"); return CN_EWORKSPACE; }
+  const bool fused = dx_minmax != nullptr;
+  if (fused && (mm_rows < 1 || M % mm_rows != 0 || mm_rows > 8192)) { cn_set_error("rangebn_bwd: %d pixels do not split into %d rows", M, mm_rows); return CN_ESHAPE; }
   const int CC = C / CH, cols = rbn_cols(CC);
   int rpr = cn_get_option("rbn_bwd_row_px", 512);   // pixels per partial row of the backward reduction (knob)
   if (rpr < 256) rpr = 256;
@@ -841,17 +960,28 @@ static int rangebn_bwd_impl(const void* g, const void* x, const float* weight, c
   dim3 grid((unsigned)((CC + cols - 1) / cols), (unsigned)rows);
   const long long nch = (long long)M * CC;
   const float route = scale_fix / (float)chunks;
-  if (dtype == CN_BF16) {
-    CN_LAUNCH(rangebn_bwd_reduce_kernel<bf16_t>, grid, dim3(Q_NT), stream, (const bf16_t*)g, (const bf16_t*)x, stats, M, C, rpr, cols, partial, xqp, qmax);
-    CN_LAUNCH(rangebn_bwd_finalize_kernel, dim3((unsigned)((C + RF_C - 1) / RF_C)), dim3(RF_C * RF_T), stream, (const float*)partial, rows, M, C, weight, stats, route, dweight, dbias, coef);
-    CN_LAUNCH(rangebn_bwd_apply_kernel<bf16_t>, dim3(q_grid_cols(nch, C / 8)), dim3(Q_NT), stream, (const bf16_t*)g, (bf16_t*)dx, (const float*)coef, nch, C);
-    CN_LAUNCH(rangebn_bwd_route_kernel<bf16_t>, dim3((unsigned)((C * chunks + Q_NT - 1) / Q_NT)), dim3(Q_NT), stream, (bf16_t*)dx, (const float*)coef, arg, C, chunks);
-  } else {
-    CN_LAUNCH(rangebn_bwd_reduce_kernel<float>, grid, dim3(Q_NT), stream, (const float*)g, (const float*)x, stats, M, C, rpr, cols, partial, xqp, qmax);
-    CN_LAUNCH(rangebn_bwd_finalize_kernel, dim3((unsigned)((C + RF_C - 1) / RF_C)), dim3(RF_C * RF_T), stream, (const float*)partial, rows, M, C, weight, stats, route, dweight, dbias, coef);
-    CN_LAUNCH(rangebn_bwd_apply_kernel<float>, dim3(q_grid_cols(nch, C / 4)), dim3(Q_NT), stream, (const float*)g, (float*)dx, (const float*)coef, nch, C);
-    CN_LAUNCH(rangebn_bwd_route_kernel<float>, dim3((unsigned)((C * chunks + Q_NT - 1) / Q_NT)), dim3(Q_NT), stream, (float*)dx, (const float*)coef, arg, C, chunks);
+  const int arows = fused ? mm_rows : 1;
+  const unsigned bpr = fused ? q_grid_rows(nch, arows, CC) : q_grid_cols(nch, CC);
+  float* mmp = nullptr;
+  if (fused) {   // the reduction partials are dead once finalize has run; coef lives behind them
+    if ((size_t)arows * bpr * 2 > (size_t)rows * 2 * C) { cn_set_error("rangebn_bwd: workspace too small for the min / max partials"); return CN_EWORKSPACE; }
+    mmp = partial;
   }
+  const dim3 agrid(bpr, (unsigned)arows);
+  const int L = M / chunks;
+  if (dtype == CN_BF16) {
+    CN_LAUNCH(rangebn_bwd_reduce_kernel<bf16_t>, grid, dim3(Q_NT), stream, (const bf16_t*)g, (const bf16_t*)x, stats, M, C, rpr, cols, partial);
+    CN_LAUNCH(rangebn_bwd_finalize_kernel, dim3((unsigned)((C + RF_C - 1) / RF_C)), dim3(RF_C * RF_T), stream, (const float*)partial, rows, M, C, weight, stats, route, dweight, dbias, coef);
+    CN_LAUNCH(rangebn_bwd_apply_kernel<bf16_t>, agrid, dim3(Q_NT), stream, (const bf16_t*)g, (bf16_t*)dx, (const float*)coef, nch, C, fused ? arg : (const int*)nullptr, chunks, L, mmp);
+    if (!fused) CN_LAUNCH(rangebn_bwd_route_kernel<bf16_t>, dim3((unsigned)((C * chunks + Q_NT - 1) / Q_NT)), dim3(Q_NT), stream, (bf16_t*)dx, (const float*)coef, arg, C, chunks);
+  } else {
+    CN_LAUNCH(rangebn_bwd_reduce_kernel<float>, grid, dim3(Q_NT), stream, (const float*)g, (const float*)x, stats, M, C, rpr, cols, partial);
+    CN_LAUNCH(rangebn_bwd_finalize_kernel, dim3((unsigned)((C + RF_C - 1) / RF_C)), dim3(RF_C * RF_T), stream, (const float*)partial, rows, M, C, weight, stats, route, dweight, dbias, coef);
+    CN_LAUNCH(rangebn_bwd_apply_kernel<float>, agrid, dim3(Q_NT), stream, (const float*)g, (float*)dx, (const float*)coef, nch, C, fused ? arg : (const int*)nullptr, chunks, L, mmp);
+    if (!fused) CN_LAUNCH(rangebn_bwd_route_kernel<float>, dim3((unsigned)((C * chunks + Q_NT - 1) / Q_NT)), dim3(Q_NT), stream, (float*)dx, (const float*)coef, arg, C, chunks);
+  }
+  if (fused)
+    CN_LAUNCH(minmax_final_kernel, dim3((unsigned)((arows + Q_NT - 1) / Q_NT)), dim3(Q_NT), stream, (const float*)mmp, arows, (int)bpr, dx_minmax);
   return cn_check_launch("rangebn_bwd");
 }
 
@@ -859,13 +989,79 @@ extern "C" int cn_rangebn_bwd(const void* g, const void* x, const float* weight,
                               void* dx, float* dweight, float* dbias, int M, int C, int chunks, float scale_fix,
                               int dtype, float* ws, size_t ws_bytes, void* stream_) {
   return rangebn_bwd_impl(g, x, weight, stats, arg, dx, dweight, dbias, M, C, chunks, scale_fix, dtype, ws, ws_bytes, stream_,
-                          nullptr, 8);
+                          0, nullptr);
 }
-// cn_rangebn_bwd with x = the RAW input cn_rangebn_fwd_q saw (re-snapped on load with the same x_qparams).
-extern "C" int cn_rangebn_bwd_q(const void* g, const void* x, const float* x_qparams, int x_bits, const float* weight,
-                                const float* stats, const int* arg, void* dx, float* dweight, float* dbias, int M, int C,
-                                int chunks, float scale_fix, int dtype, float* ws, size_t ws_bytes, void* stream_) {
-  if (x_qparams == nullptr || x_bits < 1 || x_bits > 23) { cn_set_error("rangebn_bwd_q: needs the input quantiser's parameters"); return CN_EINVAL; }
+// cn_rangebn_bwd with the routing folded into the apply pass and dx_minmax[mm_rows][2] = cn_minmax_rows(dx, mm_rows) as a
+// side output (mm_rows = batch samples).  Same dx, dweight, dbias bits.
+extern "C" int cn_rangebn_bwd_mm(const void* g, const void* x, const float* weight, const float* stats, const int* arg,
+                                 void* dx, float* dweight, float* dbias, int M, int C, int chunks, float scale_fix,
+                                 int dtype, int mm_rows, float* dx_minmax, float* ws, size_t ws_bytes, void* stream_) {
+  if (dx_minmax == nullptr) { cn_set_error("rangebn_bwd_mm: needs dx_minmax"); return CN_EINVAL; }
   return rangebn_bwd_impl(g, x, weight, stats, arg, dx, dweight, dbias, M, C, chunks, scale_fix, dtype, ws, ws_bytes, stream_,
-                          x_qparams, x_bits);
+                          mm_rows, dx_minmax);
+}
+
+// ------------------------------------------------------------------------------------------------ elementwise + min / max
+// a = b * (c > 0) (op 2: the ReLU mask of a gradient) or a = relu(b + c) (op 4: the residual junction) - cn_eltwise's
+// arithmetic - with minmax[rows][2] = cn_minmax_rows(a, rows) as a side output: the quantiser that consumes `a` next
+// (the RangeBN gradient quantiser; the next block's activation quantiser) needs no min / max pass of its own.
+template <typename T, int OP>
+__global__ __launch_bounds__(Q_NT) void eltwise_mm_kernel(char* a, const char* b, const char* c, long long nch, float* mm_partial) {
+  constexpr int CH = ElemTraits<T>::kChunk;
+  __shared__ float red[8];
+  const long long rch = nch / gridDim.y;
+  const long long row0 = (long long)blockIdx.y * rch, row1 = row0 + rch;
+  const long long stride = (long long)gridDim.x * Q_NT;
+  float mn = INFINITY, mx = -INFINITY;
+  auto one = [&](const u32x4& vb, const u32x4& vc, long long id) {
+    float fb[CH], fc[CH], fa[CH];
+    Chunk<T>::unpack(vb, fb);
+    Chunk<T>::unpack(vc, fc);
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+      if (OP == 2) fa[e] = fc[e] > 0.f ? fb[e] : 0.f;
+      else { const float v = fb[e] + fc[e]; fa[e] = v > 0.f ? v : 0.f; }
+    }
+    cn_st16(a + id * 16, Chunk<T>::pack(fa));
+#pragma unroll
+    for (int e = 0; e < CH; ++e) { mn = fminf(mn, fa[e]); mx = fmaxf(mx, fa[e]); }   // (rounded once at the end: monotonic)
+  };
+  long long id = row0 + (long long)blockIdx.x * Q_NT + threadIdx.x;
+  for (; id + stride < row1; id += 2 * stride) {   // four loads in flight
+    const u32x4 b0 = cn_ld16(b + id * 16), b1 = cn_ld16(b + (id + stride) * 16);
+    const u32x4 c0 = cn_ld16(c + id * 16), c1 = cn_ld16(c + (id + stride) * 16);
+    one(b0, c0, id);
+    one(b1, c1, id + stride);
+  }
+  for (; id < row1; id += stride) one(cn_ld16(b + id * 16), cn_ld16(c + id * 16), id);
+  q_block_minmax(mn, mx, red);
+  if (threadIdx.x == 0) {
+    mm_partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2] = q_round_to<T>(mn);
+    mm_partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + 1] = q_round_to<T>(mx);
+  }
+}
+
+extern "C" size_t cn_eltwise_mm_workspace(long long n, int rows, int dtype) {
+  const int CH = dtype == CN_F32 ? 4 : 8;
+  if (n <= 0 || rows < 1) return 0;
+  return (size_t)rows * q_grid_rows(n / CH, rows, 1) * 2 * sizeof(float);
+}
+extern "C" int cn_eltwise_mm(int op, void* a, const void* b, const void* c, long long n, int dtype, int rows, float* minmax,
+                             float* ws, size_t ws_bytes, void* stream_) {
+  if (dtype != CN_BF16 && dtype != CN_F32) { cn_set_error("eltwise_mm: bad dtype"); return CN_EINVAL; }
+  if (op != 2 && op != 4) { cn_set_error("eltwise_mm: op %d (2 or 4)", op); return CN_EINVAL; }
+  const int CH = dtype == CN_F32 ? 4 : 8;
+  if (a == nullptr || b == nullptr || c == nullptr || minmax == nullptr) { cn_set_error("eltwise_mm: null operand"); return CN_EINVAL; }
+  if (n <= 0 || rows < 1 || rows > 8192 || n % ((long long)rows * CH) != 0) { cn_set_error("eltwise_mm: n=%lld does not split into %d rows of whole chunks", n, rows); return CN_ESHAPE; }
+  if (ws == nullptr || ws_bytes < cn_eltwise_mm_workspace(n, rows, dtype)) { cn_set_error("eltwise_mm: workspace too small"); return CN_EWORKSPACE; }
+  hipStream_t stream = (hipStream_t)stream_;
+  const long long nch = n / CH;
+  const unsigned bpr = q_grid_rows(nch, rows, 1);
+  const dim3 grid(bpr, (unsigned)rows);
+#define ELTMM(T, OP) CN_LAUNCH((eltwise_mm_kernel<T, OP>), grid, dim3(Q_NT), stream, (char*)a, (const char*)b, (const char*)c, nch, ws)
+  if (dtype == CN_BF16) { if (op == 2) ELTMM(bf16_t, 2); else ELTMM(bf16_t, 4); }
+  else { if (op == 2) ELTMM(float, 2); else ELTMM(float, 4); }
+#undef ELTMM
+  CN_LAUNCH(minmax_final_kernel, dim3((unsigned)((rows + Q_NT - 1) / Q_NT)), dim3(Q_NT), stream, (const float*)ws, rows, (int)bpr, minmax);
+  return cn_check_launch("eltwise_mm");
 }

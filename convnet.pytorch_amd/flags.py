@@ -48,7 +48,7 @@ _DEFAULTS = {
     'graph_dp': 0,             # capture the RCCL bucket all-reduces too (opt-in until run on >= 2 devices)
     # ---- config 5
     'quant_int8': 0,           # QConv2d forward on the int8 MFMA kernel
-    'quant_fuse_rbn': 0,       # RangeBN's input quantiser folded into its kernels (slower: VALU-bound)
+    'quant_fuse': 1,           # producer-side fusions of the quantised chain (quant.py: FUSE_QUANT)
 }
 
 _ENV = 'CONVNET_AMD_FLAGS'

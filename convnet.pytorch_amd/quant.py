@@ -32,12 +32,34 @@ from torch.autograd import Function
 from . import _lib, flags, nn as cnn, ops
 from ._lib import check, dtype_code, ptr, stream_of
 
-# RangeBN's input quantiser folded into its kernels (cn_rangebn_fwd_q / cn_rangebn_bwd_q: the quantised copy of every
-# convolution output is neither written nor re-read).  Same results, bit for bit - and measured SLOWER on the whole step
-# (ResNet-50 bf16 b=256: 50.1 vs 49.5 ms): the three kernels that now snap on load (statistics with their per-element
-# arg-max bookkeeping, apply, backward reduce) pay the quantiser's division three times and turn VALU-bound.  Off by
-# default (flag quant_fuse_rbn).
-FUSE_RBN_QUANT = flags.on('quant_fuse_rbn')
+# Producer-side fusions of the quantised chain (round 4; flag quant_fuse, bit-identical to the separate passes,
+# tests/test_quant.py::test_producer_side_fusions_*):
+#  * RangeBN's input quantiser runs inside its statistics pass, which stores the snapped tensor (cn_rangebn_fwd_q): the
+#    separate quantise pass - one read of every convolution output - disappears.  (Round 3 snapped on load in all three
+#    RangeBN kernels without storing: three divisions per element, VALU-bound, slower; removed.)
+#  * the kernels that PRODUCE a tensor the next operator quantises also emit its per-sample min / max: RangeBN's apply
+#    (-> the next activation quantiser), the residual add + ReLU (-> the next block's), RangeBN's backward apply with the
+#    routing folded in (-> the convolution's gradient quantiser), the ReLU-mask pass (-> RangeBN's gradient quantiser).
+#    The quantisers find them in a stash and skip their own min / max pass over the tensor.
+FUSE_QUANT = flags.on('quant_fuse')
+
+# produced tensor -> its per-sample min / max ([rows][2] floats), keyed by storage address; the entry holds the tensor, so
+# the address cannot be recycled while it lives; `uses` consumers may take it, tick() (next forward) drops the rest
+_MM_STASH = {}
+
+
+def _stash_minmax(t, rows, mm, uses=1):
+    _MM_STASH[t.data_ptr()] = [t, rows, mm, uses]
+
+
+def _take_minmax(x, rows):
+    e = _MM_STASH.get(x.data_ptr())
+    if e is None or e[1] != rows or e[0].shape != x.shape or e[0].dtype != x.dtype:
+        return None
+    e[3] -= 1
+    if e[3] <= 0:
+        del _MM_STASH[x.data_ptr()]
+    return e[2]
 _NOISE_SOURCE = None
 _SEED = [0x5EED5EED]
 
@@ -79,12 +101,16 @@ def _step_counter(device):
 
 def tick(device):
     """Advance the noise step counter (once per training step, on the compute stream)."""
+    _MM_STASH.clear()
     c = _step_counter(device)
     check(_L().cn_counter_inc(ptr(c), stream_of(c)), 'cn_counter_inc')
 
 
 def minmax_rows(x, rows):
     """[rows][2] = per-row {min, max} of a contiguous tensor viewed as [rows][numel/rows]."""
+    mm = _take_minmax(x, rows)
+    if mm is not None:         # the kernel that produced x already measured it
+        return mm
     L = _L()
     row_len = x.numel() // rows
     out = torch.empty(rows * 2, dtype=torch.float32, device=x.device)
@@ -112,6 +138,25 @@ def quantize(x, zp, rng, num_bits=8, noise=None, stochastic=False):
                                                       num_bits, ptr(noise), int(stochastic), seed, ptr(step), stream_of(x)),
                                    'cn_quantize_s'), x.device)
     return y
+
+
+def eltwise_mm(op, b, c, rows):
+    """a = b * (c > 0) (op 2) or relu(b + c) (op 4) and [rows][2] per-row min / max of a (cn_eltwise_mm)."""
+    L = _L()
+    a = torch.empty_like(b)
+    mm = torch.empty(rows * 2, dtype=torch.float32, device=b.device)
+    code = dtype_code(b.dtype)
+    ws = ops.workspace(L.cn_eltwise_mm_workspace(b.numel(), rows, code), b.device, 'quant')
+    ops.PROFILER.run('quant: eltwise+minmax', 2, 0.0, 3 * b.numel() * b.element_size(),
+                     lambda: check(L.cn_eltwise_mm(op, ptr(a), ptr(b), ptr(c), b.numel(), code, rows, ptr(mm), ptr(ws),
+                                                   ws.numel() * 4, stream_of(b)), 'cn_eltwise_mm'), b.device)
+    return a, mm
+
+
+def _mm_ok(t):
+    """The fused producers split a tensor into its batch samples: whole 16-byte chunks per sample, bf16 / fp32."""
+    return (FUSE_QUANT and t.dim() >= 2 and t.dtype in (torch.bfloat16, torch.float32) and t.shape[0] <= 8192
+            and (t.numel() // t.shape[0]) % _lib.chunk_elems(t.dtype) == 0)
 
 
 def _noise_like(g):
@@ -423,39 +468,43 @@ class RangeBNFunction(Function):
         M = N * H * W
         L = _L()
         code = dtype_code(y.dtype)
-        fused = FUSE_RBN_QUANT
-        if fused:     # the kernels snap the raw convolution output on load
-            y = y.contiguous()
-            qp = mod.quantize_input.qparams_tensor(y)
-            qy = y
-        else:
-            qp = None
-            qy = mod.quantize_input(y.contiguous())
+        fused = FUSE_QUANT and y.dtype in (torch.bfloat16, torch.float32)
         if M % mod.num_chunks != 0 or M // mod.num_chunks < 2:
             raise _lib.ConvNetHipError('RangeBN: %d values per channel do not split into %d chunks of >= 2'
                                        % (M, mod.num_chunks))
         fix = _scale_fix(M // mod.num_chunks)
-        z = torch.empty_like(qy)
         stats = torch.empty(2 * C, dtype=torch.float32, device=y.device)
         arg = torch.empty(C * 2 * mod.num_chunks, dtype=torch.int32, device=y.device)
         ws = ops.workspace(L.cn_rangebn_workspace(M, C, mod.num_chunks), y.device, 'quant')
-        if fused:
-            ops.PROFILER.run('quant: rangebn_stats+finalize+apply (input quantiser folded in)', 3, 0.0,
-                             3 * qy.numel() * qy.element_size(),
-                             lambda: check(L.cn_rangebn_fwd_q(ptr(qy), ptr(qp), mod.quantize_input.num_bits, None, ptr(z),
-                                                              ptr(weight), ptr(bias), ptr(mod.running_mean),
+        if fused:     # the statistics pass snaps the raw convolution output on load and stores the snapped tensor
+            y = y.contiguous()
+            qp = mod.quantize_input.qparams_tensor(y)
+            qy = torch.empty_like(y)
+            z = torch.empty_like(y)
+            # z feeds an activation quantiser when a ReLU follows (bn1 / bn2 of a block): its per-sample extremes come along
+            want_mm = relu and _mm_ok(z) and torch.is_grad_enabled()
+            zmm = torch.empty(N * 2, dtype=torch.float32, device=y.device) if want_mm else None
+            ops.PROFILER.run('quant: rangebn quantise+stats, finalize, apply%s' % ('+minmax' if want_mm else ''),
+                             4 if want_mm else 3, 0.0, 4 * y.numel() * y.element_size(),
+                             lambda: check(L.cn_rangebn_fwd_q(ptr(y), ptr(qp), mod.quantize_input.num_bits, ptr(qy), None,
+                                                              ptr(z), ptr(weight), ptr(bias), ptr(mod.running_mean),
                                                               ptr(mod.running_var), mod.momentum, mod.eps, mod.num_chunks,
-                                                              fix, ptr(stats), ptr(arg), M, C, int(relu), 1, code, ptr(ws),
-                                                              ws.numel() * 4, stream_of(y)), 'cn_rangebn_fwd_q'), y.device)
+                                                              fix, ptr(stats), ptr(arg), M, C, int(relu), code, N if want_mm else 0,
+                                                              ptr(zmm), ptr(ws), ws.numel() * 4, stream_of(y)),
+                                           'cn_rangebn_fwd_q'), y.device)
+            if want_mm:
+                _stash_minmax(z, N, zmm)
         else:
+            qy = mod.quantize_input(y.contiguous())
+            z = torch.empty_like(qy)
             ops.PROFILER.run('quant: rangebn_stats+finalize+apply', 3, 0.0, 3 * qy.numel() * qy.element_size(),
                              lambda: check(L.cn_rangebn_fwd(ptr(qy), None, ptr(z), ptr(weight), ptr(bias),
                                                             ptr(mod.running_mean), ptr(mod.running_var), mod.momentum,
                                                             mod.eps, mod.num_chunks, fix, ptr(stats), ptr(arg), M, C,
                                                             int(relu), 1, code, ptr(ws), ws.numel() * 4, stream_of(y)),
                                            'cn_rangebn_fwd'), y.device)
-        ctx.mod, ctx.relu, ctx.fix, ctx.fused = mod, relu, fix, fused
-        ctx.save_for_backward(qy, weight, stats, arg, *((z,) if relu else ()), *((qp,) if fused else ()))
+        ctx.mod, ctx.relu, ctx.fix = mod, relu, fix
+        ctx.save_for_backward(qy, weight, stats, arg, *((z,) if relu else ()))
         return z
 
     @staticmethod
@@ -467,23 +516,29 @@ class RangeBNFunction(Function):
         M = N * H * W
         L = _L()
         dz = dz.contiguous()
+        fuse = _mm_ok(dz)
         if ctx.relu:     # the ReLU that follows the output-gradient quantiser in the reference
-            g0 = torch.empty_like(dz)
-            check(L.cn_eltwise(2, ptr(g0), ptr(dz), ptr(saved[4]), dz.numel(), dtype_code(dz.dtype), stream_of(dz)),
-                  'cn_eltwise')
+            if fuse:     # ... masked and measured in one pass
+                g0, mm = eltwise_mm(2, dz, saved[4], N)
+                _stash_minmax(g0, N, mm)
+            else:
+                g0 = torch.empty_like(dz)
+                check(L.cn_eltwise(2, ptr(g0), ptr(dz), ptr(saved[4]), dz.numel(), dtype_code(dz.dtype), stream_of(dz)),
+                      'cn_eltwise')
         else:
             g0 = dz
         gq = quantize_grad(g0, mod.num_bits_grad)
         dx = torch.empty_like(qy)
         ws = ops.workspace(L.cn_rangebn_workspace(M, C, mod.num_chunks), qy.device, 'quant')
-        if ctx.fused:
-            qp = saved[-1]
-            ops.PROFILER.run('quant: rangebn_bwd reduce+finalize+apply+route', 4, 0.0, 4 * qy.numel() * qy.element_size(),
-                             lambda: check(L.cn_rangebn_bwd_q(ptr(gq), ptr(qy), ptr(qp), mod.quantize_input.num_bits,
-                                                              ptr(weight), ptr(stats), ptr(arg), ptr(dx),
-                                                              ptr(mod.grad_view('weight')), ptr(mod.grad_view('bias')), M, C,
-                                                              mod.num_chunks, ctx.fix, dtype_code(qy.dtype), ptr(ws),
-                                                              ws.numel() * 4, stream_of(qy)), 'cn_rangebn_bwd_q'), qy.device)
+        if fuse:
+            dxmm = torch.empty(N * 2, dtype=torch.float32, device=qy.device)
+            ops.PROFILER.run('quant: rangebn_bwd reduce+finalize+apply(route, minmax)', 4, 0.0, 4 * qy.numel() * qy.element_size(),
+                             lambda: check(L.cn_rangebn_bwd_mm(ptr(gq), ptr(qy), ptr(weight), ptr(stats), ptr(arg), ptr(dx),
+                                                               ptr(mod.grad_view('weight')), ptr(mod.grad_view('bias')), M, C,
+                                                               mod.num_chunks, ctx.fix, dtype_code(qy.dtype), N, ptr(dxmm),
+                                                               ptr(ws), ws.numel() * 4, stream_of(qy)), 'cn_rangebn_bwd_mm'),
+                             qy.device)
+            _stash_minmax(dx, N, dxmm)     # for the gradient quantiser of the convolution in front (QConv2d.backward)
         else:
             ops.PROFILER.run('quant: rangebn_bwd reduce+finalize+apply+route', 4, 0.0, 4 * qy.numel() * qy.element_size(),
                              lambda: check(L.cn_rangebn_bwd(ptr(gq), ptr(qy), ptr(weight), ptr(stats), ptr(arg), ptr(dx),
@@ -552,9 +607,14 @@ class AddReLUFunction(Function):
 
     @staticmethod
     def forward(ctx, a, b):
-        z = torch.empty_like(a)
-        check(_L().cn_eltwise(4, ptr(z), ptr(a.contiguous()), ptr(b.contiguous()), a.numel(), dtype_code(a.dtype),
-                              stream_of(a)), 'cn_eltwise')
+        a, b = a.contiguous(), b.contiguous()
+        if _mm_ok(a) and torch.is_grad_enabled():     # (no stash outside training: nothing would consume it)
+            # the block output is what the next block's conv1 / projection quantise: measured here
+            z, mm = eltwise_mm(4, a, b, a.shape[0])
+            _stash_minmax(z, a.shape[0], mm)
+        else:
+            z = torch.empty_like(a)
+            check(_L().cn_eltwise(4, ptr(z), ptr(a), ptr(b), a.numel(), dtype_code(a.dtype), stream_of(a)), 'cn_eltwise')
         ctx.save_for_backward(z)
         return z
 
@@ -562,8 +622,13 @@ class AddReLUFunction(Function):
     def backward(ctx, dz):
         (z,) = ctx.saved_tensors
         dz = dz.contiguous()
-        g = torch.empty_like(dz)
-        check(_L().cn_eltwise(2, ptr(g), ptr(dz), ptr(z), dz.numel(), dtype_code(dz.dtype), stream_of(dz)), 'cn_eltwise')
+        if _mm_ok(dz):
+            # g reaches the gradient quantiser of bn3 (and of the projection's RangeBN when the block has one)
+            g, mm = eltwise_mm(2, dz, z, dz.shape[0])
+            _stash_minmax(g, dz.shape[0], mm, uses=2)
+        else:
+            g = torch.empty_like(dz)
+            check(_L().cn_eltwise(2, ptr(g), ptr(dz), ptr(z), dz.numel(), dtype_code(dz.dtype), stream_of(dz)), 'cn_eltwise')
         return g, g
 
 

@@ -418,17 +418,25 @@ int cn_rangebn_fwd(const void* x, const void* residual, void* z, const float* we
 int cn_rangebn_bwd(const void* g, const void* x, const float* weight, const float* stats, const int* arg, void* dx,
                    float* dweight, float* dbias, int M, int C, int chunks, float scale_fix, int dtype,
                    float* workspace, size_t workspace_bytes, void* stream);
-/* The same two calls on the RAW (not yet input-quantised) tensor: x_qparams = [zero_point, range] of RangeBN's own
- * x_bits-bit activation quantiser (cn_qparams' output; quantize.py:270,308 quantises the input first).  The kernels snap
- * every element on load with cn_quantize's arithmetic and rounding, so the quantised copy is never written or re-read:
- * same results as cn_quantize followed by cn_rangebn_fwd / cn_rangebn_bwd. */
-int cn_rangebn_fwd_q(const void* x, const float* x_qparams, int x_bits, const void* residual, void* z, const float* weight,
-                     const float* bias, float* running_mean, float* running_var, float momentum, float eps, int chunks,
-                     float scale_fix, float* stats, int* arg, int M, int C, int relu, int training, int dtype, float* ws,
-                     size_t ws_bytes, void* stream);
-int cn_rangebn_bwd_q(const void* g, const void* x, const float* x_qparams, int x_bits, const float* weight,
-                     const float* stats, const int* arg, void* dx, float* dweight, float* dbias, int M, int C, int chunks,
-                     float scale_fix, int dtype, float* ws, size_t ws_bytes, void* stream);
+/* Round-4 producer-side fusions of the quantised chain (same bits as the separate passes; quantize.py:158-182, 101-112,
+ * 288-326):
+ *  cn_rangebn_fwd_q   training forward on the RAW convolution output: x_qparams = [zero_point, range] of RangeBN's
+ *                     x_bits-bit input quantiser (cn_qparams); the statistics pass snaps every element on load and stores
+ *                     the snapped tensor to qx_out (= cn_quantize(x); the backward pass reads it); z_minmax (optional):
+ *                     [mm_rows][2] = cn_minmax_rows(z, mm_rows), mm_rows = batch samples, for the next activation quantiser
+ *  cn_rangebn_bwd_mm  cn_rangebn_bwd with the routing of dL/dscale folded into the apply pass and
+ *                     dx_minmax[mm_rows][2] = cn_minmax_rows(dx, mm_rows) for the gradient quantiser of the convolution
+ *  cn_eltwise_mm      a = b * (c > 0) (op 2) / a = relu(b + c) (op 4) with minmax[rows][2] = cn_minmax_rows(a, rows) */
+int cn_rangebn_fwd_q(const void* x, const float* x_qparams, int x_bits, void* qx_out, const void* residual, void* z,
+                     const float* weight, const float* bias, float* running_mean, float* running_var, float momentum,
+                     float eps, int chunks, float scale_fix, float* stats, int* arg, int M, int C, int relu, int dtype,
+                     int mm_rows, float* z_minmax, float* ws, size_t ws_bytes, void* stream);
+int cn_rangebn_bwd_mm(const void* g, const void* x, const float* weight, const float* stats, const int* arg, void* dx,
+                      float* dweight, float* dbias, int M, int C, int chunks, float scale_fix, int dtype, int mm_rows,
+                      float* dx_minmax, float* ws, size_t ws_bytes, void* stream);
+size_t cn_eltwise_mm_workspace(long long n, int rows, int dtype);
+int cn_eltwise_mm(int op, void* a, const void* b, const void* c, long long n, int dtype, int rows, float* minmax, float* ws,
+                  size_t ws_bytes, void* stream);
 
 /* ---- true int8 MFMA forward product of QConv2d (v_mfma_i32_32x32x32_i8; csrc/qconv_i8.hip).  Both operands of
  * the reference's simulated convolution (quantize.py:195-219) live on integer grids, so

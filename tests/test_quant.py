@@ -357,26 +357,107 @@ def test_bench_scale_quantised_resnet50_follows_the_reference(dtype, reference_n
 
 
 @pytest.mark.parametrize('mode', MODES)
-def test_folded_input_quantiser_and_shared_block_input_change_no_bit(mode, reference_noise):
-    """Round 3: RangeBN's input quantiser folded into its kernels (cn_rangebn_fwd_q / cn_rangebn_bwd_q, the quantised
-    copy of every convolution output is never written) and the block input quantised once for conv1 and the projection
-    shortcut: the same trajectory, bit for bit, as the separate cn_quantize passes."""
-    if mode == 'emul':
-        pytest.skip('GPU suite (85 s on the emulator; the folded form is off by default)')
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_producer_side_fusions_ops_change_no_bit(mode, dtype):
+    """Round 4, op level (quantize.py:158-182, 101-112, 288-326): cn_rangebn_fwd_q (input quantiser inside the statistics
+    pass, snapped tensor stored, per-sample min / max of z) == cn_quantize + cn_rangebn_fwd + cn_minmax_rows;
+    cn_rangebn_bwd_mm (routing folded into the apply pass, per-sample min / max of dx) == cn_rangebn_bwd + cn_minmax_rows;
+    cn_eltwise_mm == cn_eltwise + cn_minmax_rows: every tensor bit for bit."""
+    dev = _dev(mode)
+    import convnet_amd as ca
+    Q, L, lib = ca.quant, ca._lib.load(), ca._lib
+    ptr, code = lib.ptr, lib.dtype_code(dtype)
+    shapes = [(4, 6, 8, 16), (2, 4, 4, 32)] if mode == 'emul' else [(32, 28, 28, 128), (16, 14, 14, 256), (64, 56, 56, 64)]
+    for (N, H, W, C) in shapes:
+        g_ = torch.Generator().manual_seed(N + H + C)
+        M, chunks = N * H * W, 16
+        y = (torch.randn(N, H, W, C, generator=g_) * 1.3 + 0.2).to(dtype).to(dev)
+        # ties inside a chunk (first-index rule) and a routed element that is also the tensor's extreme
+        y[0, 0, 0, :] = 9.0
+        y[0, 0, 1, :] = 9.0
+        w = (torch.rand(C, generator=g_) + 0.5).to(dev)
+        b = (torch.randn(C, generator=g_) * 0.2).to(dev)
+        fix = Q._scale_fix(M // chunks)
+        for relu in (True, False):
+            outs = {}
+            for fused in (False, True):
+                rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+                stats = torch.empty(2 * C, dtype=torch.float32, device=dev)
+                arg = torch.empty(C * 2 * chunks, dtype=torch.int32, device=dev)
+                ws = ca.ops.workspace(L.cn_rangebn_workspace(M, C, chunks), dev, 'quant')
+                z = torch.empty_like(y)
+                qp = Q.qparams(Q.minmax_rows(y, N), N, 0)
+                if fused:
+                    qy = torch.full_like(y, float('nan'))
+                    zmm = torch.empty(N * 2, dtype=torch.float32, device=dev)
+                    lib.check(L.cn_rangebn_fwd_q(ptr(y), ptr(qp), 8, ptr(qy), None, ptr(z), ptr(w), ptr(b), ptr(rm), ptr(rv), 0.1,
+                                                 1e-5, chunks, fix, ptr(stats), ptr(arg), M, C, int(relu), code, N, ptr(zmm),
+                                                 ptr(ws), ws.numel() * 4, lib.stream_of(y)), 'cn_rangebn_fwd_q')
+                else:
+                    qy = Q.quantize(y, qp[0:1], qp[1:2], 8)
+                    lib.check(L.cn_rangebn_fwd(ptr(qy), None, ptr(z), ptr(w), ptr(b), ptr(rm), ptr(rv), 0.1, 1e-5, chunks, fix,
+                                               ptr(stats), ptr(arg), M, C, int(relu), 1, code, ptr(ws), ws.numel() * 4,
+                                               lib.stream_of(y)), 'cn_rangebn_fwd')
+                    zmm = Q.minmax_rows(z, N)
+                # backward on a fixed gradient
+                gq = (torch.randn(N, H, W, C, generator=torch.Generator().manual_seed(7)) * 0.1).to(dtype).to(dev)
+                dx = torch.empty_like(y)
+                dw, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+                if fused:
+                    dxmm = torch.empty(N * 2, dtype=torch.float32, device=dev)
+                    lib.check(L.cn_rangebn_bwd_mm(ptr(gq), ptr(qy), ptr(w), ptr(stats), ptr(arg), ptr(dx), ptr(dw), ptr(db), M, C,
+                                                  chunks, fix, code, N, ptr(dxmm), ptr(ws), ws.numel() * 4, lib.stream_of(y)),
+                              'cn_rangebn_bwd_mm')
+                else:
+                    lib.check(L.cn_rangebn_bwd(ptr(gq), ptr(qy), ptr(w), ptr(stats), ptr(arg), ptr(dx), ptr(dw), ptr(db), M, C,
+                                               chunks, fix, code, ptr(ws), ws.numel() * 4, lib.stream_of(y)), 'cn_rangebn_bwd')
+                    dxmm = Q.minmax_rows(dx, N)
+                outs[fused] = [t.float().cpu().clone() for t in (qy, z, stats, arg, zmm, dx, dw, db, dxmm, rm, rv)]
+            for i, (a0, a1) in enumerate(zip(outs[False], outs[True])):
+                assert torch.equal(a0, a1), ((N, H, W, C), relu, i)
+        # elementwise + min / max
+        bb = (torch.randn(N, H, W, C, generator=g_)).to(dtype).to(dev)
+        cc = (torch.randn(N, H, W, C, generator=g_)).to(dtype).to(dev)
+        for op in (2, 4):
+            a0 = torch.empty_like(bb)
+            lib.check(L.cn_eltwise(op, ptr(a0), ptr(bb), ptr(cc), bb.numel(), code, lib.stream_of(bb)), 'cn_eltwise')
+            mm0 = Q.minmax_rows(a0, N)
+            a1, mm1 = Q.eltwise_mm(op, bb, cc, N)
+            assert torch.equal(a0.cpu(), a1.cpu()) and torch.equal(mm0.cpu(), mm1.cpu()), ((N, H, W, C), op)
+
+
+@pytest.mark.parametrize('mode', MODES)
+def test_producer_side_fusions_change_no_bit_of_a_trajectory(mode, reference_noise):
+    """Round 4, model level: with quant.FUSE_QUANT on (the default) the quantised ResNet trains to the same numbers, bit for
+    bit, as with every quantiser running its own min / max and quantise passes - and the stash really is used (no
+    cn_minmax_rows launch is left for the tensors the fused producers measured)."""
     dev = _dev(mode)
     import convnet_amd as ca
     meta = json.load(open(os.path.join(GOLDEN, 'traj_r18s_quant.json')))
     res = {}
-    saved = ca.quant.FUSE_RBN_QUANT
+    saved = ca.quant.FUSE_QUANT
+    calls = {}
+    real = ca.quant._take_minmax
     try:
         for fused in (False, True):
-            ca.quant.FUSE_RBN_QUANT = fused
+            ca.quant.FUSE_QUANT = fused
+            hits = [0, 0]
+
+            def counting(x, rows, hits=hits):
+                r = real(x, rows)
+                hits[0 if r is None else 1] += 1
+                return r
+            ca.quant._take_minmax = counting
             recs, tr, model, data = _engine_trajectory(meta, 18, dev, torch.float32, 2 if mode == 'gpu' else 1)
-            if not fused:   # ... and without the shared block input
-                pass
             res[fused] = (recs, {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()})
+            calls[fused] = tuple(hits)
     finally:
-        ca.quant.FUSE_RBN_QUANT = saved
+        ca.quant.FUSE_QUANT = saved
+        ca.quant._take_minmax = real
     assert res[False][0] == res[True][0], (res[False][0], res[True][0])
     for k, v in res[False][1].items():
         assert torch.equal(v, res[True][1][k]), k
+    assert calls[False][1] == 0 and calls[True][1] > 0, calls
+    # what is still measured by its own pass: the convolution outputs (RangeBN's input quantiser), the network input, the
+    # classifier's input and bias - fewer than half of the quantisers
+    assert calls[True][1] >= calls[True][0] * 0.8, calls
