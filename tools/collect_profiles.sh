@@ -1,8 +1,9 @@
 #!/bin/bash
-# Copy the closing-set artefacts of a gpurun_out/<tag>/ directory (tools/gpu_r3final.sh) into profiles/ under r03_ names.
+# Copy the closing-set artefacts of a gpurun_out/<tag>/ directory (tools/gpu_final.sh) into profiles/ under r03_ names.
 set -e
-S=gpurun_out/${1:?tag}; P=profiles; R=${2:-r03}
+S=gpurun_out/${1:?tag}; P=profiles; R=${2:?round tag, e.g. r04}
 cp $S/bench.json $P/${R}_bench_line.json
+cp $S/bench_detail.json $P/${R}_bench_detail.json
 cp $S/bench_b8.json $P/${R}_bench_line_b8.json
 cp $S/bench_config5.json $P/${R}_bench_line_config5_quantize_bf16.json
 cp $S/bench_dist1.json $P/${R}_bench_line_world1_rccl.json

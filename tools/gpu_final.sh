@@ -1,15 +1,15 @@
 #!/bin/bash
-# Round-3 closing set: environment, GPU tests, smoke, bench line (+ live PMC traffic), rocprofv3 kernel stats, per-layer
+# Closing set of a round (tools/gpu_final.sh TAG; then tools/collect_profiles.sh TAG rNN): environment, GPU tests, smoke, bench line (+ live PMC traffic), rocprofv3 kernel stats, per-layer
 # tables, the secondary bench lines.  Everything lands under gpurun_out/<tag>/.
 export TMPDIR=/tmp
-OUT=gpurun_out/${1:-r3final}
+OUT=gpurun_out/${1:-final}
 mkdir -p $OUT
 { date; python -c "import torch;print('torch',torch.__version__,'devices',torch.cuda.device_count(),torch.cuda.get_device_name(0))"
   /opt/rocm/bin/rocminfo | grep -E "Marketing Name|Compute Unit|Max Clock Freq|gfx" | head -8
   python -c "import sys;sys.path.insert(0,'.');from oracle.convnet_oracle import usable_cpus;print('usable cpus',usable_cpus())"; nproc; } > $OUT/env.txt 2>&1
 echo "== gpu tests"; timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider 2>&1 | tail -40 | tee $OUT/pytest_gpu.txt
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee $OUT/smoke.txt
-echo "== bench (+pmc)"; timeout 1800 python bench.py --steps 20 --warmup 5 --pmc --pmc-out $OUT/pmc_traffic.json 2> $OUT/bench.err | grep '"metric"' > $OUT/bench.json; cut -c1-400 $OUT/bench.json; tail -3 $OUT/bench.err
+echo "== bench (+pmc)"; timeout 1800 python bench.py --steps 20 --warmup 5 --pmc --pmc-out $OUT/pmc_traffic.json --detail-out $OUT/bench_detail.json 2> $OUT/bench.err | tail -1 > $OUT/bench.json; cut -c1-400 $OUT/bench.json; wc -c $OUT/bench.json; tail -3 $OUT/bench.err
 echo "== layers"; timeout 600 python tools/bench_layers.py --variants 0 2>&1 | grep -v amdgpu.ids | tail -30 | tee $OUT/layers.txt
 echo "== b8"; timeout 300 python bench.py --batch 8 --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-profile 2>/dev/null | grep '"metric"' | tee $OUT/bench_b8.json | cut -c1-250
 echo "== host inputs"; timeout 300 python bench.py --host-inputs --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-profile 2>/dev/null | grep '"metric"' | tee $OUT/bench_host_inputs.json | cut -c1-250
