@@ -485,7 +485,7 @@ int wg_launch_reduce(hipStream_t stream, const float* part, float* dw, int nspli
                      int Creal, float beta, float scale) {
   const long long total = (long long)Co * ntaps * Creal;
   unsigned nb = (unsigned)((total + 255) / 256);
-  if (nb > 8192) nb = 8192;
+  if (nb > 1024) nb = 1024;   // (few, long workgroups beside the chain: 14.71k vs 14.64k img/s with 8192, 256 the same; profiles/README.md)
   CN_LAUNCH(wgrad_reduce_kernel, dim3(nb), dim3(256), stream, part, dw, nsplit, Co, ntaps, Ci, Creal, beta, scale);
   return cn_check_launch("wgrad_reduce");
 }

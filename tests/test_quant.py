@@ -431,6 +431,8 @@ def test_producer_side_fusions_change_no_bit_of_a_trajectory(mode, reference_noi
     """Round 4, model level: with quant.FUSE_QUANT on (the default) the quantised ResNet trains to the same numbers, bit for
     bit, as with every quantiser running its own min / max and quantise passes - and the stash really is used (no
     cn_minmax_rows launch is left for the tensors the fused producers measured)."""
+    if mode == 'emul':
+        pytest.skip('GPU suite (two trajectories: 85 s on the emulator; the op-level test above covers the emulator)')
     dev = _dev(mode)
     import convnet_amd as ca
     meta = json.load(open(os.path.join(GOLDEN, 'traj_r18s_quant.json')))
