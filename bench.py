@@ -216,7 +216,7 @@ def main():
     torch.cuda.synchronize()
     fence()
     elapsed = time.perf_counter() - t0
-    rank_devices = [local_rank]
+    rank_devices, params_in_sync = [local_rank], None
     if distributed:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -224,6 +224,14 @@ def main():
         # which HIP device every rank ran on, by rank (one process per GPU: rank r -> device r on a full node)
         rank_devices = [None] * world
         dist.all_gather_object(rank_devices, torch.cuda.current_device())
+        # data-parallel sanity of THIS run, outside the timed region: after W + K steps on different shards every rank must
+        # hold the same master weights (same initial broadcast, same all-reduced gradients, same update) - a transport that
+        # loses or reorders a bucket shows up here, not only in a loss curve
+        p32 = tr.arena.params.double()
+        sig = [None] * world
+        dist.all_gather_object(sig, (float(p32.sum()), float(p32.abs().sum())))
+        params_in_sync = all(abs(a - sig[0][0]) <= 1e-9 * abs(sig[0][0]) + 1e-12 and abs(b - sig[0][1]) <= 1e-9 * abs(sig[0][1])
+                             for a, b in sig)
 
     # ---- live per-kernel timing: two profiled passes after the timed region, HIP events on the launch stream ----
     #  (1) overlapped: the step keeps its two-stream schedule; the events sit on the stream each call is launched on.
@@ -386,7 +394,7 @@ def main():
                                    '%s' % (args.depth, args.depth, B, args.dtype,
                                            'dp%d gradient all-reduce' % world if world > 1 else '1 MI355X'),
                        'global_batch': B * world, 'final_loss': round(float(res['loss']), 4),
-                       'parallelism': 'dp%d' % world, 'rank_devices': rank_devices,
+                       'parallelism': 'dp%d' % world, 'rank_devices': rank_devices, 'params_in_sync_across_ranks': params_in_sync,
                        'transport': (tr.reducer.describe() if tr.reducer is not None else None) if comm_note is None
                        else '%s [%s]' % (tr.reducer.describe() if tr.reducer is not None else None, comm_note)},
             'mfma_frac_whole_step': round(step_tflops / (elapsed / args.steps) / PEAK_TFLOPS[args.dtype], 4)

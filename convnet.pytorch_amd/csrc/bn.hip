@@ -694,7 +694,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(BnPoolGeom geo, 
     }                                                                                              \
   } while (0)
 
-#define BN_TARGET_BLOCKS 512   /* reduction kernels: partial rows per channel (kept small) */
+#define BN_TARGET_BLOCKS 512   /* partial rows per channel the finalize kernels take without a compression launch */
+/* Row blocks of the standalone reduction passes (bn_stats / bn_bwd_reduce; knob "bn_reduce_blocks").  256: the kernels keep
+ * 8-12 sixteen-byte loads in flight per lane, so 256 workgroups already saturate HBM, and fewer, longer workgroups leave the
+ * chain's other kernels and the side stream more of the chip: 14.93k img/s vs 14.76k at 512, 14.59k at 128, 13.76k at 64
+ * (round 4, profiles/README.md). */
+#define BN_REDUCE_BLOCKS 256
 #define BN_APPLY_BLOCKS 2048   /* pure streaming kernels */
 /* Sweep direction of the streaming kernels, bit 0: forward apply, bit 1: backward reduce, bit 2: backward
  * apply.  A kernel that sweeps in the opposite direction to the one that last touched its input finds
@@ -751,7 +756,7 @@ extern "C" int cn_bn_fwd_train(const void* y, const void* residual, void* z, uns
   hipStream_t stream = (hipStream_t)stream_;
   const int CH = cn_dtype_chunk(dtype);
   BnMap m = bn_map(C / CH);
-  int nrb = bn_row_blocks(M, m, cn_get_option("bn_reduce_blocks", BN_TARGET_BLOCKS));
+  int nrb = bn_row_blocks(M, m, cn_get_option("bn_reduce_blocks", BN_REDUCE_BLOCKS));
   if (workspace == nullptr || ws_bytes < (size_t)nrb * 2 * C * sizeof(float)) {
     cn_set_error("bn_fwd_train: workspace too small");
     return CN_EWORKSPACE;
@@ -889,7 +894,7 @@ extern "C" int cn_bn_bwd(const void* dz, const void* y, const unsigned char* rel
   hipStream_t stream = (hipStream_t)stream_;
   const int CH = cn_dtype_chunk(dtype);
   BnMap m = bn_map(C / CH);
-  int nrb = bn_row_blocks(M, m, cn_get_option("bn_reduce_blocks", BN_TARGET_BLOCKS));
+  int nrb = bn_row_blocks(M, m, cn_get_option("bn_reduce_blocks", BN_REDUCE_BLOCKS));
   if (workspace == nullptr || ws_bytes < (size_t)nrb * 2 * C * sizeof(float)) {
     cn_set_error("bn_bwd: workspace too small");
     return CN_EWORKSPACE;
@@ -1054,7 +1059,7 @@ extern "C" int cn_bn_local_sums(const void* y, int M, int C, int dtype, const fl
   if (partial == nullptr) {
     const int CH = cn_dtype_chunk(dtype);
     BnMap m = bn_map(C / CH);
-    nrb = bn_row_blocks(M, m, cn_get_option("bn_reduce_blocks", BN_TARGET_BLOCKS));
+    nrb = bn_row_blocks(M, m, cn_get_option("bn_reduce_blocks", BN_REDUCE_BLOCKS));
     if (workspace == nullptr || ws_bytes < (size_t)nrb * 2 * C * sizeof(float)) {
       cn_set_error("bn_local_sums: workspace too small");
       return CN_EWORKSPACE;
@@ -1099,7 +1104,7 @@ extern "C" int cn_bn_bwd_local_sums(const void* dz, const void* y, const unsigne
   if (partial == nullptr) {
     const int CH = cn_dtype_chunk(dtype);
     BnMap m = bn_map(C / CH);
-    nrb = bn_row_blocks(M, m, cn_get_option("bn_reduce_blocks", BN_TARGET_BLOCKS));
+    nrb = bn_row_blocks(M, m, cn_get_option("bn_reduce_blocks", BN_REDUCE_BLOCKS));
     if (workspace == nullptr || ws_bytes < (size_t)nrb * 2 * C * sizeof(float)) {
       cn_set_error("bn_bwd_local_sums: workspace too small");
       return CN_EWORKSPACE;
@@ -1161,7 +1166,7 @@ static int bn_bwd_maxpool_impl(const void* dpool, const unsigned char* idx, cons
   hipStream_t stream = (hipStream_t)stream_;
   const int CH = cn_dtype_chunk(dtype);
   BnMap m = bn_map(C / CH);
-  int nrb = bn_row_blocks(M, m, cn_get_option("bn_reduce_blocks", BN_TARGET_BLOCKS));
+  int nrb = bn_row_blocks(M, m, cn_get_option("bn_reduce_blocks", BN_REDUCE_BLOCKS));
   if (workspace == nullptr || ws_bytes < (size_t)nrb * 2 * C * sizeof(float)) {
     cn_set_error("bn_bwd_maxpool: workspace too small");
     return CN_EWORKSPACE;
@@ -1185,7 +1190,7 @@ static int bn_bwd_maxpool_impl(const void* dpool, const unsigned char* idx, cons
     // sums over the pooled map: every pooled element sends its gradient to exactly one input pixel, whose
     // pre-BatchNorm value the forward kept (xmax), so sum g and sum g*xhat need neither the gather nor the big map
     const long long Mp = (long long)N * geo.P * geo.Q;
-    nrb = bn_row_blocks((int)Mp, m, cn_get_option("bn_reduce_blocks", BN_TARGET_BLOCKS));
+    nrb = bn_row_blocks((int)Mp, m, cn_get_option("bn_reduce_blocks", BN_REDUCE_BLOCKS));
     dim3 pgrid((unsigned)nrb, (unsigned)m.gy);
     BN_DISPATCH(bn_bwd_reduce_kernel, dtype, false, pgrid, stream, (const char*)dpool, (const char*)xmax, (const unsigned char*)nullptr, mean, invstd, scale, shift, partial, (int)Mp, C, 1, m.tpr_log2, 0);
   } else {

@@ -146,6 +146,7 @@ def test_bench_eight_rank_protocol_under_the_drivers_launcher(tmp_path):
     assert rec['n_gpus'] == 8 and rec['steps'] == 3 and rec['warmup'] == 2 and rec['scaling'] == 'weak'
     assert rec['config']['global_batch'] == 32 and rec['config']['parallelism'] == 'dp8'
     assert rec['config']['rank_devices'] == [0] * 8          # (a full node: [0, 1, ..., 7])
+    assert rec['config']['params_in_sync_across_ranks'] is True     # eight shards, one set of weights after 5 steps
     assert 'gloo' in rec['config']['transport'] and rec['transport_fallback'] is False
     assert abs(rec['value'] - 32 * 1e3 / rec['ms_per_step']) / rec['value'] < 1e-3
     assert len(lines[0]) < 8192
