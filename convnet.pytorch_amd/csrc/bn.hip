@@ -694,6 +694,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(BnPoolGeom geo, 
     }                                                                                              \
   } while (0)
 
+// (the reduction passes: cached loads only - non-temporal loads there measured slower, profiles/README.md)
+#define BN_DISPATCH_PLAIN(kern, dtype, grid, stream, ...)                                          \
+  do {                                                                                             \
+    if ((dtype) == CN_BF16) CN_LAUNCH((kern<bf16_t, false>), grid, dim3(256), stream, __VA_ARGS__); \
+    else if ((dtype) == CN_F16) CN_LAUNCH((kern<f16_t, false>), grid, dim3(256), stream, __VA_ARGS__); \
+    else CN_LAUNCH((kern<float, false>), grid, dim3(256), stream, __VA_ARGS__);                     \
+  } while (0)
+
 #define BN_TARGET_BLOCKS 512   /* partial rows per channel the finalize kernels take without a compression launch */
 /* Row blocks of the standalone reduction passes (bn_stats / bn_bwd_reduce; knob "bn_reduce_blocks").  256: the kernels keep
  * 8-12 sixteen-byte loads in flight per lane, so 256 workgroups already saturate HBM, and fewer, longer workgroups leave the
@@ -908,7 +916,7 @@ extern "C" int cn_bn_bwd(const void* dz, const void* y, const unsigned char* rel
   const int revopt = cn_get_option("bn_reverse", BN_REVERSE_DEFAULT);
   const int rev_r = (revopt >> 1) & 1, rev_a = ((revopt >> 2) & 1);
   CnMarkLast last;   // an armed completion mark goes on the apply kernel only
-  BN_DISPATCH(bn_bwd_reduce_kernel, dtype, (cn_get_option("bn_reduce_nt", 0) != 0), grid, stream, (const char*)dz, (const char*)y, relu_mask, mean, invstd, scale, shift, partial, M, C, relu, m.tpr_log2, rev_r);
+  BN_DISPATCH_PLAIN(bn_bwd_reduce_kernel, dtype, grid, stream, (const char*)dz, (const char*)y, relu_mask, mean, invstd, scale, shift, partial, M, C, relu, m.tpr_log2, rev_r);
   if (dy == nullptr) {
     // "lazy dy": reduce + finalize only, the consumers form c1*dz + c2*y + c3 themselves.  Only where dz needs no mask
     // (no ReLU behind this BatchNorm) and no residual-branch copy is wanted.
@@ -1110,7 +1118,7 @@ extern "C" int cn_bn_bwd_local_sums(const void* dz, const void* y, const unsigne
       return CN_EWORKSPACE;
     }
     dim3 grid((unsigned)nrb, (unsigned)m.gy);
-    BN_DISPATCH(bn_bwd_reduce_kernel, dtype, (cn_get_option("bn_reduce_nt", 0) != 0), grid, stream, (const char*)dz, (const char*)y, relu_mask, stats, stats + C, stats + 2 * C, stats + 3 * C, (float*)workspace, M, C, relu, m.tpr_log2, 0);
+    BN_DISPATCH_PLAIN(bn_bwd_reduce_kernel, dtype, grid, stream, (const char*)dz, (const char*)y, relu_mask, stats, stats + C, stats + 2 * C, stats + 3 * C, (float*)workspace, M, C, relu, m.tpr_log2, 0);
     partial = (const float*)workspace;
   }
   CN_LAUNCH(bn_partials_total_kernel, dim3((unsigned)((2 * C + 31) / 32)), dim3(256), stream, partial, nrb, 2 * C, sums);
@@ -1192,7 +1200,7 @@ static int bn_bwd_maxpool_impl(const void* dpool, const unsigned char* idx, cons
     const long long Mp = (long long)N * geo.P * geo.Q;
     nrb = bn_row_blocks((int)Mp, m, cn_get_option("bn_reduce_blocks", BN_REDUCE_BLOCKS));
     dim3 pgrid((unsigned)nrb, (unsigned)m.gy);
-    BN_DISPATCH(bn_bwd_reduce_kernel, dtype, false, pgrid, stream, (const char*)dpool, (const char*)xmax, (const unsigned char*)nullptr, mean, invstd, scale, shift, partial, (int)Mp, C, 1, m.tpr_log2, 0);
+    BN_DISPATCH_PLAIN(bn_bwd_reduce_kernel, dtype, pgrid, stream, (const char*)dpool, (const char*)xmax, (const unsigned char*)nullptr, mean, invstd, scale, shift, partial, (int)Mp, C, 1, m.tpr_log2, 0);
   } else {
     CN_DISPATCH_T(dtype, CN_LAUNCH(bn_bwd_reduce_pool_kernel<TT>, grid, dim3(256), stream, geo, (const char*)y, mean, invstd, scale,
                 shift, partial, M, C, m.tpr_log2));

@@ -48,11 +48,8 @@ struct IgemmParams {
   long long w_row;
   int out_f32, relu;
   int M, n_ntiles, n_mtiles;
-  int mt_fastest;   // tile order inside an XCD chunk: 0 = channel tiles fastest (share the activation tile),
-                    // 1 = pixel tiles fastest (share one filter slab in the XCD's L2; weight-heavy layers)
   unsigned int x_bytes, w_bytes;   // extents of the gather source / filter tensors (buffer descriptors)
   int simple;                      // 1: no tap of a valid row ever leaves the image (skip bounds tests)
-  int x_nt;                        // 1: every gathered element is read by one workgroup only -> non-temporal loads
   const float* xf;                 // optional per-channel fp32 tables of an operand transform applied on load (XF; modes below)
   int xf_relu;                     // (mode 3: the junction has a ReLU)
   // XF mode 2 ("lazy dy", round 3): the gathered operand is the BatchNorm-backward result c1[c]*x + c2[c]*x2 + c3[c]
@@ -71,7 +68,6 @@ struct IgemmParams {
   const float* xf2;
   char* xz;
   unsigned char* xz_mask;
-  int dbg;                         // measurement only ("igemm_dbg"): 1 = skip the reduction loop, 2 = skip the global stores
   FastDiv div_hw, div_w, div_cpt;
   int tap_dhdw[IG_MAX_TAPS];
   int tap_woff[IG_MAX_TAPS];
@@ -102,9 +98,12 @@ __device__ __forceinline__ int ig_slot(int row, int chunk) {
   return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
-// STAGES = 2: double-buffered LDS staging (one barrier per K tile, 2 workgroups/CU at 128x128);
-// STAGES = 1: single staging buffer + register prefetch (two barriers per K tile, but half the LDS
-//             so 4 workgroups/CU hide the global-load latency of short reductions, e.g. 1x1 convs).
+// STAGES = 1 (register-staged): single staging buffer + register prefetch (two barriers per K tile, half the LDS, so
+//             more workgroups per CU hide the global-load latency of short reductions, e.g. 1x1 convs);
+// STAGES = 2 (GLDS): LDS-DMA double buffer (one barrier per K tile).
+// (Measured and removed in round 4: a register-staged double buffer, 4-deep DMA rings with counted vmcnt on 4 / 8 waves,
+//  a 256 x 128 tile, 64-pixel tiles for the epilogue launches, pixel-tiles-fastest order, non-temporal operand loads:
+//  none faster on any layer, profiles/README.md.)
 // OUTF32 sizes the LDS output tile for fp32 results (fp32 compute or fp32 logits).
 //
 // The reduction loop is kept lean in VALU work (a first version spent 23 VALU instructions per MFMA
@@ -114,8 +113,6 @@ __device__ __forceinline__ int ig_slot(int row, int chunk) {
 // GLDS: operands are DMA'd straight into the (source-permuted, hence still XOR-swizzled) LDS tiles
 //       with `buffer_load ... lds`: no prefetch registers, no ds_write pass (the register-staged
 //       variant spends ~416 LDS cycles per K tile on ds_write_b128 against 512 MFMA cycles).
-//       STAGES = 4 with GLDS: a 4-deep DMA ring (3 K tiles in flight across raw barriers, counted
-//       vmcnt waits) for long reductions, one workgroup per CU.
 // XF: the pixel operand is transformed between the global load and the LDS store (register-staged variants only), with
 //     the arithmetic and rounding of the streaming pass it replaces: XF = 1 "lazy dy" (IgemmParams::xf_mode 2), XF = 3
 //     "lazy z" (mode 3).  (A plain BatchNorm apply folded in the same way was built in round 2, measured slower than
@@ -133,7 +130,7 @@ template <typename T, int WC, int WP, int TI, int TJ, int STAGES, bool OUTF32, b
 __global__ __launch_bounds__(WC * WP * 64, (XF != 0 && WC * WP == 8) ? 4 : 1) void igemm_kernel(IgemmParams p) {
   static_assert(!XF || (!GLDS && !EPI), "operand transform needs the register-staged path");
   static_assert(!ILV || (GLDS && STAGES == 2), "interleaved DMA issue: LDS-DMA double buffer");
-  static_assert(!GLDS || STAGES == 2 || STAGES == 4, "LDS-DMA needs the double-buffered tile or the 4-deep ring");
+  static_assert(GLDS ? STAGES == 2 : STAGES == 1, "LDS-DMA double buffer, or register-staged single buffer");
   constexpr int BN = WC * TI * 32;  // output channels per block
   constexpr int BM = WP * TJ * 32;  // pixels per block
   constexpr int NT = WC * WP * 64;  // threads (4 or 8 waves)
@@ -156,8 +153,8 @@ __global__ __launch_bounds__(WC * WP * 64, (XF != 0 && WC * WP == 8) ? 4 : 1) vo
   const int lane = tid & 63;
   const int wave = cn_uniform(tid >> 6);   // wave-uniform by construction: lets LDS-DMA bases live in SGPRs (no waterfall)
   const unsigned int tile = cn_xcd_remap(blockIdx.x, gridDim.x);
-  const int nt = p.mt_fastest ? (int)(tile / p.n_mtiles) : (int)(tile % p.n_ntiles);
-  const int mt = p.mt_fastest ? (int)(tile % p.n_mtiles) : (int)(tile / p.n_ntiles);
+  const int nt = (int)(tile % p.n_ntiles);   // channel tiles fastest: neighbours share the activation tile
+  const int mt = (int)(tile / p.n_ntiles);
   const int m0 = mt * BM;
   const int n0 = nt * BN;
   const int HgWg = p.Hg * p.Wg;
@@ -334,7 +331,7 @@ __global__ __launch_bounds__(WC * WP * 64, (XF != 0 && WC * WP == 8) ? 4 : 1) vo
     }
     if (XF) xf_ok |= (o < CN_OOB ? 1u : 0u) << i;
     if (GLDS) cn_buf_ld16_lds(xbuf, o, dp_ + i * RS * 128);
-    else preg[i] = (!ILV && simple && p.x_nt) ? cn_buf_ld16_nt(xbuf, o) : cn_buf_ld16(xbuf, o);
+    else preg[i] = cn_buf_ld16(xbuf, o);
     if (XF == 3) preg2[i] = cn_buf_ld16(x2buf, o);
     else if (XF) preg2[i] = cn_buf_ld16(x2buf, o);
   };
@@ -513,33 +510,10 @@ __global__ __launch_bounds__(WC * WP * 64, (XF != 0 && WC * WP == 8) ? 4 : 1) vo
     }
   };
 
-  if (nkt > 0 && !(p.dbg & 1)) {
+  if (nkt > 0) {
     load_tile(0, 0);
     if (!GLDS) store_tile(0);
-    if (!(GLDS && STAGES == 4)) __syncthreads();
-    if (GLDS && STAGES == 4) {
-      // ring: tiles kt+1, kt+2 (and, once issued, kt+3) stay in flight while tile kt is consumed.
-      // Every thread issues exactly NWR+NPR DMA instructions per tile, so "tile kt has landed" is a
-      // counted wait: at most (tiles issued after kt) * (NWR+NPR) operations may remain outstanding.
-      constexpr int L = NWR + NPR;
-      static_assert(!(GLDS && STAGES == 4) || L == 8 || L == 6 || L == 4, "wait immediates below assume 4, 6 or 8 DMA instructions per tile");
-      if (nkt > 1) load_tile(1, 1);
-      if (nkt > 2) load_tile(2, 2);
-      for (int kt = 0; kt < nkt; ++kt) {
-        const int ahead = nkt - 1 - kt < 2 ? nkt - 1 - kt : 2;   // tiles issued after kt at this point
-        if (L == 8) {
-          if (ahead == 2) CN_WAIT_VMCNT(16); else if (ahead == 1) CN_WAIT_VMCNT(8); else CN_WAIT_VMCNT(0);
-        } else if (L == 6) {
-          if (ahead == 2) CN_WAIT_VMCNT(12); else if (ahead == 1) CN_WAIT_VMCNT(6); else CN_WAIT_VMCNT(0);
-        } else {
-          if (ahead == 2) CN_WAIT_VMCNT(8); else if (ahead == 1) CN_WAIT_VMCNT(4); else CN_WAIT_VMCNT(0);
-        }
-        cn_raw_barrier();   // tile kt visible to every wave; buffer (kt+3)%4 == (kt-1)%4 is free again
-        if (kt + 3 < nkt) load_tile(kt + 3, (kt + 3) & 3);
-        compute(kt & 3);
-      }
-      __syncthreads();
-    } else
+    __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
       if (GLDS && ILV) {
         // ONE loop body for every tile (a second, DMA-free body for the last tile made the register allocator keep two
@@ -555,12 +529,6 @@ __global__ __launch_bounds__(WC * WP * 64, (XF != 0 && WC * WP == 8) ? 4 : 1) vo
         if (kt + 1 < nkt) load_tile(kt + 1, buf ^ 1);   // DMA into the other buffer while we compute
         compute(buf);
         __syncthreads();                                // (hipcc drains vmcnt before the barrier)
-      } else if (STAGES == 2) {
-        const int buf = kt & 1;
-        if (kt + 1 < nkt) load_tile(kt + 1, 0);
-        compute(buf);
-        if (kt + 1 < nkt) store_tile(buf ^ 1);
-        __syncthreads();
       } else {
         if (kt + 1 < nkt) load_tile(kt + 1, 0);
         compute(0);
@@ -730,7 +698,7 @@ __global__ __launch_bounds__(WC * WP * 64, (XF != 0 && WC * WP == 8) ? 4 : 1) vo
               v = Chunk<TO>::pack(fv);
             }
           }
-          if (!(p.dbg & 2)) cn_st16(dst, v);   // plain store: a non-temporal one measured neutral here (profiles/README.md)
+          cn_st16(dst, v);   // plain store: a non-temporal one measured neutral here (profiles/README.md)
         } else {   // ragged channel count: element-wise tail (never combined with the BN reduction)
           for (int e = 0; e < epc && c_first + e < p.Co; ++e) {
             if (OEB == 4) {
@@ -816,41 +784,22 @@ __global__ __launch_bounds__(WC * WP * 64, (XF != 0 && WC * WP == 8) ? 4 : 1) vo
 }
 
 // ------------------------------------------------------------------------------------------------
-static bool ig_epi_bm64() { return cn_get_option("igemm_epi_bm64", 0) != 0; }
-// pixels per partial row of the fused BN-backward reduction for an output of Co channels
-static int ig_epi_rows_bm(int Co) { return (Co > 64 && ig_epi_bm64()) ? 64 : 128; }
+// pixels per partial row of the fused BN-backward reduction
+static int ig_epi_rows_bm(int) { return 128; }
 
 template <typename T, bool OUTF32>
 static int ig_launch(IgemmParams& p, hipStream_t stream) {
   const int nkt = (p.nchunks + 7) / 8;
-  // variant: 1 = register-staged single buffer, 2 = register-staged double buffer, 3 = LDS-DMA double
-  // buffer, 4 = LDS-DMA 4-deep ring (4 waves), 5 = LDS-DMA 4-deep ring with 8 waves; 0 / unset = heuristic (tuning knob "igemm_variant", profiles/r01_conv_layers*)
+  // variant: 1 = register-staged single buffer (short reductions: more workgroups per CU), 3 = LDS-DMA double buffer
+  // (from "igemm_dma_min_nkt" K tiles on; measured per layer, profiles/r01_conv_layers_b256_bf16.txt); knob
+  // "igemm_variant" forces one (tests / tools/bench_layers.py), 0 / unset = the heuristic
   int variant = cn_get_option("igemm_variant", 0);
-  // short reductions: register-staged single buffer (more workgroups per CU); from "igemm_dma_min_nkt" K tiles
-  // on: LDS-DMA double buffer (measured per layer, profiles/r01_conv_layers_b256_bf16.txt)
-  if (variant < 1 || variant > 12)
-    variant = cn_get_option("igemm_default_variant", nkt < cn_get_option("igemm_dma_min_nkt", 16) ? 1 : 3);
-  if ((p.stats != nullptr || p.bn_y != nullptr || p.addend != nullptr) && variant == 6) variant = 3;   // 128-pixel tiles   // statistics rows are defined per 128-pixel tile
-  const bool epi = p.addend != nullptr || p.bn_y != nullptr;
-  // EPI launches on wide outputs can run on 64-pixel tiles (32 accumulator registers, half the prefetch
-  // registers: 3 workgroups per CU instead of 2); knob "igemm_epi_bm64"
-  // plain launches without the statistics epilogue (inner dgrads) can also run on 64-pixel tiles for short
-  // reductions: knob "igemm_plain_bm64_max_nkt" (0 = off)
-  const bool bm64_plain = !epi && p.stats == nullptr && p.Co > 64 && nkt <= cn_get_option("igemm_plain_bm64_max_nkt", 0);
-  const bool bm64 = (epi && p.Co > 64 && ig_epi_bm64()) || bm64_plain;
-  const int BM = bm64 ? 64 : ((variant == 6 && p.Co > 64) ? 256 : 128), BN = p.Co <= 64 ? 64 : 128;
+  if (variant != 1 && variant != 3) variant = nkt < cn_get_option("igemm_dma_min_nkt", 16) ? 1 : 3;
+  const bool epi = p.addend != nullptr || p.bn_y != nullptr;   // epilogue with global-side operands
+  const int BM = 128, BN = p.Co <= 64 ? 64 : 128;
   p.n_ntiles = (p.Co + BN - 1) / BN;
   const int n_mtiles = (p.M + BM - 1) / BM;
   p.n_mtiles = n_mtiles;
-  {
-    const long long wbytes = (long long)p.Co * p.nchunks * 16;   // filter bytes of this launch
-    int order = cn_get_option("igemm_order", -1);
-    (void)wbytes;   // pixel-tiles-fastest for weight-heavy layers measured 1-2 % slower (profiles/README.md)
-    p.mt_fastest = order > 0 ? 1 : 0;
-  }
-  // a 1x1 gather whose output fits one channel tile reads every input element exactly once
-  p.dbg = cn_get_option("igemm_dbg", 0);
-  p.x_nt = (cn_get_option("igemm_x_nt", 0) != 0 && p.ntaps == 1 && p.n_ntiles == 1 && p.simple) ? 1 : 0;
   dim3 grid((unsigned)(p.n_ntiles * n_mtiles));
   const char* tname = std::is_same<T, float>::value ? "float" : (std::is_same<T, f16_t>::value ? "f16_t" : "bf16_t");
   // EPI: epilogue with global-side operands (residual-branch addend, fused BN-backward reduction)
@@ -860,7 +809,6 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
                        variant == 1 ? 1 : 2, OUTF32 ? "true" : "false", variant >= 3 ? "true" : "false",      \
                        EP ? "true" : "false");                                                                 \
     if (variant == 1) CN_LAUNCH((igemm_kernel<T, WC, WP, TI, TJ, 1, OUTF32, false, false, EP>), grid, dim3(256), stream, p); \
-    else if (variant == 2) CN_LAUNCH((igemm_kernel<T, WC, WP, TI, TJ, 2, OUTF32, false, false, EP>), grid, dim3(256), stream, p); \
     else CN_LAUNCH((igemm_kernel<T, WC, WP, TI, TJ, 2, OUTF32, true, false, EP>), grid, dim3(256), stream, p);        \
   } while (0)
 #define IG_GO(WC, WP, TI, TJ) do { if (epi) IG_GO2(WC, WP, TI, TJ, true); else IG_GO2(WC, WP, TI, TJ, false); } while (0)
@@ -902,36 +850,20 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
     const bool shape_ok = p.Co >= 256 && p.Co % 128 == 0 && !epi;
     const bool want = big == 1 || (big < 0 && nkt >= cn_get_option("igemm_256sq_min_nkt", 16) &&
                                    tiles256 >= cn_get_option("igemm_256sq_min_tiles", 160));
-    if (shape_ok && big != 0 && (variant == 11 || variant == 12 || (cn_get_option("igemm_variant", 0) == 0 && want))) {
+    if (shape_ok && big != 0 && (cn_get_option("igemm_variant", 0) == 0 && want)) {
       p.n_ntiles = (p.Co + 255) / 256;
       p.n_mtiles = (p.M + 255) / 256;
       dim3 g2((unsigned)(p.n_ntiles * p.n_mtiles));
-      const bool fragdb = variant != 11;
-      const bool ilv = fragdb && cn_get_option("igemm_ilv", 2) != 0;   // interleaved DMA issue (A/B knob; bit-identical)
-      cn_set_last_kernel("igemm_kernel<%s, 4, 2, 2, 4, 2, false, true, %s, false, false, %s>", tname, (fragdb && !ilv) ? "true" : "false",
-                         ilv ? "true" : "false");
-      // (interleaved issue WITH register-double-buffered fragments measured 1-2 % slower: profiles/r03_ab_ilv_with_fragdb_rejected.txt)
-      if (ilv) CN_LAUNCH((igemm_kernel<T, 4, 2, 2, 4, 2, false, true, false, false, false, true>), g2, dim3(512), stream, p);
-      else if (fragdb) CN_LAUNCH((igemm_kernel<T, 4, 2, 2, 4, 2, false, true, true, false>), g2, dim3(512), stream, p);
-      else CN_LAUNCH((igemm_kernel<T, 4, 2, 2, 4, 2, false, true, false, false>), g2, dim3(512), stream, p);
+      // interleaved DMA issue, single fragment buffer (with register-double-buffered fragments it measured 1-2 % slower,
+      // without the interleave 7-10 % slower: profiles/r03_ab_ilv_with_fragdb_rejected.txt, r03_ab_igemm_interleaved_dma_issue.txt)
+      cn_set_last_kernel("igemm_kernel<%s, 4, 2, 2, 4, 2, false, true, false, false, false, true>", tname);
+      CN_LAUNCH((igemm_kernel<T, 4, 2, 2, 4, 2, false, true, false, false, false, true>), g2, dim3(512), stream, p);
       return cn_check_launch("igemm");
     }
   }
-  if (variant >= 7) variant = cn_get_option("igemm_default_variant", nkt < cn_get_option("igemm_dma_min_nkt", 16) ? 1 : 3);
-  if (variant >= 4 && p.Co > 64 && !epi) {
-    // 4 / 5: experimental 4-deep DMA rings (4 or 8 waves), measured slower than variant 3, kept for A/B;
-    // 6: 256-pixel x 128-channel tile, 8 waves, LDS-DMA double buffer with register-double-buffered
-    //    fragments (fewer operand bytes per flop; not faster either, profiles/README.md)
-    cn_set_last_kernel("igemm_kernel<%s, experimental variant %d>", tname, variant);
-    if (variant == 4) CN_LAUNCH((igemm_kernel<T, 2, 2, 2, 2, 4, OUTF32, true, false, false>), grid, dim3(256), stream, p);
-    else if (variant == 5) CN_LAUNCH((igemm_kernel<T, 2, 4, 2, 1, 4, OUTF32, true, false, false>), grid, dim3(512), stream, p);
-    else CN_LAUNCH((igemm_kernel<T, 2, 4, 2, 2, 2, OUTF32, true, true, false>), grid, dim3(512), stream, p);
-    return cn_check_launch("igemm");
-  }
-  if (variant >= 4) variant = 3;
   if constexpr (sizeof(T) == 2 && !OUTF32) {
-    // 128 x 128 LDS-DMA double buffer with interleaved DMA issue (see ILV): knob "igemm_ilv" >= 2 (A/B; bit-identical)
-    if (variant == 3 && !epi && !bm64 && p.Co > 64 && cn_get_option("igemm_ilv", 2) >= 2) {
+    // 128 x 128 LDS-DMA double buffer with interleaved DMA issue (see ILV)
+    if (variant == 3 && !epi && p.Co > 64) {
       cn_set_last_kernel("igemm_kernel<%s, 2, 2, 2, 2, 2, false, true, true, false, false, true>", tname);
       CN_LAUNCH((igemm_kernel<T, 2, 2, 2, 2, 2, false, true, true, false, false, true>), grid, dim3(256), stream, p);
       return cn_check_launch("igemm");
@@ -946,22 +878,20 @@ static int ig_launch(IgemmParams& p, hipStream_t stream) {
     // Knob "igemm_epi_8w" (A/B; the stored outputs are identical - same tile, same accumulation order - the per-tile
     // partial sums of the fused reduction are associated over 512 instead of 256 threads).  Whole step: -0.45 %
     // (profiles/r03_ab_whole_step_knobs.txt).
-    if (epi && p.Co > 64 && !bm64 && variant == 1 && cn_get_option("igemm_epi_8w", 1) != 0) {
+    if (epi && p.Co > 64 && variant == 1 && cn_get_option("igemm_epi_8w", 1) != 0) {
       cn_set_last_kernel("igemm_kernel<%s, 2, 4, 2, 1, 1, false, false, false, true, false, false>", tname);
       CN_LAUNCH((igemm_kernel<T, 2, 4, 2, 1, 1, false, false, false, true>), grid, dim3(512), stream, p);
       return cn_check_launch("igemm");
     }
     // the same eight-wave form of the plain register-staged tile for short reductions (A/B knob "igemm_8w": number of
     // K tiles up to which it is used; 0 = off)
-    if (!epi && p.Co > 64 && !bm64 && variant == 1 && nkt <= cn_get_option("igemm_8w", 16)) {
+    if (!epi && p.Co > 64 && variant == 1 && nkt <= cn_get_option("igemm_8w", 16)) {
       cn_set_last_kernel("igemm_kernel<%s, 2, 4, 2, 1, 1, false, false, false, false, false, false>", tname);
       CN_LAUNCH((igemm_kernel<T, 2, 4, 2, 1, 1, false, false, false, false>), grid, dim3(512), stream, p);
       return cn_check_launch("igemm");
     }
   }
   if (p.Co <= 64) IG_GO(1, 4, 2, 1);
-  else if (bm64 && epi) IG_GO2(2, 2, 2, 1, true);
-  else if (bm64) IG_GO2(2, 2, 2, 1, false);
   else IG_GO(2, 2, 2, 2);
 #undef IG_GO
 #undef IG_GO2
@@ -1225,7 +1155,7 @@ extern "C" int cn_conv2d_dgrad_sa(const void* dy, const void* w_crsk, void* dx, 
                        out_f32, nullptr, stream, addend_sub);
 }
 
-// Partial rows cn_conv2d_dgrad_bnbwd writes: one per pixel tile (128, or 64 with "igemm_epi_bm64") of every
+// Partial rows cn_conv2d_dgrad_bnbwd writes: one per 128-pixel tile of every
 // output-parity class.
 extern "C" int cn_conv2d_dgrad_bnbwd_rows(int N, int H, int W, int C, int stride_h, int stride_w) {
   int rows = 0;

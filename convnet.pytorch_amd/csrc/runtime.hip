@@ -81,25 +81,23 @@ int cn_get_option(const char* name, int dflt) {
 }
 
 // Cross-stream ordering without torch: `to` waits for everything queued on `from` so far.  Events come from a
-// ring created once (timing disabled; with the system-scope fence disabled too unless knob "fork_sysfence" = 1:
-// both streams are on this device, nothing here has to become visible to the host).
+// ring created once (timing disabled, system-scope fence disabled: both streams are on this device, nothing here has to
+// become visible to the host).
 #define CN_FORK_EVENTS 256
 extern "C" int cn_stream_fork(void* from_, void* to_) {
 #ifdef CN_EMULATE
   (void)from_; (void)to_;
   return CN_OK;
 #else
-  static thread_local hipEvent_t ring[2][CN_FORK_EVENTS];
-  static thread_local int made[2] = {0, 0}, next[2] = {0, 0};
-  const int kind = cn_get_option("fork_sysfence", 0) != 0 ? 1 : 0;
-  if (!made[kind]) {
-    const unsigned flags = hipEventDisableTiming | (kind ? 0u : (unsigned)hipEventDisableSystemFence);
+  static thread_local hipEvent_t ring[CN_FORK_EVENTS];
+  static thread_local int made = 0, next = 0;
+  if (!made) {
     for (int i = 0; i < CN_FORK_EVENTS; ++i)
-      if (hipEventCreateWithFlags(&ring[kind][i], flags) != hipSuccess) { cn_set_error("stream_fork: hipEventCreate failed"); return CN_EHIP; }
-    made[kind] = 1;
+      if (hipEventCreateWithFlags(&ring[i], hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) { cn_set_error("stream_fork: hipEventCreate failed"); return CN_EHIP; }
+    made = 1;
   }
-  hipEvent_t e = ring[kind][next[kind]];
-  next[kind] = (next[kind] + 1) % CN_FORK_EVENTS;
+  hipEvent_t e = ring[next];
+  next = (next + 1) % CN_FORK_EVENTS;
   if (hipEventRecord(e, (hipStream_t)from_) != hipSuccess || hipStreamWaitEvent((hipStream_t)to_, e, 0) != hipSuccess) {
     cn_set_error("stream_fork: %s", hipGetErrorString(hipGetLastError()));
     return CN_EHIP;

@@ -30,7 +30,6 @@ struct WgradParams {
   int n_itiles, n_jtiles;
   unsigned int x_bytes, dy_bytes;
   int simple;   // 1x1, stride 1, no padding: the gather is the identity (row m of x)
-  int nt;       // cache policy A/B knob "wgrad_nt": bit 0 = non-temporal x loads, bit 1 = non-temporal dy loads
   // "lazy dy" (register-staged kernel only): dy[m][k] = c1[k]*dy[m][k] + c2[k]*dy2[m][k] + c3[k] formed on load
   // (dy = masked gradient g, dy2 = BatchNorm input y, coef = [c1 | c2 | c3] of the Co channels), rounded to T
   const char* dy2;
@@ -42,7 +41,7 @@ struct WgradParams {
 template <typename T, int BI, int BJ, int LAZY = 0>
 // LAZY = 2: the lazy form with its 3 x CH per-thread coefficients read from an LDS table at each stage instead of held in
 // 24 registers, and the kernel held to 168 VGPRs (three workgroups per CU like the plain kernel; LAZY = 1 compiles to
-// 180 = two).  Same arithmetic, same bits.  Knob "wgrad_lazy_occ" (A/B).
+// 180 = two).  Same arithmetic, same bits.
 __global__ __launch_bounds__(256, LAZY == 2 ? 3 : 1) void wgrad_kernel(WgradParams p) {
   constexpr int EB = ElemTraits<T>::kBytes;
   constexpr int CH = ElemTraits<T>::kChunk;
@@ -135,7 +134,7 @@ __global__ __launch_bounds__(256, LAZY == 2 ? 3 : 1) void wgrad_kernel(WgradPara
       const bool ok = m < m_end && colI_b < CN_OOB;
       const unsigned int oI = ok ? (unsigned int)m * rowI_pitch + colI_b : CN_OOB;
       okI |= (ok ? 1u : 0u) << i;
-      regI[i] = (p.nt & 2) ? cn_buf_ld16_nt(dybuf, oI) : cn_buf_ld16(dybuf, oI);
+      regI[i] = cn_buf_ld16(dybuf, oI);
       if (lazy) regI2[i] = cn_buf_ld16(dy2buf, oI);
     }
     if (p.simple) {
@@ -144,7 +143,7 @@ __global__ __launch_bounds__(256, LAZY == 2 ? 3 : 1) void wgrad_kernel(WgradPara
         const int m = mb + rowJ0 + i * RJ;
         const bool ok = m < m_end && colJ_b < CN_OOB;
         const unsigned int oJ = ok ? (unsigned int)m * rowJ_pitch + colJ_b : CN_OOB;
-        regJ[i] = (p.nt & 1) ? cn_buf_ld16_nt(xbuf, oJ) : cn_buf_ld16(xbuf, oJ);
+        regJ[i] = cn_buf_ld16(xbuf, oJ);
       }
     } else {
 #pragma unroll
@@ -159,7 +158,7 @@ __global__ __launch_bounds__(256, LAZY == 2 ? 3 : 1) void wgrad_kernel(WgradPara
         const int hi = ho * p.stride_h + dh, wq = wo * p.stride_w + dw;
         ok = ok && (unsigned)hi < (unsigned)p.Hi && (unsigned)wq < (unsigned)p.Wi;
         const unsigned int oJ = ok ? (unsigned int)((n * p.Hi + hi) * p.Wi + wq) * rowJ_pitch + colJ_b : CN_OOB;
-        regJ[i] = (p.nt & 1) ? cn_buf_ld16_nt(xbuf, oJ) : cn_buf_ld16(xbuf, oJ);
+        regJ[i] = cn_buf_ld16(xbuf, oJ);
       }
     }
   };
@@ -338,8 +337,7 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(WgradParams p) {
       const int m = mb + blk * (1024 / RBI) + rI;
       const bool ok = m < m_end && colI_b < CN_OOB;
       const unsigned int oI = ok ? (unsigned int)m * rowI_pitch + colI_b : CN_OOB;
-      if (p.nt & 2) cn_buf_ld16_lds_nt(dybuf, oI, baseI + blk * 1024);
-      else cn_buf_ld16_lds(dybuf, oI, baseI + blk * 1024);
+      cn_buf_ld16_lds(dybuf, oI, baseI + blk * 1024);
     }
 #pragma unroll
     for (int i = 0; i < NJ; ++i) {
@@ -359,8 +357,7 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(WgradParams p) {
         ok = ok && (unsigned)hi < (unsigned)p.Hi && (unsigned)wq < (unsigned)p.Wi;
         off = (unsigned int)((n * p.Hi + hi) * p.Wi + wq) * rowJ_pitch + colJ_b;
       }
-      if (p.nt & 1) cn_buf_ld16_lds_nt(xbuf, ok ? off : CN_OOB, baseJ + blk * 1024);
-      else cn_buf_ld16_lds(xbuf, ok ? off : CN_OOB, baseJ + blk * 1024);
+      cn_buf_ld16_lds(xbuf, ok ? off : CN_OOB, baseJ + blk * 1024);
     }
   };
 
@@ -1036,8 +1033,7 @@ static void wg_launch(const WgradParams& p, const WgradPlan& pl, hipStream_t str
                      p.dy2 != nullptr ? ", true" : "");
   if (p.dy2 != nullptr) {
     if (pl.BI == 64) CN_LAUNCH((wgrad_kernel<T, 64, 128, 1>), grid, dim3(256), stream, p);
-    else if (cn_get_option("wgrad_lazy_occ", 1) != 0) CN_LAUNCH((wgrad_kernel<T, 128, 128, 2>), grid, dim3(256), stream, p);
-    else CN_LAUNCH((wgrad_kernel<T, 128, 128, 1>), grid, dim3(256), stream, p);
+    else CN_LAUNCH((wgrad_kernel<T, 128, 128, 2>), grid, dim3(256), stream, p);
     return;
   }
   if (pl.BI == 64) CN_LAUNCH((wgrad_kernel<T, 64, 128>), grid, dim3(256), stream, p);
@@ -1147,7 +1143,6 @@ static int wg_conv2d_wgrad(const void* x, const void* dy, float* dw_krsc, int C_
   }
   p.x_bytes = (unsigned int)xb; p.dy_bytes = (unsigned int)dyb;
   p.simple = (R == 1 && S == 1 && stride_h == 1 && stride_w == 1 && pad_h == 0 && pad_w == 0) ? 1 : 0;
-  p.nt = cn_get_option("wgrad_nt", 0);
   p.dy2 = (const char*)lazy_y; p.coef = lazy_coef;
   p.M = N * P * Q; p.m_per_split = pl.m_per_split; p.nsplit = pl.nsplit;
   p.n_itiles = pl.n_itiles; p.n_jtiles = pl.n_jtiles;

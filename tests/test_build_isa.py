@@ -23,6 +23,10 @@ def table():
     return isa_check.kernel_table(HIP_LIB)
 
 
+def _find_any(table, *needles):
+    return [(k, v) for k, v in table.items() if all(n in k for n in needles)]
+
+
 def _find(table, *needles):
     hits = [(k, v) for k, v in table.items() if all(n in k for n in needles)]
     assert hits, 'no kernel matching %r in the library' % (needles,)
@@ -31,8 +35,10 @@ def _find(table, *needles):
 
 def test_bn_streaming_passes_really_use_nontemporal_accesses(table):
     # NT = true instantiations: the activation loads are `nt`, the plain ones left are coefficient loads
+    # (the reduction pass exists with cached loads only since round 4: non-temporal loads there measured slower)
+    assert not _find_any(table, 'bn_bwd_reduce_kernel<', ', true>')
     for kern, sites in (('bn_apply_kernel', 'nt_load16'), ('bn_bwd_apply_kernel', 'nt_load16'),
-                        ('bn_bwd_apply_kernel', 'nt_store16'), ('bn_bwd_reduce_kernel', 'nt_load16')):
+                        ('bn_bwd_apply_kernel', 'nt_store16')):
         # (bn_apply_kernel<T, NT, DUAL>: the cache policy is its second parameter; the others end with it)
         on, off = ((', true, ', ', false, ') if kern == 'bn_apply_kernel' else (', true>', ', false>'))
         for name, c in _find(table, kern + '<', on):

@@ -831,12 +831,13 @@ def test_igemm_256x256_tile_is_bit_identical_to_128x128(mode):
 
 
 @pytest.mark.parametrize('mode', MODES)
-def test_igemm_interleaved_dma_issue_is_bit_identical(mode):
-    """Round 3: the LDS-DMA instructions of K tile kt+1 are issued between the MFMAs of tile kt (ILV instantiations:
-    the 256x256 tile by default, the 128x128 LDS-DMA tile with knob igemm_ilv=2) instead of in a block ahead of them.
-    Same loads, same accumulation order: outputs identical to the block-issue kernels bit for bit (forward with the
-    statistics epilogue, and dgrad), including reductions that end in a partial K tile and a single-tile reduction
-    (where every interleaved DMA is an out-of-range no-op)."""
+def test_igemm_interleaved_dma_tiles_equal_the_register_staged_tile(mode):
+    """The LDS-DMA tiles with interleaved DMA issue (round 3: the DMA instructions of K tile kt+1 are issued between the
+    MFMAs of tile kt) - the 256x256 tile and the 128x128 tile - against the register-staged 128x128 tile: same loads,
+    same accumulation order, so the stored outputs are identical bit for bit (forward with the statistics epilogue, and
+    dgrad), including reductions that end in a partial K tile and a single-tile reduction (where every interleaved DMA is
+    an out-of-range no-op).  (The block-issue LDS-DMA forms this test compared them with in round 3 were removed in
+    round 4.)"""
     dev = _dev(mode)
     import convnet_amd as ca
     ops, L = ca.ops, ca._lib.load()
@@ -857,23 +858,24 @@ def test_igemm_interleaved_dma_issue_is_bit_identical(mode):
         Hin, Win = (H - 1) * st + R - 2 * pad, (W - 1) * st + R - 2 * pad
         res = {}
         try:
-            for k, v in knobs.items():
-                L.cn_set_option(k.encode(), v)
-            for ilv in (0, 2):
-                L.cn_set_option(b'igemm_ilv', ilv)
+            for tag, kn in (('staged', {'igemm_variant': 1, 'igemm_256sq': 0, 'igemm_8w': 0}), ('ilv', knobs)):
+                for k, v in kn.items():
+                    L.cn_set_option(k.encode(), v)
                 ys = ops.conv2d_fwd(xh, wk, None, K, R, R, (st, st), (pad, pad), bn_stats=True)
                 name = L.cn_last_kernel_name().decode()
-                assert name.endswith(', true>') == bool(ilv), name
+                assert name.endswith(', true>') == (tag == 'ilv'), name
                 ps = ops.take_pending_stats(ys)
                 dx = ops.conv2d_dgrad(dy, wt.permute(3, 1, 2, 0).contiguous(), (N, Hin, Win, K), C, R, R, (st, st),
                                       (pad, pad))
-                res[ilv] = (ys.cpu(), ps.partial.cpu(), dx.cpu())
+                res[tag] = (ys.cpu(), ps.partial.double().sum(0).cpu(), dx.cpu())
+                for k in kn:
+                    L.cn_set_option(k.encode(), {'igemm_256sq': -1, 'igemm_8w': 16}.get(k, 0))
         finally:
-            for k in knobs:
-                L.cn_set_option(k.encode(), -1 if k == 'igemm_256sq' else 0)
-            L.cn_set_option(b'igemm_ilv', 2)
-        assert torch.equal(res[0][0], res[2][0]) and torch.equal(res[0][1], res[2][1]), (C, K, R)
-        assert torch.equal(res[0][2], res[2][2]), (C, K, R)
+            for k in ('igemm_variant', 'igemm_256sq', 'igemm_8w'):
+                L.cn_set_option(k.encode(), {'igemm_256sq': -1, 'igemm_8w': 16}.get(k, 0))
+        assert torch.equal(res['staged'][0], res['ilv'][0]), (C, K, R)
+        assert torch.equal(res['staged'][2], res['ilv'][2]), (C, K, R)
+        assert rel_l2(res['ilv'][1], res['staged'][1]) < 1e-6, (C, K, R)
 
 
 @pytest.mark.parametrize('mode', MODES)

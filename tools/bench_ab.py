@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Within-process interleaved A/B of kernel-variant knobs on ResNet-50 conv layers at B=256 bf16.
 
-    python tools/bench_ab.py --knob igemm_ilv --values 0,1,2 [--only 16,22] [--dirs fwd,dgrad,wgrad] [--rounds 5]
+    python tools/bench_ab.py --knob igemm_8w --values 0,16 [--only 16,22] [--dirs fwd,dgrad,wgrad] [--rounds 5]
 
 Every (layer, direction) is timed under each knob value in turn, `rounds` times (interleaved, one process), and the
 median / min per value is printed with the kernel the dispatcher picked.  GPU only."""

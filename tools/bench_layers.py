@@ -41,8 +41,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--iters', type=int, default=5)
-    ap.add_argument('--variants', default='0,1,3,5', help='igemm_variant values to A/B (0 = heuristic, 1 = reg-staged 1 buf, 2 = reg-staged 2 buf, 3 = LDS-DMA)')
-    ap.add_argument('--order', type=int, default=-1, help='igemm_order knob (-1 heuristic, 0 nt-fastest, 1 mt-fastest)')
+    ap.add_argument('--variants', default='0,1,3', help='igemm_variant values to A/B (0 = heuristic, 1 = register-staged, 3 = LDS-DMA)')
     ap.add_argument('--fragdb', type=int, default=0)
     ap.add_argument('--only', default='', help='comma-separated layer indices (default: all)')
     args = ap.parse_args()
@@ -50,7 +49,6 @@ def main():
     dt = torch.bfloat16
     L = ca._lib.load()
     variants = [int(v) for v in args.variants.split(',')]
-    L.cn_set_option(b'igemm_order', args.order)
     tot = {('fwd', v): 0.0 for v in variants}
     tot.update({('dgrad', v): 0.0 for v in variants})
     tot['wgrad'] = 0.0
