@@ -274,6 +274,8 @@ JPAIR = flags.on('jpair')
 # (cn_conv2d_dgrad_junction, csrc/junction.hip) instead of the tiled GEMM kernel's epilogue.  g bit-identical, the
 # partial sums in another fp32 association.
 JDGRAD = flags.on('jdgrad')
+# 1 = a convolution's backward launches its data gradient (main stream) before it hands the weight gradient to the side stream
+DGRAD_FIRST = flags.on('dgrad_first')
 
 
 # how often each BatchNorm path ran (tests assert that the fused paths really are the ones in use)
@@ -833,54 +835,69 @@ class Conv2dFunction(Function):
             dy = cast_from_f32(dy, x.dtype)
         if ctx.has_bias:
             colsum(dy.view(-1, mod.out_channels), mod.grad_view('bias'))
-        if SIDE.active(x):
-            def launch():
-                conv2d_wgrad(x, dy, mod.grad_view('weight'), mod.in_channels, mod.out_channels, R, S, mod.stride,
-                             mod.padding, tag='side')
-                return (x, dy)
-            SIDE.submit(x.device, launch, mod._notify_grad_ready, dy)
-        else:
-            conv2d_wgrad(x, dy, mod.grad_view('weight'), mod.in_channels, mod.out_channels, R, S, mod.stride,
-                         mod.padding)
-            mod._notify_grad_ready()
-        dx = None
-        if ctx.needs_input_grad[0]:
-            addend, addend_sub = None, 1
-            holder = getattr(mod, '_res_holder', None)
-            if holder is not None and holder.dres is not None and holder.dres.dtype == dy.dtype \
-                    and (holder.dres.shape == x.shape if holder.sub == 1 else
-                         tuple(holder.dres.shape) == (x.shape[0], (x.shape[1] + 1) // 2, (x.shape[2] + 1) // 2, x.shape[3])):
-                addend, addend_sub = holder.dres, holder.sub   # the other branch's gradient, folded into this dgrad epilogue
-                holder.fused = True
-            elif holder is not None and holder.dres is None and SUBSAMPLED_SHORTCUT_GRAD \
-                    and (R, S) == (1, 1) and mod.stride == (2, 2) and mod.padding == (0, 0):
-                # stride-2 1x1 projection shortcut, first of the two gradients that meet at the block input: its input
-                # gradient is zero off the even pixels - compute those on the coarse grid (a stride-1 dgrad), park
-                # them, and hand autograd a storage-free placeholder (ForkFunction returns the other branch's sum)
-                N_, H_, W_, C_ = x.shape
-                compact = conv2d_dgrad(dy, mod.w_crsk, (N_, (H_ + 1) // 2, (W_ + 1) // 2, C_), mod.out_channels, 1, 1,
-                                       (1, 1), (0, 0))
-                holder.dres, holder.sub, holder.fused = compact, 2, False
-                return _zero_like_placeholder(x), None, None, None
-            # this dgrad is the last contribution to the gradient of x when x has no other consumer
-            # (inner convs) or when the other branch's gradient is being added right here
-            final = holder is None or addend is not None
-            bn_args = _input_bn_state(mod, x) if (final and FUSE_BN_BWD) else None
-            if bn_args is not None and holder is None:
-                bn_args = None      # junctions only (see FUSE_BN_BWD)
-            if bn_args is not None:
-                bn_mod, bn_y, bn_mask, bn_stats, bn_relu = bn_args
-                dx, partial, rows = conv2d_dgrad(dy, mod.w_crsk, x.shape, mod.out_channels, R, S, mod.stride,
-                                                 mod.padding, addend=addend, bn=(bn_y, bn_mask, bn_stats, bn_relu),
-                                                 addend_sub=addend_sub)
-                bn_mod._bwd_partials = (dx.data_ptr(), tuple(dx.shape), partial, rows)
+        def submit_wgrad():
+            if SIDE.active(x):
+                def launch():
+                    conv2d_wgrad(x, dy, mod.grad_view('weight'), mod.in_channels, mod.out_channels, R, S, mod.stride,
+                                 mod.padding, tag='side')
+                    return (x, dy)
+                SIDE.submit(x.device, launch, mod._notify_grad_ready, dy)
             else:
-                dx = conv2d_dgrad(dy, mod.w_crsk, x.shape, mod.out_channels, R, S, mod.stride, mod.padding,
-                                  addend=addend, addend_sub=addend_sub)
-            if holder is not None and addend is None:
-                holder.dres, holder.sub = dx, 1   # first producer of the fork gradient: park it for the other
-                holder.fused = False
-        return dx, None, None, None
+                conv2d_wgrad(x, dy, mod.grad_view('weight'), mod.in_channels, mod.out_channels, R, S, mod.stride,
+                             mod.padding)
+                mod._notify_grad_ready()
+
+        def dgrad_part():
+            dx = None
+            if ctx.needs_input_grad[0]:
+                addend, addend_sub = None, 1
+                holder = getattr(mod, '_res_holder', None)
+                if holder is not None and holder.dres is not None and holder.dres.dtype == dy.dtype \
+                        and (holder.dres.shape == x.shape if holder.sub == 1 else
+                             tuple(holder.dres.shape) == (x.shape[0], (x.shape[1] + 1) // 2, (x.shape[2] + 1) // 2, x.shape[3])):
+                    addend, addend_sub = holder.dres, holder.sub   # the other branch's gradient, folded into this dgrad epilogue
+                    holder.fused = True
+                elif holder is not None and holder.dres is None and SUBSAMPLED_SHORTCUT_GRAD \
+                        and (R, S) == (1, 1) and mod.stride == (2, 2) and mod.padding == (0, 0):
+                    # stride-2 1x1 projection shortcut, first of the two gradients that meet at the block input: its input
+                    # gradient is zero off the even pixels - compute those on the coarse grid (a stride-1 dgrad), park
+                    # them, and hand autograd a storage-free placeholder (ForkFunction returns the other branch's sum)
+                    N_, H_, W_, C_ = x.shape
+                    compact = conv2d_dgrad(dy, mod.w_crsk, (N_, (H_ + 1) // 2, (W_ + 1) // 2, C_), mod.out_channels, 1, 1,
+                                           (1, 1), (0, 0))
+                    holder.dres, holder.sub, holder.fused = compact, 2, False
+                    return _zero_like_placeholder(x), None, None, None
+                # this dgrad is the last contribution to the gradient of x when x has no other consumer
+                # (inner convs) or when the other branch's gradient is being added right here
+                final = holder is None or addend is not None
+                bn_args = _input_bn_state(mod, x) if (final and FUSE_BN_BWD) else None
+                if bn_args is not None and holder is None:
+                    bn_args = None      # junctions only (see FUSE_BN_BWD)
+                if bn_args is not None:
+                    bn_mod, bn_y, bn_mask, bn_stats, bn_relu = bn_args
+                    dx, partial, rows = conv2d_dgrad(dy, mod.w_crsk, x.shape, mod.out_channels, R, S, mod.stride,
+                                                     mod.padding, addend=addend, bn=(bn_y, bn_mask, bn_stats, bn_relu),
+                                                     addend_sub=addend_sub)
+                    bn_mod._bwd_partials = (dx.data_ptr(), tuple(dx.shape), partial, rows)
+                else:
+                    dx = conv2d_dgrad(dy, mod.w_crsk, x.shape, mod.out_channels, R, S, mod.stride, mod.padding,
+                                      addend=addend, addend_sub=addend_sub)
+                if holder is not None and addend is None:
+                    holder.dres, holder.sub = dx, 1   # first producer of the fork gradient: park it for the other
+                    holder.fused = False
+            return dx, None, None, None
+
+        # The data gradient is the backward chain's next kernel; the weight gradient only has to start some time.  Launching
+        # the chain's kernel FIRST keeps the host-side cost of the side-stream hand-off (fork / mark wait + a second ctypes
+        # call, ~40 us) off the chain where the host runs only just ahead of the device (the late, small layers): the
+        # rocprofv3 trace showed 10-14 us of idle main queue in front of 26 of these data gradients.  Untraced the effect is at
+        # the noise level (14871 vs 14819 img/s, three interleaved rounds); kept because it is the natural order (flag dgrad_first).
+        if not DGRAD_FIRST:
+            submit_wgrad()
+        out = dgrad_part()
+        if DGRAD_FIRST:
+            submit_wgrad()
+        return out
 
 
 def _sync_group(mod):
