@@ -1017,15 +1017,16 @@ extern "C" size_t cn_conv2d_wgrad_workspace(int N, int H, int W, int C, int K, i
 template <typename T>
 static void wg_launch(const WgradParams& p, const WgradPlan& pl, hipStream_t stream) {
   dim3 grid((unsigned)(pl.n_itiles * pl.n_jtiles * pl.nsplit));
-  // bf16, identity gather (1x1 stride 1): LDS-DMA staging (+5-10 % on those layers); with a real gather
-  // (3x3, strided) the register-staged kernel at 3 workgroups/CU measured 20-30 % faster than the DMA one
-  // at 2 (profiles/README.md).  Tuning knob "wgrad_variant": 0 = this heuristic, 1 = register-staged,
-  // 2 = LDS-DMA everywhere.
+  // bf16, identity gather (1x1 stride 1), more than 64 output channels: LDS-DMA staging (+5-10 % on those layers alone).
+  // With a real gather (3x3, strided) the register-staged kernel at 3 workgroups/CU measured 20-30 % faster than the DMA
+  // one at 2 (profiles/README.md); for <= 64 output channels (the 256 -> 64 convolutions on the 56x56 maps) the DMA kernel
+  // is faster alone (5.6 vs 5.0 TB/s) and the STEP is 0.5 % faster without it - half the LDS beside the chain - so it was
+  // removed in round 4 (14760 vs 14678 img/s, four interleaved rounds).  Knob "wgrad_variant": 0 = this heuristic,
+  // 1 = register-staged everywhere (tests).
   const int wv = p.dy2 != nullptr ? 1 : cn_get_option("wgrad_variant", 0);   // lazy dy: register-staged only
-  if (std::is_same<T, bf16_t>::value && (wv == 2 || (wv == 0 && p.simple))) {   // (the LDS-DMA kernels are bf16 instantiations)
-    cn_set_last_kernel("wgrad_dma_kernel<%d>", pl.BI == 64 ? 64 : 128);
-    if (pl.BI == 64) CN_LAUNCH((wgrad_dma_kernel<64>), grid, dim3(256), stream, p);
-    else CN_LAUNCH((wgrad_dma_kernel<128>), grid, dim3(256), stream, p);
+  if (std::is_same<T, bf16_t>::value && wv == 0 && p.simple && pl.BI != 64) {   // (the LDS-DMA kernel is a bf16 instantiation)
+    cn_set_last_kernel("wgrad_dma_kernel<128>");
+    CN_LAUNCH((wgrad_dma_kernel<128>), grid, dim3(256), stream, p);
     return;
   }
   cn_set_last_kernel("wgrad_kernel<%s, %d, 128%s>",
