@@ -203,6 +203,9 @@ def main():
 
     def fence():
         if distributed:
+            # this rank's own bucket all-reduces (direct communicator, its own stream) are complete before the rank enters
+            # the process group's barrier: two RCCL communicators never have kernels in flight on one device at once
+            torch.cuda.synchronize()
             if dist.get_backend() == 'nccl':
                 dist.barrier(device_ids=[local_rank])   # RCCL barrier on this rank's own device
             else:
