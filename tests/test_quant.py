@@ -191,6 +191,17 @@ def _engine_trajectory(meta, depth, dev, dtype, steps):
     return recs, tr, model, data
 
 
+# rel-L2 bounds on the tensors the config-5 fixtures keep after the last step (one 0.15 band before).
+# Measured on the MI355X, fp32 engine on the reference's noise stream, maxima over ResNet-18s / ResNet-50s / full-size
+# ResNet-50: conv1.weight 0.061, fc.weight 0.037, bn1.running_mean 0.043, fc range 0.0099, downsample 0.0028, fc.bias 0.0016,
+# bn1.running_var 0.0014, bn1 range 0.00073, layer1.0.conv1.weight 8.6e-6, conv1 range 6.2e-8.  The stem filter and the
+# classifier see every rounding flip of the three steps (the oracle itself is 7 % from the reference there).
+FINAL_TOL = {'conv1.weight': 0.10, 'fc.weight': 0.07, 'bn1.running_mean': 0.08, 'fc.quantize_input.running_range': 0.03,
+             'layer2.0.downsample.0.weight': 0.01, 'fc.bias': 5e-3, 'bn1.running_var': 5e-3,
+             'bn1.quantize_input.running_range': 3e-3, 'layer1.0.conv1.weight': 1e-4,
+             'conv1.quantize_input.running_range': 1e-5}
+
+
 @pytest.mark.parametrize('mode', MODES)
 @pytest.mark.parametrize('tag,depth', [('r18s_quant', 18), ('r50s_quant', 50)])
 def test_quantised_fp32_trajectory_follows_the_reference(mode, tag, depth, reference_noise):
@@ -209,11 +220,10 @@ def test_quantised_fp32_trajectory_follows_the_reference(mode, tag, depth, refer
         final = torch.load(os.path.join(GOLDEN, 'traj_%s_final.pt' % tag))
         sd = model.state_dict()
         # after three steps at lr 0.1 the fp32 ORACLE already sits 0.001-7 % away from the fp32 reference on
-        # these tensors (35 % on a last-BN gamma that starts at zero): rounding flips compound.  Same band here.
-        for k in ('conv1.weight', 'layer1.0.conv1.weight', 'layer2.0.downsample.0.weight', 'fc.weight', 'fc.bias',
-                  'bn1.running_mean', 'bn1.running_var', 'conv1.quantize_input.running_range',
-                  'bn1.quantize_input.running_range', 'fc.quantize_input.running_range'):
-            assert rel_l2(sd[k].float().cpu(), final[k]) < 0.15, k
+        # these tensors (35 % on a last-BN gamma that starts at zero): rounding flips compound.  Per-tensor bounds =
+        # ~2x the deviation measured on the MI355X (round 4; FINAL_TOL above), not one loose band.
+        for k, tol in FINAL_TOL.items():
+            assert rel_l2(sd[k].float().cpu(), final[k]) < tol, (k, rel_l2(sd[k].float().cpu(), final[k]), tol)
         val = tr.validate(data[:2])     # eval mode: running ranges / statistics
         assert val['loss'] == pytest.approx(meta['validate']['loss'], abs=5e-2)
 
@@ -314,7 +324,7 @@ def test_full_size_quantised_resnet50_follows_the_reference(reference_noise):
     sd = model.state_dict()
     for k in ('conv1.weight', 'layer1.0.conv1.weight', 'bn1.running_mean', 'bn1.running_var',
               'conv1.quantize_input.running_range', 'fc.quantize_input.running_range'):
-        assert rel_l2(sd[k].float().cpu(), final[k]) < 0.15, k
+        assert rel_l2(sd[k].float().cpu(), final[k]) < FINAL_TOL[k], (k, rel_l2(sd[k].float().cpu(), final[k]))
 
 
 @pytest.mark.gpu
