@@ -36,6 +36,10 @@ import os
 import sys
 import time
 
+# the host driver supports dmabuf IPC only: without this RCCL / cross-process device buffers fail with
+# "hipIpcGetMemHandle: invalid argument" (already exported on the GPU boxes; kept here for a bare launch)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
 import torch
 import torch.distributed as dist
 
