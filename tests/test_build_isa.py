@@ -79,3 +79,29 @@ def test_round3_kernels_are_what_they_claim(table):
     for kern in ('jbwd_kernel<bf16_t', 'stem_wgrad_kernel<bf16_t'):
         for name, c in _find(table, kern):
             assert c['mfma'] >= 2 and c['tr_read'] >= 4, (name, c)
+
+
+def test_workgroup_footprints_of_the_two_stream_schedule():
+    """Round 4: what the backward chain pays for is the FOOTPRINT a weight-gradient workgroup takes from its CU (LDS,
+    registers), not the side kernel's duration (profiles/README.md, round-4 A/Bs).  The figures the dispatch rules and
+    DESIGN.md quote, read from the code objects' metadata: the register-staged 64 x 128 weight-gradient tile is the
+    small one (32 KB; the LDS-DMA tile it replaced for <= 64 output channels held 48 KB), the 128-wide LDS-DMA kernel
+    holds 64 KB (two per CU), no kernel exceeds the CU's 160 KB, and no bf16 kernel of the headline step spills more
+    than a few set-up registers."""
+    import isa_check
+    res = isa_check.kernel_resources(HIP_LIB)
+
+    def one(*needles):
+        hits = [(k, v) for k, v in res.items() if all(n in k for n in needles)]
+        assert len(hits) == 1, (needles, [k for k, _ in hits])
+        return hits[0][1]
+    assert one('wgrad_kernel<bf16_t, 64, 128, 0>')['lds'] <= 32 * 1024
+    assert one('wgrad_kernel<bf16_t, 64, 128, 0>')['vgpr'] + one('wgrad_kernel<bf16_t, 64, 128, 0>')['agpr'] <= 136
+    assert one('wgrad_dma_kernel<128>')['lds'] == 64 * 1024
+    assert one('wgrad3x3_kernel<bf16_t, 128>')['lds'] <= 80 * 1024       # two per CU
+    assert one('jbwd_kernel<bf16_t')['lds'] <= 160 * 1024
+    assert not any('wgrad_dma_kernel<64>' in k for k in res)             # removed from the dispatch and from the library
+    assert all(v['lds'] <= 160 * 1024 for v in res.values())
+    for k, v in res.items():
+        if 'bf16_t' in k or 'wgrad_dma' in k:
+            assert v['scratch'] <= 16, (k, v)                            # bytes per lane; 0 for all but two set-up spills

@@ -88,6 +88,38 @@ def counts(lines):
     return c
 
 
+READELF = '/opt/rocm/lib/llvm/bin/llvm-readelf'
+
+
+def kernel_resources(path):
+    """{demangled kernel: {'lds': static LDS bytes, 'vgpr': VGPRs, 'agpr': AGPRs, 'sgpr': SGPRs, 'scratch': private bytes}}
+    from the code objects' AMDGPU metadata notes: the footprint a resident workgroup takes from its CU - what a kernel of
+    the other stream has to fit beside (profiles/README.md, round-4 weight-gradient A/Bs)."""
+    res = {}
+    for triple, data in code_objects(path):
+        with tempfile.NamedTemporaryFile(suffix='.co', delete=False) as f:
+            f.write(data)
+            name = f.name
+        try:
+            txt = subprocess.run([READELF, '--notes', name], capture_output=True, text=True, check=True).stdout
+        finally:
+            os.unlink(name)
+        for blk in txt.split('- .agpr_count')[1:]:
+            blk = '.agpr_count' + blk
+
+            def field(key, b=blk):
+                m = re.search(r'\.%s:\s+(\S+)' % key, b)
+                return m.group(1) if m else None
+            sym = field('name')
+            if sym is None:
+                continue
+            res[sym] = {'lds': int(field('group_segment_fixed_size') or 0), 'vgpr': int(field('vgpr_count') or 0),
+                        'agpr': int(field('agpr_count') or 0), 'sgpr': int(field('sgpr_count') or 0),
+                        'scratch': int(field('private_segment_fixed_size') or 0)}
+    dm = demangle(list(res))
+    return {dm[k]: v for k, v in res.items()}
+
+
 def kernel_table(path):
     dis = disassemble(path)
     dm = demangle(list(dis))
@@ -96,7 +128,15 @@ def kernel_table(path):
 
 def main():
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(here, 'convnet.pytorch_amd', 'libconvnet_hip.so')
+    args = [a for a in sys.argv[1:] if not a.startswith('--')]
+    path = args[0] if args else os.path.join(here, 'convnet.pytorch_amd', 'libconvnet_hip.so')
+    if '--resources' in sys.argv:
+        res = kernel_resources(path)
+        print('%-100s %8s %5s %5s %5s %7s' % ('kernel', 'LDS B', 'VGPR', 'AGPR', 'SGPR', 'scratch'))
+        for name in sorted(res):
+            r = res[name]
+            print('%-100s %8d %5d %5d %5d %7d' % (name[:100], r['lds'], r['vgpr'], r['agpr'], r['sgpr'], r['scratch']))
+        return
     tab = kernel_table(path)
     for name in sorted(tab):
         c = tab[name]
