@@ -131,6 +131,8 @@ class SideStream(object):
         self.used = False
         self.marks = flags.on('marks')     # 0: always hand off with an event record
         self.capturing = False      # set by Trainer around HIP-graph capture
+        self.hold = flags.on('side_hold')
+        self._held = []
         self._mark = None
 
     def get(self, device):
@@ -168,8 +170,14 @@ class SideStream(object):
             self.fork(cur, side)
         with torch.cuda.stream(side):
             held = launch()
-        for t in held:
-            t.record_stream(side)
+        if self.hold:
+            # the operands stay referenced until the chain has waited for the side stream (join, once per step): the
+            # caching allocator then needs no cross-stream bookkeeping for them.  record_stream would make it record an
+            # event (with torch's default flags: a system-scope fence) on the side stream at every free and poll it
+            self._held.append(held)
+        else:
+            for t in held:
+                t.record_stream(side)
         self.used = True
         notify()
 
@@ -191,6 +199,7 @@ class SideStream(object):
         if self.used and device.type == 'cuda':
             torch.cuda.current_stream(device).wait_stream(self.gather(device))
             self.used = False
+        self._held = []     # (what the current stream does from here on is ordered behind the side stream's reads)
 
 
 SIDE = SideStream()

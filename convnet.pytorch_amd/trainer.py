@@ -74,6 +74,44 @@ class DevicePrefetcher(object):
             yield x, t
 
 
+class EagerWatch(object):
+    """Re-examines an 'eager launches' verdict of graph = auto while it is in force.  The verdict is taken once, on the
+    fourth step; a host that slows down later (other tenants on its cores, a box whose first minutes are slow) turns the
+    same step host-bound - measured on this pool: 7.4k and 11.1k img/s eager against 13.9k replayed in the same minute.
+    One timing event per step is recorded behind the step (cn_step_timer_*: no system-scope fence, unlike torch's timing
+    events); completed pairs give the step PERIOD on the device timeline
+    (= max(host, device) time per step) without a synchronisation.  The verdict is withdrawn when the MEDIAN of the last
+    `window` periods exceeds `factor` x the step time it was based on (a replayed single-chain graph costs ~1.07 x that);
+    the median, because single long periods are normal - the pause between two train() calls, a validation pass."""
+
+    def __init__(self, ref_ms, window=9, factor=1.2):
+        self.ref_ms, self.window, self.factor = float(ref_ms), window, factor
+        self.periods = []
+        _lib.load().cn_step_timer_reset()
+
+    def add_period(self, ms):
+        """Pure bookkeeping (unit-tested on the CPU): True when the verdict should be withdrawn."""
+        self.periods.append(float(ms))
+        if len(self.periods) > self.window:
+            self.periods.pop(0)
+        return len(self.periods) == self.window and self.recent_ms() > self.factor * self.ref_ms
+
+    def recent_ms(self):
+        p = sorted(self.periods)
+        return p[len(p) // 2] if p else 0.0
+
+    def step(self, stream):
+        """One mark behind the step just queued on `stream`; folds in every period that has completed since (no wait)."""
+        import ctypes
+        L = _lib.load()
+        check(L.cn_step_timer_mark(stream.cuda_stream), 'cn_step_timer_mark')
+        ms = ctypes.c_float(0.0)
+        fire = False
+        while L.cn_step_timer_poll(ctypes.byref(ms)) == 1:
+            fire = self.add_period(ms.value) or fire
+        return fire
+
+
 class Trainer(object):
 
     def __init__(self, model, criterion, optimizer=None,
@@ -117,6 +155,7 @@ class Trainer(object):
         self._graph_dp = flags.on('graph_dp')   # capture RCCL buckets too (opt-in)
         self._gstates = {}               # per (shapes, step options) key: {'seen': warm-up / timing bookkeeping, 'graph': capture}
         self._graph_eager_for = set()    # (shapes, chunking) for which auto mode settled on eager launches
+        self._watch = {}                 # key -> EagerWatch: the eager verdict is re-examined while it is in force
         from . import nn as cnn
         # a captured step replays the SAME kernels: host-drawn Dropout masks (models/mnist.py) rule it out
         # modules whose capturability can change at run time (quant.QuantMeasure.no_graph follows the noise source) are
@@ -160,9 +199,15 @@ class Trainer(object):
             self.optimizer.update(self.epoch, self.training_steps)
             # configurations for which auto mode already settled on eager launches go straight to the eager body (the
             # bookkeeping of _graph_step costs a nearly host-bound step 1 %); the verdict is keyed like the graphs are
-            if self._graph_key(inputs_batch, target_batch, chunk_batch) not in self._graph_eager_for \
-                    and self._graph_ok(inputs_batch, target_batch):
-                return self._graph_step(inputs_batch, target_batch, chunk_batch)
+            key = self._graph_key(inputs_batch, target_batch, chunk_batch)
+            if key not in self._graph_eager_for:
+                if self._graph_ok(inputs_batch, target_batch):
+                    return self._graph_step(inputs_batch, target_batch, chunk_batch)
+            elif key in self._watch and not ops.PROFILER.enabled:
+                res = self._body(inputs_batch, target_batch, training, chunk_batch)
+                if self._watch[key].step(torch.cuda.current_stream(self.device)):
+                    self._eager_verdict_withdrawn(key)
+                return res
         return self._body(inputs_batch, target_batch, training, chunk_batch)
 
     def _body(self, inputs_batch, target_batch, training, chunk_batch):
@@ -297,6 +342,7 @@ class Trainer(object):
                 seen['eager_ms'] = dev_ms
                 if not seen['use']:
                     self._graph_eager_for.add(eager_key)
+                    self._watch[eager_key] = EagerWatch(dev_ms)
                 logging.debug('step: host %.2f ms, device %.2f ms -> %s', host_ms, dev_ms,
                               'try a HIP graph' if seen['use'] else 'eager launches')
                 return res
@@ -337,6 +383,21 @@ class Trainer(object):
         self.arena.bump_version()      # what optimizer.step() does on the host: master weights moved
         self.training_steps += 1
         return st['out'], st['loss'], st['grad']
+
+    def _eager_verdict_withdrawn(self, key):
+        """The eager step of this configuration has been running slower than a replayed graph would for a window of
+        steps (EagerWatch): the host has become the limit after the verdict was taken (a loaded host, a slow box: the
+        eager step needs ~11 ms of host time per ResNet-50 step, a replay none).  The next step captures; the usual
+        check of the second replay against the eager time - now the recent one - still applies."""
+        w = self._watch.pop(key)
+        self._graph_eager_for.discard(key)
+        gs = self._gstates.get(key)
+        if gs is None:
+            gs = self._gstates[key] = {'seen': {'n': 4}, 'graph': None}
+        gs['seen'].update(use=True, eager_ms=w.recent_ms(), n=max(gs['seen'].get('n', 0), 4))
+        gs['seen'].pop('graph_ms', None)
+        gs['seen'].pop('replays', None)
+        logging.info('eager step %.2f ms against %.2f ms when it was chosen: trying a HIP graph', w.recent_ms(), w.ref_ms)
 
     def _capture(self, inputs, target, chunk_batch, key):
         cur = torch.cuda.current_stream(self.device)

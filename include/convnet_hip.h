@@ -64,6 +64,12 @@ int cn_stream_fork(void* from_stream, void* to_stream);
 int cn_stream_arm(void);
 int cn_stream_disarm(void);
 int cn_stream_wait_mark(int handle, void* to_stream);
+/* step timer (Trainer's graph = auto policy): mark = record the next ring event behind the stream's work (timing on, no
+ * system-scope fence); poll = time in ms between the oldest two marks once both have completed (returns 1), never waits
+ * (returns 0); reset forgets the recorded marks */
+int cn_step_timer_mark(void* stream);
+int cn_step_timer_poll(float* period_ms);
+int cn_step_timer_reset(void);
 
 /* ---- nn.Conv2d / nn.Linear (models/resnet.py:75-78,126-132,178-179,226-227,242) ------------- */
 /* y[N,P,Q,K] = conv(x[N,H,W,C], w[K,R,S,C]) (+bias[K]) (ReLU optional); out_f32 writes fp32

@@ -38,3 +38,26 @@ def test_no_other_environment_switches_in_the_package():
             if f.endswith('.py'):
                 seen |= set(re.findall(r"CONVNET_AMD_[A-Z0-9_]+", open(os.path.join(d, f)).read()))
     assert seen <= allowed, sorted(seen - allowed)
+
+
+def test_eager_verdict_watch_window_logic():
+    """graph = auto: the 'eager launches' verdict is withdrawn when the MEDIAN step period of the last nine steps exceeds
+    1.2 x the step time the verdict was based on - not by single long periods (the pause between two train() calls, a
+    validation pass), not by a window that is still filling."""
+    import convnet_amd as ca
+    W = ca.trainer.EagerWatch
+    w = W(17.0)
+    assert not any(w.add_period(17.1) for _ in range(50))                       # healthy
+    w = W(17.0)
+    assert not any(w.add_period(p) for p in [17.0] * 4 + [300.0] + [17.0] * 20)   # one pause
+    w = W(17.0)
+    assert not any(w.add_period(p) for p in [17.0, 90.0, 17.0, 17.0] * 10)        # bursts in a quarter of the steps
+    w = W(17.0)
+    fired = [w.add_period(34.0) for _ in range(12)]                              # a host-bound step, twice the time
+    assert fired.index(True) == 8 and abs(w.recent_ms() - 34.0) < 1e-9            # as soon as the window is full
+    w = W(17.0)
+    seq = [17.0] * 9 + [21.0] * 9
+    fired = [w.add_period(p) for p in seq]
+    assert fired.index(True) == 13                                               # five of the last nine are slow
+    w = W(17.0)
+    assert not any(w.add_period(19.5) for _ in range(30))                        # 15 % slower: a replay would not help

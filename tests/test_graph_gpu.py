@@ -84,3 +84,58 @@ def test_graph_replay_with_lazy_dy_is_bit_identical_to_eager(tmp_path):
     """The same with the junction BatchNorms' backward apply left to the consumers (ops.LAZY_DY forced on for this
     small model): the placeholder gradients and the finalize-only BatchNorm calls are capture-safe."""
     assert 'GRAPH_OK single' in _run(tmp_path, {'CONVNET_AMD_FLAGS': 'lazy_min_mb=0'}, 29555)
+
+
+WATCH_WORKER = r'''
+import sys, torch
+sys.path.insert(0, %(root)r)
+import convnet_amd as ca
+torch.cuda.set_device(0)
+kw = dict(depth=50, width=(16, 32, 64, 128), inplanes=16, num_classes=32)
+g = torch.Generator().manual_seed(9)
+data = [(torch.randn(16, 3, 64, 64, generator=g).cuda(), torch.randint(0, 32, (16,), generator=g).cuda())
+        for _ in range(24)]
+
+def run(mode):
+    torch.manual_seed(123)
+    model = ca.models.resnet(**kw)
+    tr = ca.Trainer(model, ca.CrossEntropyLoss(), ca.OptimRegime(model, model.regime), device='cuda:0',
+                    dtype=torch.bfloat16, print_freq=10**9)
+    tr._graph_mode = mode
+    tr._use_graph = mode != '0'
+    key = None
+    recs, states = [], []
+    for i, b in enumerate(data):
+        if mode == 'auto' and i == 5:
+            (key,) = list(tr._gstates.keys())      # the one configuration this loop runs (shapes + step options)
+            # Whatever auto decided for this small (host-bound) model: install the state a DEVICE-bound configuration
+            # is in after its fourth step - eager verdict, watch armed - with a reference time no real step can meet.
+            tr._gstates[key] = {'seen': {'n': 4, 'use': False, 'eager_ms': 1e-3}, 'graph': None}
+            tr._graph_eager_for.add(key)
+            tr._watch[key] = ca.trainer.EagerWatch(1e-3)
+        recs.append(tr.train([b])['loss'])
+        states.append((key in tr._graph_eager_for, key in tr._watch,
+                       tr._gstates.get(key, {}).get('graph') is not None))
+    torch.cuda.synchronize()
+    return recs, states, tr
+
+e_recs, _, _ = run('0')
+a_recs, states, tr = run('auto')
+assert e_recs == a_recs, (e_recs, a_recs)              # eager -> watched eager -> capture -> replays: the same numbers
+assert states[5][0] and states[5][1] and not states[5][2]          # eager verdict in force, watched
+fired = [i for i, s in enumerate(states) if i > 5 and not s[0]]
+assert fired and 13 <= fired[0] <= 16, states                      # nine periods after the watch was armed
+assert states[-1] == (False, False, True), states[-1]              # the graph was captured and kept (it IS faster here)
+print('WATCH_OK', fired[0])
+'''
+
+
+def test_auto_mode_withdraws_an_eager_verdict_when_the_step_slows_down(tmp_path):
+    """graph = auto: a configuration that was found device-bound keeps being watched (trainer.EagerWatch); when its step
+    period stays above 1.2 x the time the verdict was based on, the step is captured after all, and the numbers do not
+    change.  (The window logic itself: tests/test_flags.py.)"""
+    script = tmp_path / 'watch_worker.py'
+    script.write_text(WATCH_WORKER % {'root': ROOT})
+    env = dict(os.environ, CONVNET_AMD_EMULATE='0')
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and 'WATCH_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
