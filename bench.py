@@ -61,6 +61,14 @@ def _pmc_file_order(name):
     return (int(m.group(1)), m.group(2) == '', name) if m else (-1, False, name)
 
 
+def _flush_c_stdio():
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 LIVE_PMC = {'pm': None}      # per-kernel traffic measured by this command (--pmc), shared by the two places that quote it
 
 
@@ -449,10 +457,28 @@ def main():
         line = json.dumps(out)
         # the contract line must stay readable by whatever tails stdout: compact, and the LAST line
         assert len(line) < 8192, 'contract line grew to %d bytes' % len(line)
-        sys.stdout.flush()
-        print(line, flush=True)
+    # The LAST line of the job's stdout: RCCL prints its version banner through C stdio ("RCCL version : ...", five lines,
+    # rank 0), which a pipe buffers until the process exits - i.e. BEHIND a line Python printed earlier (seen with the
+    # 1-rank RCCL run of this script).  So: every rank tears down its communicators and flushes C stdio, the other
+    # ranks leave without running exit handlers, rank 0 prints the line after them and leaves the same way.
     if distributed:
+        ca.comm.destroy_default()
+        try:
+            dist.barrier()
+        except Exception:
+            pass
         dist.destroy_process_group()
+    _flush_c_stdio()
+    if rank != 0:
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
+    if distributed and world > 1:
+        time.sleep(1.0)      # the other ranks' last bytes reach the launcher's pipe first
+    print(line, flush=True)
+    sys.stderr.flush()
+    if distributed:
+        os._exit(0)          # no exit handler (RCCL / c10d destructors) gets to write behind the line
 
 
 if __name__ == '__main__':

@@ -13,7 +13,7 @@ for r in range(rounds):
         env.update(kv.split('=', 1) for kv in spec[1:])
         p = subprocess.run(cmd, env=env, capture_output=True, text=True)
         try:
-            v = json.loads(p.stdout.strip().splitlines()[-1])['value']
+            v = json.loads([l for l in p.stdout.strip().splitlines() if l.startswith('{"metric"')][-1])['value']
         except Exception:
             v = None
             open(os.path.join(out, 'err_%s.txt' % spec[0]), 'w').write(p.stdout[-2000:] + p.stderr[-4000:])
