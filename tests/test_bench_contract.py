@@ -47,3 +47,21 @@ def test_contract_line_is_last_compact_and_complete(tmp_path):
         assert k not in rec
     d = json.load(open(detail))
     assert d['kernels'] and d['kernels_overlapped'] and d['conv_layers'] and d['value'] == rec['value']
+
+
+@pytest.mark.gpu
+def test_contract_line_is_last_in_an_rccl_run_too(tmp_path):
+    """A distributed run (here: a 1-rank RCCL group, the only one a 1-GPU box can build) brings RCCL's version banner into
+    the process - five lines through C stdio that a piped stdout used to deliver BEHIND the contract line.  The line must
+    still be the last one, and the only {"metric" line."""
+    env = dict(os.environ, CONVNET_AMD_EMULATE='0', BENCH_FORCE_DIST='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29571')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '2', '--no-cpu-baseline',
+                        '--no-kernel-profile'], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.split('\n') if l.strip()]
+    assert lines[-1].startswith('{"metric"'), lines[-3:]
+    assert sum(l.startswith('{"metric"') for l in lines) == 1
+    rec = json.loads(lines[-1])
+    assert rec['n_gpus'] == 1 and rec['transport_fallback'] is False and 'RCCL' in (rec['config']['transport'] or '')
