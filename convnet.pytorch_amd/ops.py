@@ -197,7 +197,9 @@ class SideStream(object):
     def join(self, device):
         """Make the current stream wait for everything queued on the side stream(s)."""
         if self.used and device.type == 'cuda':
-            torch.cuda.current_stream(device).wait_stream(self.gather(device))
+            # the library's device-scope ring event, as for the hand-offs in the other direction (torch's wait_stream
+            # records an event with the default flags: a system-scope fence on the side stream)
+            self.fork(self.gather(device), torch.cuda.current_stream(device))
             self.used = False
         self._held = []     # (what the current stream does from here on is ordered behind the side stream's reads)
 
