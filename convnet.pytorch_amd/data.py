@@ -130,8 +130,11 @@ class RandomResizedCrop(object):
         return (w - cw) // 2, (h - ch) // 2, cw, ch
 
     def __call__(self, img):
+        # torchvision's F.resized_crop: crop FIRST, then resize the crop (PIL: img.crop(...).resize(...)).  NOT PIL's
+        # resize(box=...): that form lets the antialiasing window read source pixels outside the box, which changes the
+        # outermost ring of the 224 x 224 result (up to 18 grey levels on noise; round 4 fix)
         left, top, cw, ch = self.get_params(*img.size)
-        return img.resize((self.size, self.size), _pil().BILINEAR, box=(left, top, left + cw, top + ch))
+        return img.crop((left, top, left + cw, top + ch)).resize((self.size, self.size), _pil().BILINEAR)
 
     def __repr__(self):
         return 'RandomResizedCrop(%d)' % self.size

@@ -83,6 +83,28 @@ def test_random_resized_crop_invariants():
     assert a == [rrc.get_params(w, h) for _ in range(5)]
 
 
+def test_random_resized_crop_is_crop_then_resize():
+    """torchvision.transforms.functional.resized_crop on a PIL image = img.crop(box) THEN .resize(size, BILINEAR)
+    (/root/reference preprocess.py:73 uses transforms.RandomResizedCrop): the resampling window is clamped at the CROP's
+    edges.  PIL's resize(box=...) reads beyond the box and differs on the outermost ring of the result - the form this
+    module used until round 4."""
+    from convnet_amd import data as D
+    rng = np.random.RandomState(0)
+    img = Image.fromarray((rng.rand(375, 500, 3) * 255).astype(np.uint8))
+    rrc = D.RandomResizedCrop(224)
+    for seed in (0, 1, 2):
+        torch.manual_seed(seed)
+        left, top, cw, ch = rrc.get_params(*img.size)
+        torch.manual_seed(seed)
+        got = np.asarray(rrc(img))
+        want = np.asarray(img.crop((left, top, left + cw, top + ch)).resize((224, 224), Image.BILINEAR))
+        assert np.array_equal(got, want)
+        boxed = np.asarray(img.resize((224, 224), Image.BILINEAR, box=(left, top, left + cw, top + ch)))
+        if (left, top, cw, ch) != (0, 0, 500, 375):
+            assert not np.array_equal(boxed, want)       # the two forms really are different operations
+            assert np.array_equal(boxed[8:-8, 8:-8], want[8:-8, 8:-8])   # ... on the border ring only
+
+
 def test_augmentation_draws_follow_torchvisions_sequence():
     """The crop / flip draws are torchvision's, call for call (RandomResizedCrop.get_params: uniform_(scale),
     uniform_(log ratio), randint(top), randint(left); RandomHorizontalFlip: rand(1) < p), on torch's global
