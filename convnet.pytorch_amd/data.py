@@ -166,6 +166,20 @@ class ToTensor(object):
         return 'ToTensor()'
 
 
+class ToUint8HWC(object):
+    """PIL image -> uint8 HWC tensor: what leaves the workers when ToTensor + Normalize run on the device
+    (`device_normalize`; ops.u8_nhwc_to_nchw, bit-identical to the two host transforms)."""
+
+    def __call__(self, img):
+        a = np.array(img, dtype=np.uint8)      # (a writable copy: torch.from_numpy refuses to share PIL's read-only buffer)
+        if a.ndim == 2:
+            a = a[:, :, None]
+        return torch.from_numpy(a)
+
+    def __repr__(self):
+        return 'ToUint8HWC()'
+
+
 class Normalize(object):
     def __init__(self, mean, std):
         self.mean = torch.tensor(mean, dtype=torch.float32).view(-1, 1, 1)
@@ -178,23 +192,27 @@ class Normalize(object):
         return 'Normalize(mean=%s, std=%s)' % (self.mean.flatten().tolist(), self.std.flatten().tolist())
 
 
-def scale_crop(input_size, scale_size=None, normalize=None):
+def _to_tensor(normalize, device_normalize):
+    return [ToUint8HWC()] if device_normalize else [ToTensor(), Normalize(**normalize)]
+
+
+def scale_crop(input_size, scale_size=None, normalize=None, device_normalize=False):
     """Evaluation transform (preprocess.py:21-41, num_crops = 1)."""
     normalize = normalize or _IMAGENET_STATS
-    t = [CenterCrop(input_size), ToTensor(), Normalize(**normalize)]
+    t = [CenterCrop(input_size)] + _to_tensor(normalize, device_normalize)
     if scale_size != input_size:
         t = [Resize(scale_size)] + t
     return Compose(t)
 
 
-def inception_preprocess(input_size, normalize=None):
+def inception_preprocess(input_size, normalize=None, device_normalize=False):
     """Training transform (preprocess.py:71-77)."""
     normalize = normalize or _IMAGENET_STATS
-    return Compose([RandomResizedCrop(input_size), RandomHorizontalFlip(), ToTensor(), Normalize(**normalize)])
+    return Compose([RandomResizedCrop(input_size), RandomHorizontalFlip()] + _to_tensor(normalize, device_normalize))
 
 
 def get_transform(transform_name='imagenet', input_size=None, scale_size=None, normalize=None, augment=True,
-                  cutout=None, autoaugment=False, padding=None, duplicates=1, num_crops=1):
+                  cutout=None, autoaugment=False, padding=None, duplicates=1, num_crops=1, device_normalize=False):
     """preprocess.get_transform (preprocess.py:115-161) for the ImageNet family; the research
     augmentations (autoaugment, cutout, duplicates, multi-crop) are outside the hot path."""
     if 'imagenet' not in transform_name:
@@ -203,9 +221,11 @@ def get_transform(transform_name='imagenet', input_size=None, scale_size=None, n
         raise NotImplementedError('autoaugment / cutout / duplicates / multi-crop are not part of the hot path')
     input_size = input_size or 224
     scale_size = scale_size or int(input_size * 8 / 7)
+    # device_normalize (not in the reference; off by default): the workers stop at the uint8 crop and ToTensor + Normalize
+    # run on the device behind the host->device copy (trainer.DevicePrefetcher) - the same fp32 NCHW batch, bit for bit
     if augment:
-        return inception_preprocess(input_size, normalize=normalize)
-    return scale_crop(input_size=input_size, scale_size=scale_size, normalize=normalize)
+        return inception_preprocess(input_size, normalize=normalize, device_normalize=device_normalize)
+    return scale_crop(input_size=input_size, scale_size=scale_size, normalize=normalize, device_normalize=device_normalize)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -262,7 +282,7 @@ _DATA_ARGS = {'name', 'split', 'transform', 'target_transform', 'download', 'dat
 _DATALOADER_ARGS = {'batch_size', 'shuffle', 'sampler', 'batch_sampler', 'num_workers', 'collate_fn', 'pin_memory',
                     'drop_last', 'timeout', 'worker_init_fn'}
 _TRANSFORM_ARGS = {'transform_name', 'input_size', 'scale_size', 'normalize', 'augment', 'cutout', 'duplicates',
-                   'num_crops', 'autoaugment'}
+                   'num_crops', 'autoaugment', 'device_normalize'}
 _OTHER_ARGS = {'distributed'}
 
 
@@ -314,6 +334,9 @@ class DataRegime(object):
                 loader.setdefault('worker_init_fn', _seed_worker)
                 loader.setdefault('persistent_workers', True)
             self._loader = DataLoader(self._data, **loader)
+            # uint8 HWC batches carry what the device-side ToTensor + Normalize needs (trainer.DevicePrefetcher reads it)
+            self._loader.device_normalize = dict(setting['transform'].get('normalize') or _IMAGENET_STATS) \
+                if setting['transform'].get('device_normalize') else None
         return self._loader
 
     def set_epoch(self, epoch):

@@ -55,6 +55,9 @@ def build_parser():
     p.add_argument('--dist-init', default='env://', type=str, help='init used to set up distributed training')
     p.add_argument('--dist-backend', default='nccl', type=str, help='distributed backend (nccl = RCCL)')
     p.add_argument('-j', '--workers', default=8, type=int, metavar='N')
+    p.add_argument('--host-normalize', action='store_true',
+                   help='(not in the reference) keep ToTensor + Normalize in the loader workers; default: uint8 crops leave '
+                        'the workers and the two transforms run on the device behind the copy - same batch, bit for bit')
     p.add_argument('--epochs', default=90, type=int, metavar='N')
     p.add_argument('--start-epoch', default=-1, type=int, metavar='N')
     p.add_argument('-b', '--batch-size', default=256, type=int, metavar='N')
@@ -275,7 +278,8 @@ def main_worker(args):
                               defaults={'datasets_path': args.datasets_dir, 'name': args.dataset, 'split': 'val',
                                         'augment': False, 'input_size': args.input_size,
                                         'batch_size': args.eval_batch_size, 'shuffle': False,
-                                        'num_workers': args.workers, 'pin_memory': True, 'drop_last': False})
+                                        'num_workers': args.workers, 'pin_memory': True, 'drop_last': False,
+                                        'device_normalize': not args.host_normalize})
         val_loader = val_data.get_loader
         if not args.evaluate:
             train_data = DataRegime(getattr(model, 'data_regime', None),
@@ -285,7 +289,8 @@ def main_worker(args):
                                               'num_workers': args.workers, 'pin_memory': True, 'drop_last': True,
                                               'distributed': args.distributed, 'duplicates': args.duplicates,
                                               'autoaugment': args.autoaugment,
-                                              'cutout': {'holes': 1, 'length': 16} if args.cutout else None})
+                                              'cutout': {'holes': 1, 'length': 16} if args.cutout else None,
+                                              'device_normalize': not args.host_normalize})
             train_loader = train_data.get_loader
             logging.info('data regime: %s', train_data)
     if args.evaluate:

@@ -664,6 +664,31 @@ def nchw_to_nhwc(x_nchw, dtype, c_pad=None):
     return y
 
 
+def normalize_lut(mean, std):
+    """lut[c][u] = ToTensor + Normalize of byte u in channel c, with the reference pipeline's own fp32 operations
+    (`.float().div_(255)`, then `(t - mean) / std`): what cn_u8_nhwc_to_nchw_lut looks up."""
+    u = torch.arange(256, dtype=torch.uint8).float().div_(255.0).view(1, 256)
+    m = torch.tensor(mean, dtype=torch.float32).view(-1, 1)
+    s = torch.tensor(std, dtype=torch.float32).view(-1, 1)
+    return ((u - m) / s).contiguous()
+
+
+def u8_nhwc_to_nchw(x_u8, lut):
+    """uint8 [N, H, W, C] crops -> the normalised fp32 [N, C, H, W] batch (device-side ToTensor + Normalize)."""
+    if x_u8.dtype != torch.uint8 or x_u8.dim() != 4:
+        raise _lib.ConvNetHipError('u8_nhwc_to_nchw expects uint8 [N, H, W, C], got %s %s' % (x_u8.dtype, tuple(x_u8.shape)))
+    N, H, W, C = x_u8.shape
+    x_u8 = x_u8.contiguous()
+    lut = lut.to(device=x_u8.device, dtype=torch.float32).contiguous()
+    if tuple(lut.shape) != (C, 256):
+        raise _lib.ConvNetHipError('u8_nhwc_to_nchw: lut %s for %d channels' % (tuple(lut.shape), C))
+    y = torch.empty((N, C, H, W), dtype=torch.float32, device=x_u8.device)
+    PROFILER.run('u8_nhwc_to_nchw', 1, 0.0, x_u8.numel() + y.numel() * 4,
+                 lambda: check(_L().cn_u8_nhwc_to_nchw_lut(ptr(x_u8), ptr(y), N, H, W, C, ptr(lut), stream_of(x_u8)),
+                               'cn_u8_nhwc_to_nchw_lut'), x_u8.device)
+    return y
+
+
 def nchw_to_pairs(x_nchw, pad):
     """fp32 NCHW (C <= 4) -> zero-padded bf16 pixel-pair image [N, H+2ph, (W+2pw)/2, 8] (cn_nchw_to_pairs)."""
     N, C, H, W = x_nchw.shape

@@ -37,6 +37,18 @@ class DevicePrefetcher(object):
     def __init__(self, loader, device):
         self.loader, self.device = loader, device
         self.stream = torch.cuda.Stream(device) if device.type == 'cuda' else None
+        # loaders built with `device_normalize` (data.DataRegime) hand over uint8 NHWC crops: ToTensor + Normalize happen
+        # here, behind the copy (a quarter of the bytes over PCIe), and produce the very fp32 NCHW batch the host transforms
+        # would have (ops.u8_nhwc_to_nchw: a per-channel table of the reference's own fp32 arithmetic)
+        norm = getattr(loader, 'device_normalize', None)
+        self._lut = ops.normalize_lut(norm['mean'], norm['std']).to(device) if norm else None
+
+    def _finish(self, inputs):
+        if inputs.dtype == torch.uint8:
+            if self._lut is None:
+                raise ValueError('uint8 batches need a loader built with device_normalize (mean / std travel with it)')
+            return ops.u8_nhwc_to_nchw(inputs, self._lut)
+        return inputs
 
     def __len__(self):
         return len(self.loader)
@@ -44,11 +56,14 @@ class DevicePrefetcher(object):
     def _stage(self, batch):
         inputs, target = batch
         if self.stream is None or (inputs.is_cuda and target.is_cuda):
-            return inputs, target, None
+            return self._finish(inputs), target, None
         with torch.cuda.stream(self.stream):
             if not inputs.is_pinned():
                 inputs = inputs.pin_memory()
-            x = inputs.to(self.device, dtype=torch.float32, non_blocking=True)
+            if inputs.dtype == torch.uint8:
+                x = self._finish(inputs.to(self.device, non_blocking=True))
+            else:
+                x = inputs.to(self.device, dtype=torch.float32, non_blocking=True)
             t = target.to(self.device, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.stream)

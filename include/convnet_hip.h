@@ -323,6 +323,11 @@ int cn_avgpool_bwd(const void* dy, void* dx, int N, int HW, int C, int dtype, vo
 /* ---- host->device boundary and autograd fan-in (trainer.py:116-117; models/resnet.py:115,162) */
 int cn_nchw_to_nhwc(const float* x_nchw, void* y_nhwc, int N, int C, int H, int W, int Cpad, int dtype,
                     void* stream);
+/* transforms.ToTensor() + Normalize(mean, std) (preprocess.py:23-25) on the device: uint8 NHWC crops -> fp32 NCHW batch,
+ * y[n][c][h][w] = lut[c][x[n][h][w][c]]; the caller fills lut[C][256] = (u / 255 - mean[c]) / std[c] with the reference's fp32
+ * operations, so the batch is bit-identical to the host pipeline's.  1 <= C <= 4. */
+int cn_u8_nhwc_to_nchw_lut(const unsigned char* x_nhwc, float* y_nchw, int N, int H, int W, int C, const float* lut,
+                           void* stream);
 /* Stride-2 stem (models/resnet.py:226, 7x7/2 pad 3 on 3 channels) in "pixel pair" form: the fp32 NCHW batch
  * becomes a zero-padded bf16 image [N][H+2*pad_h][(W+2*pad_w)/2][8] whose 16-byte chunks hold two adjacent
  * pixels x 4 channels; with the filter packed the same way (cn_weight_prep_pairs: [K][R][ceil(S/2)][8]) the

@@ -191,3 +191,69 @@ def test_folder_pipeline_feeds_the_gpu_trainer(tmp_path):
     assert not torch.equal(model.fc.weight.detach().float().cpu(), w0)
     val = tr.validate(dr.get_loader())
     assert val['loss'] == val['loss']
+
+
+@pytest.mark.gpu
+def test_device_side_totensor_normalize_on_the_gpu(tmp_path):
+    """The same on the MI355X (cn_u8_nhwc_to_nchw_lut on the copy stream, pinned uint8 batches, two workers), plus a
+    training pass fed that way: the loss equals the host-normalised run's, bit for bit."""
+    import convnet_amd as ca
+    from convnet_amd import data as D
+    assert not ca._lib.is_emulated()
+    test_device_side_totensor_normalize_is_bit_identical(tmp_path)
+    _make_folder(str(tmp_path / 'f'), per_class=6, size=(70, 64))
+    losses = []
+    for dn in (False, True):
+        torch.manual_seed(7)
+        dr = D.DataRegime(None, defaults={'datasets_path': str(tmp_path / 'f'), 'name': 'imagenet', 'split': 'train',
+                                          'augment': True, 'input_size': 64, 'batch_size': 8, 'shuffle': False,
+                                          'num_workers': 0, 'pin_memory': True, 'drop_last': True, 'device_normalize': dn})
+        torch.manual_seed(123)
+        model = ca.models.resnet(dataset='imagenet', depth=18, num_classes=8)
+        tr = ca.Trainer(model, ca.CrossEntropyLoss(), ca.OptimRegime(model, model.regime), device='cuda:0',
+                        dtype=torch.bfloat16, print_freq=10 ** 9)
+        torch.manual_seed(11)
+        losses.append(tr.train(dr.get_loader())['loss'])
+    assert losses[0] == losses[1] and 0 < losses[0] < 20, losses
+
+
+def test_device_side_totensor_normalize_is_bit_identical(tmp_path):
+    """`device_normalize` (DataRegime setting; main.py default, `--host-normalize` turns it off): the workers stop at the
+    uint8 HWC crop, trainer.DevicePrefetcher runs ToTensor + Normalize behind the copy (ops.u8_nhwc_to_nchw: a per-channel
+    table of the reference's own fp32 arithmetic, preprocess.py:23-25).  The batches the step receives are the host
+    pipeline's, bit for bit - train (same crops / flips under the same seed) and eval."""
+    from convnet_amd import data as D
+    import convnet_amd as ca
+    root = tmp_path / 'ds'
+    rng = np.random.RandomState(1)
+    for split in ('train', 'val'):
+        for c in range(3):
+            d = root / 'imagenet' / split / ('c%d' % c)
+            d.mkdir(parents=True)
+            for i in range(4):
+                a = (rng.rand(40 + 7 * i, 50 + 5 * c, 3) * 255).astype(np.uint8)
+                Image.fromarray(a).save(str(d / ('%d.png' % i)))
+    dev = torch.device('cpu')        # the emulator build serves host tensors; on a GPU box the same test runs on cuda:0
+    if torch.cuda.is_available() and not ca._lib.is_emulated():
+        dev = torch.device('cuda', 0)
+    for split, augment in (('train', True), ('val', False)):
+        got = {}
+        for dn in (False, True):
+            torch.manual_seed(5)
+            dr = D.DataRegime([{'epoch': 0}], defaults={'datasets_path': str(root), 'name': 'imagenet', 'split': split,
+                                                         'augment': augment, 'input_size': 32, 'batch_size': 4,
+                                                         'shuffle': False, 'num_workers': 0, 'drop_last': False,
+                                                         'device_normalize': dn})
+            loader = dr.get_loader()
+            assert (loader.device_normalize is not None) == dn
+            first = next(iter(loader))[0]
+            assert first.dtype == (torch.uint8 if dn else torch.float32)
+            assert tuple(first.shape) == ((4, 32, 32, 3) if dn else (4, 3, 32, 32))
+            torch.manual_seed(5)
+            got[dn] = [(x.cpu().clone(), t.cpu().clone()) for x, t in ca.trainer.DevicePrefetcher(loader, dev)]
+        assert len(got[False]) == len(got[True]) == 3
+        for (x0, t0), (x1, t1) in zip(got[False], got[True]):
+            assert x1.dtype == torch.float32 and torch.equal(x0, x1) and torch.equal(t0, t1)
+    # uint8 batches without the loader's mean / std are refused, not guessed
+    with pytest.raises(ValueError):
+        list(ca.trainer.DevicePrefetcher([(torch.zeros(1, 4, 4, 3, dtype=torch.uint8), torch.zeros(1, dtype=torch.long))], dev))

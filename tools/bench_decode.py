@@ -19,6 +19,7 @@ def main():
     ap.add_argument('--images', type=int, default=512)
     ap.add_argument('--workers', default='1,4,8')
     ap.add_argument('--batch', type=int, default=64)
+    ap.add_argument('--device-normalize', action='store_true', help='workers stop at the uint8 crop (ToTensor + Normalize on the device)')
     args = ap.parse_args()
     from PIL import Image
     import torch
@@ -33,7 +34,8 @@ def main():
     for nw in [int(w) for w in args.workers.split(',')]:
         dr = D.DataRegime([{'epoch': 0}], defaults={'datasets_path': root, 'name': 'imagenet', 'split': 'train',
                                                      'augment': True, 'input_size': 224, 'batch_size': args.batch,
-                                                     'shuffle': True, 'num_workers': nw, 'drop_last': True})
+                                                     'shuffle': True, 'num_workers': nw, 'drop_last': True,
+                                                     'device_normalize': args.device_normalize})
         loader = dr.get_loader()
         n = 0
         for x, t in loader:     # warm-up epoch (worker start-up, page cache)
