@@ -363,7 +363,21 @@ class Trainer(object):
                 return res
             if not seen.get('use', True):
                 return self._body(inputs, target, True, chunk_batch)
-            st = gs['graph'] = self._capture(inputs, target, chunk_batch, key)
+            try:
+                st = gs['graph'] = self._capture(inputs, target, chunk_batch, key)
+            except RuntimeError as e:      # (torch.cuda.OutOfMemoryError is one)
+                # A capture needs its own pool for the step's tensors, next to the blocks the eager steps keep cached.  When
+                # the capture was the WATCH's idea (a verdict withdrawn after many eager steps) and it does not fit, the
+                # configuration simply stays eager; a capture the configuration started with fails as it always did.
+                if not seen.get('withdrawn'):
+                    raise
+                logging.warning('HIP-graph capture of a running configuration failed (%s): staying with eager launches',
+                                str(e).split('\n')[0][:200])
+                gs['graph'] = None
+                seen['use'] = False
+                self._graph_eager_for.add(eager_key)
+                torch.cuda.empty_cache()
+                return self._body(inputs, target, True, chunk_batch)
         st['x'].copy_(inputs, non_blocking=True)
         st['t'].copy_(target, non_blocking=True)
         if self._graph_mode == 'auto' and 'graph_ms' not in seen and 'eager_ms' in seen:
@@ -409,7 +423,7 @@ class Trainer(object):
         gs = self._gstates.get(key)
         if gs is None:
             gs = self._gstates[key] = {'seen': {'n': 4}, 'graph': None}
-        gs['seen'].update(use=True, eager_ms=w.recent_ms(), n=max(gs['seen'].get('n', 0), 4))
+        gs['seen'].update(use=True, withdrawn=True, eager_ms=w.recent_ms(), n=max(gs['seen'].get('n', 0), 4))
         gs['seen'].pop('graph_ms', None)
         gs['seen'].pop('replays', None)
         logging.info('eager step %.2f ms against %.2f ms when it was chosen: trying a HIP graph', w.recent_ms(), w.ref_ms)
@@ -427,7 +441,7 @@ class Trainer(object):
                 out, loss, grad = self._body(x, t, True, chunk_batch)
         finally:
             ops.SIDE.capturing = False
-        self.training_steps = steps_before     # capture executes nothing: the replay is the step
+            self.training_steps = steps_before     # capture executes nothing: the replay is the step
         logging.debug('captured the training step as one HIP graph (%s)', (key[0],))
         return {'key': key, 'graph': g, 'x': x, 't': t, 'out': out, 'loss': loss, 'grad': grad}
 
