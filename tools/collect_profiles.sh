@@ -1,5 +1,5 @@
 #!/bin/bash
-# Copy the closing-set artefacts of a gpurun_out/<tag>/ directory (tools/gpu_final.sh) into profiles/ under r03_ names.
+# Copy the closing-set artefacts of a gpurun_out/<tag>/ directory (tools/gpu_final.sh) into profiles/ under <rNN>_ names.
 set -e
 S=gpurun_out/${1:?tag}; P=profiles; R=${2:?round tag, e.g. r04}
 cp $S/bench.json $P/${R}_bench_line.json

@@ -1,3 +1,5 @@
+# rocprofv3 kernel trace of the same short bench run, eager (graph=0) and replayed (graph=1): stats, gaps, per-grid times and
+# the last three steps as (queue, kernel, start, end) rows under gpurun_out/r4tr/ (which hardware queues each mode uses).
 export TMPDIR=/tmp
 OUT=gpurun_out/r4tr
 mkdir -p $OUT
