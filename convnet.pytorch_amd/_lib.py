@@ -38,9 +38,8 @@ _SIGNATURES = {
     'cn_set_option': (c_i, [ctypes.c_char_p, c_i]),
     'cn_stream_fork': (c_i, [c_p, c_p]),
     'cn_stream_arm': (c_i, []),
-    'cn_step_timer_mark': (c_i, [c_p]),
-    'cn_step_timer_poll': (c_i, [c_p]),
-    'cn_step_timer_reset': (c_i, []),
+    'cn_step_timer_mark': (c_i, [c_p, ctypes.c_longlong]),
+    'cn_step_timer_poll': (c_i, [c_p, c_p, c_p]),
     'cn_stream_disarm': (c_i, []),
     'cn_stream_wait_mark': (c_i, [c_i, c_p]),
     'cn_conv2d_fwd': (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 11 + [c_i, c_i, c_i, c_p]),

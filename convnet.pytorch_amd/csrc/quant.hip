@@ -623,7 +623,11 @@ extern "C" size_t cn_rangebn_workspace(int M, int C, int chunks) {
   if (M <= 0 || C <= 0 || chunks <= 0) return 0;
   int sub = 64;   // upper bound over the tunable slice lengths (rbn_sub)
   const size_t stats = (size_t)chunks * sub * C * sizeof(RbnPartial);
-  const size_t bwd = ((size_t)((M + 255) / 256) * 2 * C + 3 * (size_t)C) * sizeof(float);   // >= 256 pixels per partial row
+  // backward: >= 256 pixels per partial row, the coefficients, and room behind them for the per-sample min / max partials
+  // of the fused form when they do not fit in the (then dead) partial rows - few pixels per sample, few channels, a large
+  // batch (rows x blocks-per-row <= 8192 + one rounding step per row: q_grid_rows)
+  const size_t mmtail = (size_t)(8192 + 8192 * (size_t)(1 + C / Q_NT)) * 2;
+  const size_t bwd = ((size_t)((M + 255) / 256) * 2 * C + 3 * (size_t)C + mmtail) * sizeof(float);
   return stats > bwd ? stats : bwd;
 }
 static int rbn_sub(int M, int chunks) {
@@ -964,8 +968,9 @@ static int rangebn_bwd_impl(const void* g, const void* x, const float* weight, c
   const unsigned bpr = fused ? q_grid_rows(nch, arows, CC) : q_grid_cols(nch, CC);
   float* mmp = nullptr;
   if (fused) {   // the reduction partials are dead once finalize has run; coef lives behind them
-    if ((size_t)arows * bpr * 2 > (size_t)rows * 2 * C) { cn_set_error("rangebn_bwd: workspace too small for the min / max partials"); return CN_EWORKSPACE; }
-    mmp = partial;
+    if ((size_t)arows * bpr * 2 <= (size_t)rows * 2 * C) mmp = partial;
+    else if (((size_t)rows * 2 * C + 3 * (size_t)C + (size_t)arows * bpr * 2) * sizeof(float) <= ws_bytes) mmp = coef + 3 * (size_t)C;   // (HW = 1, C = 64, N > 64 ...)
+    else { cn_set_error("rangebn_bwd: workspace too small for the min / max partials"); return CN_EWORKSPACE; }
   }
   const dim3 agrid(bpr, (unsigned)arows);
   const int L = M / chunks;

@@ -156,19 +156,22 @@ extern "C" int cn_stream_wait_mark(int handle, void* to_stream) {
 #endif
 }
 
-// Step timer: cn_step_timer_mark(stream) records the next event of a ring behind the stream's work (timing enabled, NO
-// system-scope fence: torch's timing events flush the caches at every record - 0.5 % of a 17 ms step when one is recorded
-// per step); cn_step_timer_poll(&ms) consumes the oldest pair whose events have both completed and returns the time between
-// them, without waiting (0: nothing complete yet).  The caller's policy lives in trainer.EagerWatch.
+// Step timer: cn_step_timer_mark(stream, tag) records the next event of a ring behind the stream's work (timing enabled,
+// NO system-scope fence: torch's timing events flush the caches at every record - 0.5 % of a 17 ms step when one is
+// recorded per step) and remembers the caller's tag with it; cn_step_timer_poll(&ms, &tag_prev, &tag_cur) consumes the
+// oldest pair whose events have both completed and returns the time between them with the two marks' tags, without
+// waiting (0: nothing complete yet).  Several watchers share the ring: each tags its marks and keeps only the periods
+// whose two ends are its own (trainer.EagerWatch); nothing here resets another watcher's marks.
 #ifndef CN_EMULATE
 #define CN_TIMER_EVENTS 64
 static thread_local hipEvent_t g_timer[CN_TIMER_EVENTS];
+static thread_local long long g_timer_tag[CN_TIMER_EVENTS];
 static thread_local int g_timer_made = 0;
 static thread_local long long g_timer_head = 0, g_timer_tail = 0;   // [head, tail): recorded, not yet consumed
 #endif
-extern "C" int cn_step_timer_mark(void* stream) {
+extern "C" int cn_step_timer_mark(void* stream, long long tag) {
 #ifdef CN_EMULATE
-  (void)stream;
+  (void)stream; (void)tag;
   return CN_OK;
 #else
   if (!g_timer_made) {
@@ -181,28 +184,28 @@ extern "C" int cn_step_timer_mark(void* stream) {
     cn_set_error("step_timer: %s", hipGetErrorString(hipGetLastError()));
     return CN_EHIP;
   }
+  g_timer_tag[g_timer_tail % CN_TIMER_EVENTS] = tag;
   ++g_timer_tail;
   return CN_OK;
 #endif
 }
-extern "C" int cn_step_timer_poll(float* period_ms) {
+extern "C" int cn_step_timer_poll(float* period_ms, long long* tag_prev, long long* tag_cur) {
 #ifdef CN_EMULATE
-  (void)period_ms;
+  (void)period_ms; (void)tag_prev; (void)tag_cur;
   return 0;
 #else
   if (period_ms == nullptr || !g_timer_made || g_timer_tail - g_timer_head < 2) return 0;
-  hipEvent_t a = g_timer[g_timer_head % CN_TIMER_EVENTS], b = g_timer[(g_timer_head + 1) % CN_TIMER_EVENTS];
-  if (hipEventQuery(b) != hipSuccess) { (void)hipGetLastError(); return 0; }   // hipErrorNotReady is not an error here
-  if (hipEventElapsedTime(period_ms, a, b) != hipSuccess) { (void)hipGetLastError(); ++g_timer_head; return 0; }
+  const int ia = (int)(g_timer_head % CN_TIMER_EVENTS), ib = (int)((g_timer_head + 1) % CN_TIMER_EVENTS);
+  if (hipEventQuery(g_timer[ib]) != hipSuccess) { (void)hipGetLastError(); return 0; }   // hipErrorNotReady is not an error here
+  if (tag_prev) *tag_prev = g_timer_tag[ia];
+  if (tag_cur) *tag_cur = g_timer_tag[ib];
   ++g_timer_head;
+  if (hipEventElapsedTime(period_ms, g_timer[ia], g_timer[ib]) != hipSuccess) {
+    (void)hipGetLastError();
+    *period_ms = -1.0f;      // the pair is consumed all the same: the caller sees its tags and a negative period
+  }
   return 1;
 #endif
-}
-extern "C" int cn_step_timer_reset(void) {
-#ifndef CN_EMULATE
-  g_timer_head = g_timer_tail;
-#endif
-  return CN_OK;
 }
 
 extern "C" int cn_is_emulator(void) {

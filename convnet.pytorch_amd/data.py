@@ -221,7 +221,7 @@ def get_transform(transform_name='imagenet', input_size=None, scale_size=None, n
         raise NotImplementedError('autoaugment / cutout / duplicates / multi-crop are not part of the hot path')
     input_size = input_size or 224
     scale_size = scale_size or int(input_size * 8 / 7)
-    # device_normalize (not in the reference; off by default): the workers stop at the uint8 crop and ToTensor + Normalize
+    # device_normalize (not in the reference; main.py turns it on unless --host-normalize is given): the workers stop at the uint8 crop and ToTensor + Normalize
     # run on the device behind the host->device copy (trainer.DevicePrefetcher) - the same fp32 NCHW batch, bit for bit
     if augment:
         return inception_preprocess(input_size, normalize=normalize, device_normalize=device_normalize)

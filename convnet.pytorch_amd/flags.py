@@ -83,3 +83,17 @@ def on(name):
 
 def text(name):
     return str(_VALUES[name])
+
+
+def graph_mode():
+    """The `graph` flag as one of 'auto' / '0' / '1': every spelling `on()` counts as off means NEVER capture (it used to
+    be compared as text, so graph=off meant 'always'); anything else is an error, not a silent A/B mistake."""
+    v = str(_VALUES['graph'])
+    if v == 'auto':
+        return 'auto'
+    if v in ('0', 'off', 'False', ''):
+        return '0'
+    if v in ('1', 'on', 'True'):
+        return '1'
+    raise ValueError("CONVNET_AMD_FLAGS graph=%r: expected auto, 0 / off / False or 1 / on / True" % v)
+

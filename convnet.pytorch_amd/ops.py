@@ -133,6 +133,10 @@ class SideStream(object):
         self.capturing = False      # set by Trainer around HIP-graph capture
         self.hold = flags.on('side_hold')
         self._held = []
+        # a caller that runs backward passes without ever joining (anything but Trainer / BucketReducer) must not pin
+        # every operand for ever: beyond this many pending hand-offs the oldest go back to the allocator the
+        # record_stream way (correct without a join, just slower).  ResNet-200 with 8 accumulation chunks stays below.
+        self.hold_max = 2048
         self._mark = None
 
     def get(self, device):
@@ -175,6 +179,9 @@ class SideStream(object):
             # caching allocator then needs no cross-stream bookkeeping for them.  record_stream would make it record an
             # event (with torch's default flags: a system-scope fence) on the side stream at every free and poll it
             self._held.append(held)
+            if len(self._held) > self.hold_max:
+                for t in self._held.pop(0):
+                    t.record_stream(side)
         else:
             for t in held:
                 t.record_stream(side)
@@ -195,7 +202,10 @@ class SideStream(object):
         check(_L().cn_stream_fork(cur.cuda_stream, side.cuda_stream), 'cn_stream_fork')
 
     def join(self, device):
-        """Make the current stream wait for everything queued on the side stream(s)."""
+        """Make the current stream wait for everything queued on the side stream(s).  MANDATORY once per step for whoever
+        drives backward passes of this package by hand (Trainer._body and BucketReducer.finish do it): the optimizer
+        step must not read weight gradients the side stream is still writing, and the operands held for it are released
+        here."""
         if self.used and device.type == 'cuda':
             # the library's device-scope ring event, as for the hand-offs in the other direction (torch's wait_stream
             # records an event with the default flags: a system-scope fence on the side stream)

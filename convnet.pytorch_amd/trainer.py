@@ -18,6 +18,7 @@ tensorwatch streams, nn.DataParallel.
 import logging
 import os
 import time
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -94,19 +95,35 @@ class EagerWatch(object):
     fourth step; a host that slows down later (other tenants on its cores, a box whose first minutes are slow) turns the
     same step host-bound - measured on this pool: 7.4k and 11.1k img/s eager against 13.9k replayed in the same minute.
     One timing event per step is recorded behind the step (cn_step_timer_*: no system-scope fence, unlike torch's timing
-    events); completed pairs give the step PERIOD on the device timeline
-    (= max(host, device) time per step) without a synchronisation.  The verdict is withdrawn when the MEDIAN of the last
-    `window` periods exceeds `factor` x the step time it was based on (a replayed single-chain graph costs ~1.07 x that);
-    the median, because single long periods are normal - the pause between two train() calls, a validation pass."""
+    events); completed pairs give the step PERIOD on the device timeline without a synchronisation.  That period is
+    max(loader wait + host launches, device time): the time the loop spent WAITING FOR THE LOADER before the step
+    (measured on the host by Trainer.forward, handed to `step`) is subtracted, so a loader-bound run - the normal case
+    for main.py with PIL workers - is not mistaken for a launch-bound one (a replayed graph cannot make the loader
+    faster).  The verdict is withdrawn when the MEDIAN of the last `window` corrected periods exceeds
+    `factor` x the step time it was based on (a replayed single-chain graph costs ~1.07 x that); the median, because
+    single long periods are normal - the pause between two train() calls, a validation pass.
+
+    The library's ring of timing marks is shared by every watch of the process: a mark carries (watch id, sequence
+    number) as its tag, a polled period belongs to the watch whose id BOTH of its marks carry (two consecutive steps of
+    that configuration) and is routed there whichever watch happened to poll it; periods between marks of different
+    watches are dropped.  Nothing is reset globally."""
+
+    _next_id = [1]
+    _live = weakref.WeakValueDictionary()     # watch id -> watch (periods polled by another watch are routed here)
 
     def __init__(self, ref_ms, window=9, factor=1.2):
         self.ref_ms, self.window, self.factor = float(ref_ms), window, factor
         self.periods = []
-        _lib.load().cn_step_timer_reset()
+        self.id = EagerWatch._next_id[0]
+        EagerWatch._next_id[0] += 1
+        EagerWatch._live[self.id] = self
+        self._seq = 0
+        self._waits = {}          # sequence number of a mark -> loader wait (ms) in front of the step it closes
+        self._fire = False
 
-    def add_period(self, ms):
+    def add_period(self, ms, wait_ms=0.0):
         """Pure bookkeeping (unit-tested on the CPU): True when the verdict should be withdrawn."""
-        self.periods.append(float(ms))
+        self.periods.append(max(float(ms) - float(wait_ms), 0.0))
         if len(self.periods) > self.window:
             self.periods.pop(0)
         return len(self.periods) == self.window and self.recent_ms() > self.factor * self.ref_ms
@@ -115,16 +132,37 @@ class EagerWatch(object):
         p = sorted(self.periods)
         return p[len(p) // 2] if p else 0.0
 
-    def step(self, stream):
-        """One mark behind the step just queued on `stream`; folds in every period that has completed since (no wait)."""
+    def _deliver(self, ms, seq):
+        wait = self._waits.pop(seq, 0.0)
+        for k in [k for k in self._waits if k < seq]:      # marks whose period never arrived (dropped by the ring)
+            del self._waits[k]
+        if ms >= 0.0:
+            self._fire = self.add_period(ms, wait) or self._fire
+
+    def step(self, stream, wait_ms=0.0):
+        """One mark behind the step just queued on `stream` (`wait_ms`: host time the loop waited for the loader in front
+        of this step); folds in every period that has completed since (no wait).  True: withdraw the verdict."""
         import ctypes
         L = _lib.load()
-        check(L.cn_step_timer_mark(stream.cuda_stream), 'cn_step_timer_mark')
-        ms = ctypes.c_float(0.0)
-        fire = False
-        while L.cn_step_timer_poll(ctypes.byref(ms)) == 1:
-            fire = self.add_period(ms.value) or fire
+        self._seq += 1
+        self._waits[self._seq] = float(wait_ms)
+        check(L.cn_step_timer_mark(stream.cuda_stream, (self.id << 32) | self._seq), 'cn_step_timer_mark')
+        ms, ta, tb = ctypes.c_float(0.0), ctypes.c_longlong(0), ctypes.c_longlong(0)
+        while L.cn_step_timer_poll(ctypes.byref(ms), ctypes.byref(ta), ctypes.byref(tb)) == 1:
+            self.route(ms.value, ta.value, tb.value)
+        fire, self._fire = self._fire, False
         return fire
+
+    @classmethod
+    def route(cls, ms, tag_prev, tag_cur):
+        """A polled period goes to the watch both of whose marks it lies between (unit-tested on the CPU)."""
+        wid = tag_cur >> 32
+        if wid != (tag_prev >> 32) or (tag_cur & 0xffffffff) != (tag_prev & 0xffffffff) + 1:
+            return None           # the two marks close steps of different configurations (or a mark was dropped)
+        w = cls._live.get(wid)
+        if w is not None:
+            w._deliver(ms, tag_cur & 0xffffffff)
+        return w
 
 
 class Trainer(object):
@@ -165,8 +203,9 @@ class Trainer(object):
         self.reducer = None
         self._main_stream = None   # high-priority HIP stream of the step loop (created lazily on a GPU)
         # flag graph: 'auto' (default) captures only when the eager step is host-bound, 1 = always, 0 = never
-        self._graph_mode = flags.text('graph')
+        self._graph_mode = flags.graph_mode()
         self._use_graph = self._graph_mode != '0'
+        self._data_wait_ms = 0.0         # host time Trainer.forward waited for the loader in front of the current step
         self._graph_dp = flags.on('graph_dp')   # capture RCCL buckets too (opt-in)
         self._gstates = {}               # per (shapes, step options) key: {'seen': warm-up / timing bookkeeping, 'graph': capture}
         self._graph_eager_for = set()    # (shapes, chunking) for which auto mode settled on eager launches
@@ -220,7 +259,7 @@ class Trainer(object):
                     return self._graph_step(inputs_batch, target_batch, chunk_batch)
             elif key in self._watch and not ops.PROFILER.enabled:
                 res = self._body(inputs_batch, target_batch, training, chunk_batch)
-                if self._watch[key].step(torch.cuda.current_stream(self.device)):
+                if self._watch[key].step(torch.cuda.current_stream(self.device), self._data_wait_ms):
                     self._eager_verdict_withdrawn(key)
                 return res
         return self._body(inputs_batch, target_batch, training, chunk_batch)
@@ -417,7 +456,7 @@ class Trainer(object):
         """The eager step of this configuration has been running slower than a replayed graph would for a window of
         steps (EagerWatch): the host has become the limit after the verdict was taken (a loaded host, a slow box: the
         eager step needs ~11 ms of host time per ResNet-50 step, a replay none).  The next step captures; the usual
-        check of the second replay against the eager time - now the recent one - still applies."""
+        check of the second replay against the eager time - now the recent one, loader wait excluded - still applies."""
         w = self._watch.pop(key)
         self._graph_eager_for.discard(key)
         gs = self._gstates.get(key)
@@ -501,6 +540,7 @@ class Trainer(object):
                 if inputs.dim() > 4:
                     raise NotImplementedError('duplicates (B x D x C x H x W inputs) are outside the hot path')
                 meters['data'].update(time.time() - end)
+                self._data_wait_ms = meters['data'].val * 1e3     # (EagerWatch: not the step's own time)
 
                 output, loss, grad = self._step(inputs, target, training=training,
                                                 average_output=average_output, chunk_batch=chunk_batch)

@@ -65,11 +65,11 @@ int cn_stream_arm(void);
 int cn_stream_disarm(void);
 int cn_stream_wait_mark(int handle, void* to_stream);
 /* step timer (Trainer's graph = auto policy): mark = record the next ring event behind the stream's work (timing on, no
- * system-scope fence); poll = time in ms between the oldest two marks once both have completed (returns 1), never waits
- * (returns 0); reset forgets the recorded marks */
-int cn_step_timer_mark(void* stream);
-int cn_step_timer_poll(float* period_ms);
-int cn_step_timer_reset(void);
+ * system-scope fence) together with the caller's tag; poll = time in ms between the oldest two marks once both have
+ * completed, with their tags (returns 1; a negative period = the pair could not be timed), never waits (returns 0).
+ * Watchers share the ring and keep the periods whose two tags are their own. */
+int cn_step_timer_mark(void* stream, long long tag);
+int cn_step_timer_poll(float* period_ms, long long* tag_prev, long long* tag_cur);
 
 /* ---- nn.Conv2d / nn.Linear (models/resnet.py:75-78,126-132,178-179,226-227,242) ------------- */
 /* y[N,P,Q,K] = conv(x[N,H,W,C], w[K,R,S,C]) (+bias[K]) (ReLU optional); out_f32 writes fp32

@@ -1,5 +1,7 @@
 """convnet.pytorch_amd/flags.py: one table of engine switches (round 4).  CPU test."""
 import os
+
+import pytest
 import subprocess
 import sys
 
@@ -61,3 +63,40 @@ def test_eager_verdict_watch_window_logic():
     assert fired.index(True) == 13                                               # five of the last nine are slow
     w = W(17.0)
     assert not any(w.add_period(19.5) for _ in range(30))                        # 15 % slower: a replay would not help
+
+
+def test_eager_watch_ignores_loader_wait_and_foreign_marks():
+    """(i) the step period on the device timeline includes the time the loop waited for the loader; that
+    wait (measured on the host, handed to the watch) is subtracted, so a loader-bound run is not taken for a
+    launch-bound one; (ii) the library's ring of marks is shared: a period is routed to the watch BOTH of whose marks
+    bound it, whichever watch polled it, and periods between two configurations' marks are dropped."""
+    import convnet_amd as ca
+    W = ca.trainer.EagerWatch
+    w = W(17.0)
+    assert not any(w.add_period(60.0, wait_ms=45.0) for _ in range(30))          # loader-bound: 15 ms of step
+    w = W(17.0)
+    fired = [w.add_period(60.0, wait_ms=20.0) for _ in range(12)]                # 40 ms of launches: host-bound
+    assert fired.index(True) == 8 and abs(w.recent_ms() - 40.0) < 1e-9
+    a, b = W(17.0), W(17.0)
+    tag = lambda w_, seq: (w_.id << 32) | seq
+    a._waits.update({2: 0.0, 3: 30.0})
+    assert W.route(34.0, tag(a, 1), tag(a, 2)) is a and a.periods == [34.0]      # polled by anyone: lands in a
+    assert W.route(64.0, tag(a, 2), tag(a, 3)) is a and a.periods == [34.0, 34.0]   # ... minus ITS step's loader wait
+    assert W.route(500.0, tag(a, 3), tag(b, 1)) is None and b.periods == []      # a step of a, then one of b: nobody's
+    assert W.route(500.0, tag(b, 1), tag(b, 3)) is None and b.periods == []      # a mark of b was dropped in between
+    assert W.route(-1.0, tag(b, 3), tag(b, 4)) is b and b.periods == []          # a pair the runtime could not time
+    nb = len(a.periods)
+    c = W(17.0)                                                                  # a new watch resets nobody
+    assert len(a.periods) == nb and c.id not in (a.id, b.id)
+
+
+def test_graph_flag_spellings(monkeypatch):
+    """graph=off / False used to mean 'always capture' (compared as text against '0')."""
+    import convnet_amd as ca
+    for v, want in (('auto', 'auto'), ('0', '0'), ('off', '0'), ('False', '0'), ('', '0'), ('1', '1'), ('on', '1')):
+        monkeypatch.setitem(ca.flags._VALUES, 'graph', v)
+        assert ca.flags.graph_mode() == want, v
+    monkeypatch.setitem(ca.flags._VALUES, 'graph', 'sometimes')
+    with pytest.raises(ValueError):
+        ca.flags.graph_mode()
+
