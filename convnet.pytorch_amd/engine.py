@@ -29,109 +29,6 @@ class _Slot(object):
     __slots__ = ('name', 'param', 'offset', 'numel', 'bucket', 'module', 'is_filter')
 
 
-class DeferredWgrad(object):
-    """Weight gradients that leave the step they belong to (round 5).
-
-    The backward chain has the weight-gradient kernels beside it from the first layer to the last (4.3 ms of them alone
-    next to ~9 ms of chain: the step pays 2.6 ms for their company), the forward pass nothing.  The filters whose
-    gradients backward reaches FIRST (the late stages) are the ones the next forward pass needs LAST: for the modules
-    named here a convolution's backward only parks its weight-gradient launch; when the next step begins, the parked
-    launches, the SGD update of exactly those filters and the refresh of their 16-bit copies are queued on the side
-    stream - beside that step's stem / early stages - and the forward pass waits for them in front of the first
-    deferred convolution (`gate`).  Same kernels, same operands, same order of every floating-point operation: the
-    training trajectory does not change by a bit.
-
-    States: idle -> (backward parks launches, Trainer runs the optimizer on the other ranges) queued -> (`flush`, at the
-    start of the next step or at the end of the loop) inflight -> (`gate`: the current stream waits for the side
-    stream) idle.  `active` is decided per step by the Trainer (plain eager single-process steps only: no chunked
-    accumulation, no clipping by the global norm, no gradient all-reduce, no graph capture); a step that does not
-    defer starts with flush + gate, i.e. with every earlier gradient applied in stream order."""
-
-    def __init__(self, arena, prefixes):
-        from . import nn as cnn
-        self.arena = arena
-        self.prefixes = tuple(p for p in prefixes if p)
-        self.slots = [s for s in arena.slots if s.is_filter and isinstance(s.module, cnn.Conv2d) and s.param.dim() == 4
-                      and any(s.name.startswith(p + '.') for p in self.prefixes)]
-        self.mod_ids = set(id(s.module) for s in self.slots)
-        self.ranges = []                    # merged [start, end) float ranges of the arena that are deferred
-        for s in sorted(self.slots, key=lambda s: s.offset):
-            end = s.offset + _round_up(s.numel, _ALIGN)
-            if self.ranges and self.ranges[-1][1] == s.offset:
-                self.ranges[-1][1] = end
-            else:
-                self.ranges.append([s.offset, end])
-        self.ranges = [tuple(r) for r in self.ranges]
-        self.pending = []                   # parked launches of the backward pass just run: (module, launch)
-        self.apply = None                   # optimizer update of `ranges` for that backward pass (set with `queue`)
-        self.state = 'idle'
-        self.active = False
-        self.flushes = 0                    # (tests: how many steps really deferred)
-
-    def owns(self, mod):
-        return self.active and id(mod) in self.mod_ids
-
-    def park(self, mod, launch):
-        self.pending.append((mod, launch))
-
-    def complement(self):
-        """The arena ranges that are NOT deferred."""
-        out, pos = [], 0
-        for a, b in self.ranges:
-            if a > pos:
-                out.append((pos, a))
-            pos = b
-        if pos < self.arena.total:
-            out.append((pos, self.arena.total))
-        return out
-
-    def queue(self, apply):
-        """End of a deferring step: `apply()` is the optimizer update of the deferred ranges for this step."""
-        self.apply = apply
-        self.state = 'queued'
-
-    def flush(self):
-        """Queue the parked weight gradients, their update and the refresh of their compute-dtype copies on the side
-        stream (the current stream when there is none).  No-op unless a deferring step is waiting."""
-        if self.state != 'queued':
-            return
-        dev = self.arena.device
-        pending, self.pending = self.pending, []
-        apply, self.apply = self.apply, None
-        side_on = dev.type == 'cuda' and ops.SIDE.active(self.arena.params)
-        if side_on:
-            cur = torch.cuda.current_stream(dev)
-            side = ops.SIDE.get(dev)
-            ops.SIDE.fork(cur, side)         # the operands were produced on this stream (the backward chain)
-            ctx = torch.cuda.stream(side)
-        else:
-            import contextlib
-            ctx = contextlib.nullcontext()
-        with ctx:
-            held = []
-            for mod, launch in pending:
-                held.append(launch())
-                mod._notify_grad_ready()
-            apply()
-            self.arena.prepare_weights(part='deferred')
-        if side_on:
-            ops.SIDE._held.extend(held)
-            ops.SIDE.used = True
-            self.state = 'inflight'
-        else:
-            self.state = 'idle'
-        self.flushes += 1
-
-    def gate(self):
-        """The current stream waits for everything `flush` queued: call before anything reads the deferred filters."""
-        if self.state == 'queued':
-            self.flush()
-        if self.state == 'inflight':
-            dev = self.arena.device
-            ops.SIDE.fork(ops.SIDE.get(dev), torch.cuda.current_stream(dev))
-            self.state = 'idle'
-
-
 class ParamArena(object):
     def __init__(self, model, device, bucket_mb=25.0):
         from . import nn as cnn
@@ -205,30 +102,6 @@ class ParamArena(object):
         self._wbytes = 0
         self._wtotal = 0
         self._wversion = -1
-        self._wtiles_split = None    # (tiles of the non-deferred filters, tiles of the deferred ones): set_deferred
-        self.defer = None            # DeferredWgrad, when the Trainer asked for it (flag wgrad_defer)
-
-    def set_deferred(self, prefixes):
-        """Enable cross-step deferral of the weight gradients of the convolutions under the named sub-modules
-        (DeferredWgrad); [] switches it off.  Returns the DeferredWgrad or None."""
-        if self.defer is not None:
-            self.defer.gate()
-        d = DeferredWgrad(self, prefixes) if prefixes else None
-        if d is not None and not d.slots:
-            d = None
-        self.defer = d
-        self._split_tiles()
-        return d
-
-    def _split_tiles(self):
-        self._wtiles_split = None
-        if self.defer is None or self._wtiles is None or self._wdesc_reg is None:
-            return
-        offs = set(s.offset for s in self.defer.slots)
-        rows = self._wdesc_reg.tolist()
-        t = self._wtiles
-        is_def = torch.tensor([rows[di][0] in offs for di in t[:, 0].tolist()], dtype=torch.bool, device=t.device)
-        self._wtiles_split = (t[~is_def].contiguous(), t[is_def].contiguous())
 
     # -- compute-dtype filter copies ------------------------------------------------------
     def build_weight_plan(self, dtype):
@@ -283,39 +156,19 @@ class ParamArena(object):
         for mod, krsc_off, crsk_off, n in mods:
             mod.w_krsc = self.wbuf[krsc_off:krsc_off + n]
             mod.w_crsk = self.wbuf[crsk_off:crsk_off + n] if crsk_off >= 0 else None
-        self._split_tiles()
 
-    def prepare_weights(self, part=None):
-        """Refresh the compute-dtype filter copies when the masters moved.  With deferred weight gradients
-        (DeferredWgrad) the filters whose update is still on its way are left out here (`part` None while a deferred
-        update is queued / in flight) and refreshed by DeferredWgrad.flush behind that update (`part` = 'deferred')."""
-        from . import _lib
-        d = self.defer
-        if part == 'deferred':
-            tiles = self._wtiles_split[1] if self._wtiles_split is not None else None
-            if tiles is None or tiles.shape[0] == 0:
-                return
-            L = _lib.load()
-            code, st = _lib.dtype_code(self.wbuf.dtype), _lib.stream_of(self.params)
-            ops.PROFILER.run('weight_prep', 1, 0.0, 0.0,
-                             lambda: _lib.check(L.cn_weight_prep_tiled(self.params.data_ptr(), self.wbuf.data_ptr(),
-                                                                       self._wdesc_reg.data_ptr(), tiles.data_ptr(),
-                                                                       tiles.shape[0], code, st), 'cn_weight_prep_tiled'),
-                             self.device)
-            return
+    def prepare_weights(self):
         if self._wversion == self.version or (self._wdesc is None and self._wdesc_reg is None):
             return
+        from . import _lib
         L = _lib.load()
         code, st = _lib.dtype_code(self.wbuf.dtype), _lib.stream_of(self.params)
-        wtiles = self._wtiles
-        if d is not None and d.state != 'idle' and self._wtiles_split is not None:
-            wtiles = self._wtiles_split[0]      # the deferred filters follow behind their own update
 
         def run():
-            if self._wdesc_reg is not None and wtiles.shape[0] > 0:
+            if self._wdesc_reg is not None:
                 _lib.check(L.cn_weight_prep_tiled(self.params.data_ptr(), self.wbuf.data_ptr(),
-                                                  self._wdesc_reg.data_ptr(), wtiles.data_ptr(),
-                                                  wtiles.shape[0], code, st), 'cn_weight_prep_tiled')
+                                                  self._wdesc_reg.data_ptr(), self._wtiles.data_ptr(),
+                                                  self._wtiles.shape[0], code, st), 'cn_weight_prep_tiled')
             if self._wdesc is not None:
                 _lib.check(L.cn_weight_prep_multi(self.params.data_ptr(), self.wbuf.data_ptr(),
                                                   self._wdesc.data_ptr(), self._wdesc.shape[0], self._wtotal, code,
@@ -325,13 +178,6 @@ class ParamArena(object):
 
     # -- gradient lifecycle ---------------------------------------------------------------
     def zero_grad(self):
-        d = self.defer
-        if d is not None and d.active:
-            # the deferred ranges are overwritten (beta = 0) by their own weight gradients, and the previous step's may
-            # still be on their way to the optimizer on the side stream: this stream must not touch them
-            for a, b in d.complement():
-                ops.fill_f32_(self.grads[a:b], 0.0)
-            return
         ops.fill_f32_(self.grads, 0.0)
 
     def bump_version(self):

@@ -43,7 +43,6 @@ _DEFAULTS = {
     # ---- schedule
     'wgrad_stream': 1,         # weight gradients on a side stream beside the backward chain
     'side_hold': 1,            # side-stream operands held until the step's join instead of Tensor.record_stream (allocator events)
-    'wgrad_defer': '',         # sub-modules ('layer3+layer4') whose weight gradients run beside the NEXT step's forward pass (engine.DeferredWgrad)
     'dgrad_first': 1,          # a convolution's backward launches its data gradient before the side-stream hand-off of the weight gradient
     'marks': 1,                # the side stream waits for the producing kernel's completion mark, not a queued event
     'main_stream_prio': '-1',  # the step loop's own high-priority stream ('off': the default stream)

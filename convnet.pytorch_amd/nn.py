@@ -92,9 +92,6 @@ class Conv2d(_ArenaModule):
         """Compute-dtype filter copies (KRSC + CRSK) are refreshed for the whole model in one launch
         whenever the fp32 masters changed (engine.ParamArena.prepare_weights)."""
         self._require_prepared()
-        d = self._arena.defer
-        if d is not None and d.state != 'idle' and id(self) in d.mod_ids:
-            d.gate()      # this filter's update for the previous step is still on the side stream (engine.DeferredWgrad)
         self._arena.prepare_weights()
 
     def forward(self, x):

@@ -829,11 +829,6 @@ class Conv2dFunction(Function):
         lazy = getattr(mod, '_lazy_dy', None)     # (g, bn_y, coef): the BatchNorm behind this conv left dy unformed
         mod._lazy_dy = None
         R, S = mod.kernel_size
-        # engine.DeferredWgrad: this filter's gradient range is not zeroed by the step (its previous update may still be on
-        # the side stream) - the weight gradient OVERWRITES it (beta = 0), and on the plain path its launch is parked
-        dfr = mod._arena.defer if getattr(mod, '_arena', None) is not None else None
-        deferred = dfr is not None and dfr.owns(mod)
-        beta = 0.0 if deferred else 1.0
         if lazy is None and _is_zero_placeholder(dy):
             raise _lib.ConvNetHipError('lazy dy: the gradient placeholder reached a convolution with an empty mailbox '
                                        '(the BatchNorm that parked the gradient is not this convolution\'s consumer)')
@@ -849,7 +844,7 @@ class Conv2dFunction(Function):
                 holder = getattr(mod, '_res_holder', None)
                 if holder is not None and holder.dres is not None:
                     raise _lib.ConvNetHipError('lazy dy met a fused-addend dgrad: the junction layout changed')
-                dx = conv2d_bwd1x1_lazy(x, g, bn_y, coef, mod.w_crsk, mod.grad_view('weight'), mod.out_channels, beta=beta)
+                dx = conv2d_bwd1x1_lazy(x, g, bn_y, coef, mod.w_crsk, mod.grad_view('weight'), mod.out_channels)
                 mod._notify_grad_ready()
                 COUNTERS['jpair'] = COUNTERS.get('jpair', 0) + 1
                 if holder is not None:
@@ -858,12 +853,12 @@ class Conv2dFunction(Function):
             if SIDE.active(x):
                 def launch():
                     conv2d_wgrad_lazy(x, g, bn_y, coef, mod.grad_view('weight'), mod.in_channels, mod.out_channels, R, S,
-                                      mod.stride, mod.padding, beta=beta, tag='side')
+                                      mod.stride, mod.padding, tag='side')
                     return (x, g, bn_y, coef)
                 SIDE.submit(x.device, launch, mod._notify_grad_ready, coef)
             else:
                 conv2d_wgrad_lazy(x, g, bn_y, coef, mod.grad_view('weight'), mod.in_channels, mod.out_channels, R, S,
-                                  mod.stride, mod.padding, beta=beta)
+                                  mod.stride, mod.padding)
                 mod._notify_grad_ready()
             if not ctx.needs_input_grad[0]:
                 return None, None, None, None
@@ -887,14 +882,7 @@ class Conv2dFunction(Function):
         if ctx.has_bias:
             colsum(dy.view(-1, mod.out_channels), mod.grad_view('bias'))
         def submit_wgrad():
-            if deferred:
-                # parked: queued on the side stream when the NEXT step begins, beside its forward pass (DeferredWgrad.flush)
-                def launch():
-                    conv2d_wgrad(x, dy, mod.grad_view('weight'), mod.in_channels, mod.out_channels, R, S, mod.stride,
-                                 mod.padding, beta=0.0, tag='side')
-                    return (x, dy)
-                dfr.park(mod, launch)
-            elif SIDE.active(x):
+            if SIDE.active(x):
                 def launch():
                     conv2d_wgrad(x, dy, mod.grad_view('weight'), mod.in_channels, mod.out_channels, R, S, mod.stride,
                                  mod.padding, tag='side')

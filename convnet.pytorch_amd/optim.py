@@ -20,28 +20,6 @@ from . import _lib, engine, ops
 from ._lib import check, ptr, stream_of
 
 
-def _intersect_runs(runs, ranges):
-    """(start, end, wd) runs clipped to the [start, end) `ranges`."""
-    out = []
-    for a, b, wd in runs:
-        for c, d in ranges:
-            lo, hi = max(a, c), min(b, d)
-            if lo < hi:
-                out.append((lo, hi, wd))
-    return out
-
-
-def _complement(ranges, total):
-    out, pos = [], 0
-    for a, b in sorted(ranges):
-        if a > pos:
-            out.append((pos, a))
-        pos = max(pos, b)
-    if pos < total:
-        out.append((pos, total))
-    return out
-
-
 def eval_func(f, x):
     if isinstance(f, str):
         f = eval(f)  # regime lambdas are strings in the reference (models/resnet.py:70-72)
@@ -201,52 +179,23 @@ class OptimRegime(Regime):
         pass
 
     def step(self, *args, **kwargs):
-        """One SGD + momentum update of the flat arena.  `exclude` / `only` (keyword, lists of [start, end) arena ranges)
-        restrict it to the complement of / to those ranges: engine.DeferredWgrad updates the filters whose weight
-        gradients were deferred in a second call (`deferred_step`) behind those gradients."""
         self._bind()
         if self._runs is None:
             self._build_runs()
+        L = _lib.load()
         a = self.arena
         lr, mu = float(self.hyper['lr']), float(self.hyper['momentum'])
         self.push_hyper()
-        runs = self._runs
-        if kwargs.get('only') is not None:
-            runs = _intersect_runs(runs, kwargs['only'])
-        elif kwargs.get('exclude'):
-            runs = _intersect_runs(runs, _complement(kwargs['exclude'], a.total))
-        self._launch_runs(runs, lr, mu, float(self.grad_scale), self.clip_coef, self.hyper_dev)
-        a.bump_version()
-
-    def _launch_runs(self, runs, lr, mu, grad_scale, clip_coef, hyper_dev):
-        L = _lib.load()
-        a = self.arena
-        for start, end, wd in runs:
+        for start, end, wd in self._runs:
             n = end - start
             ops.PROFILER.run('sgd_momentum', 1, 0.0, 20.0 * n,
                              lambda: check(L.cn_sgd_momentum(ptr(a.params[start:]), ptr(a.grads[start:]),
                                                              ptr(self.momentum_buf[start:]), n, lr, mu, float(wd),
-                                                             grad_scale, ptr(clip_coef),
-                                                             ptr(hyper_dev), stream_of(a.params)),
+                                                             float(self.grad_scale), ptr(self.clip_coef),
+                                                             ptr(self.hyper_dev), stream_of(a.params)),
                                                'cn_sgd_momentum'),
                              a.device)
-
-    def deferred_step(self, ranges):
-        """The update of `ranges` for THIS step as a closure that can run later, on another stream: learning rate,
-        momentum and gradient scale are taken now, by value (the schedule may have moved - and the device copy the
-        main update reads been rewritten - by the time it runs)."""
-        self._bind()
-        if self._runs is None:
-            self._build_runs()
-        runs = _intersect_runs(self._runs, ranges)
-        lr, mu, gs = float(self.hyper['lr']), float(self.hyper['momentum']), float(self.grad_scale)
-        if self.clip_coef is not None:
-            raise _lib.ConvNetHipError('a deferred update cannot follow the global gradient norm of its own step')
-
-        def apply():
-            self._launch_runs(runs, lr, mu, gs, None, None)
-            self.arena.bump_version()
-        return apply
+        a.bump_version()
 
     def push_hyper(self):
         """Device copy of (lr, momentum) for the SGD kernel; one tiny H2D copy whenever the schedule moves."""

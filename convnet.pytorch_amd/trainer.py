@@ -200,9 +200,6 @@ class Trainer(object):
         self.loss_scale = loss_scale
         self.watcher = None
         self.arena = engine.prepare(model, self.device, dtype, bucket_mb=bucket_mb)
-        # weight gradients of the late stages leave their step and run beside the NEXT forward pass (engine.DeferredWgrad;
-        # flag wgrad_defer = sub-module names joined with '+', '' = off)
-        self.arena.set_deferred([n for n in flags.text('wgrad_defer').split('+') if n])
         self.reducer = None
         self._main_stream = None   # high-priority HIP stream of the step loop (created lazily on a GPU)
         # flag graph: 'auto' (default) captures only when the eager step is host-bound, 1 = always, 0 = never
@@ -274,17 +271,6 @@ class Trainer(object):
         total_loss = None
         grad = None
 
-        dfr = self.arena.defer
-        if dfr is not None:
-            # the previous step's parked weight gradients, their update and weight refresh go to the side stream now, beside
-            # this step's forward pass; a step that does not defer itself first waits for them (stream order)
-            dfr.flush()
-            dfr.active = (training and chunk_batch == 1 and not (self.grad_clip > 0) and self.reducer is None
-                          and (self.device.type == 'cuda' or _lib.is_emulated()) and not ops.SIDE.capturing and ops.SIDE.enabled
-                          and torch.is_grad_enabled())
-            if not dfr.active:
-                dfr.gate()
-
         if training:
             self.optimizer.zero_grad()
             if self.reducer is not None:
@@ -337,11 +323,7 @@ class Trainer(object):
                 clip_coef = self._norm_out[1:2]
             self.optimizer.grad_scale = gscale
             self.optimizer.clip_coef = clip_coef
-            if dfr is not None and dfr.active and dfr.pending:
-                self.optimizer.step(exclude=dfr.ranges)
-                dfr.queue(self.optimizer.deferred_step(dfr.ranges))
-            else:
-                self.optimizer.step()
+            self.optimizer.step()
             self.training_steps += 1
 
         outputs = outputs[0] if len(outputs) == 1 else torch.cat(outputs, dim=0)
@@ -593,14 +575,10 @@ class Trainer(object):
 
                 if num_steps is not None and i >= num_steps:
                     break
-            if self.arena.defer is not None:
-                self.arena.defer.gate()      # the last step's deferred weight gradients and their update: queued and waited for
             sync_meters(None)
         finally:
             if device_meters:
                 self.criterion.meters = None
-            if self.arena.defer is not None:
-                self.arena.defer.active = False
         return meter_results(meters)
 
     def train(self, data_loader, average_output=False, chunk_batch=1):
