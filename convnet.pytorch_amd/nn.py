@@ -209,6 +209,11 @@ class BatchNorm2d(_ArenaModule):
         and the shortcut BatchNorm as `residual_bn`, applies both in its one apply pass.  Ignored in eval mode."""
         self._require_prepared()
         if self.training or not self.track_running_stats:
+            if self.training and y.dim() == 4 and y.shape[0] * y.shape[1] * y.shape[2] <= 1:
+                # torch.nn.functional.batch_norm's check (the reference stops here too: a batch of one image on a 1 x 1 map
+                # has no variance); the size is printed the way the reference sees the tensor, NCHW
+                raise ValueError('Expected more than 1 value per channel when training, got input size {}'.format(
+                    torch.Size([y.shape[0], y.shape[3], y.shape[1], y.shape[2]])))
             if torch.is_grad_enabled():
                 return ops.BatchNormActFunction.apply(y, self.weight, self.bias, residual, self, relu, defer_apply,
                                                       residual_bn)

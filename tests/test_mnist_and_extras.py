@@ -212,3 +212,24 @@ def test_reference_optimizer_state_resumes_with_its_momentum(device):
             assert torch.equal(mine[n].float().cpu(), ref_state['state'][i]['momentum_buffer']), n
     with pytest.raises(ca._lib.ConvNetHipError):
         opt.load_state_dict({'something': 'else'})
+
+
+def test_batch_of_one_on_a_1x1_map_raises_like_the_reference(device):
+    """Error behaviour at the operator seam (seam 2): torch's BatchNorm2d - the class the reference model
+    instantiates, models/resnet.py:128 - refuses to train on one value per channel; so does ours, with the same
+    exception type and message (it used to run on and train on zeros)."""
+    import torch.nn.functional as F
+    import convnet_amd as ca
+    with pytest.raises(ValueError) as ref:
+        F.batch_norm(torch.randn(1, 64, 1, 1), torch.zeros(64), torch.ones(64), training=True)
+    kw = dict(depth=18, num_classes=10, inplanes=8, width=(8, 16, 32, 64))
+    torch.manual_seed(123)
+    model = ca.models.resnet(**kw)
+    tr = ca.Trainer(model, ca.CrossEntropyLoss(), ca.OptimRegime(model, model.regime), device=str(device),
+                    dtype=torch.float32, print_freq=10 ** 9)
+    with pytest.raises(ValueError) as ours:
+        tr.train([(torch.randn(1, 3, 32, 32), torch.tensor([3]))])
+    assert str(ours.value) == str(ref.value)
+    # ... and evaluates such a batch fine, like the reference (running statistics)
+    r = tr.validate([(torch.randn(1, 3, 32, 32), torch.tensor([3]))])
+    assert r['loss'] == r['loss']
