@@ -77,9 +77,6 @@ _SIGNATURES = {
     'cn_conv2d_dgrad_lazy_stream_ok': (c_i, [c_i, c_i, c_i]),
     'cn_conv2d_dgrad_lazy_stream': (c_i, [c_p] * 5 + [c_i] * 6 + [c_p]),
     'cn_conv1x1_stream_fwd_lazya': (c_i, [c_p, c_p, c_i, c_p, c_p, c_p] + [c_i] * 6 + [c_p, c_i, c_p]),
-    'cn_conv3x3_img_ok': (c_i, [c_i] * 5),
-    'cn_conv3x3_img_rows': (c_i, [c_i, c_i, c_i]),
-    'cn_conv3x3_img': (c_i, [c_p, c_p, c_p] + [c_i] * 6 + [c_p, c_i, c_p]),
     'cn_conv3x3_c64_lazya': (c_i, [c_p, c_p, c_i, c_p, c_p, c_p] + [c_i] * 4 + [c_p, c_i, c_p]),
     'cn_conv2d_dgrad_junction_rows_k': (c_i, [c_i] * 5),
     'cn_bn_workspace': (c_sz, [c_i, c_i, c_i]),

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void weight_prep_multi_kernel(const float* mas
 // copy (transposed: rows (c*taps + t), co contiguous) are written with coalesced stores.  The
 // per-element kernel above spends a descriptor binary search and a scattered 2-byte store per
 // weight (0.33 ms per ResNet-50 step, profiles/r01_*kernel_stats*); this one streams.
-//   tiles: int[ntiles][4] = {descriptor index, co0, j0, 1 when the descriptor's d[1] / d[7] name slab copies (below) else 0}
+//   tiles: int[ntiles][4] = {descriptor index, co0, j0, 0}
 template <typename T>
 __global__ __launch_bounds__(256) void weight_prep_tiled_kernel(const float* master, T* wbuf, const long long* desc,
                                                                const int* tiles) {
@@ -149,39 +149,6 @@ __global__ __launch_bounds__(256) void weight_prep_tiled_kernel(const float* mas
       if (j < J && co < Co) {
         const int t = j / C, c = j - t * C;
         cn_store_elem<T>(crsk + ((size_t)c * taps + t) * Co + co, tile[lane64][jj]);
-      }
-    }
-  }
-  // Slab copies for the image-resident 3x3 kernels (conv3x3_img.hip; 16-bit, Co == C, C % 64 == 0, nine taps): the filter in
-  // k-step order, [tap][k block of 16][32-row tile][lane = k half * 32 + row][8].  d[1]: forward (rows = output channels,
-  // k = input channels), d[7]: data gradient (rows = input channels, k = output channels); < 0: none.  A 64-wide block of
-  // j lies inside one tap; consecutive threads write consecutive rows = consecutive 16-byte pieces.
-  if constexpr (sizeof(T) == 2) {
-    if (tl[3] != 0 && taps == 9 && Co == C && (C & 63) == 0) {
-      const int t = j0 / C, c0 = j0 - t * C, NKB = C >> 4, NT = C >> 5;
-      if (d[1] >= 0) {
-        T* slab = wbuf + d[1];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int ch = grp + 4 * i, co = co0 + lane64, c = c0 + ch * 8;
-          float f[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) f[e] = tile[lane64][ch * 8 + e];
-          const size_t idx = ((size_t)(t * NKB + (c >> 4)) * NT + (co >> 5)) * 512 + (size_t)((((c >> 3) & 1) * 32 + (co & 31)) * 8);
-          *(u32x4*)(slab + idx) = Chunk<T>::pack(f);
-        }
-      }
-      if (d[7] >= 0) {
-        T* slab = wbuf + d[7];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int chq = grp + 4 * i, c = c0 + lane64, co = co0 + chq * 8;
-          float f[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) f[e] = tile[chq * 8 + e][lane64];
-          const size_t idx = ((size_t)(t * NKB + (co >> 4)) * NT + (c >> 5)) * 512 + (size_t)((((co >> 3) & 1) * 32 + (c & 31)) * 8);
-          *(u32x4*)(slab + idx) = Chunk<T>::pack(f);
-        }
       }
     }
   }

@@ -16,7 +16,7 @@ MI355X-first re-design of what the reference gets from ``model.to(device, dtype)
 import torch
 import torch.distributed as dist
 
-from . import flags, ops
+from . import ops
 
 _ALIGN = 64  # floats; keeps every parameter segment 256-byte aligned
 
@@ -128,29 +128,14 @@ class ParamArena(object):
             if want_crsk:
                 crsk_off = off
                 off += _round_up(n, _ALIGN)
-            # image-resident 3x3 kernels (csrc/conv3x3_img.hip): two more copies of the filter in k-step order (forward /
-            # data gradient), written by the same tiled launch
-            slab_f = slab_b = -1
-            if (flags.on('conv3x3_img') and dtype != torch.float32 and isinstance(mod, cnn.Conv2d) and taps == 9
-                    and co == creal and co in (128, 256, 512) and mod.stride == (1, 1) and mod.padding == (1, 1)):
-                slab_f = off
-                off += _round_up(n, _ALIGN)
-                if want_crsk:
-                    slab_b = off
-                    off += _round_up(n, _ALIGN)
             rows.append([s.offset, start, krsc_off, crsk_off, co, taps, creal, cpad])
             start += n
-            mods.append((mod, krsc_off, crsk_off, n, slab_f, slab_b))
+            mods.append((mod, krsc_off, crsk_off, n))
         self.wbuf = torch.zeros(max(off, _ALIGN), dtype=dtype, device=self.device)
         # regular filters (no channel padding) go through the tiled, coalescing kernel; the few padded
         # ones (the 3 -> 8 channel stem) through the per-element kernel
-        slabs = {r[2]: (m[4], m[5]) for r, m in zip(rows, mods)}
-        self._wbytes = sum(r[4] * r[5] * (r[6] * 4 + r[7] * self.wbuf.element_size() * (2 if r[3] >= 0 else 1))
-                           for r in rows)
-        regular = [list(r) for r in rows if r[6] == r[7]]
+        regular = [r for r in rows if r[6] == r[7]]
         ragged = [list(r) for r in rows if r[6] != r[7]]
-        for r in regular:            # (entries 1 and 7 are free in the tiled kernel's rows: the slab copies' offsets)
-            r[1], r[7] = slabs[r[2]]
         start = 0
         for r in ragged:
             r[1] = start
@@ -163,14 +148,14 @@ class ParamArena(object):
             co, J = r[4], r[5] * r[6]
             for co0 in range(0, co, 64):
                 for j0 in range(0, J, 64):
-                    tiles.append((di, co0, j0, 1 if (r[1] >= 0 or r[7] >= 0) else 0))
+                    tiles.append((di, co0, j0, 0))
         self._wtiles = torch.tensor(tiles, dtype=torch.int32, device=self.device) if tiles else None
+        self._wbytes = sum(r[4] * r[5] * (r[6] * 4 + r[7] * self.wbuf.element_size() * (2 if r[3] >= 0 else 1))
+                           for r in rows)
         self._wversion = -1
-        for mod, krsc_off, crsk_off, n, slab_f, slab_b in mods:
+        for mod, krsc_off, crsk_off, n in mods:
             mod.w_krsc = self.wbuf[krsc_off:krsc_off + n]
             mod.w_crsk = self.wbuf[crsk_off:crsk_off + n] if crsk_off >= 0 else None
-            mod.w_slab = self.wbuf[slab_f:slab_f + n] if slab_f >= 0 else None
-            mod.w_slab_t = self.wbuf[slab_b:slab_b + n] if slab_b >= 0 else None
 
     def prepare_weights(self):
         if self._wversion == self.version or (self._wdesc is None and self._wdesc_reg is None):

@@ -40,7 +40,6 @@ _DEFAULTS = {
     'centered_stats': '1',     # statistics centred on the running mean: 0 never, 1 fp32 models, all every dtype
     # ---- kernel families (0 = the tiled implicit-GEMM kernel serves the layer)
     'stem_pairs': 1, 'stem_halo': 1, 'conv3x3_halo': 1, 'conv1x1_stream': 1,
-    'conv3x3_img': 1,          # image-resident kernel for the 128 / 256 / 512-channel stride-1 3x3 convolutions (csrc/conv3x3_img.hip)
     # ---- schedule
     'wgrad_stream': 1,         # weight gradients on a side stream beside the backward chain
     'side_hold': 1,            # side-stream operands held until the step's join instead of Tensor.record_stream (allocator events)

@@ -82,8 +82,6 @@ class Conv2d(_ArenaModule):
             self.register_parameter('bias', None)
         self.w_krsc = None      # compute-dtype filter copies: views into ParamArena.wbuf
         self.w_crsk = None
-        self.w_slab = None      # k-step-ordered copies for the image-resident 3x3 kernels (forward / data gradient)
-        self.w_slab_t = None
         self.needs_dgrad = True
 
     def padded_in_channels(self):

@@ -256,9 +256,6 @@ STEM_HALO = flags.on('stem_halo')
 # 0 = the 64 -> 64 channel 3x3 convolutions run through the tiled implicit-GEMM kernel instead of the halo kernel
 # (csrc/conv3x3.hip)
 CONV3X3_HALO = flags.on('conv3x3_halo')
-# 0 = the 128 / 256 / 512-channel stride-1 3x3 convolutions run through the tiled implicit-GEMM kernels instead of the
-# image-resident kernel (csrc/conv3x3_img.hip)
-CONV3X3_IMG = flags.on('conv3x3_img')
 # 0 = conv3 / the stride-1 projection forward through the tiled kernel instead of the streaming kernel
 CONV1X1_STREAM = flags.on('conv1x1_stream')
 # 0 = the stem's bn1 -> relu -> maxpool runs as separate BatchNorm and max-pool passes
@@ -348,30 +345,10 @@ def _halo3x3_ok(x, C, K, R, S, stride, pad):
             and _L().cn_conv3x3_c64_ok(x.shape[1], x.shape[2], C, K, dtype_code(x.dtype)))
 
 
-def _img3x3_ok(x, slab, C, K, R, S, stride, pad):
-    """The image-resident 3x3 kernel (csrc/conv3x3_img.hip) serves this call: a slab copy of the filter exists (built for
-    C = K = 128 / 256 / 512 stride-1 3x3 layers, 16-bit) and the map is the one the instantiation was built for."""
-    return (CONV3X3_IMG and slab is not None and (R, S) == (3, 3) and tuple(stride) == (1, 1) and tuple(pad) == (1, 1)
-            and bool(_L().cn_conv3x3_img_ok(x.shape[1], x.shape[2], C, K, dtype_code(x.dtype))))
-
-
-def conv2d_fwd(x, w_krsc, bias, K, R, S, stride, pad, out_f32=False, relu=False, bn_stats=False, pivot=None, w_slab=None):
+def conv2d_fwd(x, w_krsc, bias, K, R, S, stride, pad, out_f32=False, relu=False, bn_stats=False, pivot=None):
     N, H, W, C = x.shape
     P, Q = conv_out_hw(H, W, R, S, stride, pad)
     y = torch.empty((N, P, Q, K), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
-    if bias is None and not out_f32 and not relu and pivot is None and _img3x3_ok(x, w_slab, C, K, R, S, stride, pad):
-        L = _L()
-        want = bn_stats
-        rows = L.cn_conv3x3_img_rows(N, H, C) if want else 0
-        partial = torch.empty((rows, 2 * K), dtype=torch.float32, device=x.device) if want else None
-        PROFILER.run(_last_kernel(), 1, 2.0 * N * P * Q * K * C * R * S,
-                     x.numel() * _esize(x) + y.numel() * _esize(y) + K * R * S * C * _esize(x),
-                     lambda: check(L.cn_conv3x3_img(ptr(x), ptr(w_slab), ptr(y), N, H, W, C, dtype_code(x.dtype), 0,
-                                                    ptr(partial), rows, stream_of(x)), 'cn_conv3x3_img'),
-                     x.device, detail=_conv_detail('fwd', C, H, K, R, stride))
-        if want:
-            _park_stats(y, partial, rows, None)
-        return y
     if CONV1X1_STREAM and bias is None and not out_f32 and not relu and pivot is None and (R, S) == (1, 1) \
             and tuple(stride) == (1, 1) and tuple(pad) == (0, 0) \
             and _L().cn_conv1x1_stream_fwd_ok(C, K, dtype_code(x.dtype)):
@@ -519,7 +496,7 @@ def lazy_z_consumer_ok(conv):
             and not getattr(conv, 'out_f32', False))
 
 
-def conv2d_dgrad(dy, w_crsk, x_shape, K, R, S, stride, pad, addend=None, bn=None, addend_sub=1, w_slab_t=None):
+def conv2d_dgrad(dy, w_crsk, x_shape, K, R, S, stride, pad, addend=None, bn=None, addend_sub=1):
     """dx (NHWC).  With bn = (bn_y, bn_mask_or_None, bn_stats[4C], relu) the epilogue also does the
     reduction half of that BatchNorm's backward: returns (g = dx*relu_mask, partial, rows).
     addend_sub = 2: `addend` holds only the even (h, w) pixels of a gradient that is zero elsewhere."""
@@ -532,12 +509,6 @@ def conv2d_dgrad(dy, w_crsk, x_shape, K, R, S, stride, pad, addend=None, bn=None
         + (addend.numel() * _esize(addend) if addend is not None else 0)
     if addend is not None and addend_sub == 2:
         assert tuple(addend.shape) == (N, (H + 1) // 2, (W + 1) // 2, C), 'subsampled addend shape'
-    if bn is None and addend is None and tuple(dy.shape[1:3]) == (H, W) and _img3x3_ok(dy, w_slab_t, K, C, R, S, stride, pad):
-        PROFILER.run(name, 1, flops, nbytes,
-                     lambda: check(_L().cn_conv3x3_img(ptr(dy), ptr(w_slab_t), ptr(dx), N, H, W, C, dtype_code(dy.dtype), 1,
-                                                       None, 0, stream_of(dy)), 'cn_conv3x3_img'),
-                     dy.device, detail=detail)
-        return dx
     if bn is None and addend is None and _halo3x3_ok(dy, K, C, R, S, stride, pad) and tuple(dy.shape[1:3]) == (H, W):
         PROFILER.run(name, 1, flops, nbytes,
                      lambda: check(_L().cn_conv3x3_c64(ptr(dy), ptr(w_crsk), ptr(dx), N, H, W, dtype_code(dy.dtype), 1, None,
@@ -842,7 +813,7 @@ class Conv2dFunction(Function):
             y = conv2d_fwd(x, mod.w_krsc, bias, mod.out_channels, mod.kernel_size[0], mod.kernel_size[1],
                            mod.stride, mod.padding, out_f32=mod.out_f32,
                            bn_stats=FUSE_BN_STATS and mod.training and getattr(mod, 'feeds_batchnorm', False),
-                           pivot=stats_pivot(mod), w_slab=getattr(mod, 'w_slab', None))
+                           pivot=stats_pivot(mod))
         ctx.mod = mod
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x)
@@ -956,7 +927,7 @@ class Conv2dFunction(Function):
                     bn_mod._bwd_partials = (dx.data_ptr(), tuple(dx.shape), partial, rows)
                 else:
                     dx = conv2d_dgrad(dy, mod.w_crsk, x.shape, mod.out_channels, R, S, mod.stride, mod.padding,
-                                      addend=addend, addend_sub=addend_sub, w_slab_t=getattr(mod, 'w_slab_t', None))
+                                      addend=addend, addend_sub=addend_sub)
                 if holder is not None and addend is None:
                     holder.dres, holder.sub = dx, 1   # first producer of the fork gradient: park it for the other
                     holder.fused = False

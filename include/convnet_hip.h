@@ -103,18 +103,6 @@ int cn_conv3x3_c64_ok(int H, int W, int C, int K, int dtype);
 int cn_conv3x3_c64_rows(int N, int H);
 int cn_conv3x3_c64(const void* x, const void* w, void* y, int N, int H, int W, int dtype, int flip, float* partial,
                    int partial_rows, void* stream);
-/* 3x3 / stride-1 / pad-1 convolution with C -> C channels, C = 128 on 28-wide, 256 on 14-wide, 512 on 7-wide maps (conv2 of
- * the second / third / fourth stage, /root/reference models/resnet.py:126-132) as an image-resident kernel
- * (csrc/conv3x3_img.hip): a workgroup keeps a band of whole image rows in LDS and owns all their pixels, a wave streams the
- * filter slice of its own output channels through a wave-private LDS ring - no workgroup barrier in the main loop.  w_slab:
- * the filter in k-step order (the slab copies cn_weight_prep_tiled writes: [tap][C/16][C/32][64][8]; forward: of the KRSC
- * filter, flip = 1 / data gradient: of the CRSK filter, x = dy, taps mirrored).  partial (optional, forward):
- * cn_conv3x3_img_rows(N, H, C) rows of 2*C floats [sum | sum of squares] for cn_bn_fwd_train_partials.  Same output bits
- * as cn_conv2d_fwd / cn_conv2d_dgrad. */
-int cn_conv3x3_img_ok(int H, int W, int C, int K, int dtype);
-int cn_conv3x3_img_rows(int N, int H, int C);
-int cn_conv3x3_img(const void* x, const void* w_slab, void* y, int N, int H, int W, int C, int dtype, int flip,
-                   float* partial, int partial_rows, void* stream);
 /* "Lazy a" for the 3x3 halo kernel (forward): the input is the INPUT bn_y of the BatchNorm in front of the convolution;
  * a = relu?(bn_y * scale + shift) is formed on the way into the halo (zero padding pads a) and written to a_out.  Replaces
  * the bn1 -> relu -> conv2 sequence of /root/reference models/resnet.py:122-128 in the first stage. */
@@ -381,10 +369,8 @@ int cn_weight_prep(const float* w_master_krsc, void* w_krsc, void* w_crsk /*opti
 int cn_weight_prep_multi(const float* master_arena, void* wbuf, const long long* desc, int nd, long long total,
                          int dtype, void* stream);
 /* Same conversion for the descriptors with Cpad == Creal, one workgroup per 64x64 tile of a filter
- * matrix (coalesced KRSC and CRSK stores).  tiles: int[ntiles][4] = {descriptor row, co0, j0, slabs},
- * j = tap*C + c.  slabs != 0 (16-bit, nine taps, Co == C, C % 64 == 0): the descriptor's entries 1 and 7 are the element
- * offsets (or < 0) of the k-step-ordered copies cn_conv3x3_img reads - forward (of the KRSC filter) and data gradient (of
- * the CRSK filter): [tap][C/16][C/32][lane = k half * 32 + row][8]. */
+ * matrix (coalesced KRSC and CRSK stores).  tiles: int[ntiles][4] = {descriptor row, co0, j0, 0},
+ * j = tap*C + c. */
 int cn_weight_prep_tiled(const float* master, void* wbuf, const long long* desc, const int* tiles, int ntiles,
                          int dtype, void* stream);
 size_t cn_colsum_workspace(int C);
