@@ -23,4 +23,6 @@ STATS=$(find $OUT/prof -name "*kernel_stats.csv" | head -1)
 [ -n "$STATS" ] && cp "$STATS" $OUT/kernel_stats.csv && head -30 $OUT/kernel_stats.csv | cut -c1-170
 python tools/trace_by_grid.py $(find $OUT/prof -name "*kernel_trace.csv" | head -1) > $OUT/kernel_trace_by_grid.txt 2>&1
 find $OUT/prof -name "*kernel_trace.csv" -size +20M -delete
+echo "== MFMA utilisation from SQ counters"; timeout 900 python tools/pmc_mfma_step.py $OUT 2>&1 | tail -32
+rm -rf $OUT/sqstep
 echo "== done"; date
