@@ -139,3 +139,57 @@ def test_auto_mode_withdraws_an_eager_verdict_when_the_step_slows_down(tmp_path)
     env = dict(os.environ, CONVNET_AMD_EMULATE='0')
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and 'WATCH_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+TWO_KEYS_WORKER = r'''
+import sys, torch
+sys.path.insert(0, %(root)r)
+import convnet_amd as ca
+torch.cuda.set_device(0)
+kw = dict(depth=50, width=(16, 32, 64, 128), inplanes=16, num_classes=32)
+g = torch.Generator().manual_seed(9)
+big = [(torch.randn(16, 3, 64, 64, generator=g).cuda(), torch.randint(0, 32, (16,), generator=g).cuda()) for _ in range(4)]
+small = [(torch.randn(8, 3, 64, 64, generator=g).cuda(), torch.randint(0, 32, (8,), generator=g).cuda()) for _ in range(4)]
+torch.manual_seed(123)
+model = ca.models.resnet(**kw)
+tr = ca.Trainer(model, ca.CrossEntropyLoss(), ca.OptimRegime(model, model.regime), device='cuda:0', dtype=torch.bfloat16,
+                print_freq=10**9)
+tr._graph_mode, tr._use_graph = 'auto', True
+# two configurations, each with an 'eager' verdict under watch against a reference no step can exceed (1e9 ms)
+keys = []
+for b in (big[0], small[0]):
+    tr.train([b])
+    (k,) = [k for k in tr._gstates if k not in keys]
+    keys.append(k)
+    tr._gstates[k] = {'seen': {'n': 4, 'use': False, 'eager_ms': 1e9}, 'graph': None}
+    tr._graph_eager_for.add(k)
+    tr._watch[k] = ca.trainer.EagerWatch(1e9)
+wa, wb = tr._watch[keys[0]], tr._watch[keys[1]]
+# strictly alternating configurations: every period lies between marks of DIFFERENT watches -> nobody collects one
+for i in range(12):
+    tr.train([big[i %% 4] if i %% 2 == 0 else small[i %% 4]])
+torch.cuda.synchronize()
+tr.train([big[0]]); tr.train([small[0]])          # (polls what completed)
+assert wa.periods == [] and wb.periods == [], (wa.periods, wb.periods)
+# runs of one configuration: its watch collects periods (len - 1 per run of consecutive steps), the other stays empty
+tr.train(big * 2)
+torch.cuda.synchronize()
+tr.train([big[0]])
+assert len(wa.periods) >= 6 and wb.periods == [], (len(wa.periods), wb.periods)
+assert all(0.0 < p < 1e4 for p in wa.periods), wa.periods
+n_a = len(wa.periods)
+c = ca.trainer.EagerWatch(1e9)                     # a third watch resets nobody
+assert len(wa.periods) == n_a
+print('TWO_KEYS_OK', n_a)
+'''
+
+
+def test_step_periods_are_attributed_to_the_configuration_they_belong_to(tmp_path):
+    """ADVICE r4: the library's ring of timing marks is shared by every EagerWatch of the process.  Marks carry the watch's
+    tag; a period whose two marks belong to different configurations (an odd-shaped last batch between full ones) is
+    nobody's, a new watch discards nothing."""
+    script = tmp_path / 'two_keys_worker.py'
+    script.write_text(TWO_KEYS_WORKER % {'root': ROOT})
+    env = dict(os.environ, CONVNET_AMD_EMULATE='0')
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and 'TWO_KEYS_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
