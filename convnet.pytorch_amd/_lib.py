@@ -79,8 +79,6 @@ _SIGNATURES = {
     'cn_conv1x1_stream_fwd_lazya': (c_i, [c_p, c_p, c_i, c_p, c_p, c_p] + [c_i] * 6 + [c_p, c_i, c_p]),
     'cn_conv3x3_c64_lazya': (c_i, [c_p, c_p, c_i, c_p, c_p, c_p] + [c_i] * 4 + [c_p, c_i, c_p]),
     'cn_conv2d_dgrad_junction_rows_k': (c_i, [c_i] * 5),
-    'cn_conv2d_dgrad_junction_lazy_ok': (c_i, [c_i, c_i, c_i]),
-    'cn_conv2d_dgrad_junction_lazy': (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_i] + [c_i] * 6 + [c_p, c_p, c_p, c_p, c_i, c_p]),
     'cn_bn_workspace': (c_sz, [c_i, c_i, c_i]),
     'cn_bn_fwd_train': (c_i, [c_p] * 9 + [c_f, c_f, c_p, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
     'cn_bn_fwd_train_partials': (c_i, [c_p] * 9 + [c_f, c_f, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_sz, c_p]),
@@ -88,7 +86,6 @@ _SIGNATURES = {
     'cn_bn_fwd_infer': (c_i, [c_p] * 7 + [c_f, c_p, c_i, c_i, c_i, c_i, c_p]),
     'cn_bn_apply_dual': (c_i, [c_p] * 6 + [c_i, c_i, c_i, c_i, c_p]),
     'cn_bn_bwd': (c_i, [c_p] * 9 + [c_f, c_f, c_p, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
-    'cn_bn_bwd_apply': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     'cn_bn_bwd_partials': (c_i, [c_p] * 7 + [c_f, c_f, c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_sz, c_p]),
     'cn_bn_local_sums': (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_sz, c_p]),
     'cn_bn_fwd_train_sums': (c_i, [c_p] * 9 + [c_f, c_f, c_p, c_i, c_i, c_i, c_i, c_p, c_ll, c_p]),

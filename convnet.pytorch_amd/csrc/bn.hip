@@ -918,10 +918,9 @@ extern "C" int cn_bn_bwd(const void* dz, const void* y, const unsigned char* rel
   CnMarkLast last;   // an armed completion mark goes on the apply kernel only
   BN_DISPATCH_PLAIN(bn_bwd_reduce_kernel, dtype, grid, stream, (const char*)dz, (const char*)y, relu_mask, mean, invstd, scale, shift, partial, M, C, relu, m.tpr_log2, rev_r);
   if (dy == nullptr) {
-    // "lazy dy": reduce + finalize only, the consumers form c1*dz + c2*y + c3 themselves.  No residual-branch copy can be
-    // wanted.  With a ReLU behind this BatchNorm (relu != 0, mask recomputed from y: the inner BatchNorms) the consumer
-    // masks dz itself from y, scale and shift (cn_conv2d_dgrad_junction_lazy); with ReLU bits it cannot.
-    if (dres != nullptr || (relu != 0 && relu_mask != nullptr)) { cn_set_error("bn_bwd: dy = NULL needs no dres and no ReLU bits"); return CN_EINVAL; }
+    // "lazy dy": reduce + finalize only, the consumers form c1*dz + c2*y + c3 themselves.  Only where dz needs no mask
+    // (no ReLU behind this BatchNorm) and no residual-branch copy is wanted.
+    if (relu != 0 || dres != nullptr) { cn_set_error("bn_bwd: dy = NULL needs relu = 0 and no dres"); return CN_EINVAL; }
     last.release();
   }
   CN_LAUNCH(bn_bwd_finalize_kernel, dim3((unsigned)((C + BN_FC - 1) / BN_FC)), dim3(256), stream, (const float*)partial,
@@ -932,25 +931,6 @@ extern "C" int cn_bn_bwd(const void* dz, const void* y, const unsigned char* rel
   last.release();
   BN_DISPATCH(bn_bwd_apply_kernel, dtype, bn_nt_flag(M, C, dtype), agrid, stream, (const char*)dz, (const char*)y, relu_mask, scale, shift, (const float*)coef_scratch, (char*)dy, (char*)dres, M, C, relu, m.tpr_log2, rev_a);
   return cn_check_launch("bn_bwd");
-}
-
-// The apply pass of cn_bn_bwd alone: dy = c1*(dz masked) + c2*y + c3 from the coefficients a cn_bn_bwd(dy = NULL) call left
-// in coef (the fallback of the "lazy dy" forms: a consumer that turns out not to be able to form dy itself).
-extern "C" int cn_bn_bwd_apply(const void* dz, const void* y, const float* stats, const float* coef, void* dy, int M, int C,
-                               int relu, int dtype, void* stream_) {
-  int rc = bn_check("bn_bwd_apply", M, C, dtype);
-  if (rc) return rc;
-  if (dz == nullptr || y == nullptr || stats == nullptr || coef == nullptr || dy == nullptr) { cn_set_error("bn_bwd_apply: null operand"); return CN_EINVAL; }
-  hipStream_t stream = (hipStream_t)stream_;
-  const int CH = cn_dtype_chunk(dtype);
-  BnMap m = bn_map(C / CH);
-  const float* scale = stats + 2 * C;
-  const float* shift = stats + 3 * C;
-  int nab = bn_row_blocks(M, m, cn_get_option("bn_apply_blocks", BN_APPLY_BLOCKS));
-  dim3 agrid((unsigned)nab, (unsigned)m.gy);
-  const int rev_a = ((cn_get_option("bn_reverse", BN_REVERSE_DEFAULT) >> 2) & 1);
-  BN_DISPATCH(bn_bwd_apply_kernel, dtype, bn_nt_flag(M, C, dtype), agrid, stream, (const char*)dz, (const char*)y, (const unsigned char*)nullptr, scale, shift, coef, (char*)dy, (char*)nullptr, M, C, relu, m.tpr_log2, rev_a);
-  return cn_check_launch("bn_bwd_apply");
 }
 
 // Training backward when the producer of the upstream gradient already masked it and reduced it

@@ -41,20 +41,11 @@ struct JdParams {
   int addend_sub, H, W, add_H, add_W;
   FastDiv div_hw, div_w;
   unsigned int dy_bytes, out_bytes, add_bytes, mask_bytes;
-  // LZ ("lazy dy" of the INNER BatchNorm in front of conv1's output, round 5): `dy` is that BatchNorm's upstream gradient
-  // dz, lz_y its input, lz_coef = [c1 | c2 | c3 | scale | shift] (5 * KD floats: the backward finalize's coefficients and
-  // the forward's scale / shift for the ReLU mask); the kernel forms  dy = c1 * (dz masked) + c2 * y + c3  on the way to its
-  // LDS tile (bn_bwd_apply_kernel's arithmetic and rounding) and writes it to dy_out for the weight gradient
-  const char* lz_y;
-  const float* lz_coef;    // [c1 | c2 | c3] (3 * KD)
-  const float* lz_stats;   // that BatchNorm's [mean | invstd | scale | shift] (4 * KD)
-  char* dy_out;
-  int lz_relu;
 };
 
 // The epilogue operands of stage s + 1 are requested before stage s is processed (72 registers).  A workgroup computes
 // the CO channels from blockIdx.y * CO on of p.co_total.
-template <typename T, int KD, int CO, bool LZ = false>
+template <typename T, int KD, int CO>
 __global__ __launch_bounds__(512) void jdgrad_kernel(JdParams p) {
   static_assert(sizeof(T) == 2, "16-bit storage");
   constexpr int NCW = CO / 64;          // wave columns of 64 channels
@@ -105,25 +96,13 @@ __global__ __launch_bounds__(512) void jdgrad_kernel(JdParams p) {
     unsigned int bits[4];
   };
   u32x4 dreg[ND];
-  u32x4 yreg[LZ ? ND : 1];
-  const cn_buf_t lybuf = cn_make_buf(LZ ? p.lz_y : p.dy, p.dy_bytes);
-  // LZ: the thread's chunk column of the dy tile is fixed (512 % NCD == 0); its 5 x 8 coefficients sit in an LDS table
-  // (in registers they push the 128-channel forms over the 256-VGPR budget)
-  __shared__ float s_lz[LZ ? 5 * KD : 1];
-  if constexpr (LZ) {
-    static_assert(512 % NCD == 0, "a thread keeps one chunk column");
-    for (int c = tid; c < 5 * KD; c += 512) s_lz[c] = c < 3 * KD ? p.lz_coef[c] : p.lz_stats[c - KD];   // scale | shift sit at 2 KD .. 4 KD of stats
-    __syncthreads();
-  }
   auto load_dy = [&](int mb) {
 #pragma unroll
     for (int i = 0; i < ND; ++i) {
       const int id = tid + 512 * i;
       const int row = id / NCD, c = id - row * NCD;
       const int m = mb + row;
-      const unsigned int o = m < m_end ? ((unsigned int)m * (unsigned int)KD + (unsigned int)c * 8u) * 2u : CN_OOB;
-      dreg[i] = cn_buf_ld16(dybuf, o);
-      if constexpr (LZ) yreg[i] = cn_buf_ld16(lybuf, o);
+      dreg[i] = cn_buf_ld16(dybuf, m < m_end ? ((unsigned int)m * (unsigned int)KD + (unsigned int)c * 8u) * 2u : CN_OOB);
     }
   };
   auto load_epi = [&](int mb, Epi& e) {
@@ -148,28 +127,13 @@ __global__ __launch_bounds__(512) void jdgrad_kernel(JdParams p) {
       e.bits[k] = ok ? (unsigned int)p.bn_mask[(size_t)m * (COT / 8) + (cb >> 3)] : 0u;
     }
   };
-  auto store_dy = [&](int mb, int buf) {
+  auto store_dy = [&](int buf) {
     char* t = lds + buf * DYB;
 #pragma unroll
     for (int i = 0; i < ND; ++i) {
       const int id = tid + 512 * i;
       const int row = id / NCD, c = id - row * NCD;
       const int cs = NCD == 8 ? (c ^ ((row >> 1) & 7)) : (c ^ (row & (NCD - 1)));
-      if constexpr (LZ) {   // dy = c1 * (dz where relu(bn(y)) > 0) + c2 * y + c3: bn_bwd_apply_kernel's operations and rounding
-        const float* cf = s_lz + (tid % NCD) * 8;
-        float gg[8], vv[8];
-        Chunk<T>::unpack(dreg[i], gg);
-        Chunk<T>::unpack(yreg[i], vv);
-        if (p.lz_relu) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) gg[e] = fmaf(vv[e], cf[3 * KD + e], cf[4 * KD + e]) > 0.f ? gg[e] : 0.f;
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) gg[e] = fmaf(cf[e], gg[e], fmaf(cf[KD + e], vv[e], cf[2 * KD + e]));
-        dreg[i] = Chunk<T>::pack(gg);
-        const int m = mb + row;
-        if (m < m_end && blockIdx.y == 0) cn_st16(p.dy_out + ((size_t)m * KD + (size_t)c * 8) * 2, dreg[i]);
-      }
       cn_st16(t + row * (KD * 2) + (cs << 4), dreg[i]);
     }
   };
@@ -241,7 +205,7 @@ __global__ __launch_bounds__(512) void jdgrad_kernel(JdParams p) {
     load_epi(m_begin, cur);
     int buf = 0;
     for (int mb = m_begin; mb < m_end; mb += BM) {
-      store_dy(mb, buf);
+      store_dy(buf);
       __syncthreads();    // (two dy tiles: the tile of stage s + 1 is written while stage s is still being read: one barrier per stage)
       const bool more = mb + BM < m_end;
       if (more) { load_dy(mb + BM); load_epi(mb + BM, nxt); }
@@ -508,13 +472,11 @@ extern "C" int cn_conv2d_dgrad_junction_rows_k(int N, int H, int W, int C, int K
 // ReLU bits given (bn_mask) and an addend (dense, or addend_sub = 2: the even pixels of a stride-2 projection's
 // gradient), as one persistent streaming kernel (see the head of this file).  partial: cn_conv2d_dgrad_junction_rows
 // rows of 2*C floats for cn_bn_bwd_partials.  g: the bits of cn_conv2d_dgrad_bnbwd_sa.
-static int jd_impl(const void* dy, const void* w_crsk, void* g, const void* addend, int addend_sub,
-                   int N, int H, int W, int C, int K, int dtype, const void* bn_y,
-                   const unsigned char* bn_mask, const float* bn_coef, float* partial,
-                   int partial_rows, void* stream, const void* lz_y, const float* lz_coef, const float* lz_stats, int lz_relu,
-                   void* dy_out) {
-  const bool lz = lz_y != nullptr;
-  if (!cn_conv2d_dgrad_junction_ok(C, K, dtype) || (lz && K >= 256)) { cn_set_error("conv2d_dgrad_junction: K=%d -> C=%d dtype %d%s is not an instantiated shape", K, C, dtype, lz ? " (lazy dy)" : ""); return CN_ESHAPE; }
+extern "C" int cn_conv2d_dgrad_junction(const void* dy, const void* w_crsk, void* g, const void* addend, int addend_sub,
+                                        int N, int H, int W, int C, int K, int dtype, const void* bn_y,
+                                        const unsigned char* bn_mask, const float* bn_coef, float* partial,
+                                        int partial_rows, void* stream) {
+  if (!cn_conv2d_dgrad_junction_ok(C, K, dtype)) { cn_set_error("conv2d_dgrad_junction: K=%d -> C=%d dtype %d is not an instantiated shape", K, C, dtype); return CN_ESHAPE; }
   if (dy == nullptr || w_crsk == nullptr || g == nullptr || addend == nullptr || bn_y == nullptr || bn_mask == nullptr ||
       bn_coef == nullptr || partial == nullptr) { cn_set_error("conv2d_dgrad_junction: null operand"); return CN_EINVAL; }
   if (addend_sub != 1 && addend_sub != 2) { cn_set_error("conv2d_dgrad_junction: addend subsampling %d (1 or 2)", addend_sub); return CN_EINVAL; }
@@ -538,7 +500,6 @@ static int jd_impl(const void* dy, const void* w_crsk, void* g, const void* adde
   p.addend_sub = addend_sub; p.H = H; p.W = W; p.add_H = aH; p.add_W = aW;
   p.div_hw = cn_make_fastdiv((unsigned)(H * W)); p.div_w = cn_make_fastdiv((unsigned)W);
   p.dy_bytes = (unsigned int)db; p.out_bytes = (unsigned int)ob; p.add_bytes = (unsigned int)ab;
-  p.lz_y = (const char*)lz_y; p.lz_coef = lz_coef; p.lz_stats = lz_stats; p.dy_out = (char*)dy_out; p.lz_relu = lz_relu;
   hipStream_t st = (hipStream_t)stream;
   const char* tn = dtype == CN_F16 ? "f16_t" : "bf16_t";
   if (w32) {
@@ -548,49 +509,18 @@ static int jd_impl(const void* dy, const void* w_crsk, void* g, const void* adde
     else CN_LAUNCH((jdgrad_w32_kernel<bf16_t, 256>), g32, dim3(512), st, p);
     return cn_check_launch("jdgrad_w32");
   }
-  cn_set_last_kernel("jdgrad_kernel<%s, %d, %d%s>", tn, K, C, lz ? ", true" : "");
+  cn_set_last_kernel("jdgrad_kernel<%s, %d, %d>", tn, K, C);
   dim3 grid((unsigned)nsplit, (unsigned)(C > 512 ? C / 512 : 1));
-#define JD_GO(KD, CO)                                                                                  \
-  do {                                                                                                 \
-    if (lz) {                                                                                          \
-      if (dtype == CN_F16) CN_LAUNCH((jdgrad_kernel<f16_t, KD, CO, true>), grid, dim3(512), st, p);    \
-      else CN_LAUNCH((jdgrad_kernel<bf16_t, KD, CO, true>), grid, dim3(512), st, p);                   \
-    } else {                                                                                           \
-      if (dtype == CN_F16) CN_LAUNCH((jdgrad_kernel<f16_t, KD, CO>), grid, dim3(512), st, p);          \
-      else CN_LAUNCH((jdgrad_kernel<bf16_t, KD, CO>), grid, dim3(512), st, p);                         \
-    }                                                                                                  \
+#define JD_GO(KD, CO)                                                                           \
+  do {                                                                                          \
+    if (dtype == CN_F16) CN_LAUNCH((jdgrad_kernel<f16_t, KD, CO>), grid, dim3(512), st, p);      \
+    else CN_LAUNCH((jdgrad_kernel<bf16_t, KD, CO>), grid, dim3(512), st, p);                     \
   } while (0)
   if (C == 256 && K == 64) JD_GO(64, 256);
   else if (C == 256 && K == 128) JD_GO(128, 256);
   else JD_GO(128, 512);
 #undef JD_GO
   return cn_check_launch("jdgrad");
-}
-extern "C" int cn_conv2d_dgrad_junction(const void* dy, const void* w_crsk, void* g, const void* addend, int addend_sub,
-                                        int N, int H, int W, int C, int K, int dtype, const void* bn_y,
-                                        const unsigned char* bn_mask, const float* bn_coef, float* partial,
-                                        int partial_rows, void* stream) {
-  return jd_impl(dy, w_crsk, g, addend, addend_sub, N, H, W, C, K, dtype, bn_y, bn_mask, bn_coef, partial, partial_rows,
-                 stream, nullptr, nullptr, nullptr, 0, nullptr);
-}
-// The K <= 128 forms also take conv1's upstream gradient UNFORMED ("lazy dy" of the inner BatchNorm behind conv1, round 5):
-// dz = that BatchNorm's upstream gradient, lz_y its input, lz_coef = [c1 | c2 | c3] (3 * K floats: what cn_bn_bwd leaves in
-// coef_scratch when called with dy = NULL), lz_stats = that BatchNorm's [mean | invstd | scale | shift], lz_relu = the
-// BatchNorm is followed by a ReLU.  The kernel forms dy = c1 * (dz masked) + c2 * y + c3 on the way to its LDS tile
-// (bn_bwd_apply_kernel's arithmetic: the same bits) and writes it to dy_out [M][K] for the weight gradient: the
-// BatchNorm's apply pass (read dz, read y, write dy) and this kernel's read of dy become one read of dz and y and one
-// write of dy.  Replaces the bn1 backward + conv1 backward pair of /root/reference models/resnet.py:141-147 run in reverse.
-extern "C" int cn_conv2d_dgrad_junction_lazy_ok(int C, int K, int dtype) {
-  return cn_conv2d_dgrad_junction_ok(C, K, dtype) && K < 256 ? 1 : 0;
-}
-extern "C" int cn_conv2d_dgrad_junction_lazy(const void* dz, const void* lz_y, const float* lz_coef, const float* lz_stats,
-                                             int lz_relu, void* dy_out,
-                                             const void* w_crsk, void* g, const void* addend, int addend_sub, int N, int H,
-                                             int W, int C, int K, int dtype, const void* bn_y, const unsigned char* bn_mask,
-                                             const float* bn_coef, float* partial, int partial_rows, void* stream) {
-  if (lz_y == nullptr || lz_coef == nullptr || lz_stats == nullptr || dy_out == nullptr) { cn_set_error("conv2d_dgrad_junction_lazy: null operand"); return CN_EINVAL; }
-  return jd_impl(dz, w_crsk, g, addend, addend_sub, N, H, W, C, K, dtype, bn_y, bn_mask, bn_coef, partial, partial_rows,
-                 stream, lz_y, lz_coef, lz_stats, lz_relu, dy_out);
 }
 
 // ------------------------------------------------------------------------------------------------

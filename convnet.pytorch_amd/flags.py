@@ -41,8 +41,6 @@ _DEFAULTS = {
     # ---- kernel families (0 = the tiled implicit-GEMM kernel serves the layer)
     'stem_pairs': 1, 'stem_halo': 1, 'conv3x3_halo': 1, 'conv1x1_stream': 1,
     # ---- schedule
-    'lazy_dy1': 1,             # bn1's backward apply formed by conv1's streaming junction kernel (dy written as a side output)
-    'lazy_dy1_min_mb': 32.0,   # ... for bn1 inputs of at least this many MB
     'wgrad_stream': 1,         # weight gradients on a side stream beside the backward chain
     'side_hold': 1,            # side-stream operands held until the step's join instead of Tensor.record_stream (allocator events)
     'dgrad_first': 1,          # a convolution's backward launches its data gradient before the side-stream hand-off of the weight gradient

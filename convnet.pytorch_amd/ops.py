@@ -272,12 +272,6 @@ FUSE_BN_BWD = flags.on('fuse_bn_bwd')
 # (flags.LAZY_MIN_BYTES: 0.6 of the Infinity Cache; the smaller maps keep the LDS-DMA weight-gradient kernels).
 LAZY_DY = flags.on('lazy_dy')
 LAZY_DY_MIN_MB = float(flags.get('lazy_min_mb'))
-# "Lazy dy1" (round 5): the INNER BatchNorm behind conv1 (bn1, followed by a ReLU) runs reduce + finalize only; conv1's
-# data gradient - the streaming junction kernel - forms dy1 = c1*(dz masked) + c2*y + c3 on the way to its LDS tile and
-# writes it for conv1's weight gradient (cn_conv2d_dgrad_junction_lazy): the apply pass (read dz, read y, write dy) and the
-# junction kernel's read of dy become one read of dz and y and one write of dy.  Bit-identical.
-LAZY_DY1 = flags.on('lazy_dy1')
-LAZY_DY1_MIN_MB = float(flags.get('lazy_dy1_min_mb'))
 # Junction behind a projection shortcut (round 3): the shortcut BatchNorm only finalises its statistics; its apply runs
 # inside the junction BatchNorm's apply pass (cn_bn_apply_dual), so the normalised shortcut tensor is neither written nor
 # re-read.  Bit-identical.
@@ -826,7 +820,6 @@ class Conv2dFunction(Function):
         # the lazy-dy mailbox is matched against THIS output in backward; an entry left by an aborted backward dies here
         ctx.out_ptr, ctx.out_shape = y.data_ptr(), tuple(y.shape)
         mod._lazy_dy = None
-        mod._lazy_dy1 = None
         return y
 
     @staticmethod
@@ -835,15 +828,7 @@ class Conv2dFunction(Function):
         mod = ctx.mod
         lazy = getattr(mod, '_lazy_dy', None)     # (g, bn_y, coef): the BatchNorm behind this conv left dy unformed
         mod._lazy_dy = None
-        lz1 = getattr(mod, '_lazy_dy1', None)     # (dz, y, coef, stats, relu): the INNER BatchNorm behind conv1 did (lazy dy1)
-        mod._lazy_dy1 = None
         R, S = mod.kernel_size
-        dx_lz1 = None
-        if lz1 is not None:
-            if lz1[1].data_ptr() != ctx.out_ptr or tuple(lz1[1].shape) != ctx.out_shape or lazy is not None:
-                raise _lib.ConvNetHipError('lazy dy1: the parked gradient does not belong to this convolution\'s output')
-            # the junction kernel forms dy (and the data gradient) now, or the apply pass alone does: dy exists from here on
-            dx_lz1, dy = _conv1_backward_lazy1(ctx, x, mod, lz1)
         if lazy is None and _is_zero_placeholder(dy):
             raise _lib.ConvNetHipError('lazy dy: the gradient placeholder reached a convolution with an empty mailbox '
                                        '(the BatchNorm that parked the gradient is not this convolution\'s consumer)')
@@ -910,8 +895,6 @@ class Conv2dFunction(Function):
 
         def dgrad_part():
             dx = None
-            if dx_lz1 is not None:      # (lazy dy1: the junction kernel already produced it, addend and reduction included)
-                return dx_lz1, None, None, None
             if ctx.needs_input_grad[0]:
                 addend, addend_sub = None, 1
                 holder = getattr(mod, '_res_holder', None)
@@ -961,50 +944,6 @@ class Conv2dFunction(Function):
         if DGRAD_FIRST:
             submit_wgrad()
         return out
-
-
-def _conv1_backward_lazy1(ctx, x, mod, lz1):
-    """Backward of a block's conv1 (1x1 / stride 1) whose upstream gradient was left unformed by bn1 (lazy dy1): the data
-    gradient runs as the streaming junction kernel in its lazy form, which also writes dy1; the weight gradient follows on the
-    side stream.  When the junction kernel cannot serve the call after all (no addend parked, no junction state, a shape it
-    was not built for) dy1 is formed by the apply pass alone and the ordinary path continues - same bits either way."""
-    dz, y1, coef, stats, relu = lz1
-    R, S = mod.kernel_size
-    L = _L()
-    N, H, W, C = x.shape
-    K = mod.out_channels
-    holder = getattr(mod, '_res_holder', None)
-    addend, addend_sub = None, 1
-    if ctx.needs_input_grad[0] and holder is not None and holder.dres is not None and holder.dres.dtype == dz.dtype \
-            and (holder.dres.shape == x.shape if holder.sub == 1 else
-                 tuple(holder.dres.shape) == (N, (H + 1) // 2, (W + 1) // 2, C)):
-        addend, addend_sub = holder.dres, holder.sub
-    bn_args = _input_bn_state(mod, x) if (addend is not None and FUSE_BN_BWD) else None
-    use = (bn_args is not None and bn_args[2] is not None and JDGRAD and not ctx.has_bias
-           and bool(L.cn_conv2d_dgrad_junction_lazy_ok(C, K, dtype_code(dz.dtype))))
-    if not use:
-        COUNTERS['lazy_dy1_fallback'] = COUNTERS.get('lazy_dy1_fallback', 0) + 1
-        return None, bn_bwd_apply(dz, y1, stats, coef, relu)
-    bn_mod, bn_y, bn_mask, bn_stats, bn_relu = bn_args
-    holder.fused = True
-    dx = torch.empty((N, H, W, C), dtype=dz.dtype, device=dz.device)
-    dy = torch.empty_like(y1)
-    rows = L.cn_conv2d_dgrad_junction_rows_k(N, H, W, C, K)
-    partial = torch.empty((rows, 2 * C), dtype=torch.float32, device=dz.device)
-    nbytes = 2 * dz.numel() * _esize(dz) + dy.numel() * _esize(dy) + 3 * dx.numel() * _esize(dx) + K * C * _esize(dz) \
-        + partial.numel() * 4
-    with SIDE.mark(dy):
-        PROFILER.run(_last_kernel(' [lazy dy1]'), 1, 2.0 * dz.numel() * C, nbytes,
-                     lambda: check(L.cn_conv2d_dgrad_junction_lazy(ptr(dz), ptr(y1), ptr(coef), ptr(stats), int(relu), ptr(dy),
-                                                                   ptr(mod.w_crsk), ptr(dx), ptr(addend), int(addend_sub), N, H,
-                                                                   W, C, K, dtype_code(dz.dtype), ptr(bn_y), ptr(bn_mask),
-                                                                   ptr(bn_stats), ptr(partial), rows, stream_of(dz)),
-                                   'cn_conv2d_dgrad_junction_lazy'),
-                     dz.device, detail=_conv_detail('dgrad', C, H, K, R, mod.stride))
-    COUNTERS['jdgrad'] = COUNTERS.get('jdgrad', 0) + 1
-    COUNTERS['jdgrad_lazy1'] = COUNTERS.get('jdgrad_lazy1', 0) + 1
-    bn_mod._bwd_partials = (dx.data_ptr(), tuple(dx.shape), partial, rows)
-    return dx, dy
 
 
 def _sync_group(mod):
@@ -1122,32 +1061,6 @@ def _lazy_dy_ok(bn_mod, y):
     if y.shape[-1] > 512 or y.dtype not in (torch.bfloat16, torch.float16, torch.float32):
         return False
     return y.numel() * _esize(y) >= LAZY_DY_MIN_MB * 2 ** 20
-
-
-def _lazy_dy1_ok(bn_mod, y):
-    """This inner BatchNorm (ReLU behind it, no residual) feeds conv1's backward of a block whose data gradient can run as
-    the streaming junction kernel in its lazy form: leave the apply pass to that kernel."""
-    conv = getattr(bn_mod, 'producer_conv', None)
-    if not (LAZY_DY1 and JDGRAD and FUSE_BN_BWD) or conv is None or not getattr(conv, 'junction_conv1', False):
-        return False
-    if getattr(conv, 'kernel_size', None) != (1, 1) or getattr(conv, 'stride', None) != (1, 1) \
-            or getattr(conv, 'padding', None) != (0, 0) or getattr(conv, 'bias', None) is not None:
-        return False
-    if y.dtype not in (torch.bfloat16, torch.float16) or y.shape[-1] != conv.out_channels:
-        return False
-    if not _L().cn_conv2d_dgrad_junction_lazy_ok(conv.in_channels, conv.out_channels, dtype_code(y.dtype)):
-        return False
-    return y.numel() * _esize(y) >= LAZY_DY1_MIN_MB * 2 ** 20
-
-
-def bn_bwd_apply(dz, y, stats, coef, relu):
-    """The apply pass alone (cn_bn_bwd_apply): dy from the coefficients of a finalize-only BatchNorm backward."""
-    N, H, W, C = y.shape
-    dy = torch.empty_like(y)
-    PROFILER.run('bn_bwd_apply', 1, 0.0, 3 * y.numel() * _esize(y),
-                 lambda: check(_L().cn_bn_bwd_apply(ptr(dz), ptr(y), ptr(stats), ptr(coef), ptr(dy), N * H * W, C, int(relu),
-                                                    dtype_code(y.dtype), stream_of(y)), 'cn_bn_bwd_apply'), y.device)
-    return dy
 
 
 class BatchNormActFunction(Function):
@@ -1344,19 +1257,6 @@ class BatchNormActFunction(Function):
                                                        ws.numel() * 4, stream_of(y)), 'cn_bn_bwd'),
                              y.device)
             mod.producer_conv._lazy_dy = (dz, y, coef)
-            dy = _zero_like_placeholder(y)
-        elif ctx.relu and not ctx.has_res and zmask is None and _lazy_dy1_ok(mod, y):
-            # bn1 of a block: reduce + finalize; conv1's junction kernel forms dy (with the ReLU mask) on its operand path
-            COUNTERS['bn_bwd_plain'] += 1
-            COUNTERS['bn_bwd_lazy1'] = COUNTERS.get('bn_bwd_lazy1', 0) + 1
-            dres = None
-            PROFILER.run('bn_bwd_reduce+bn_bwd_finalize (lazy dy1)', 2, 0.0, nb * 2,
-                         lambda: check(L.cn_bn_bwd(ptr(dz), ptr(y), None, ptr(mod.weight), ptr(stats), None,
-                                                   None, ptr(mod.grad_view('weight')), ptr(mod.grad_view('bias')),
-                                                   1.0, 1.0, ptr(coef), M, C, 1, code, ptr(ws),
-                                                   ws.numel() * 4, stream_of(y)), 'cn_bn_bwd'),
-                         y.device)
-            mod.producer_conv._lazy_dy1 = (dz, y, coef, stats, True)
             dy = _zero_like_placeholder(y)
         else:
             COUNTERS['bn_bwd_plain'] += 1

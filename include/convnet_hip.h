@@ -189,19 +189,6 @@ int cn_conv2d_dgrad_junction_rows_k(int N, int H, int W, int C, int K);   /* ...
 int cn_conv2d_dgrad_junction(const void* dy, const void* w_crsk, void* g, const void* addend, int addend_sub, int N, int H,
                              int W, int C, int K, int dtype, const void* bn_y, const unsigned char* bn_mask,
                              const float* bn_coef, float* partial, int partial_rows, void* stream);
-/* The K <= 128 forms with conv1's upstream gradient UNFORMED ("lazy dy" of the inner BatchNorm behind conv1's output): dz =
- * that BatchNorm's upstream gradient, lz_y its input, lz_coef = [c1 | c2 | c3] (3*K floats: what cn_bn_bwd leaves in
- * coef_scratch when called with dy = NULL), lz_stats = its [mean | invstd | scale | shift], lz_relu = a ReLU follows the
- * BatchNorm.  dy = c1 * (dz where relu(bn(y)) > 0) + c2 * y + c3 is formed on the way to the kernel's LDS tile (the bits of
- * cn_bn_bwd's apply pass) and written to dy_out [N*H*W][K] for the weight gradient: that apply pass and this kernel's read of
- * dy become one read of dz and y and one write of dy.  Replaces the bn1 -> conv1 backward pair of /root/reference
- * models/resnet.py:141-147 (run in reverse by loss.backward(), trainer.py:162). */
-int cn_conv2d_dgrad_junction_lazy_ok(int C, int K, int dtype);
-int cn_conv2d_dgrad_junction_lazy(const void* dz, const void* lz_y, const float* lz_coef, const float* lz_stats, int lz_relu,
-                                  void* dy_out,
-                                  const void* w_crsk, void* g, const void* addend, int addend_sub, int N, int H, int W, int C,
-                                  int K, int dtype, const void* bn_y, const unsigned char* bn_mask, const float* bn_coef,
-                                  float* partial, int partial_rows, void* stream);
 /* dw[K,R,S,C_real] (fp32) = beta*dw + scale * sum_pixels dy (x) x ; split reduction through
  * `workspace` (cn_conv2d_wgrad_workspace bytes), fixed summation order. */
 size_t cn_conv2d_wgrad_workspace(int N, int H, int W, int C, int K, int R, int S, int stride_h, int stride_w,
@@ -274,18 +261,11 @@ int cn_bn_fwd_infer(const void* y, const void* residual, void* z, const float* g
 int cn_bn_apply_dual(const void* y, const void* res_y, void* z, unsigned char* relu_mask, const float* stats,
                      const float* res_stats, int M, int C, int relu, int dtype, void* stream);
 /* relu_mask: the byte mask of cn_bn_fwd_train (needed when a residual was added), NULL => ReLU mask
- * recomputed from y.  dres (optional) receives the masked upstream gradient for the residual branch.  dy = NULL ("lazy dy"):
- * reduce + finalize only - coef_scratch = [c1 | c2 | c3] for consumers that form dy = c1 * (dz masked) + c2 * y + c3
- * themselves (no dres, no ReLU bits). */
+ * recomputed from y.  dres (optional) receives the masked upstream gradient for the residual branch. */
 int cn_bn_bwd(const void* dz, const void* y, const unsigned char* relu_mask, const float* gamma, const float* stats,
               void* dy, void* dres, float* dgamma, float* dbeta, float beta_acc, float gscale,
               float* coef_scratch /*3C*/, int M, int C, int relu, int dtype, void* workspace,
               size_t ws_bytes, void* stream);
-
-/* the apply pass of cn_bn_bwd alone, from the coefficients a cn_bn_bwd(dy = NULL) call left in coef: the fallback of the
- * "lazy dy" forms (a consumer that cannot form dy itself after all) */
-int cn_bn_bwd_apply(const void* dz, const void* y, const float* stats, const float* coef, void* dy, int M, int C, int relu,
-                    int dtype, void* stream);
 
 /* cn_bn_bwd when the upstream gradient arrives already masked (g = dz * relu_mask) together with its
  * reduction partials ([nrb][2*C]: sum g | sum g*xhat) from cn_conv2d_dgrad_bnbwd: finalize + apply only. */

@@ -1506,89 +1506,3 @@ def test_streaming_lazy_dgrad_equals_tiled_kernel(mode, dtype):
         else:
             assert rel_l2(d1.float().cpu(), d0.float().cpu()) < 2e-4
         assert float(d1.float().abs().sum()) > 0
-
-
-@pytest.mark.parametrize('mode', MODES)
-@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
-def test_junction_dgrad_lazy_dy1_equals_apply_then_junction(mode, dtype):
-    """Round 5, cn_conv2d_dgrad_junction_lazy: the inner BatchNorm behind conv1 (bn1, ReLU behind it) runs reduce + finalize
-    only (cn_bn_bwd with dy = NULL, relu = 1); conv1's streaming junction kernel forms dy1 = c1*(dz masked) + c2*y + c3 on
-    the way to its LDS tile and writes it as a side output.  Against the separate passes (cn_bn_bwd with its apply pass, then
-    cn_conv2d_dgrad_junction on that dy1): dy1, g and the partial rows bit for bit; cn_bn_bwd_apply (the fallback) too."""
-    _f16_emul_subset(mode, dtype, keep=True)
-    dev = _dev(mode)
-    import convnet_amd as ca
-    ops, L, lib = ca.ops, ca._lib.load(), ca._lib
-    ptr, code = lib.ptr, lib.dtype_code(dtype)
-    if mode == 'emul':
-        cases = [(1, 6, 10, 256, 64, 1, 3), (2, 6, 6, 256, 128, 2, 2), (1, 5, 9, 512, 128, 1, 5)]
-    else:
-        cases = [(8, 56, 56, 256, 64, 1, 256), (8, 56, 56, 256, 128, 2, 256), (16, 28, 28, 512, 128, 1, 256),
-                 (3, 17, 13, 256, 64, 2, 7), (256, 56, 56, 256, 64, 1, 256), (256, 28, 28, 512, 128, 1, 256)]
-    for (N, H, W, C, K, sub, splits) in cases:
-        g_ = torch.Generator().manual_seed(C + K + H)
-        M = N * H * W
-        # bn1's side: its upstream gradient dz1, its input y1 (K channels), its forward statistics
-        dz1 = torch.randn(N, H, W, K, generator=g_).to(dtype).to(dev)
-        y1 = (torch.randn(N, H, W, K, generator=g_) * 1.3 + 0.2).to(dtype).to(dev)
-        y1f = y1.float().reshape(M, K)
-        m1, v1 = y1f.mean(0), y1f.var(0, unbiased=False)
-        is1 = 1.0 / torch.sqrt(v1 + 1e-5)
-        gam1 = (torch.rand(K, generator=g_) + 0.5).to(dev)
-        bet1 = (torch.randn(K, generator=g_) * 0.2).to(dev)
-        stats1 = torch.cat([m1, is1, gam1 * is1, bet1 - m1 * gam1 * is1]).contiguous()
-        # the junction's side
-        wc = (torch.randn(C, 1, 1, K, generator=g_) * (2.0 / K) ** 0.5).to(dtype).to(dev)
-        bn_y = (torch.randn(N, H, W, C, generator=g_) * 1.5 + 0.3).to(dtype).to(dev)
-        shp = (N, (H + 1) // 2, (W + 1) // 2, C) if sub == 2 else (N, H, W, C)
-        addend = torch.randn(*shp, generator=g_).to(dtype).to(dev)
-        yf = bn_y.float().reshape(M, C)
-        mean, var = yf.mean(0), yf.var(0, unbiased=False)
-        invstd = 1.0 / torch.sqrt(var + 1e-5)
-        gamma = (torch.rand(C, generator=g_) + 0.5).to(dev)
-        beta = (torch.randn(C, generator=g_) * 0.2).to(dev)
-        stats = torch.cat([mean, invstd, gamma * invstd, beta - mean * gamma * invstd]).contiguous()
-        on = torch.rand(M, C, generator=g_).to(dev) > 0.4
-        w8 = (2 ** torch.arange(8, device=dev)).view(1, 1, 8)
-        bits = (on.view(M, C // 8, 8).long() * w8).sum(-1).to(torch.uint8).contiguous()
-        ws = ops.workspace(L.cn_bn_workspace(M, K, code), dev)
-
-        def bn1_bwd(dy):
-            coef = torch.empty(3 * K, dtype=torch.float32, device=dev)
-            dg, db = torch.zeros(K, device=dev), torch.zeros(K, device=dev)
-            lib.check(L.cn_bn_bwd(ptr(dz1), ptr(y1), None, ptr(gam1), ptr(stats1), ptr(dy), None, ptr(dg), ptr(db), 0.0, 1.0,
-                                  ptr(coef), M, K, 1, code, ptr(ws), ws.numel() * 4, lib.stream_of(y1)), 'cn_bn_bwd')
-            return coef, dg, db
-        L.cn_set_option(b'jdgrad_splits', splits)
-        try:
-            # separate passes
-            dy_ref = torch.empty_like(y1)
-            coef0, dg0, db0 = bn1_bwd(dy_ref)
-            g0, p0, r0 = ops.conv2d_dgrad(dy_ref, wc, (N, H, W, C), K, 1, 1, (1, 1), (0, 0), addend=addend,
-                                          bn=(bn_y, bits, stats, True), addend_sub=sub)
-            assert L.cn_last_kernel_name().decode().startswith('jdgrad_kernel')
-            # lazy: finalize only, the junction kernel forms dy1
-            coef1, dg1, db1 = bn1_bwd(None)
-            assert torch.equal(coef0.cpu(), coef1.cpu()) and torch.equal(dg0.cpu(), dg1.cpu()) and torch.equal(db0.cpu(), db1.cpu())
-            assert L.cn_conv2d_dgrad_junction_lazy_ok(C, K, code) == 1
-            g1 = torch.empty((N, H, W, C), dtype=dtype, device=dev)
-            dy1 = torch.full_like(y1, float('nan'))
-            rows = L.cn_conv2d_dgrad_junction_rows_k(N, H, W, C, K)
-            p1 = torch.empty((rows, 2 * C), dtype=torch.float32, device=dev)
-            lib.check(L.cn_conv2d_dgrad_junction_lazy(ptr(dz1), ptr(y1), ptr(coef1), ptr(stats1), 1, ptr(dy1), ptr(wc), ptr(g1),
-                                                      ptr(addend), sub, N, H, W, C, K, code, ptr(bn_y), ptr(bits), ptr(stats),
-                                                      ptr(p1), rows, lib.stream_of(y1)), 'cn_conv2d_dgrad_junction_lazy')
-            assert ', true>' in L.cn_last_kernel_name().decode()
-            dy2 = ops.bn_bwd_apply(dz1, y1, stats1, coef1, True)
-        finally:
-            L.cn_set_option(b'jdgrad_splits', 256)
-        assert torch.equal(dy1.cpu(), dy_ref.cpu()), (N, H, W, C, K, sub)
-        assert torch.equal(dy2.cpu(), dy_ref.cpu()), (N, H, W, C, K, sub)
-        assert torch.equal(g1.cpu(), g0.cpu()), (N, H, W, C, K, sub)
-        assert r0 == rows and torch.equal(p1.cpu(), p0.cpu()), (N, H, W, C, K, sub)
-        # ... and dy1 is what the definition says
-        xh1 = (y1f - m1) * is1
-        gm = dz1.float().reshape(M, K) * ((y1f * stats1[2 * K:3 * K] + stats1[3 * K:]) > 0)
-        want = gam1 * is1 * (gm - gm.mean(0) - xh1 * (gm * xh1).mean(0))
-        assert rel_l2(dy1.float().reshape(M, K).cpu(), want.cpu()) < _tol(dtype)
-    assert L.cn_conv2d_dgrad_junction_lazy_ok(1024, 256, code) == 0
