@@ -41,6 +41,13 @@ _SIGNATURES = {
     'cn_step_timer_mark': (c_i, [c_p, ctypes.c_longlong]),
     'cn_step_timer_poll': (c_i, [c_p, c_p, c_p]),
     'cn_stream_disarm': (c_i, []),
+    'cn_plan_begin': (c_i, [c_p, c_p]),
+    'cn_plan_end': (c_i, [c_p]),
+    'cn_plan_import_graph': (c_i, [c_p, c_p]),
+    'cn_plan_replay': (c_i, [c_p]),
+    'cn_plan_info': (c_i, [c_p, c_p]),
+    'cn_plan_describe': (ctypes.c_char_p, [c_p]),
+    'cn_plan_destroy': (c_i, [c_p]),
     'cn_stream_wait_mark': (c_i, [c_i, c_p]),
     'cn_conv2d_fwd': (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 11 + [c_i, c_i, c_i, c_p]),
     'cn_conv2d_bnstats_rows': (c_i, [c_ll]),

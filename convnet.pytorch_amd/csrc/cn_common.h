@@ -47,16 +47,30 @@ void cn_set_last_kernel(const char* fmt, ...);
 // ---------------------------------------------------------------- launch macro
 #ifdef CN_EMULATE
 struct CnMarkLast { void release() {} };
+// (launch plans, plan.hip: while a plan is being recorded every launch is also kept as a closure)
+extern int cn_plan_recording;
+int cn_plan_rec_closure(const std::function<void()>& launch);
 #define CN_LAUNCH(kern, grid, block, stream, ...)                                   \
   do {                                                                              \
     (void)(stream);                                                                 \
-    cn_emul::launch((grid), (block), [=]() { kern(__VA_ARGS__); });                 \
+    const dim3 cn_g_ = (grid), cn_b_ = (block);                                     \
+    auto cn_body_ = [=]() { kern(__VA_ARGS__); };                                   \
+    if (cn_plan_recording) cn_plan_rec_closure([=]() { cn_emul::launch(cn_g_, cn_b_, cn_body_); }); \
+    cn_emul::launch(cn_g_, cn_b_, cn_body_);                                        \
   } while (0)
 #else
 // While a mark is armed (cn_stream_arm, runtime.hip) every launch of this thread carries the mark's event as the
 // kernel's own completion event (hipExtLaunchKernel's stopEvent): another stream can wait for that kernel without a
 // marker packet in this stream's queue.
 #include <hip/hip_ext.h>
+#include <tuple>
+#include <type_traits>
+#include <utility>
+template <typename Tup, size_t... I>
+static inline void cn_tuple_ptrs(const Tup& t, const void** out, std::index_sequence<I...>) {
+  const void* p[] = {(const void*)&std::get<I>(t)..., nullptr};
+  for (size_t i = 0; i < sizeof...(I); ++i) out[i] = p[i];
+}
 extern thread_local hipEvent_t cn_tl_stop_event;
 extern thread_local int cn_tl_stop_recorded;
 extern thread_local int cn_tl_stop_hold;   // > 0: launches stay plain (CnMarkLast: only a call's last kernel takes the event)
@@ -66,9 +80,39 @@ struct CnMarkLast {   // scope guard of a multi-kernel entry point: release() ri
   void release() { if (held) { --cn_tl_stop_hold; held = false; } }
   bool held = true;
 };
+// Launch plans (plan.hip): while one is being recorded every launch is logged with a private copy of its arguments
+// (converted to the kernel's own parameter types) and issued plainly; an armed mark becomes an event recorded right
+// behind the kernel - the recording normally runs under stream capture, where a kernel's stop event would be lost.
+extern int cn_plan_recording;
+extern thread_local int cn_tl_stop_handle;
+int cn_plan_rec_kernel(const void* func, dim3 grid, dim3 block, hipStream_t stream, int nargs, const void* const* ptrs,
+                       const size_t* sizes, const size_t* aligns, int mark_handle);
+void cn_plan_rec_kernel_node(int op_index, hipStream_t stream);
+template <typename... P, typename... A>
+static inline void cn_plan_launch(void (*kern)(P...), dim3 grid, dim3 block, hipStream_t stream, A&&... a) {
+  static_assert(sizeof...(P) == sizeof...(A), "CN_LAUNCH: argument count differs from the kernel's parameter count");
+  std::tuple<typename std::decay<P>::type...> vals{static_cast<typename std::decay<P>::type>(a)...};
+  const bool marked = cn_tl_stop_event != nullptr && cn_tl_stop_hold == 0;
+  const size_t sizes[] = {sizeof(typename std::decay<P>::type)..., 0};
+  const size_t aligns[] = {alignof(typename std::decay<P>::type)..., 1};
+  const void* ptrs[sizeof...(P) + 1];
+  cn_tuple_ptrs(vals, ptrs, std::index_sequence_for<P...>{});
+  const int op = cn_plan_rec_kernel((const void*)kern, grid, block, stream, (int)sizeof...(P), ptrs, sizes, aligns,
+                                    marked ? cn_tl_stop_handle : -1);
+  void* args[sizeof...(P) + 1];
+  for (size_t i = 0; i < sizeof...(P); ++i) args[i] = const_cast<void*>(ptrs[i]);
+  (void)hipLaunchKernel((const void*)kern, grid, block, args, 0, stream);
+  cn_plan_rec_kernel_node(op, stream);
+  if (marked) {
+    (void)hipEventRecord(cn_tl_stop_event, stream);
+    cn_tl_stop_recorded = 1;
+  }
+}
 #define CN_LAUNCH(kern, grid, block, stream, ...)                                                              \
   do {                                                                                                          \
-    if (cn_tl_stop_event != nullptr && cn_tl_stop_hold == 0) {                                                  \
+    if (cn_plan_recording) {                                                                                    \
+      cn_plan_launch(kern, dim3(grid), dim3(block), (hipStream_t)(stream), __VA_ARGS__);                        \
+    } else if (cn_tl_stop_event != nullptr && cn_tl_stop_hold == 0) {                                           \
       hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, (stream), (hipEvent_t) nullptr, cn_tl_stop_event, \
                             0, __VA_ARGS__);                                                                    \
       cn_tl_stop_recorded = 1;                                                                                  \

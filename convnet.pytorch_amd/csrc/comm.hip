@@ -34,6 +34,9 @@ extern "C" int cn_comm_join(void*, void*) { return CN_ERCCL; }
 extern "C" int cn_comm_allreduce(void*, void*, long long, int, void*) { return CN_ERCCL; }
 extern "C" int cn_comm_broadcast(void*, void*, long long, int, void*) { return CN_ERCCL; }
 extern "C" int cn_comm_destroy(void*) { return CN_OK; }
+int cn_comm_allreduce_bucket_issue(void*, float*, long long, void*, void*, int) { return CN_ERCCL; }
+int cn_comm_join_issue(void*, void*) { return CN_ERCCL; }
+int cn_comm_allreduce_issue(void*, void*, long long, int, void*) { return CN_ERCCL; }
 #else
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -180,8 +183,23 @@ extern "C" int cn_comm_info(void* handle, int* rank, int* world, int* rccl_versi
 // In-place SUM all-reduce of one gradient bucket (fp32) on the communicator's own stream, ordered after
 // everything queued so far on the first `n_after` (0, 1 or 2) of the producer streams after_a, after_b
 // (NULL there means the default stream, as everywhere in this ABI).
+// (cn_comm_allreduce_bucket / _join / _allreduce: while a launch plan is being recorded - plan.hip - the call is
+// logged, not issued: the recording runs under stream capture, RCCL runs live in every replay.)
+void cn_plan_rec_comm(int kind, void* comm, void* buf, long long count, int dtype, void* s0, void* s1, int n_after);
+int cn_comm_allreduce_bucket_issue(void* handle, float* buf, long long count, void* after_a, void* after_b, int n_after);
+int cn_comm_join_issue(void* handle, void* stream);
+int cn_comm_allreduce_issue(void* handle, void* buf, long long count, int dtype, void* stream);
+
 extern "C" int cn_comm_allreduce_bucket(void* handle, float* buf, long long count, void* after_a, void* after_b,
                                         int n_after) {
+  if (cn_plan_recording) {
+    if (handle == nullptr || buf == nullptr || count <= 0 || n_after < 0 || n_after > 2) { cn_set_error("cn_comm_allreduce_bucket: bad arguments"); return CN_EINVAL; }
+    cn_plan_rec_comm(0, handle, buf, count, 0, after_a, after_b, n_after);
+    return CN_OK;
+  }
+  return cn_comm_allreduce_bucket_issue(handle, buf, count, after_a, after_b, n_after);
+}
+int cn_comm_allreduce_bucket_issue(void* handle, float* buf, long long count, void* after_a, void* after_b, int n_after) {
   Comm* c = (Comm*)handle;
   const RcclApi* api = rccl();
   if (c == nullptr || api == nullptr || buf == nullptr || count <= 0 || n_after < 0 || n_after > 2) {
@@ -202,6 +220,14 @@ extern "C" int cn_comm_allreduce_bucket(void* handle, float* buf, long long coun
 
 // `stream` waits for every bucket all-reduce queued so far.
 extern "C" int cn_comm_join(void* handle, void* stream) {
+  if (cn_plan_recording) {
+    if (handle == nullptr) { cn_set_error("cn_comm_join: no communicator"); return CN_EINVAL; }
+    cn_plan_rec_comm(1, handle, nullptr, 0, 0, stream, nullptr, 0);
+    return CN_OK;
+  }
+  return cn_comm_join_issue(handle, stream);
+}
+int cn_comm_join_issue(void* handle, void* stream) {
   Comm* c = (Comm*)handle;
   if (c == nullptr) { cn_set_error("cn_comm_join: no communicator"); return CN_EINVAL; }
   hipEvent_t e = next_event(c);
@@ -212,6 +238,14 @@ extern "C" int cn_comm_join(void* handle, void* stream) {
 
 // In-stream, in-place SUM all-reduce.  dtype: 0 = fp32, 2 = fp64 (the SyncBatchNorm sums).
 extern "C" int cn_comm_allreduce(void* handle, void* buf, long long count, int dtype, void* stream) {
+  if (cn_plan_recording) {
+    if (handle == nullptr || buf == nullptr || count <= 0 || (dtype != 0 && dtype != 2)) { cn_set_error("cn_comm_allreduce: bad arguments (dtype %d)", dtype); return CN_EINVAL; }
+    cn_plan_rec_comm(2, handle, buf, count, dtype, stream, nullptr, 0);
+    return CN_OK;
+  }
+  return cn_comm_allreduce_issue(handle, buf, count, dtype, stream);
+}
+int cn_comm_allreduce_issue(void* handle, void* buf, long long count, int dtype, void* stream) {
   Comm* c = (Comm*)handle;
   const RcclApi* api = rccl();
   if (c == nullptr || api == nullptr || buf == nullptr || count <= 0 || (dtype != 0 && dtype != 2)) {

@@ -83,10 +83,14 @@ int cn_get_option(const char* name, int dflt) {
 // Cross-stream ordering without torch: `to` waits for everything queued on `from` so far.  Events come from a
 // ring created once (timing disabled, system-scope fence disabled: both streams are on this device, nothing here has to
 // become visible to the host).
+// launch plans (plan.hip) log the hand-offs below while one is being recorded
+void cn_plan_rec_fork(void* from, void* to);
+int cn_plan_rec_wait_mark(int handle, void* to);
+
 #define CN_FORK_EVENTS 256
 extern "C" int cn_stream_fork(void* from_, void* to_) {
 #ifdef CN_EMULATE
-  (void)from_; (void)to_;
+  if (cn_plan_recording) cn_plan_rec_fork(from_, to_);
   return CN_OK;
 #else
   static thread_local hipEvent_t ring[CN_FORK_EVENTS];
@@ -98,6 +102,7 @@ extern "C" int cn_stream_fork(void* from_, void* to_) {
   }
   hipEvent_t e = ring[next];
   next = (next + 1) % CN_FORK_EVENTS;
+  if (cn_plan_recording) cn_plan_rec_fork(from_, to_);     // (the event ops below still run: under capture they are the graph's edges)
   if (hipEventRecord(e, (hipStream_t)from_) != hipSuccess || hipStreamWaitEvent((hipStream_t)to_, e, 0) != hipSuccess) {
     cn_set_error("stream_fork: %s", hipGetErrorString(hipGetLastError()));
     return CN_EHIP;
@@ -112,6 +117,7 @@ extern "C" int cn_stream_fork(void* from_, void* to_) {
 thread_local hipEvent_t cn_tl_stop_event = nullptr;
 thread_local int cn_tl_stop_recorded = 0;
 thread_local int cn_tl_stop_hold = 0;
+thread_local int cn_tl_stop_handle = -1;   // ring handle of the armed event (launch plans record marks by handle)
 static thread_local hipEvent_t g_marks[CN_FORK_EVENTS];
 static thread_local int g_marks_made = 0, g_mark_next = 0;
 #endif
@@ -130,6 +136,7 @@ extern "C" int cn_stream_arm(void) {
   const int h = g_mark_next;
   g_mark_next = (g_mark_next + 1) % CN_FORK_EVENTS;
   cn_tl_stop_event = g_marks[h];
+  cn_tl_stop_handle = h;
   cn_tl_stop_recorded = 0;
   return h;
 #endif
@@ -148,6 +155,10 @@ extern "C" int cn_stream_wait_mark(int handle, void* to_stream) {
   return CN_OK;
 #else
   if (!g_marks_made || handle < 0 || handle >= CN_FORK_EVENTS) { cn_set_error("stream_wait_mark: bad handle %d", handle); return CN_EINVAL; }
+  if (cn_plan_recording) {
+    const int rc = cn_plan_rec_wait_mark(handle, to_stream);
+    if (rc != CN_OK) return rc;
+  }
   if (hipStreamWaitEvent((hipStream_t)to_stream, g_marks[handle], 0) != hipSuccess) {
     cn_set_error("stream_wait_mark: %s", hipGetErrorString(hipGetLastError()));
     return CN_EHIP;

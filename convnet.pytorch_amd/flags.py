@@ -48,6 +48,7 @@ _DEFAULTS = {
     'main_stream_prio': '-1',  # the step loop's own high-priority stream ('off': the default stream)
     'graph': 'auto',           # whole-step HIP graph: auto (when the host is the limit) / 0 / 1
     'graph_dp': 0,             # capture the RCCL bucket all-reduces too (opt-in until run on >= 2 devices)
+    'plan': 1,                 # launch plan (csrc/plan.hip): the step re-issued from one C call on both streams, RCCL live
     # ---- config 5
     'quant_int8': 0,           # QConv2d forward on the int8 MFMA kernel
     'quant_fuse': 1,           # producer-side fusions of the quantised chain (quant.py: FUSE_QUANT)

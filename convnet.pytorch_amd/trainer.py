@@ -15,6 +15,7 @@ What is different by design (MI355X-first):
 Out of the hot path (raise if requested): mixup / cutmix, duplicates + adapt_grad_norm,
 tensorwatch streams, nn.DataParallel.
 """
+import ctypes
 import logging
 import os
 import time
@@ -165,6 +166,41 @@ class EagerWatch(object):
         return w
 
 
+class PlanRefused(RuntimeError):
+    """The recorded step holds something a launch plan cannot re-issue (cn_plan_import_graph says what)."""
+
+
+class LaunchPlan(object):
+    """Handle of one recording of csrc/plan.hip (created = recording started)."""
+
+    def __init__(self, L, main_stream):
+        self._L = L
+        self.handle = ctypes.c_void_p()
+        check(L.cn_plan_begin(ctypes.byref(self.handle), ctypes.c_void_p(main_stream)), 'cn_plan_begin')
+
+    def end(self):
+        check(self._L.cn_plan_end(self.handle), 'cn_plan_end')
+
+    def info(self):
+        c = (ctypes.c_longlong * 8)()
+        check(self._L.cn_plan_info(self.handle, c), 'cn_plan_info')
+        return list(c)
+
+    def describe(self):
+        return self._L.cn_plan_describe(self.handle).decode()
+
+    def destroy(self):
+        if self.handle:
+            self._L.cn_plan_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
 class Trainer(object):
 
     def __init__(self, model, criterion, optimizer=None,
@@ -207,6 +243,10 @@ class Trainer(object):
         self._use_graph = self._graph_mode != '0'
         self._data_wait_ms = 0.0         # host time Trainer.forward waited for the loader in front of the current step
         self._graph_dp = flags.on('graph_dp')   # capture RCCL buckets too (opt-in)
+        # launch plans (csrc/plan.hip): the step recorded once, re-issued from one C call on BOTH streams.  Where a
+        # plan can be built it is what runs after the warm-up steps, whatever the batch size: it costs the host ~1 ms
+        # per step instead of 11-12 ms and keeps the eager step's two-stream schedule (a replayed HIP graph does not).
+        self._plan = flags.on('plan')
         self._gstates = {}               # per (shapes, step options) key: {'seen': warm-up / timing bookkeeping, 'graph': capture}
         self._graph_eager_for = set()    # (shapes, chunking) for which auto mode settled on eager launches
         self._watch = {}                 # key -> EagerWatch: the eager verdict is re-examined while it is in force
@@ -345,8 +385,8 @@ class Trainer(object):
             return False
         if self._graph_dynamic and any(getattr(m, 'no_graph', False) for m in self._graph_dynamic):
             return False     # (a host-side noise source was installed after construction: quant.set_noise_source)
-        if self.reducer is not None and (self.reducer.comm is None or not self._graph_dp):
-            return False
+        if self.reducer is not None and (self.reducer.comm is None or not (self._graph_dp or self._plan)):
+            return False     # (a plan re-issues the RCCL buckets live; a HIP graph captures them: opt-in)
         return True
 
     def _graph_key(self, inputs, target, chunk_batch):
@@ -392,7 +432,9 @@ class Trainer(object):
                 host_ms = (time.perf_counter() - t0) * 1e3
                 e1.synchronize()
                 dev_ms = e0.elapsed_time(e1)
-                seen['use'] = host_ms > 0.75 * dev_ms
+                seen['host_bound'] = host_ms > 0.75 * dev_ms
+                seen['plan'] = self._plan
+                seen['use'] = seen['plan'] or seen['host_bound']
                 seen['eager_ms'] = dev_ms
                 if not seen['use']:
                     self._graph_eager_for.add(eager_key)
@@ -403,7 +445,24 @@ class Trainer(object):
             if not seen.get('use', True):
                 return self._body(inputs, target, True, chunk_batch)
             try:
-                st = gs['graph'] = self._capture(inputs, target, chunk_batch, key)
+                try:
+                    st = gs['graph'] = self._capture(inputs, target, chunk_batch, key,
+                                                     plan=seen.get('plan', self._plan))
+                except PlanRefused as e:
+                    # the step holds something a plan cannot re-issue: the HIP graph (when the host is the limit and
+                    # nothing but this library's kernels would be captured) or eager launches serve it
+                    logging.warning('launch plan refused (%s): %s', e, 'HIP graph / eager launches instead')
+                    seen['plan'] = False
+                    if self._graph_mode == 'auto':
+                        seen['use'] = seen.get('host_bound', False)
+                    if self.reducer is not None and not self._graph_dp:
+                        seen['use'] = False
+                    if not seen['use']:
+                        self._graph_eager_for.add(eager_key)
+                        if 'eager_ms' in seen:
+                            self._watch[eager_key] = EagerWatch(seen['eager_ms'])
+                        return self._body(inputs, target, True, chunk_batch)
+                    st = gs['graph'] = self._capture(inputs, target, chunk_batch, key, plan=False)
             except RuntimeError as e:      # (torch.cuda.OutOfMemoryError is one)
                 # A capture needs its own pool for the step's tensors, next to the blocks the eager steps keep cached.  When
                 # the capture was the WATCH's idea (a verdict withdrawn after many eager steps) and it does not fit, the
@@ -429,11 +488,13 @@ class Trainer(object):
                 torch.cuda.synchronize(self.device)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                st['graph'].replay()
+                self._replay(st)
                 e1.record()
                 e1.synchronize()
                 seen['graph_ms'] = e0.elapsed_time(e1)
-                if seen['graph_ms'] > 0.98 * seen['eager_ms']:
+                # (a plan is the eager schedule minus the host: it is kept unless it measures clearly slower - what it
+                # buys is independence from the host's load, which a quiet-box comparison cannot show)
+                if seen['graph_ms'] > (1.05 if st.get('plan') else 0.98) * seen['eager_ms']:
                     seen['use'] = False
                     self._graph_eager_for.add(eager_key)
                     logging.debug('replayed step %.2f ms vs eager %.2f ms -> eager launches from now on',
@@ -447,7 +508,7 @@ class Trainer(object):
                     grad = grad.clone() if grad is not None else None
                     gs['graph'] = None
                 return out, loss, grad
-        st['graph'].replay()
+        self._replay(st)
         self.arena.bump_version()      # what optimizer.step() does on the host: master weights moved
         self.training_steps += 1
         return st['out'], st['loss'], st['grad']
@@ -467,20 +528,51 @@ class Trainer(object):
         gs['seen'].pop('replays', None)
         logging.info('eager step %.2f ms against %.2f ms when it was chosen: trying a HIP graph', w.recent_ms(), w.ref_ms)
 
-    def _capture(self, inputs, target, chunk_batch, key):
+    def _replay(self, st):
+        if st.get('plan') is not None:
+            if torch.cuda.current_stream(self.device).cuda_stream != st['stream']:
+                raise RuntimeError('a launch plan is tied to the stream it was recorded on')
+            check(_lib.load().cn_plan_replay(st['plan'].handle), 'cn_plan_replay')
+        else:
+            st['graph'].replay()
+
+    def _capture(self, inputs, target, chunk_batch, key, plan=False):
+        """plan = False: the step as one HIP graph (single chain: ops.SIDE folds the side stream in).  plan = True: the
+        same capture with the two-stream schedule kept and the library logging its launches, hand-offs and communicator
+        calls (cn_plan_begin / _end); the captured graph is never launched - it is the cross-check (every logged launch
+        must be a node of it), the source of whatever torch itself put on the stream, and the owner of the memory pool
+        the step's tensors live in."""
         cur = torch.cuda.current_stream(self.device)
         x, t = torch.empty_like(inputs), torch.empty_like(target)
         x.copy_(inputs)
         t.copy_(target)
         steps_before = self.training_steps
-        g = torch.cuda.CUDAGraph()
-        ops.SIDE.capturing = True
+        L = _lib.load()
+        g = torch.cuda.CUDAGraph(keep_graph=True) if plan else torch.cuda.CUDAGraph()
+        rec = LaunchPlan(L, cur.cuda_stream) if plan else None
+        ops.SIDE.capturing = not plan
         try:
             with torch.cuda.graph(g, stream=cur, capture_error_mode='thread_local'):
                 out, loss, grad = self._body(x, t, True, chunk_batch)
+        except BaseException:
+            if rec is not None:
+                rec.destroy()
+            raise
         finally:
             ops.SIDE.capturing = False
             self.training_steps = steps_before     # capture executes nothing: the replay is the step
+        if rec is not None:
+            rec.end()
+            n = L.cn_plan_import_graph(rec.handle, ctypes.c_void_p(g.raw_cuda_graph()))
+            if n < 0:
+                why = _lib.last_error()
+                rec.destroy()
+                raise PlanRefused(why)
+            info = rec.info()
+            logging.debug('recorded the training step as a launch plan (%s): %d launches + %d imported on %d streams, '
+                          '%d hand-offs, %d communicator calls', key[0], info[1], info[2], info[6], info[4], info[5])
+            return {'key': key, 'graph': g, 'plan': rec, 'stream': cur.cuda_stream, 'x': x, 't': t, 'out': out,
+                    'loss': loss, 'grad': grad}
         logging.debug('captured the training step as one HIP graph (%s)', (key[0],))
         return {'key': key, 'graph': g, 'x': x, 't': t, 'out': out, 'loss': loss, 'grad': grad}
 

@@ -71,6 +71,25 @@ int cn_stream_wait_mark(int handle, void* to_stream);
 int cn_step_timer_mark(void* stream, long long tag);
 int cn_step_timer_poll(float* period_ms, long long* tag_prev, long long* tag_cur);
 
+/* ---- launch plans (csrc/plan.hip): the per-batch host loop of trainer.py:106-177 issued from one C call ---------
+ * cn_plan_begin starts a process-wide recording (the autograd engine's thread launches too): until cn_plan_end every
+ * kernel launch of this library is logged with a private copy of its arguments and the stream it went to, every
+ * cn_stream_fork / cn_stream_arm mark / cn_stream_wait_mark hand-off with its two ends, and every cn_comm_allreduce_bucket
+ * / _join / _allreduce call is logged INSTEAD of issued.  The recording is meant to run under stream capture of
+ * `main_stream` (nothing executes; the capturing allocator keeps the step's addresses for the plan): then
+ * cn_plan_import_graph(plan, hipGraph_t) pairs every logged launch with its graph node and imports the nodes somebody
+ * else put on the streams (returns their number; < 0: the step holds something a plan cannot re-issue).
+ * cn_plan_replay issues the whole step: the same launches on the same streams in the same order, marks as kernel
+ * completion events, RCCL calls live.  cn_plan_info: counts[8] = ops, own launches, imported nodes, events, hand-offs,
+ * communicator calls, streams, replays.  A plan is tied to the buffers and streams it was recorded on. */
+int cn_plan_begin(void** plan, void* main_stream);
+int cn_plan_end(void* plan);
+int cn_plan_import_graph(void* plan, void* hip_graph);
+int cn_plan_replay(void* plan);
+int cn_plan_info(void* plan, long long* counts);
+const char* cn_plan_describe(void* plan);
+int cn_plan_destroy(void* plan);
+
 /* ---- nn.Conv2d / nn.Linear (models/resnet.py:75-78,126-132,178-179,226-227,242) ------------- */
 /* y[N,P,Q,K] = conv(x[N,H,W,C], w[K,R,S,C]) (+bias[K]) (ReLU optional); out_f32 writes fp32
  * regardless of dtype (used for the classifier logits).  Linear = 1x1 conv on a 1x1 image. */

@@ -51,6 +51,17 @@ for dtype in (torch.float32, torch.bfloat16):
         e_recs, e_val, e_sd, _ = run(False, dtype, clip)
         g_recs, g_val, g_sd, tr = run(True, dtype, clip)
         assert any(g['graph'] is not None for g in tr._gstates.values()), 'the step was never captured'
+        sts = [g['graph'] for g in tr._gstates.values() if g['graph'] is not None]
+        if os.environ.get('TEST_EXPECT_PLAN') == '1':
+            # the launch plan is what ran: this library's launches on TWO streams (the weight gradients kept their side
+            # stream), torch's own kernels of the step (loss scaling: mul + its backward) imported, RCCL buckets as calls
+            assert all(st.get('plan') is not None for st in sts)
+            info = sts[0]['plan'].info()
+            assert info[1] > 100 and info[6] == 2 and info[7] >= 3, info
+            assert info[2] >= 1, info
+            assert (info[5] > 0) == DIST, info
+        else:
+            assert all(st.get('plan') is None for st in sts)
         assert tr.optimizer.hyper['lr'] == 0.01
         assert e_recs == g_recs, (e_recs, g_recs)
         assert e_val['loss'] == g_val['loss'] and e_val['prec1'] == g_val['prec1']
@@ -73,17 +84,32 @@ def _run(tmp_path, env_extra, port):
 
 
 def test_graph_replay_is_bit_identical_to_eager(tmp_path):
-    assert 'GRAPH_OK single' in _run(tmp_path, {}, 29551)
+    assert 'GRAPH_OK single' in _run(tmp_path, {'CONVNET_AMD_FLAGS': 'plan=0'}, 29551)
 
 
 def test_graph_with_world1_rccl_buckets_inside(tmp_path):
-    assert 'GRAPH_OK dist' in _run(tmp_path, {'TEST_DIST': '1', 'CONVNET_AMD_FLAGS': 'graph_dp=1'}, 29553)
+    assert 'GRAPH_OK dist' in _run(tmp_path, {'TEST_DIST': '1', 'CONVNET_AMD_FLAGS': 'graph_dp=1,plan=0'}, 29553)
 
 
 def test_graph_replay_with_lazy_dy_is_bit_identical_to_eager(tmp_path):
     """The same with the junction BatchNorms' backward apply left to the consumers (ops.LAZY_DY forced on for this
     small model): the placeholder gradients and the finalize-only BatchNorm calls are capture-safe."""
-    assert 'GRAPH_OK single' in _run(tmp_path, {'CONVNET_AMD_FLAGS': 'lazy_min_mb=0'}, 29555)
+    assert 'GRAPH_OK single' in _run(tmp_path, {'CONVNET_AMD_FLAGS': 'lazy_min_mb=0,plan=0'}, 29555)
+
+
+# ---- launch plan (csrc/plan.hip; the default): the same bit-identity, with the two-stream schedule kept ------------
+def test_plan_replay_is_bit_identical_to_eager(tmp_path):
+    assert 'GRAPH_OK single' in _run(tmp_path, {'TEST_EXPECT_PLAN': '1'}, 29561)
+
+
+def test_plan_with_world1_rccl_buckets_issued_live(tmp_path):
+    """distributed=True on the direct-RCCL communicator: the bucket all-reduces and the join are plan entries that call
+    RCCL in every replay (never captured), default flags."""
+    assert 'GRAPH_OK dist' in _run(tmp_path, {'TEST_DIST': '1', 'TEST_EXPECT_PLAN': '1'}, 29563)
+
+
+def test_plan_replay_with_lazy_dy_is_bit_identical_to_eager(tmp_path):
+    assert 'GRAPH_OK single' in _run(tmp_path, {'CONVNET_AMD_FLAGS': 'lazy_min_mb=0', 'TEST_EXPECT_PLAN': '1'}, 29565)
 
 
 WATCH_WORKER = r'''
