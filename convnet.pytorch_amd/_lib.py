@@ -46,6 +46,8 @@ _SIGNATURES = {
     'cn_plan_import_graph': (c_i, [c_p, c_p]),
     'cn_plan_replay': (c_i, [c_p]),
     'cn_plan_info': (c_i, [c_p, c_p]),
+    'cn_plan_bind_input': (c_i, [c_p, c_i, c_p, c_sz]),
+    'cn_plan_set_input': (c_i, [c_p, c_i, c_p]),
     'cn_plan_describe': (ctypes.c_char_p, [c_p]),
     'cn_plan_destroy': (c_i, [c_p]),
     'cn_stream_wait_mark': (c_i, [c_i, c_p]),

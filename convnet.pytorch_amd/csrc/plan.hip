@@ -64,7 +64,10 @@ struct PlanOp {
 #endif
 };
 
+struct InputSite { size_t op; size_t arg; size_t byte; uintptr_t delta; };   // an 8-byte argument word holding base + delta
+
 struct Plan {
+  std::vector<InputSite> sites[4];   // rebindable inputs (cn_plan_bind_input)
   hipStream_t main = nullptr;
   std::vector<PlanOp> ops;
   int n_events = 0;
@@ -429,6 +432,44 @@ extern "C" int cn_plan_import_graph(void* plan, void* graph_) {
   p->n_foreign = (int)ins.size();
   return (int)ins.size();
 #endif
+}
+
+// Rebindable inputs: the step reads its batch through pointers baked into argument blocks.  bind finds every 8-byte
+// aligned argument word of this library's launches whose value lies inside [base, base + bytes) (a batch tensor of the
+// recording) and remembers it; set_input points all of them at another buffer of the same layout - the next replay
+// reads the caller's batch in place instead of a copy of it.  Returns the number of words found (0: nothing to
+// rebind, keep copying).  Launches imported from the graph are not searched: the caller must know that only this
+// library reads the tensor (Trainer: the model's first operator is the layout cast).
+extern "C" int cn_plan_bind_input(void* plan, int slot, const void* base_, size_t bytes) {
+  Plan* p = (Plan*)plan;
+  if (p == nullptr || !p->ended || slot < 0 || slot >= 4 || base_ == nullptr || bytes == 0) { cn_set_error("cn_plan_bind_input: bad arguments"); return CN_EINVAL; }
+  const uintptr_t base = (uintptr_t)base_;
+  p->sites[slot].clear();
+  for (size_t i = 0; i < p->ops.size(); ++i) {
+    PlanOp& op = p->ops[i];
+    if (op.kind != OP_KERNEL) continue;
+    for (size_t a = 0; a < op.args.size(); ++a) {
+      const char* lo = (const char*)op.args[a];
+      const char* b0 = op.blob.data() + ((16 - ((uintptr_t)op.blob.data() & 15)) & 15);      // (as laid out by cn_plan_rec_kernel)
+      const char* hi = a + 1 < op.args.size() ? (const char*)op.args[a + 1] : b0 + (op.blob.size() - 16);
+      for (const char* q = lo; q + 8 <= hi; q += 8) {
+        if (((uintptr_t)q & 7) != 0) break;
+        uintptr_t v;
+        memcpy(&v, q, 8);
+        if (v >= base && v < base + bytes) p->sites[slot].push_back({i, a, (size_t)(q - lo), v - base});
+      }
+    }
+  }
+  return (int)p->sites[slot].size();
+}
+extern "C" int cn_plan_set_input(void* plan, int slot, const void* base_) {
+  Plan* p = (Plan*)plan;
+  if (p == nullptr || slot < 0 || slot >= 4 || base_ == nullptr) { cn_set_error("cn_plan_set_input: bad arguments"); return CN_EINVAL; }
+  for (const InputSite& st : p->sites[slot]) {
+    const uintptr_t v = (uintptr_t)base_ + st.delta;
+    memcpy((char*)p->ops[st.op].args[st.arg] + st.byte, &v, 8);
+  }
+  return CN_OK;
 }
 
 // communicator entry points that really issue (comm.hip)

@@ -87,6 +87,10 @@ int cn_plan_end(void* plan);
 int cn_plan_import_graph(void* plan, void* hip_graph);
 int cn_plan_replay(void* plan);
 int cn_plan_info(void* plan, long long* counts);
+/* rebindable batch: bind finds the argument words of the plan's own launches that point into [base, base + bytes) (returns
+ * how many); set_input re-points them at another buffer of the same layout, so a replay reads the caller's batch in place */
+int cn_plan_bind_input(void* plan, int slot, const void* base, size_t bytes);
+int cn_plan_set_input(void* plan, int slot, const void* base);
 const char* cn_plan_describe(void* plan);
 int cn_plan_destroy(void* plan);
 

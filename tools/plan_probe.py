@@ -29,6 +29,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--rounds', type=int, default=3)
     ap.add_argument('--burners', type=int, default=0)
+    ap.add_argument('--pin', type=int, default=0, help='confine this process AND the burners to the first N allowed cores')
     ap.add_argument('--depth', type=int, default=50)
     ap.add_argument('--dtype', default='bf16')
     ap.add_argument('--describe', action='store_true')
@@ -36,6 +37,9 @@ def main():
     ap.add_argument('--out', default='')
     args = ap.parse_args()
 
+    allowed = sorted(os.sched_getaffinity(0))
+    if args.pin > 0:
+        os.sched_setaffinity(0, set(allowed[:args.pin]))      # (inherited by the burners)
     stop = mp.Value('i', 0)
     procs = [mp.Process(target=burn, args=(stop,), daemon=True) for _ in range(args.burners)]
     for p in procs:
@@ -50,13 +54,38 @@ def main():
              torch.randint(0, 1000, (args.batch,), generator=g).to(dev)) for _ in range(2)]
 
     def make(mode):
+        mode = mode.rstrip('0123456789')       # (eager2, plan3: further instances of a mode - instance-to-instance spread)
         torch.manual_seed(123)
         model = ca.models.resnet(dataset='imagenet', depth=args.depth)
         tr = ca.Trainer(model, ca.CrossEntropyLoss(), ca.OptimRegime(model, model.regime), device=str(dev), dtype=dt,
                         print_freq=10 ** 9)
-        tr._graph_mode = '0' if mode == 'eager' else '1'
-        tr._use_graph = mode != 'eager'
-        tr._plan = mode == 'plan'
+        eager = mode in ('eager', 'eagerpool')
+        tr._graph_mode = '0' if eager else '1'
+        tr._use_graph = not eager
+        tr._plan = mode in ('plan', 'planthrottle')
+        if mode == 'eagerpool':
+            # the eager step with its tensors in a private allocator pool (what a capture gives the plan): address layout A/B
+            mp_ = torch.cuda.MemPool()
+            orig_body = tr._body
+
+            def body(*a, **k):
+                with torch.cuda.use_mem_pool(mp_):
+                    return orig_body(*a, **k)
+            tr._body = body
+            tr._keep = mp_
+        if mode == 'planthrottle':
+            # the plan with the host held one step behind the device's previous step (queue-depth A/B)
+            orig_replay = tr._replay
+            ev = [None]
+
+            def replay(st):
+                if ev[0] is not None:
+                    ev[0].synchronize()
+                orig_replay(st)
+                e = torch.cuda.Event()
+                e.record(torch.cuda.current_stream(dev))
+                ev[0] = e
+            tr._replay = replay
         tr.train([pool[i % 2] for i in range(6)])      # warm-up + capture + first replays
         torch.cuda.synchronize()
         return tr
@@ -66,10 +95,10 @@ def main():
     for m, tr in trainers.items():
         for gs in tr._gstates.values():
             st = gs.get('graph')
-            if st is not None and st.get('plan') is not None:
+            if st is not None and st.get('plan') is not None and not m[-1].isdigit():
                 info = st['plan'].info()
-                print('plan[%s]: ops %d, own launches %d, imported %d, events %d, hand-offs %d, comm %d, streams %d' %
-                      (m, info[0], info[1], info[2], info[3], info[4], info[5], info[6]))
+                print('plan[%s]: ops %d, own launches %d, imported %d, events %d, hand-offs %d, comm %d, streams %d; input sites %d' %
+                      (m, info[0], info[1], info[2], info[3], info[4], info[5], info[6], st.get('x_sites', -1)))
                 if args.describe:
                     text = st['plan'].describe()
                     print('\n'.join(l for l in text.split('\n') if ' foreign ' in l or ' memset ' in l)[:6000])
@@ -107,7 +136,8 @@ def main():
         torch.cuda.synchronize()
         res[m]['issue_ms'] = (t1 - t0) * 1e3 / 5
     stop.value = 1
-    out = {'batch': args.batch, 'burners': args.burners, 'cores': os.cpu_count()}
+    out = {'batch': args.batch, 'burners': args.burners, 'cores_allowed': len(allowed),
+           'cores_used': len(os.sched_getaffinity(0))}
     for m in modes:
         d = res[m]
         out[m] = {'dev_ms_med': statistics.median(d['dev_ms']), 'dev_ms_all': [round(v, 3) for v in d['dev_ms']],
