@@ -137,7 +137,7 @@ def main():
     ap.add_argument('--detail-out', default=os.path.join(ROOT, 'gpurun_out', 'bench_detail.json'),
                     help='file for the per-kernel / per-layer tables (never part of the contract line)')
     ap.add_argument('--detail-stdout', action='store_true', help='also print the tables as an earlier {"detail": ...} line')
-    ap.add_argument('--cpu-steps', type=int, default=5, help='timed steps of the CPU baseline (batch 32, 1 warm-up)')
+    ap.add_argument('--cpu-steps', type=int, default=15, help='timed steps of the CPU baseline (batch 32, 1 warm-up; ~1.7 s each)')
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -224,6 +224,7 @@ def main():
                 dist.barrier()
         torch.cuda.synchronize()
 
+    t_gpu0 = time.perf_counter()
     tr.train(loader(args.warmup))          # W untimed warm-up steps
     fence()
     t0 = time.perf_counter()
@@ -231,6 +232,20 @@ def main():
     torch.cuda.synchronize()
     fence()
     elapsed = time.perf_counter() - t0
+    # how the steps of the timed region were issued, and the host time one step costs (5 steps issued back to back with the
+    # device left to drain afterwards - outside the timed region)
+    modes = [('plan' if g['graph'].get('plan') is not None else 'hip-graph') for g in tr._gstates.values()
+             if g.get('graph') is not None]
+    with torch.cuda.stream(tr._main_stream) if tr._main_stream is not None else torch.cuda.stream(torch.cuda.current_stream(device)):
+        tr.model.train()
+        xb, tb = (t.to(device) for t in pool[0])
+        fence()
+        th0 = time.perf_counter()
+        for _ in range(5):
+            tr._step(xb, tb, training=True)
+        host_ms = (time.perf_counter() - th0) * 1e3 / 5
+    fence()
+    step_issue = {'mode': modes[0] if modes else 'eager', 'host_ms_per_step': round(host_ms, 2)}
     rank_devices, params_in_sync = [local_rank], None
     if distributed:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -377,13 +392,18 @@ def main():
                 roof['traffic_unit'] = 'HBM bytes/launch, rocprofv3 --pmc FETCH_SIZE x2 (gfx950) + WRITE_SIZE, separate passes'
                 roof['traffic_source'] = 'live: --pmc passes run by this command' if live else \
                     'static: profiles/%s' % pm_file
+    gpu_active = time.perf_counter() - t_gpu0      # warm-up + timed region + issue probe + profiled passes (GPU busy throughout)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import convnet_oracle as O
         r = O.time_cpu_baseline(depth=args.depth, batch=32, steps=args.cpu_steps, warmup=1, size=224)
         cpu = {'value': round(r['img_per_s'], 2), 'unit': 'images/sec', 'cores': r['cores'], 'kind': 'port',
+               'stat': 'median of %d steps' % args.cpu_steps,
+               'spread': {'min': round(r['img_per_s_min'], 2), 'max': round(r['img_per_s_max'], 2),
+                          'mean': round(r['img_per_s_mean'], 2)},
                'sample': 'oracle/convnet_oracle.py (CPU restatement of the reference Trainer step) ResNet-%d fp32 training, '
-                         'batch 32, 1 warm-up + %d timed steps (%.2f s/step)' % (args.depth, args.cpu_steps, r['s_per_step'])}
+                         'batch 32, 1 warm-up + %d timed steps, each timed on its own (median %.2f s/step, %.0f s in all)'
+                         % (args.depth, args.cpu_steps, r['s_per_step'], r['s_total'])}
         try:   # how the port compares with the REAL reference Trainer on the same cores (measured in the build container)
             with open(os.path.join(ROOT, 'tests', 'golden', 'reference_cpu_timing.json')) as f:
                 rt = json.load(f)
@@ -421,6 +441,12 @@ def main():
             # nothing about csrc/comm.hip)
             'transport_fallback': comm_note is not None,
             'roofline': roof, 'cpu_baseline': cpu,
+            # which step the timed region ran (launch plan = csrc/plan.hip) and what it cost the host; which sources the
+            # measured binary was built from (== the tree's hash exactly when libconvnet_hip.so is a build of this tree)
+            'step_issue': step_issue,
+            'build': {'binary_src_hash': ca._lib.build_hash(), 'tree_src_hash': ca._lib.source_hash(),
+                      'binary_is_this_tree': ca._lib.build_hash() == ca._lib.source_hash()},
+            'gpu_active_s': round(gpu_active, 2),
         }
         # measured HBM traffic of the whole step (all kernels, latest committed PMC passes: static, like
         # roofline.traffic) over this run's step time: how close the step as a whole runs to the memory system

@@ -217,6 +217,29 @@ def _apply_env_options(lib):
             lib.cn_set_option(k.strip().encode(), int(v))
 
 
+def source_hash():
+    """Content hash of the library's sources + headers in THIS tree, by the recipe of csrc/build.sh (SRC_HASH): equal to
+    the hash inside cn_build_info() exactly when the loaded binary was built from these files."""
+    import glob
+    import hashlib
+    import re
+    csrc = os.path.join(_HERE, 'csrc')
+    srcs = re.search(r'^SRCS="([^"]+)"', open(os.path.join(csrc, 'build.sh')).read(), re.M).group(1).split()
+    files = [os.path.join(csrc, f) for f in srcs] + sorted(glob.glob(os.path.join(csrc, '*.h'))) + \
+        [os.path.join(_HERE, '..', 'include', 'convnet_hip.h')]
+    h = hashlib.sha1()
+    for f in files:
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def build_hash():
+    """The source hash compiled into the loaded library ('unknown' for a build that bypassed csrc/build.sh)."""
+    info = load().cn_build_info().decode()
+    return info.rsplit('src ', 1)[1] if 'src ' in info else 'unknown'
+
+
 def is_emulated():
     load()
     return _emulated

@@ -16,13 +16,17 @@ if [ "$1" != "emul-only" ]; then
   ODIR=${CN_OBJ_DIR:-/tmp/cn_hip_obj}_$KEY
   mkdir -p $ODIR
   HDRS=$(cat *.h ../../include/convnet_hip.h | sha1sum | cut -c1-40)
+  # content hash of EVERY source + header of the library, compiled into runtime.hip: cn_build_info() reports which tree
+  # the binary was built from (bench.py prints it beside the hash of the tree it runs in; _lib.source_hash() is the same recipe)
+  SRC_HASH=$(cat $SRCS *.h ../../include/convnet_hip.h | sha1sum | cut -c1-16)
   pids=""
   for s in $SRCS; do
     o=$ODIR/${s%.hip}.o
-    h=$(printf '%s|%s|%s' "$(sha1sum < $s)" "$HDRS" "$CN_EXTRA_FLAGS" | sha1sum | cut -c1-40)
+    XF=""; if [ $s = runtime.hip ]; then XF="-DCN_SRC_HASH=\"$SRC_HASH\""; fi
+    h=$(printf '%s|%s|%s|%s' "$(sha1sum < $s)" "$HDRS" "$CN_EXTRA_FLAGS" "$XF" | sha1sum | cut -c1-40)
     if [ ! -f $o ] || [ "$(cat $o.sha 2>/dev/null)" != "$h" ]; then
       rm -f $o.sha
-      ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result $CN_EXTRA_FLAGS -c $s -o $o \
+      ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result $CN_EXTRA_FLAGS $XF -c $s -o $o \
         && echo $h > $o.sha ) &
       pids="$pids $!"
     fi

@@ -231,6 +231,9 @@ extern "C" const char* cn_build_info(void) {
 #ifdef CN_EMULATE
   return "convnet_hip TEST-ONLY SIMT emulator build (host C++)";
 #else
-  return "convnet_hip gfx950 (CDNA4 / MI355X) HIP build";
+#ifndef CN_SRC_HASH
+#define CN_SRC_HASH "unknown"
+#endif
+  return "convnet_hip gfx950 (CDNA4 / MI355X) HIP build; src " CN_SRC_HASH;
 #endif
 }

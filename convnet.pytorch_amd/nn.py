@@ -203,15 +203,21 @@ class BatchNorm2d(_ArenaModule):
             return 1.0 / float(self._host_batches)
         return float(self.momentum)
 
+    def _stats_span_ranks(self):
+        """True when this BatchNorm's batch statistics are all-reduced over >= 2 ranks (--sync-bn)."""
+        return ops._sync_group(self) is not None      # ((group, world) only for an initialised group of > 1 rank)
+
     def forward(self, y, residual=None, relu=False, defer_apply=False, residual_bn=None):
         """defer_apply / residual_bn (ops.DUAL_BN): a projection shortcut's BatchNorm called with defer_apply=True only
         finalises its batch statistics and returns its input; the junction BatchNorm, given that tensor as `residual`
         and the shortcut BatchNorm as `residual_bn`, applies both in its one apply pass.  Ignored in eval mode."""
         self._require_prepared()
         if self.training or not self.track_running_stats:
-            if self.training and y.dim() == 4 and y.shape[0] * y.shape[1] * y.shape[2] <= 1:
-                # torch.nn.functional.batch_norm's check (the reference stops here too: a batch of one image on a 1 x 1 map
-                # has no variance); the size is printed the way the reference sees the tensor, NCHW
+            if y.dim() == 4 and y.shape[0] * y.shape[1] * y.shape[2] <= 1 and not self._stats_span_ranks():
+                # torch.nn.functional.batch_norm's check, keyed like torch's bn_training (training OR no running
+                # statistics to fall back on); the reference stops here too: a batch of one image on a 1 x 1 map has no
+                # variance.  SyncBatchNorm over >= 2 ranks has one value per channel PER RANK: torch accepts that, so does
+                # this.  The size is printed the way the reference sees the tensor, NCHW
                 raise ValueError('Expected more than 1 value per channel when training, got input size {}'.format(
                     torch.Size([y.shape[0], y.shape[3], y.shape[1], y.shape[2]])))
             if torch.is_grad_enabled():

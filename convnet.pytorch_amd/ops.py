@@ -7,6 +7,7 @@ NCHW / OIHW shapes at their boundary): activations are contiguous NHWC tensors i
 PyTorch is used here for allocation, stream handles and the autograd tape only; every arithmetic
 pass over tensor data is one of the `cn_*` kernels.
 """
+import collections
 import contextlib
 import os
 import weakref
@@ -132,11 +133,15 @@ class SideStream(object):
         self.marks = flags.on('marks')     # 0: always hand off with an event record
         self.capturing = False      # set by Trainer around HIP-graph capture
         self.hold = flags.on('side_hold')
-        self._held = []
+        self._held = collections.deque()
         # a caller that runs backward passes without ever joining (anything but Trainer / BucketReducer) must not pin
         # every operand for ever: beyond this many pending hand-offs the oldest go back to the allocator the
         # record_stream way (correct without a join, just slower).  ResNet-200 with 8 accumulation chunks stays below.
         self.hold_max = 2048
+        # ... nor more than this many bytes of them (a count alone lets thousands of activation-sized operands pile up:
+        # one ResNet-50 b=256 step holds ~20 GB)
+        self.hold_max_bytes = 64 * 2 ** 30
+        self._held_bytes = 0
         self._mark = None
 
     def get(self, device):
@@ -178,9 +183,13 @@ class SideStream(object):
             # the operands stay referenced until the chain has waited for the side stream (join, once per step): the
             # caching allocator then needs no cross-stream bookkeeping for them.  record_stream would make it record an
             # event (with torch's default flags: a system-scope fence) on the side stream at every free and poll it
-            self._held.append(held)
-            if len(self._held) > self.hold_max:
-                for t in self._held.pop(0):
+            nbytes = sum(t.numel() * t.element_size() for t in held)
+            self._held.append((held, nbytes))
+            self._held_bytes += nbytes
+            while len(self._held) > self.hold_max or (self._held_bytes > self.hold_max_bytes and len(self._held) > 1):
+                old, ob = self._held.popleft()
+                self._held_bytes -= ob
+                for t in old:
                     t.record_stream(side)
         else:
             for t in held:
@@ -211,7 +220,8 @@ class SideStream(object):
             # records an event with the default flags: a system-scope fence on the side stream)
             self.fork(self.gather(device), torch.cuda.current_stream(device))
             self.used = False
-        self._held = []     # (what the current stream does from here on is ordered behind the side stream's reads)
+        self._held.clear()     # (what the current stream does from here on is ordered behind the side stream's reads)
+        self._held_bytes = 0
 
 
 SIDE = SideStream()

@@ -124,7 +124,10 @@ class EagerWatch(object):
 
     def add_period(self, ms, wait_ms=0.0):
         """Pure bookkeeping (unit-tested on the CPU): True when the verdict should be withdrawn."""
-        self.periods.append(max(float(ms) - float(wait_ms), 0.0))
+        # (the loader wait is host time: when the host runs ahead of a backlogged device it overlaps device work, and
+        # subtracting it in full would under-report the step - never below the time the verdict was based on)
+        ms, wait_ms = float(ms), float(wait_ms)
+        self.periods.append(max(ms - wait_ms, min(ms, self.ref_ms)))
         if len(self.periods) > self.window:
             self.periods.pop(0)
         return len(self.periods) == self.window and self.recent_ms() > self.factor * self.ref_ms
@@ -147,6 +150,9 @@ class EagerWatch(object):
         L = _lib.load()
         self._seq += 1
         self._waits[self._seq] = float(wait_ms)
+        if len(self._waits) > 64:        # periods that never arrive (every pair foreign: alternating configurations) must
+            for k in [k for k in self._waits if k <= self._seq - 64]:      # not accumulate: the ring holds 64 marks
+                del self._waits[k]
         check(L.cn_step_timer_mark(stream.cuda_stream, (self.id << 32) | self._seq), 'cn_step_timer_mark')
         ms, ta, tb = ctypes.c_float(0.0), ctypes.c_longlong(0), ctypes.c_longlong(0)
         while L.cn_step_timer_poll(ctypes.byref(ms), ctypes.byref(ta), ctypes.byref(tb)) == 1:

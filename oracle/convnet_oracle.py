@@ -270,11 +270,17 @@ def time_cpu_baseline(depth=50, batch=32, steps=2, warmup=1, size=224, threads=N
     torch.set_num_threads(threads)
     torch.manual_seed(123)
     model = OracleResNet(depth)
-    batches = synthetic_batches(warmup + steps, batch, size)
+    batches = synthetic_batches(min(warmup + steps, 4), batch, size)     # (cycled: the timing does not depend on the data)
     opt = OracleSGD(model)
     oracle_train(model, batches[:warmup], optimizer=opt)
-    t0 = time.time()
-    oracle_train(model, batches[warmup:], optimizer=opt)
-    dt = time.time() - t0
-    return {'img_per_s': batch * steps / dt, 's_per_step': dt / steps, 'cores': torch.get_num_threads(),
+    per_step = []
+    for i in range(steps):          # every step timed on its own: the line reports the MEDIAN and the spread
+        t0 = time.perf_counter()
+        oracle_train(model, [batches[(warmup + i) % len(batches)]], optimizer=opt)
+        per_step.append(time.perf_counter() - t0)
+    srt = sorted(per_step)
+    med = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
+    dt = sum(per_step)
+    return {'img_per_s': batch / med, 'img_per_s_mean': batch * steps / dt, 'img_per_s_min': batch / srt[-1],
+            'img_per_s_max': batch / srt[0], 's_per_step': med, 's_total': dt, 'cores': torch.get_num_threads(),
             'batch': batch, 'steps': steps}

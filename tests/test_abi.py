@@ -35,6 +35,25 @@ def test_hip_library_exports_every_declared_symbol():
     assert b'gfx950' in lib.cn_build_info()
 
 
+def test_hip_library_was_built_from_this_tree():
+    """cn_build_info() carries the content hash of the sources + headers the binary was compiled from (csrc/build.sh);
+    _lib.source_hash() is the same recipe over the tree: a stale libconvnet_hip.so - which gpurun would ship to the GPU box
+    and bench.py would measure - fails here (bench.py prints both hashes in its line)."""
+    import convnet_amd as ca
+    lib = ctypes.CDLL(HIP_LIB)
+    lib.cn_build_info.restype = ctypes.c_char_p
+    info = lib.cn_build_info().decode()
+    if ca._lib.source_hash() not in info:
+        import __graft_entry__ as g
+        g.build()          # (rebuilt: the next process loads the fresh binary; this one checks the file again)
+        import subprocess
+        import sys
+        out = subprocess.check_output([sys.executable, '-c', 'import ctypes; l = ctypes.CDLL(%r); '
+                                       'l.cn_build_info.restype = ctypes.c_char_p; print(l.cn_build_info().decode())' % HIP_LIB])
+        info = out.decode()
+    assert ca._lib.source_hash() in info, (ca._lib.source_hash(), info)
+
+
 def test_loader_fails_loudly_without_library(monkeypatch, tmp_path):
     import convnet_amd as ca
     monkeypatch.setattr(ca._lib, '_lib', None)
