@@ -133,7 +133,13 @@ _SIGNATURES = {
     'cn_quantize': (c_i, [c_p, c_p, c_ll, c_i, c_p, c_p, c_i, c_p, c_i, c_ull, c_p]),
     'cn_quantize_s': (c_i, [c_p, c_p, c_ll, c_i, c_p, c_p, c_i, c_p, c_i, c_ull, c_p, c_p]),
     'cn_counter_inc': (c_i, [c_p, c_p]),
+    'cn_quantize_levels': (c_i, [c_p, c_p, c_ll, c_i, c_p, c_p, c_i, c_p, c_i, c_ull, c_p, c_p]),
+    'cn_rangebn_fwd_q8': (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_i,
+                                c_p, c_p, c_sz, c_p]),
+    'cn_rangebn_bwd_q8': (c_i, [c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_i, c_i, c_p, c_p,
+                                c_sz, c_p]),
     'cn_quantize_rows': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
+    'cn_quantize_rows_multi': (c_i, [c_p, c_p, c_p, c_i, c_p]),
     'cn_rangebn_workspace': (c_sz, [c_i, c_i, c_i]),
     'cn_rangebn_fwd': (c_i, [c_p] * 7 + [c_f, c_f, c_i, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]),
     'cn_rangebn_fwd_q': (c_i, [c_p, c_p, c_i] + [c_p] * 7 + [c_f, c_f, c_i, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_sz, c_p]),

@@ -144,11 +144,21 @@ __global__ __launch_bounds__(Q_NT) void qparams_kernel(const float* minmax, int 
   sred[tid] = a;
   sred[Q_NT + tid] = b;
   __syncthreads();
-  if (tid == 0) {
-    for (int t = 1; t < Q_NT; ++t) {   // fixed order
-      if (mode == 0) { a += sred[t]; b += sred[Q_NT + t]; }
-      else { a = sred[t] < a ? sred[t] : a; b = sred[Q_NT + t] > b ? sred[Q_NT + t] : b; }
+  // fixed-order tree over the Q_NT partials (round 6: thread 0 used to add them one by one - 255 dependent LDS reads,
+  // 18 us per call, 214 calls per config-5 step = 4 ms; the double sums round to the same float either way)
+  for (int h = Q_NT / 2; h > 0; h >>= 1) {
+    if (tid < h) {
+      if (mode == 0) { sred[tid] += sred[tid + h]; sred[Q_NT + tid] += sred[Q_NT + tid + h]; }
+      else {
+        sred[tid] = sred[tid + h] < sred[tid] ? sred[tid + h] : sred[tid];
+        sred[Q_NT + tid] = sred[Q_NT + tid + h] > sred[Q_NT + tid] ? sred[Q_NT + tid + h] : sred[Q_NT + tid];
+      }
     }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    a = sred[0];
+    b = sred[Q_NT];
     float zp, mxv;
     if (mode == 0) { zp = (float)(a / rows); mxv = (float)(b / rows); } else { zp = (float)a; mxv = (float)b; }
     float range = mxv - zp;
@@ -193,19 +203,71 @@ __host__ __device__ __forceinline__ float q_hash_noise(unsigned int key, unsigne
 
 // UniformQuantize.forward, unsigned, dequantised (quantize.py:55-76), operation for operation:
 //   t = (x + (-zp)) / scale  [+ noise];  t = round_half_even(clamp(t, 0, qmax));  y = t * scale + zp
-__host__ __device__ __forceinline__ float q_snap(float x, float zp, float scale, float qmax, float noise) {
+// (split into the LEVEL t and its de-quantisation so that the kernels which store 8-bit levels instead of snapped values -
+// round 6 - run the very same arithmetic as the ones that store the values)
+__host__ __device__ __forceinline__ float q_level(float x, float zp, float scale, float qmax, float noise) {
   float t = (x + (-zp)) / scale;
   t = t + noise;
   t = fminf(fmaxf(t, 0.f), qmax);
-  t = rintf(t);
-  return t * scale + zp;
+  return rintf(t);
+}
+__host__ __device__ __forceinline__ float q_dequant(float t, float zp, float scale) { return t * scale + zp; }
+__host__ __device__ __forceinline__ float q_snap(float x, float zp, float scale, float qmax, float noise) {
+  return q_dequant(q_level(x, zp, scale, qmax, noise), zp, scale);
 }
 
+// ---- 8-bit level storage (round 6).  A tensor snapped to a <= 256-level grid is kept as one byte per element (CH bytes per
+// chunk of CH elements, same chunk order) and de-quantised on load: value = T-rounded q_dequant(level) - exactly what the
+// kernels that store snapped values write.  `raw` carries either the 16 bytes of a value chunk or the CH level bytes.
 template <typename T>
+__device__ __forceinline__ void q_st_levels(unsigned char* base, long long chunk, const float* lv) {
+  constexpr int CH = ElemTraits<T>::kChunk;
+  unsigned int w0 = 0, w1 = 0;
+#pragma unroll
+  for (int e = 0; e < CH; ++e) {
+    const unsigned int b = (unsigned int)lv[e] & 255u;
+    if (e < 4) w0 |= b << (8 * e); else w1 |= b << (8 * (e - 4));
+  }
+  if (CH == 8) { u32x2 v; v.x = w0; v.y = w1; *(u32x2*)(base + chunk * 8) = v; }
+  else *(unsigned int*)(base + chunk * 4) = w0;
+}
+template <typename T, bool Q8>
+__device__ __forceinline__ u32x4 q_ld_raw(const void* base, long long chunk) {
+  constexpr int CH = ElemTraits<T>::kChunk;
+  if (!Q8) return cn_ld16((const char*)base + chunk * 16);
+  u32x4 r = cn_zero16();
+  if (CH == 8) { const u32x2 v = *(const u32x2*)((const char*)base + chunk * 8); r.x = v.x; r.y = v.y; }
+  else r.x = *(const unsigned int*)((const char*)base + chunk * 4);
+  return r;
+}
+struct QOp {        // how an operand is stored: values (q8 == 0) or levels of the grid (zp, scale)
+  int q8;
+  float zp, scale;
+};
+__device__ __forceinline__ QOp q_op_make(const float* qp, float qmax) {
+  QOp o;
+  o.q8 = qp != nullptr;
+  o.zp = o.q8 ? qp[0] : 0.f;
+  const float range = o.q8 ? qp[1] : 1.f;
+  o.scale = (range == 0.f ? 1.f : range) / qmax;
+  return o;
+}
+template <typename T, bool Q8>
+__device__ __forceinline__ void q_unpack_raw(const u32x4& raw, const QOp& o, float* f) {
+  constexpr int CH = ElemTraits<T>::kChunk;
+  if (!Q8) { Chunk<T>::unpack(raw, f); return; }
+#pragma unroll
+  for (int e = 0; e < CH; ++e) {
+    const unsigned int w = e < 4 ? raw.x : raw.y;
+    f[e] = q_round_to<T>(q_dequant((float)((w >> (8 * (e & 3))) & 255u), o.zp, o.scale));
+  }
+}
+
+template <typename T, bool Y8>
 __global__ __launch_bounds__(Q_NT) void quantize_kernel(const T* x, T* y, long long n, const float* zero_point,
                                                        const float* range, float qmax, const float* noise,
                                                        int stochastic, unsigned long long seed,
-                                                       const unsigned long long* step) {
+                                                       const unsigned long long* step, unsigned char* y8) {
   constexpr int CH = ElemTraits<T>::kChunk;
   // `step` (optional): a device counter the caller advances once per training step, mixed into the seed - a launch
   // replayed from a captured HIP graph (frozen kernel arguments) still draws fresh rounding noise every step
@@ -221,9 +283,10 @@ __global__ __launch_bounds__(Q_NT) void quantize_kernel(const T* x, T* y, long l
     for (int e = 0; e < CH; ++e) {
       const long long i = c * CH + e;
       const float nz = noise != nullptr ? noise[i] : (stochastic ? q_hash_noise(key, (unsigned long long)i) : 0.f);
-      f[e] = q_snap(f[e], zp, scale, qmax, nz);
+      f[e] = Y8 ? q_level(f[e], zp, scale, qmax, nz) : q_snap(f[e], zp, scale, qmax, nz);
     }
-    cn_st16((char*)y + c * 16, Chunk<T>::pack(f));
+    if (Y8) q_st_levels<T>(y8, c, f);      // (8-bit LEVELS: the consumer de-quantises on load, q_unpack_raw)
+    else cn_st16((char*)y + c * 16, Chunk<T>::pack(f));
   };
   const long long stride = (long long)gridDim.x * Q_NT;
   long long c = (long long)blockIdx.x * Q_NT + threadIdx.x;
@@ -260,20 +323,28 @@ static unsigned q_grid(long long work_items) {
 // generator keyed by (seed, element index) when stochastic != 0, else none (deterministic rounding).
 static int quantize_impl(const void* x, void* y, long long n, int dtype, const float* zero_point, const float* range,
                          int num_bits, const float* noise, int stochastic, unsigned long long seed,
-                         const unsigned long long* step, void* stream_) {
+                         const unsigned long long* step, void* stream_, unsigned char* y8 = nullptr) {
   if (n <= 0) return CN_OK;
-  if (x == nullptr || y == nullptr || zero_point == nullptr || range == nullptr || num_bits < 1 || num_bits > 23) { cn_set_error("quantize: bad arguments"); return CN_EINVAL; }
-  if (((uintptr_t)x & 15) != 0 || ((uintptr_t)y & 15) != 0) { cn_set_error("quantize: buffers must be 16-byte aligned"); return CN_EINVAL; }
+  if (x == nullptr || (y == nullptr && y8 == nullptr) || zero_point == nullptr || range == nullptr || num_bits < 1 || num_bits > 23) { cn_set_error("quantize: bad arguments"); return CN_EINVAL; }
+  if (((uintptr_t)x & 15) != 0 || ((uintptr_t)y & 15) != 0 || ((uintptr_t)y8 & 7) != 0) { cn_set_error("quantize: buffers must be 16-byte aligned"); return CN_EINVAL; }
+  if (y8 != nullptr && (num_bits > 8 || n % (dtype == CN_F32 ? 4 : 8) != 0)) { cn_set_error("quantize_levels: <= 8 bits, whole chunks"); return CN_EINVAL; }
   hipStream_t stream = (hipStream_t)stream_;
   const float qmax = (float)((1 << num_bits) - 1);
-  if (dtype == CN_BF16)
-    CN_LAUNCH(quantize_kernel<bf16_t>, dim3(q_grid((n + 7) / 8)), dim3(Q_NT), stream, (const bf16_t*)x, (bf16_t*)y, n,
-              zero_point, range, qmax, noise, stochastic, seed, step);
-  else if (dtype == CN_F32)
-    CN_LAUNCH(quantize_kernel<float>, dim3(q_grid((n + 3) / 4)), dim3(Q_NT), stream, (const float*)x, (float*)y, n,
-              zero_point, range, qmax, noise, stochastic, seed, step);
+#define QK(T, Y8, CHN) CN_LAUNCH((quantize_kernel<T, Y8>), dim3(q_grid((n + CHN - 1) / CHN)), dim3(Q_NT), stream, (const T*)x, (T*)y, n, \
+                                zero_point, range, qmax, noise, stochastic, seed, step, y8)
+  if (dtype == CN_BF16) { if (y8 != nullptr) QK(bf16_t, true, 8); else QK(bf16_t, false, 8); }
+  else if (dtype == CN_F32) { if (y8 != nullptr) QK(float, true, 4); else QK(float, false, 4); }
+#undef QK
   else { cn_set_error("quantize: bad dtype %d", dtype); return CN_EINVAL; }
   return cn_check_launch("quantize");
+}
+// cn_quantize_s storing the 8-bit LEVELS (one byte per element, element order kept) instead of the snapped values: the
+// consumer de-quantises on load with the same (zero_point, range) - cn_rangebn_bwd_q8.  value = T(level * scale + zp).
+extern "C" int cn_quantize_levels(const void* x, unsigned char* y8, long long n, int dtype, const float* zero_point,
+                                  const float* range, int num_bits, const float* noise, int stochastic,
+                                  unsigned long long seed, const unsigned long long* step_counter, void* stream_) {
+  if (y8 == nullptr) { cn_set_error("quantize_levels: null output"); return CN_EINVAL; }
+  return quantize_impl(x, nullptr, n, dtype, zero_point, range, num_bits, noise, stochastic, seed, step_counter, stream_, y8);
 }
 extern "C" int cn_quantize(const void* x, void* y, long long n, int dtype, const float* zero_point, const float* range,
                            int num_bits, const float* noise, int stochastic, unsigned long long seed, void* stream_) {
@@ -318,6 +389,32 @@ extern "C" int cn_quantize_rows(const float* x, float* y, int rows, int row_len,
   return cn_check_launch("quantize_rows");
 }
 
+// The same for EVERY filter of a model in one launch (round 6: 54 launches of the kernel above + 54 single-layer
+// weight preparations per ResNet-50 step became one launch + the arena's two): x / y are the flat fp32 parameter arena and
+// its quantised shadow, rowtab holds {element offset, row length, 2^bits - 1} per output channel of every layer.
+__global__ __launch_bounds__(Q_NT) void quantize_rows_multi_kernel(const float* x, float* y, const long long* rowtab) {
+  __shared__ float red[8];
+  const int tid = threadIdx.x;
+  const long long off = rowtab[3 * (size_t)blockIdx.x];
+  const int row_len = (int)rowtab[3 * (size_t)blockIdx.x + 1];
+  const float qmax = (float)rowtab[3 * (size_t)blockIdx.x + 2];
+  const float* row = x + off;
+  float mn = INFINITY, mx = -INFINITY;
+  for (int e = tid; e < row_len; e += Q_NT) { mn = fminf(mn, row[e]); mx = fmaxf(mx, row[e]); }
+  q_block_minmax(mn, mx, red);
+  float range = mx - mn;
+  if (range == 0.f) range = 1.f;
+  const float scale = range / qmax;
+  for (int e = tid; e < row_len; e += Q_NT) y[off + e] = q_snap(row[e], mn, scale, qmax, 0.f);
+}
+
+extern "C" int cn_quantize_rows_multi(const float* x, float* y, const long long* rowtab, int rows, void* stream) {
+  if (rows <= 0) return CN_OK;
+  if (x == nullptr || y == nullptr || rowtab == nullptr) { cn_set_error("quantize_rows_multi: bad arguments"); return CN_EINVAL; }
+  CN_LAUNCH(quantize_rows_multi_kernel, dim3((unsigned)rows), dim3(Q_NT), (hipStream_t)stream, x, y, rowtab);
+  return cn_check_launch("quantize_rows_multi");
+}
+
 // Input quantiser folded into RangeBN's STATISTICS pass (round 4): RangeBN's QuantMeasure (quantize.py:270,308) snaps its
 // input to the 8-bit grid before anything else; with xqp = [zero_point, range] (cn_qparams' output) rangebn_stats_kernel
 // reads the RAW convolution output, snaps each element on load - quantize_kernel's arithmetic, rounded to T - takes its
@@ -357,9 +454,10 @@ struct RbnPartial {   // one per (chunk, slice, channel)
   int imx, imn;
 };
 
-template <typename T>
+template <typename T, bool Q8OUT>
 __global__ __launch_bounds__(Q_NT) void rangebn_stats_kernel(const T* x, int M, int C, int chunks, int sub, int cols,
-                                                            RbnPartial* part, const float* xqp, float qmax, T* qx_out) {
+                                                            RbnPartial* part, const float* xqp, float qmax, T* qx_out,
+                                                            unsigned char* q8_out) {
   constexpr int CH = ElemTraits<T>::kChunk;
   __shared__ float s_mx[Q_NT * CH], s_mn[Q_NT * CH], s_sum[Q_NT * CH];
   __shared__ int s_imx[Q_NT * CH], s_imn[Q_NT * CH];
@@ -384,8 +482,18 @@ __global__ __launch_bounds__(Q_NT) void rangebn_stats_kernel(const T* x, int M, 
     auto visit = [&](const u32x4& v, int p) {
       float f[CH];
       Chunk<T>::unpack(v, f);
-      rbn_snap_chunk<T>(snap, f);
-      if (qx_out != nullptr) cn_st16((char*)qx_out + ((size_t)p * CC + cc) * 16, Chunk<T>::pack(f));   // (every element is visited once)
+      if (Q8OUT) {        // the snapped input kept as 8-bit levels; the statistics see the values a load gives back
+        float lv[CH];
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+          lv[e] = q_level(f[e], snap.zp, snap.scale, snap.qmax, 0.f);
+          f[e] = q_round_to<T>(q_dequant(lv[e], snap.zp, snap.scale));
+        }
+        q_st_levels<T>(q8_out, (long long)p * CC + cc, lv);
+      } else {
+        rbn_snap_chunk<T>(snap, f);
+        if (qx_out != nullptr) cn_st16((char*)qx_out + ((size_t)p * CC + cc) * 16, Chunk<T>::pack(f));   // (every element is visited once)
+      }
 #pragma unroll
       for (int e = 0; e < CH; ++e) {
         if (f[e] > mx[e]) { mx[e] = f[e]; imx[e] = p; }
@@ -542,12 +650,13 @@ __global__ __launch_bounds__(Q_NT) void rangebn_infer_stats_kernel(const float* 
 // Grid (blocks per row, rows): `rows` consecutive equal parts of the nch chunks (the samples of the batch; 1 = the whole
 // tensor).  mm_partial (optional): [rows][gridDim.x][2] = {min, max} of the values AS STORED per block - the per-sample
 // extremes the next activation quantiser needs (QuantMeasure, quantize.py:158-182), so its min / max pass over z disappears.
-template <typename T>
+template <typename T, bool X8>
 __global__ __launch_bounds__(Q_NT) void rangebn_apply_kernel(const T* x, const T* residual, T* z, const float* stats,
                                                             const float* weight, const float* bias, long long nch,
-                                                            int C, int relu, float* mm_partial) {
+                                                            int C, int relu, float* mm_partial, const float* x8qp, float x8qmax) {
   constexpr int CH = ElemTraits<T>::kChunk;
   __shared__ float red[8];
+  const QOp xop = q_op_make(x8qp, x8qmax);      // x8qp != nullptr: x holds 8-bit levels of that grid
   const int CC = C / CH;
   const long long rch = nch / gridDim.y;                       // chunks per row (a multiple of CC)
   const long long row0 = (long long)blockIdx.y * rch, row1 = row0 + rch;
@@ -565,7 +674,7 @@ __global__ __launch_bounds__(Q_NT) void rangebn_apply_kernel(const T* x, const T
   };
   auto apply = [&](const u32x4& vx, const u32x4& vr, long long id) {
     float f[CH], r[CH];
-    Chunk<T>::unpack(vx, f);
+    q_unpack_raw<T, X8>(vx, xop, f);
     if (residual != nullptr) Chunk<T>::unpack(vr, r);
 #pragma unroll
     for (int e = 0; e < CH; ++e) {
@@ -586,7 +695,7 @@ __global__ __launch_bounds__(Q_NT) void rangebn_apply_kernel(const T* x, const T
   if (id < row1) load_coef(id);
   if (fixed_col) {
     for (; id + stride < row1; id += 2 * stride) {   // two (four with a residual) loads in flight
-      const u32x4 v0 = cn_ld16((const char*)x + id * 16), v1 = cn_ld16((const char*)x + (id + stride) * 16);
+      const u32x4 v0 = q_ld_raw<T, X8>(x, id), v1 = q_ld_raw<T, X8>(x, id + stride);
       u32x4 r0 = cn_zero16(), r1 = cn_zero16();
       if (residual != nullptr) { r0 = cn_ld16((const char*)residual + id * 16); r1 = cn_ld16((const char*)residual + (id + stride) * 16); }
       apply(v0, r0, id);
@@ -595,7 +704,7 @@ __global__ __launch_bounds__(Q_NT) void rangebn_apply_kernel(const T* x, const T
   }
   for (; id < row1; id += stride) {
     if (!fixed_col) load_coef(id);
-    apply(cn_ld16((const char*)x + id * 16), residual != nullptr ? cn_ld16((const char*)residual + id * 16) : cn_zero16(), id);
+    apply(q_ld_raw<T, X8>(x, id), residual != nullptr ? cn_ld16((const char*)residual + id * 16) : cn_zero16(), id);
   }
   if (mm_partial != nullptr) {
     q_block_minmax(mn, mx, red);
@@ -653,7 +762,11 @@ static int rangebn_fwd_impl(const void* x, const void* residual, void* z, const 
                               float* running_mean, float* running_var, float momentum, float eps, int chunks,
                               float scale_fix, float* stats, int* arg, int M, int C, int relu, int training, int dtype,
                               float* ws, size_t ws_bytes, void* stream_, const float* xqp, int x_bits, void* qx_out,
-                              int mm_rows, float* z_minmax) {
+                              int mm_rows, float* z_minmax, unsigned char* qx8_out = nullptr) {
+  // qx8_out (with xqp): the snapped input is kept as 8-bit LEVELS there instead of values in qx_out; the apply pass
+  // de-quantises them on load (same numbers; 1 byte instead of 2 / 4 per element written once and read twice)
+  if (qx8_out != nullptr && (xqp == nullptr || x_bits > 8 || !training)) { cn_set_error("rangebn_fwd: 8-bit level storage needs the folded <= 8-bit input quantiser"); return CN_EINVAL; }
+  if (qx8_out != nullptr) qx_out = qx8_out;     // (non-null marker for the checks below; never written as values)
   const float qmax = (float)((1 << (x_bits > 0 ? x_bits : 8)) - 1);
   hipStream_t stream = (hipStream_t)stream_;
   const int CH = dtype == CN_BF16 ? 8 : 4;
@@ -669,10 +782,10 @@ static int rangebn_fwd_impl(const void* x, const void* residual, void* z, const 
     if (ws == nullptr || ws_bytes < cn_rangebn_workspace(M, C, chunks)) { cn_set_error("rangebn_fwd: workspace too small"); return CN_EWORKSPACE; }
     const int sub = rbn_sub(M, chunks), cols = rbn_cols(CC);
     dim3 grid((unsigned)((CC + cols - 1) / cols), (unsigned)(chunks * sub));
-    if (dtype == CN_BF16)
-      CN_LAUNCH(rangebn_stats_kernel<bf16_t>, grid, dim3(Q_NT), stream, (const bf16_t*)x, M, C, chunks, sub, cols, (RbnPartial*)ws, xqp, qmax, (bf16_t*)qx_out);
-    else
-      CN_LAUNCH(rangebn_stats_kernel<float>, grid, dim3(Q_NT), stream, (const float*)x, M, C, chunks, sub, cols, (RbnPartial*)ws, xqp, qmax, (float*)qx_out);
+#define RSK(T, Q8) CN_LAUNCH((rangebn_stats_kernel<T, Q8>), grid, dim3(Q_NT), stream, (const T*)x, M, C, chunks, sub, cols, (RbnPartial*)ws, xqp, qmax, (T*)qx_out, qx8_out)
+    if (dtype == CN_BF16) { if (qx8_out != nullptr) RSK(bf16_t, true); else RSK(bf16_t, false); }
+    else { if (qx8_out != nullptr) RSK(float, true); else RSK(float, false); }
+#undef RSK
     if (2 * chunks <= RF_T)
       CN_LAUNCH(rangebn_finalize_par_kernel, dim3((unsigned)((C + RF_C - 1) / RF_C)), dim3(RF_C * RF_T), stream, (const RbnPartial*)ws, M,
               C, chunks, sub, scale_fix, eps, momentum, running_mean, running_var, stats, arg);
@@ -693,12 +806,11 @@ static int rangebn_fwd_impl(const void* x, const void* residual, void* z, const 
     if (ws == nullptr || ws_bytes < (size_t)rows * bpr * 2 * sizeof(float)) { cn_set_error("rangebn_fwd: workspace too small for the min / max partials"); return CN_EWORKSPACE; }
     mmp = ws;
   }
-  if (dtype == CN_BF16)
-    CN_LAUNCH(rangebn_apply_kernel<bf16_t>, dim3(bpr, (unsigned)rows), dim3(Q_NT), stream, (const bf16_t*)xa, (const bf16_t*)residual,
-              (bf16_t*)z, (const float*)stats, weight, bias, nch, C, relu, mmp);
-  else
-    CN_LAUNCH(rangebn_apply_kernel<float>, dim3(bpr, (unsigned)rows), dim3(Q_NT), stream, (const float*)xa, (const float*)residual,
-              (float*)z, (const float*)stats, weight, bias, nch, C, relu, mmp);
+#define RAK(T, X8) CN_LAUNCH((rangebn_apply_kernel<T, X8>), dim3(bpr, (unsigned)rows), dim3(Q_NT), stream, (const T*)xa, (const T*)residual, \
+                             (T*)z, (const float*)stats, weight, bias, nch, C, relu, mmp, X8 ? xqp : (const float*)nullptr, qmax)
+  if (dtype == CN_BF16) { if (qx8_out != nullptr) RAK(bf16_t, true); else RAK(bf16_t, false); }
+  else { if (qx8_out != nullptr) RAK(float, true); else RAK(float, false); }
+#undef RAK
   if (z_minmax != nullptr)
     CN_LAUNCH(minmax_final_kernel, dim3((unsigned)((rows + Q_NT - 1) / Q_NT)), dim3(Q_NT), stream, (const float*)mmp, rows, (int)bpr, z_minmax);
   return cn_check_launch("rangebn_fwd");
@@ -726,16 +838,30 @@ extern "C" int cn_rangebn_fwd_q(const void* x, const float* x_qparams, int x_bit
                           arg, M, C, relu, 1, dtype, ws, ws_bytes, stream_, x_qparams, x_bits, qx_out, mm_rows, z_minmax);
 }
 
+// cn_rangebn_fwd_q with the snapped input kept as 8-bit LEVELS (qx8_out: one byte per element) instead of values: the same
+// z / stats / arg / z_minmax bits; the backward pass takes the levels and x_qparams (cn_rangebn_bwd_q8).  x_bits <= 8.
+extern "C" int cn_rangebn_fwd_q8(const void* x, const float* x_qparams, int x_bits, unsigned char* qx8_out, void* z,
+                                 const float* weight, const float* bias, float* running_mean, float* running_var,
+                                 float momentum, float eps, int chunks, float scale_fix, float* stats, int* arg, int M,
+                                 int C, int relu, int dtype, int mm_rows, float* z_minmax, float* ws, size_t ws_bytes,
+                                 void* stream_) {
+  if (x_qparams == nullptr || x_bits < 1 || x_bits > 8 || qx8_out == nullptr) { cn_set_error("rangebn_fwd_q8: needs the <= 8-bit input quantiser's parameters and qx8_out"); return CN_EINVAL; }
+  return rangebn_fwd_impl(x, nullptr, z, weight, bias, running_mean, running_var, momentum, eps, chunks, scale_fix, stats,
+                          arg, M, C, relu, 1, dtype, ws, ws_bytes, stream_, x_qparams, x_bits, nullptr, mm_rows, z_minmax, qx8_out);
+}
+
 // ---- backward.  g = the (already quantised) gradient of the RangeBN output, x = its quantised input.
 //   S1 = sum g, S2 = sum g * (x - mean), r = 1 / (scale + eps):
 //   dbias += S1;  dweight += r * S2;  dx = g * (w r) - (w r) S1 / M
 //   dL/dscale = -w r^2 S2 reaches x through the chunk maxima / minima: scale = fix/chunks * sum_j (max_j - min_j)
 //   => dx[first argmax of chunk j] += dL/dscale * fix / chunks,  dx[first argmin of chunk j] -= the same.
-template <typename T>
+template <typename T, bool G8, bool X8>
 __global__ __launch_bounds__(Q_NT) void rangebn_bwd_reduce_kernel(const T* g, const T* x, const float* stats, int M, int C,
-                                                                 int rows_per, int cols, float* partial) {
+                                                                 int rows_per, int cols, float* partial, const float* g8qp,
+                                                                 float g8qmax, const float* x8qp, float x8qmax) {
   constexpr int CH = ElemTraits<T>::kChunk;
   __shared__ float s1[Q_NT * CH], s2[Q_NT * CH];
+  const QOp gop = q_op_make(g8qp, g8qmax), xop = q_op_make(x8qp, x8qmax);   // operands stored as 8-bit levels (or values)
   const int tid = threadIdx.x, CC = C / CH;
   const int lanes = Q_NT / cols, col = tid % cols, lane = tid / cols;
   const int cc = blockIdx.x * cols + col;
@@ -747,8 +873,8 @@ __global__ __launch_bounds__(Q_NT) void rangebn_bwd_reduce_kernel(const T* g, co
   if (cc < CC) {
     auto visit = [&](const u32x4& vg, const u32x4& vx) {
       float fg[CH], fx[CH];
-      Chunk<T>::unpack(vg, fg);
-      Chunk<T>::unpack(vx, fx);
+      q_unpack_raw<T, G8>(vg, gop, fg);
+      q_unpack_raw<T, X8>(vx, xop, fx);
 #pragma unroll
       for (int e = 0; e < CH; ++e) { a1[e] += fg[e]; a2[e] += fg[e] * (fx[e] - mean[e]); }
     };
@@ -757,14 +883,14 @@ __global__ __launch_bounds__(Q_NT) void rangebn_bwd_reduce_kernel(const T* g, co
       u32x4 vg[4], vx[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        vg[u] = cn_ld16((const char*)g + ((size_t)(p + u * lanes) * CC + cc) * 16);
-        vx[u] = cn_ld16((const char*)x + ((size_t)(p + u * lanes) * CC + cc) * 16);
+        vg[u] = q_ld_raw<T, G8>(g, (long long)(p + u * lanes) * CC + cc);
+        vx[u] = q_ld_raw<T, X8>(x, (long long)(p + u * lanes) * CC + cc);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) visit(vg[u], vx[u]);
     }
     for (; p < p1; p += lanes)
-      visit(cn_ld16((const char*)g + ((size_t)p * CC + cc) * 16), cn_ld16((const char*)x + ((size_t)p * CC + cc) * 16));
+      visit(q_ld_raw<T, G8>(g, (long long)p * CC + cc), q_ld_raw<T, X8>(x, (long long)p * CC + cc));
   }
 #pragma unroll
   for (int e = 0; e < CH; ++e) { s1[tid * CH + e] = a1[e]; s2[tid * CH + e] = a2[e]; }
@@ -827,11 +953,13 @@ __global__ __launch_bounds__(RF_C * RF_T) void rangebn_bwd_finalize_kernel(const
 // arg == nullptr: no routing here (rangebn_bwd_route_kernel follows).  Grid (blocks per row, rows) and mm_partial as
 // rangebn_apply_kernel: per-sample {min, max} of the FINAL dx for the gradient quantiser of the convolution in front
 // (UniformQuantizeGrad, quantize.py:101-112), so its min / max pass over dx disappears.
-template <typename T>
+template <typename T, bool G8>
 __global__ __launch_bounds__(Q_NT) void rangebn_bwd_apply_kernel(const T* g, T* dx, const float* coef, long long nch, int C,
-                                                                const int* arg, int chunks, int L, float* mm_partial) {
+                                                                const int* arg, int chunks, int L, float* mm_partial,
+                                                                const float* g8qp, float g8qmax) {
   constexpr int CH = ElemTraits<T>::kChunk;
   __shared__ float red[8];
+  const QOp gop = q_op_make(g8qp, g8qmax);
   const int CC = C / CH;
   const long long rch = nch / gridDim.y;
   const long long row0 = (long long)blockIdx.y * rch, row1 = row0 + rch;
@@ -852,7 +980,7 @@ __global__ __launch_bounds__(Q_NT) void rangebn_bwd_apply_kernel(const T* g, T* 
   // (m = pixel of chunk `id`, carried by the caller: no 64-bit division per element)
   auto apply = [&](const u32x4& v, long long id, int m) {
     float f[CH];
-    Chunk<T>::unpack(v, f);
+    q_unpack_raw<T, G8>(v, gop, f);
 #pragma unroll
     for (int e = 0; e < CH; ++e) f[e] = f[e] * a[e] + b[e];
     u32x4 o = Chunk<T>::pack(f);
@@ -899,15 +1027,15 @@ __global__ __launch_bounds__(Q_NT) void rangebn_bwd_apply_kernel(const T* g, T* 
   if (id < row1) { load_coef(id); m = (int)(id / CC); }
   if (fixed_col) {
     for (; id + stride < row1; id += 2 * stride, m += 2 * dm) {
-      const u32x4 v0 = cn_ld16((const char*)g + id * 16), v1 = cn_ld16((const char*)g + (id + stride) * 16);
+      const u32x4 v0 = q_ld_raw<T, G8>(g, id), v1 = q_ld_raw<T, G8>(g, id + stride);
       apply(v0, id, m);
       apply(v1, id + stride, m + dm);
     }
-    for (; id < row1; id += stride, m += dm) apply(cn_ld16((const char*)g + id * 16), id, m);
+    for (; id < row1; id += stride, m += dm) apply(q_ld_raw<T, G8>(g, id), id, m);
   } else {
     for (; id < row1; id += stride) {
       load_coef(id);
-      apply(cn_ld16((const char*)g + id * 16), id, (int)(id / CC));
+      apply(q_ld_raw<T, G8>(g, id), id, (int)(id / CC));
     }
   }
   if (mm_partial != nullptr) {
@@ -945,7 +1073,12 @@ __global__ __launch_bounds__(Q_NT) void rangebn_bwd_route_kernel(T* dx, const fl
 // of it (3 launches); else apply + routing pass (4 launches).  Same dx bits.
 static int rangebn_bwd_impl(const void* g, const void* x, const float* weight, const float* stats, const int* arg,
                               void* dx, float* dweight, float* dbias, int M, int C, int chunks, float scale_fix,
-                              int dtype, float* ws, size_t ws_bytes, void* stream_, int mm_rows, float* dx_minmax) {
+                              int dtype, float* ws, size_t ws_bytes, void* stream_, int mm_rows, float* dx_minmax,
+                              const float* g8qp = nullptr, int g_bits = 8, const float* x8qp = nullptr, int x_bits = 8) {
+  // g8qp / x8qp: that operand holds 8-bit LEVELS of the grid (zero point, range) = g8qp[0..1] / x8qp[0..1] (cn_quantize_levels,
+  // cn_rangebn_fwd_q8) instead of values
+  if ((g8qp != nullptr && (g_bits < 1 || g_bits > 8)) || (x8qp != nullptr && (x_bits < 1 || x_bits > 8))) { cn_set_error("rangebn_bwd: level operands have <= 8 bits"); return CN_EINVAL; }
+  const float gqmax = (float)((1 << g_bits) - 1), xqmax = (float)((1 << x_bits) - 1);
   hipStream_t stream = (hipStream_t)stream_;
   const int CH = dtype == CN_BF16 ? 8 : 4;
   if (dtype != CN_BF16 && dtype != CN_F32) { cn_set_error("rangebn_bwd: bad dtype"); return CN_EINVAL; }
@@ -974,17 +1107,20 @@ static int rangebn_bwd_impl(const void* g, const void* x, const float* weight, c
   }
   const dim3 agrid(bpr, (unsigned)arows);
   const int L = M / chunks;
+  const bool g8 = g8qp != nullptr, x8 = x8qp != nullptr;
+#define RBW(T, G8, X8)                                                                                                                  \
+  do {                                                                                                                                  \
+    CN_LAUNCH((rangebn_bwd_reduce_kernel<T, G8, X8>), grid, dim3(Q_NT), stream, (const T*)g, (const T*)x, stats, M, C, rpr, cols, partial, g8qp, gqmax, x8qp, xqmax); \
+    CN_LAUNCH(rangebn_bwd_finalize_kernel, dim3((unsigned)((C + RF_C - 1) / RF_C)), dim3(RF_C * RF_T), stream, (const float*)partial, rows, M, C, weight, stats, route, dweight, dbias, coef); \
+    CN_LAUNCH((rangebn_bwd_apply_kernel<T, G8>), agrid, dim3(Q_NT), stream, (const T*)g, (T*)dx, (const float*)coef, nch, C, fused ? arg : (const int*)nullptr, chunks, L, mmp, g8qp, gqmax); \
+    if (!fused) CN_LAUNCH(rangebn_bwd_route_kernel<T>, dim3((unsigned)((C * chunks + Q_NT - 1) / Q_NT)), dim3(Q_NT), stream, (T*)dx, (const float*)coef, arg, C, chunks); \
+  } while (0)
   if (dtype == CN_BF16) {
-    CN_LAUNCH(rangebn_bwd_reduce_kernel<bf16_t>, grid, dim3(Q_NT), stream, (const bf16_t*)g, (const bf16_t*)x, stats, M, C, rpr, cols, partial);
-    CN_LAUNCH(rangebn_bwd_finalize_kernel, dim3((unsigned)((C + RF_C - 1) / RF_C)), dim3(RF_C * RF_T), stream, (const float*)partial, rows, M, C, weight, stats, route, dweight, dbias, coef);
-    CN_LAUNCH(rangebn_bwd_apply_kernel<bf16_t>, agrid, dim3(Q_NT), stream, (const bf16_t*)g, (bf16_t*)dx, (const float*)coef, nch, C, fused ? arg : (const int*)nullptr, chunks, L, mmp);
-    if (!fused) CN_LAUNCH(rangebn_bwd_route_kernel<bf16_t>, dim3((unsigned)((C * chunks + Q_NT - 1) / Q_NT)), dim3(Q_NT), stream, (bf16_t*)dx, (const float*)coef, arg, C, chunks);
+    if (g8 && x8) RBW(bf16_t, true, true); else if (g8) RBW(bf16_t, true, false); else if (x8) RBW(bf16_t, false, true); else RBW(bf16_t, false, false);
   } else {
-    CN_LAUNCH(rangebn_bwd_reduce_kernel<float>, grid, dim3(Q_NT), stream, (const float*)g, (const float*)x, stats, M, C, rpr, cols, partial);
-    CN_LAUNCH(rangebn_bwd_finalize_kernel, dim3((unsigned)((C + RF_C - 1) / RF_C)), dim3(RF_C * RF_T), stream, (const float*)partial, rows, M, C, weight, stats, route, dweight, dbias, coef);
-    CN_LAUNCH(rangebn_bwd_apply_kernel<float>, agrid, dim3(Q_NT), stream, (const float*)g, (float*)dx, (const float*)coef, nch, C, fused ? arg : (const int*)nullptr, chunks, L, mmp);
-    if (!fused) CN_LAUNCH(rangebn_bwd_route_kernel<float>, dim3((unsigned)((C * chunks + Q_NT - 1) / Q_NT)), dim3(Q_NT), stream, (float*)dx, (const float*)coef, arg, C, chunks);
+    if (g8 && x8) RBW(float, true, true); else if (g8) RBW(float, true, false); else if (x8) RBW(float, false, true); else RBW(float, false, false);
   }
+#undef RBW
   if (fused)
     CN_LAUNCH(minmax_final_kernel, dim3((unsigned)((arows + Q_NT - 1) / Q_NT)), dim3(Q_NT), stream, (const float*)mmp, arows, (int)bpr, dx_minmax);
   return cn_check_launch("rangebn_bwd");
@@ -1004,6 +1140,18 @@ extern "C" int cn_rangebn_bwd_mm(const void* g, const void* x, const float* weig
   if (dx_minmax == nullptr) { cn_set_error("rangebn_bwd_mm: needs dx_minmax"); return CN_EINVAL; }
   return rangebn_bwd_impl(g, x, weight, stats, arg, dx, dweight, dbias, M, C, chunks, scale_fix, dtype, ws, ws_bytes, stream_,
                           mm_rows, dx_minmax);
+}
+
+// cn_rangebn_bwd_mm on operands stored as 8-bit LEVELS: g (the quantised output gradient: cn_quantize_levels with
+// g_qparams, g_bits) and / or x (the snapped input: cn_rangebn_fwd_q8 with x_qparams, x_bits); a null qparams pointer
+// means that operand holds values as before.  Same dx, dweight, dbias, dx_minmax bits as on the stored values.
+extern "C" int cn_rangebn_bwd_q8(const void* g, const float* g_qparams, int g_bits, const void* x, const float* x_qparams,
+                                 int x_bits, const float* weight, const float* stats, const int* arg, void* dx,
+                                 float* dweight, float* dbias, int M, int C, int chunks, float scale_fix, int dtype,
+                                 int mm_rows, float* dx_minmax, float* ws, size_t ws_bytes, void* stream_) {
+  if (dx_minmax == nullptr) { cn_set_error("rangebn_bwd_q8: needs dx_minmax"); return CN_EINVAL; }
+  return rangebn_bwd_impl(g, x, weight, stats, arg, dx, dweight, dbias, M, C, chunks, scale_fix, dtype, ws, ws_bytes, stream_,
+                          mm_rows, dx_minmax, g_qparams, g_bits, x_qparams, x_bits);
 }
 
 // ------------------------------------------------------------------------------------------------ elementwise + min / max

@@ -132,6 +132,19 @@ class ParamArena(object):
             start += n
             mods.append((mod, krsc_off, crsk_off, n))
         self.wbuf = torch.zeros(max(off, _ALIGN), dtype=dtype, device=self.device)
+        # config 5 (quant.QConv2d / QLinear: per-output-channel 8-bit filters, quantize.py:201-203): when EVERY filter
+        # of the model is a quantised operator's, one launch snaps all of them into a shadow of the arena and the
+        # compute-dtype copies below are made from the shadow (quant._quantize_filters then has nothing left to do)
+        self._qrows, self._qshadow = None, None
+        if mods and all(hasattr(m, 'num_bits_weight') for m, _, _, _ in mods) \
+                and len(mods) == sum(1 for s in self.slots if s.is_filter):
+            tab = []
+            for r, (m, _, _, _) in zip(rows, mods):
+                row_len = r[5] * r[6]
+                qmax = (1 << int(m.num_bits_weight)) - 1
+                tab.extend([r[0] + k * row_len, row_len, qmax] for k in range(r[4]))
+            self._qrows = torch.tensor(tab, dtype=torch.int64, device=self.device)
+            self._qshadow = torch.zeros(_round_up(self.n_filter, _ALIGN), dtype=torch.float32, device=self.device)
         # regular filters (no channel padding) go through the tiled, coalescing kernel; the few padded
         # ones (the 3 -> 8 channel stem) through the per-element kernel
         regular = [r for r in rows if r[6] == r[7]]
@@ -163,14 +176,19 @@ class ParamArena(object):
         from . import _lib
         L = _lib.load()
         code, st = _lib.dtype_code(self.wbuf.dtype), _lib.stream_of(self.params)
+        src = self.params if self._qrows is None else self._qshadow
 
         def run():
+            if self._qrows is not None:
+                _lib.check(L.cn_quantize_rows_multi(self.params.data_ptr(), self._qshadow.data_ptr(),
+                                                    self._qrows.data_ptr(), self._qrows.shape[0], st),
+                           'cn_quantize_rows_multi')
             if self._wdesc_reg is not None:
-                _lib.check(L.cn_weight_prep_tiled(self.params.data_ptr(), self.wbuf.data_ptr(),
+                _lib.check(L.cn_weight_prep_tiled(src.data_ptr(), self.wbuf.data_ptr(),
                                                   self._wdesc_reg.data_ptr(), self._wtiles.data_ptr(),
                                                   self._wtiles.shape[0], code, st), 'cn_weight_prep_tiled')
             if self._wdesc is not None:
-                _lib.check(L.cn_weight_prep_multi(self.params.data_ptr(), self.wbuf.data_ptr(),
+                _lib.check(L.cn_weight_prep_multi(src.data_ptr(), self.wbuf.data_ptr(),
                                                   self._wdesc.data_ptr(), self._wdesc.shape[0], self._wtotal, code,
                                                   st), 'cn_weight_prep_multi')
         ops.PROFILER.run('weight_prep', 2, 0.0, float(self._wbytes), run, self.device)

@@ -85,8 +85,15 @@ class ResidualBlock(tnn.Module):
             self.dropout = cnn.Dropout(0)
         self.stride = stride
         self.expansion = expansion
-        if self.quantized:   # plain operator chain: no cross-operator fusion in the simulated-8-bit model
-            self._holder = None
+        if self.quantized:   # the reference's operator chain; what is shared / fused is listed in quant.py
+            # the two gradients meeting at the block input are summed in the later data gradient's epilogue
+            # (quant.JUNCTION_ADD): conv1 + the identity shortcut's gradient (parked by quant.add_relu), or conv1 + the
+            # projection convolution
+            from ..ops import ResGradHolder
+            self._holder = ResGradHolder()
+            self.conv1._res_holder = self._holder
+            if downsample is not None:
+                downsample[0]._res_holder = self._holder
             if downsample is not None and hasattr(downsample[0], 'quantize_input'):
                 # conv1 and the projection read the same block input: one min / max + quantise pass for both
                 self.conv1.__dict__['share_q_out'] = True
@@ -138,7 +145,7 @@ class ResidualBlock(tnn.Module):
             if self.downsample is not None:
                 residual = self.downsample[1](self.downsample[0](xb))
             from ..quant import add_relu
-            return add_relu(out, residual)
+            return add_relu(out, residual, self._holder if self.downsample is None else None)
         if self.downsample is not None:
             ds_conv, ds_bn = self.downsample[0], self.downsample[1]
             from .. import ops

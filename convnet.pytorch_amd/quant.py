@@ -42,6 +42,14 @@ from ._lib import check, dtype_code, ptr, stream_of
 #    routing folded in (-> the convolution's gradient quantiser), the ReLU-mask pass (-> RangeBN's gradient quantiser).
 #    The quantisers find them in a stash and skip their own min / max pass over the tensor.
 FUSE_QUANT = flags.on('quant_fuse')
+# the block-input gradient sum folded into the later data gradient's epilogue (QConv2dFunction.backward)
+JUNCTION_ADD = flags.on('quant_junction_add')
+# QConv2d's weight gradients on the side stream (0: on the chain, as through round 5)
+WGRAD_SIDE = flags.on('quant_wgrad_side')
+# 8-bit LEVEL storage (round 6): RangeBN's snapped input (saved for its backward pass) and the quantised gradient its
+# backward kernels read are kept as one byte per element and de-quantised on load - bit-identical to storing the snapped
+# values, 6 of the 16 bytes per element RangeBN's passes move.  0: values in the compute dtype, as through round 5.
+STORE8 = flags.on('quant_store8')
 
 # produced tensor -> its per-sample min / max ([rows][2] floats), keyed by storage address; the entry holds the tensor, so
 # the address cannot be recycled while it lives; `uses` consumers may take it, tick() (next forward) drops the rest
@@ -170,12 +178,30 @@ def _noise_like(g):
     return _NOISE_SOURCE(tuple(g.shape)).to(device=g.device, dtype=torch.float32).contiguous()
 
 
-def quantize_grad(g, num_bits=8):
-    """UniformQuantizeGrad.backward (quantize.py:101-112): global min / max, stochastic rounding."""
+def quantize_grad(g, num_bits=8, levels=False):
+    """UniformQuantizeGrad.backward (quantize.py:101-112): global min / max, stochastic rounding.
+    levels: return (uint8 levels, [zero_point, range]) instead of the snapped values (STORE8: the consumer - RangeBN's
+    backward kernels - de-quantises on load; one byte per element written and read instead of two)."""
     g = g.contiguous()
     rows = g.shape[0]
     qp = qparams(minmax_rows(g, rows), rows, 1)
-    return quantize(g, qp[0:1], qp[1:2], num_bits, noise=_noise_like(g), stochastic=True)
+    if not levels:
+        return quantize(g, qp[0:1], qp[1:2], num_bits, noise=_noise_like(g), stochastic=True)
+    noise = _noise_like(g)
+    y8 = torch.empty(g.shape, dtype=torch.uint8, device=g.device)
+    seed = _next_seed() if noise is None else 0
+    step = _step_counter(g.device) if noise is None else None
+    ops.PROFILER.run('quant: quantize (8-bit levels out)', 1, 0.0, g.numel() * (g.element_size() + 1),
+                     lambda: check(_L().cn_quantize_levels(ptr(g), ptr(y8), g.numel(), dtype_code(g.dtype), ptr(qp[0:1]),
+                                                           ptr(qp[1:2]), num_bits, ptr(noise), 1, seed, ptr(step), stream_of(g)),
+                                   'cn_quantize_levels'), g.device)
+    return y8, qp
+
+
+def _store8_ok(t, bits):
+    """8-bit level storage applies: flag on, <= 8 bits, whole 16-byte chunks of a 16 / 32-bit float tensor."""
+    return (STORE8 and bits <= 8 and t.dtype in (torch.bfloat16, torch.float32)
+            and t.numel() % _lib.chunk_elems(t.dtype) == 0)
 
 
 class QuantMeasure(tnn.Module):
@@ -224,6 +250,8 @@ class QuantMeasure(tnn.Module):
 def _quantize_filters(mod, num_bits):
     """Per-output-channel quantisation of the fp32 master filter into the compute-dtype KRSC / CRSK copies."""
     mod.ensure_prepared()
+    if getattr(mod._arena, '_qrows', None) is not None:
+        return      # every filter of the model was snapped and laid out by the arena's one refresh (engine.prepare_weights)
     K = mod.out_channels
     taps = mod.kernel_size[0] * mod.kernel_size[1]
     c_real = mod.in_channels
@@ -365,13 +393,36 @@ class QConv2dFunction(Function):
         mod = ctx.mod
         dy = dy.contiguous()
         R, S = mod.kernel_size
-        ops.conv2d_wgrad(qx, dy, mod.grad_view('weight'), mod.in_channels, mod.out_channels, R, S, mod.stride,
-                         mod.padding)
-        mod._notify_grad_ready()
+        # the weight gradient sees the full-precision dy (bi-precision, quantize.py:115-121) and nothing on the chain waits
+        # for it: it goes to the weight-gradient side stream like the float convolutions' (ops.SIDE; dy's producer is the
+        # last launch on the chain at this point, so the hand-off event waits for exactly that kernel), beside the
+        # gradient quantiser and the data gradient
+        if ops.SIDE.active(qx) and WGRAD_SIDE:
+            def launch():
+                ops.conv2d_wgrad(qx, dy, mod.grad_view('weight'), mod.in_channels, mod.out_channels, R, S, mod.stride,
+                                 mod.padding, tag='side')
+                return (qx, dy)
+            ops.SIDE.submit(qx.device, launch, mod._notify_grad_ready, None)
+        else:
+            ops.conv2d_wgrad(qx, dy, mod.grad_view('weight'), mod.in_channels, mod.out_channels, R, S, mod.stride,
+                             mod.padding)
+            mod._notify_grad_ready()
         dx = None
         if ctx.needs_input_grad[0]:   # (the stem never gets here: no noise is drawn for it, as in the reference)
             gq = quantize_grad(dy, mod.num_bits_grad)
-            dx = ops.conv2d_dgrad(gq, mod.w_crsk, qx.shape, mod.out_channels, R, S, mod.stride, mod.padding)
+            # The two gradients that meet at a block's input (conv1's and the shortcut's: models/resnet.py:154-163) are
+            # summed in the data gradient's epilogue of whichever of the two arrives second (ops.ResGradHolder, as in
+            # the float blocks) instead of a separate add pass over the block input: fp32 identical, 16-bit storage
+            # rounds the sum once instead of twice.
+            holder = getattr(mod, '_res_holder', None) if JUNCTION_ADD else None
+            addend = None
+            if holder is not None and holder.dres is not None and holder.sub == 1 and holder.dres.dtype == gq.dtype \
+                    and tuple(holder.dres.shape) == tuple(qx.shape):
+                addend, holder.fused = holder.dres, True
+            dx = ops.conv2d_dgrad(gq, mod.w_crsk, qx.shape, mod.out_channels, R, S, mod.stride, mod.padding,
+                                  addend=addend)
+            if holder is not None and addend is None:
+                holder.dres, holder.sub, holder.fused = dx, 1, False
         return dx, None, None, None
 
 
@@ -463,7 +514,9 @@ def _scale_fix(values_per_chunk):
 
 class RangeBNFunction(Function):
     @staticmethod
-    def forward(ctx, y, weight, bias, mod, relu):
+    def forward(ctx, y, weight, bias, mod, relu, train_graph=False):
+        # train_graph: the caller saw grad mode ON (torch.is_grad_enabled() is always False in here: autograd runs a
+        # Function's forward with grad mode off - round 4's forward-side min / max fusions tested it in here and never ran)
         N, H, W, C = y.shape
         M = N * H * W
         L = _L()
@@ -479,21 +532,33 @@ class RangeBNFunction(Function):
         if fused:     # the statistics pass snaps the raw convolution output on load and stores the snapped tensor
             y = y.contiguous()
             qp = mod.quantize_input.qparams_tensor(y)
-            qy = torch.empty_like(y)
+            store8 = _store8_ok(y, mod.quantize_input.num_bits) and _mm_ok(y)     # (_mm_ok: the fused backward pass will run)
+            qy = torch.empty(y.shape, dtype=torch.uint8, device=y.device) if store8 else torch.empty_like(y)
             z = torch.empty_like(y)
             # z feeds an activation quantiser when a ReLU follows (bn1 / bn2 of a block): its per-sample extremes come along
-            want_mm = relu and _mm_ok(z) and torch.is_grad_enabled()
+            want_mm = relu and _mm_ok(z) and train_graph
             zmm = torch.empty(N * 2, dtype=torch.float32, device=y.device) if want_mm else None
-            ops.PROFILER.run('quant: rangebn quantise+stats, finalize, apply%s' % ('+minmax' if want_mm else ''),
-                             4 if want_mm else 3, 0.0, 4 * y.numel() * y.element_size(),
-                             lambda: check(L.cn_rangebn_fwd_q(ptr(y), ptr(qp), mod.quantize_input.num_bits, ptr(qy), None,
-                                                              ptr(z), ptr(weight), ptr(bias), ptr(mod.running_mean),
-                                                              ptr(mod.running_var), mod.momentum, mod.eps, mod.num_chunks,
-                                                              fix, ptr(stats), ptr(arg), M, C, int(relu), code, N if want_mm else 0,
-                                                              ptr(zmm), ptr(ws), ws.numel() * 4, stream_of(y)),
-                                           'cn_rangebn_fwd_q'), y.device)
+            if store8:
+                ops.PROFILER.run('quant: rangebn quantise(8-bit levels)+stats, finalize, apply%s' % ('+minmax' if want_mm else ''),
+                                 4 if want_mm else 3, 0.0, y.numel() * (3 * y.element_size() + 2),
+                                 lambda: check(L.cn_rangebn_fwd_q8(ptr(y), ptr(qp), mod.quantize_input.num_bits, ptr(qy),
+                                                                   ptr(z), ptr(weight), ptr(bias), ptr(mod.running_mean),
+                                                                   ptr(mod.running_var), mod.momentum, mod.eps, mod.num_chunks,
+                                                                   fix, ptr(stats), ptr(arg), M, C, int(relu), code,
+                                                                   N if want_mm else 0, ptr(zmm), ptr(ws), ws.numel() * 4,
+                                                                   stream_of(y)), 'cn_rangebn_fwd_q8'), y.device)
+            else:
+                ops.PROFILER.run('quant: rangebn quantise+stats, finalize, apply%s' % ('+minmax' if want_mm else ''),
+                                 4 if want_mm else 3, 0.0, 4 * y.numel() * y.element_size(),
+                                 lambda: check(L.cn_rangebn_fwd_q(ptr(y), ptr(qp), mod.quantize_input.num_bits, ptr(qy), None,
+                                                                  ptr(z), ptr(weight), ptr(bias), ptr(mod.running_mean),
+                                                                  ptr(mod.running_var), mod.momentum, mod.eps, mod.num_chunks,
+                                                                  fix, ptr(stats), ptr(arg), M, C, int(relu), code, N if want_mm else 0,
+                                                                  ptr(zmm), ptr(ws), ws.numel() * 4, stream_of(y)),
+                                               'cn_rangebn_fwd_q'), y.device)
             if want_mm:
                 _stash_minmax(z, N, zmm)
+            ctx.x_qp = qp if store8 else None
         else:
             qy = mod.quantize_input(y.contiguous())
             z = torch.empty_like(qy)
@@ -503,7 +568,9 @@ class RangeBNFunction(Function):
                                                             mod.eps, mod.num_chunks, fix, ptr(stats), ptr(arg), M, C,
                                                             int(relu), 1, code, ptr(ws), ws.numel() * 4, stream_of(y)),
                                            'cn_rangebn_fwd'), y.device)
+            ctx.x_qp = None
         ctx.mod, ctx.relu, ctx.fix = mod, relu, fix
+        ctx.cdtype = y.dtype
         ctx.save_for_backward(qy, weight, stats, arg, *((z,) if relu else ()))
         return z
 
@@ -527,10 +594,30 @@ class RangeBNFunction(Function):
                       'cn_eltwise')
         else:
             g0 = dz
-        gq = quantize_grad(g0, mod.num_bits_grad)
-        dx = torch.empty_like(qy)
+        x_qp = ctx.x_qp                       # not None: qy holds 8-bit levels of that grid (STORE8)
+        cdt = ctx.cdtype
+        g8 = fuse and _store8_ok(g0, mod.num_bits_grad)
+        if g8:
+            gq, g_qp = quantize_grad(g0, mod.num_bits_grad, levels=True)
+        else:
+            gq, g_qp = quantize_grad(g0, mod.num_bits_grad), None
+        dx = torch.empty(qy.shape, dtype=cdt, device=qy.device)
         ws = ops.workspace(L.cn_rangebn_workspace(M, C, mod.num_chunks), qy.device, 'quant')
-        if fuse:
+        if x_qp is not None and not fuse:
+            raise _lib.ConvNetHipError('RangeBN: the 8-bit level storage of the forward pass needs the fused backward pass')
+        if fuse and (g8 or x_qp is not None):
+            dxmm = torch.empty(N * 2, dtype=torch.float32, device=qy.device)
+            esz = dx.element_size()
+            ops.PROFILER.run('quant: rangebn_bwd reduce+finalize+apply(route, minmax) on 8-bit levels', 4, 0.0,
+                             qy.numel() * (esz + (2 if g8 else 2 * esz) + (1 if x_qp is not None else esz)),
+                             lambda: check(L.cn_rangebn_bwd_q8(ptr(gq), ptr(g_qp), mod.num_bits_grad, ptr(qy), ptr(x_qp),
+                                                               mod.quantize_input.num_bits, ptr(weight), ptr(stats), ptr(arg),
+                                                               ptr(dx), ptr(mod.grad_view('weight')), ptr(mod.grad_view('bias')),
+                                                               M, C, mod.num_chunks, ctx.fix, dtype_code(cdt), N, ptr(dxmm),
+                                                               ptr(ws), ws.numel() * 4, stream_of(qy)), 'cn_rangebn_bwd_q8'),
+                             qy.device)
+            _stash_minmax(dx, N, dxmm)     # for the gradient quantiser of the convolution in front (QConv2d.backward)
+        elif fuse:
             dxmm = torch.empty(N * 2, dtype=torch.float32, device=qy.device)
             ops.PROFILER.run('quant: rangebn_bwd reduce+finalize+apply(route, minmax)', 4, 0.0, 4 * qy.numel() * qy.element_size(),
                              lambda: check(L.cn_rangebn_bwd_mm(ptr(gq), ptr(qy), ptr(weight), ptr(stats), ptr(arg), ptr(dx),
@@ -546,7 +633,7 @@ class RangeBNFunction(Function):
                                                             mod.num_chunks, ctx.fix, dtype_code(qy.dtype), ptr(ws),
                                                             ws.numel() * 4, stream_of(qy)), 'cn_rangebn_bwd'), qy.device)
         mod._notify_grad_ready()
-        return dx, None, None, None, None
+        return dx, None, None, None, None, None
 
 
 class RangeBN(cnn.BatchNorm2d):
@@ -578,9 +665,9 @@ class RangeBN(cnn.BatchNorm2d):
         if self.training:
             fn = RangeBNFunction.apply
             if torch.is_grad_enabled():
-                return fn(y, self.weight, self.bias, self, relu)
+                return fn(y, self.weight, self.bias, self, relu, True)
             with torch.no_grad():
-                return fn(y, self.weight, self.bias, self, relu)
+                return fn(y, self.weight, self.bias, self, relu, False)
         N, H, W, C = y.shape
         L = _L()
         qy = self.quantize_input(y.contiguous())
@@ -606,9 +693,10 @@ class AddReLUFunction(Function):
     the last RangeBN so that the backward pass visits the operators in the reference's order."""
 
     @staticmethod
-    def forward(ctx, a, b):
+    def forward(ctx, a, b, train_graph=False, holder=None):
+        ctx.holder = holder
         a, b = a.contiguous(), b.contiguous()
-        if _mm_ok(a) and torch.is_grad_enabled():     # (no stash outside training: nothing would consume it)
+        if _mm_ok(a) and train_graph:     # (no stash outside training: nothing would consume it; see RangeBNFunction)
             # the block output is what the next block's conv1 / projection quantise: measured here
             z, mm = eltwise_mm(4, a, b, a.shape[0])
             _stash_minmax(z, a.shape[0], mm)
@@ -629,8 +717,12 @@ class AddReLUFunction(Function):
         else:
             g = torch.empty_like(dz)
             check(_L().cn_eltwise(2, ptr(g), ptr(dz), ptr(z), dz.numel(), dtype_code(dz.dtype), stream_of(dz)), 'cn_eltwise')
-        return g, g
+        if ctx.holder is not None and JUNCTION_ADD:
+            # identity shortcut: g IS the shortcut branch's gradient at the block input; conv1's data gradient adds it
+            ctx.holder.dres, ctx.holder.sub, ctx.holder.fused = g, 1, False
+        return g, g, None, None
 
 
-def add_relu(a, b):
-    return AddReLUFunction.apply(a, b)
+def add_relu(a, b, holder=None):
+    """holder: the block's ResGradHolder when the shortcut is the identity (b is the block input itself)."""
+    return AddReLUFunction.apply(a, b, torch.is_grad_enabled(), holder)

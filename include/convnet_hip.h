@@ -437,6 +437,9 @@ int cn_counter_inc(unsigned long long* counter, void* stream);
 /* per-row (= per output channel) quantisation of an fp32 filter matrix with the row's own min / max
  * (QConv2d / QLinear weights, quantize.py:201-203,239-240) */
 int cn_quantize_rows(const float* x, float* y, int rows, int row_len, int num_bits, void* stream);
+/* the same for every filter of a model in one launch: x / y = the flat fp32 parameter arena and its quantised shadow,
+ * rowtab[rows][3] = {element offset, row length, 2^bits - 1} per output channel (engine.ParamArena.prepare_weights) */
+int cn_quantize_rows_multi(const float* x, float* y, const long long* rowtab, int rows, void* stream);
 /* RangeBN (quantize.py:256-330) on an input-quantised x[M][C]: per channel mean and
  * scale = (mean of `chunks` chunk maxima - mean of chunk minima) * scale_fix over the M values in (n,h,w) order;
  * z = act(((x - mean)/(scale + eps))*weight + bias [+ residual]).  training: running statistics updated
@@ -468,6 +471,22 @@ int cn_rangebn_fwd_q(const void* x, const float* x_qparams, int x_bits, void* qx
 int cn_rangebn_bwd_mm(const void* g, const void* x, const float* weight, const float* stats, const int* arg, void* dx,
                       float* dweight, float* dbias, int M, int C, int chunks, float scale_fix, int dtype, int mm_rows,
                       float* dx_minmax, float* ws, size_t ws_bytes, void* stream);
+/* ---- 8-bit LEVEL storage of the snapped tensors (round 6): one byte per element instead of a value in the compute dtype.
+ * cn_quantize_levels = cn_quantize_s writing levels; cn_rangebn_fwd_q8 = cn_rangebn_fwd_q keeping the snapped input as levels
+ * (qx8_out) for the backward pass; cn_rangebn_bwd_q8 = cn_rangebn_bwd_mm taking g and / or x as levels with their
+ * [zero_point, range] (NULL qparams: that operand holds values).  value = T(level * range / (2^bits - 1) + zero_point):
+ * every output has the bits of the value-storing entry points.  bits <= 8, element counts in whole 16-byte chunks. */
+int cn_quantize_levels(const void* x, unsigned char* y8, long long n, int dtype, const float* zero_point, const float* range,
+                       int num_bits, const float* noise, int stochastic, unsigned long long seed,
+                       const unsigned long long* step_counter, void* stream);
+int cn_rangebn_fwd_q8(const void* x, const float* x_qparams, int x_bits, unsigned char* qx8_out, void* z, const float* weight,
+                      const float* bias, float* running_mean, float* running_var, float momentum, float eps, int chunks,
+                      float scale_fix, float* stats, int* arg, int M, int C, int relu, int dtype, int mm_rows,
+                      float* z_minmax, float* ws, size_t ws_bytes, void* stream);
+int cn_rangebn_bwd_q8(const void* g, const float* g_qparams, int g_bits, const void* x, const float* x_qparams, int x_bits,
+                      const float* weight, const float* stats, const int* arg, void* dx, float* dweight, float* dbias,
+                      int M, int C, int chunks, float scale_fix, int dtype, int mm_rows, float* dx_minmax, float* ws,
+                      size_t ws_bytes, void* stream);
 size_t cn_eltwise_mm_workspace(long long n, int rows, int dtype);
 int cn_eltwise_mm(int op, void* a, const void* b, const void* c, long long n, int dtype, int rows, float* minmax, float* ws,
                   size_t ws_bytes, void* stream);

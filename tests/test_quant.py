@@ -476,3 +476,74 @@ def test_producer_side_fusions_change_no_bit_of_a_trajectory(mode, reference_noi
     # what is still measured by its own pass: the convolution outputs (RangeBN's input quantiser), the network input, the
     # classifier's input and bias - fewer than half of the quantisers
     assert calls[True][1] >= calls[True][0] * 0.8, calls
+
+
+@pytest.mark.parametrize('mode', MODES)
+@pytest.mark.parametrize('depth', [18, 50])
+def test_block_input_gradient_sum_in_the_dgrad_epilogue_changes_no_bit_in_fp32(mode, depth, reference_noise):
+    """Round 6 (quant.JUNCTION_ADD): the two gradients meeting at a quantised block's input are summed in the data
+    gradient's epilogue of whichever branch arrives second (identity shortcut: conv1's; projection: conv1's or the
+    projection's) instead of a separate add pass.  fp32: the same numbers bit for bit, and no separate add is launched."""
+    dev = _dev(mode)
+    if mode == 'emul' and depth != 18:
+        pytest.skip('emulated suite: ResNet-18 only')
+    import convnet_amd as ca
+    meta = json.load(open(os.path.join(GOLDEN, 'traj_r%ds_quant.json' % depth)))
+    res, adds = {}, {}
+    saved, real_add = ca.quant.JUNCTION_ADD, ca.ops.add_
+    try:
+        for fused in (False, True):
+            ca.quant.JUNCTION_ADD = fused
+            n = [0]
+
+            def counting(a, b, n=n):
+                n[0] += 1
+                return real_add(a, b)
+            ca.ops.add_ = counting
+            recs, tr, model, data = _engine_trajectory(meta, depth, dev, torch.float32, 2 if mode == 'gpu' else 1)
+            res[fused] = (recs, {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()})
+            adds[fused] = n[0]
+    finally:
+        ca.quant.JUNCTION_ADD = saved
+        ca.ops.add_ = real_add
+    assert res[False][0] == res[True][0], (res[False][0], res[True][0])
+    for k, v in res[False][1].items():
+        assert torch.equal(v, res[True][1][k]), k
+    assert adds[False] > 0 and adds[True] == 0, adds
+
+
+@pytest.mark.parametrize('mode', MODES)
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_8bit_level_storage_changes_no_bit_of_a_trajectory(mode, dtype, reference_noise):
+    """Round 6 (quant.STORE8): RangeBN's snapped input (saved for backward) and the quantised gradient its backward kernels
+    read are kept as one byte per element - the LEVELS - and de-quantised on load (cn_rangebn_fwd_q8, cn_quantize_levels,
+    cn_rangebn_bwd_q8).  Same trajectory and same final state bit for bit as with the snapped values stored in the compute
+    dtype, fp32 and bf16; and the level tensors really are what is saved (uint8)."""
+    dev = _dev(mode)
+    if mode == 'emul' and dtype != torch.float32:
+        pytest.skip('emulated suite: fp32 only (the GPU run does both)')
+    import convnet_amd as ca
+    meta = json.load(open(os.path.join(GOLDEN, 'traj_r18s_quant.json')))
+    res, kinds = {}, {}
+    saved = ca.quant.STORE8
+    real = ca.quant.RangeBNFunction.forward
+    try:
+        for on in (False, True):
+            ca.quant.STORE8 = on
+            seen = set()
+
+            def spy(ctx, *a, _seen=seen, **k):
+                out = real(ctx, *a, **k)
+                _seen.add(ctx.to_save[0].dtype if hasattr(ctx, 'to_save') else None)
+                return out
+            ca.quant.RangeBNFunction.forward = staticmethod(spy)
+            recs, tr, model, data = _engine_trajectory(meta, 18, dev, dtype, 2 if mode == 'gpu' else 1)
+            res[on] = (recs, {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()})
+            kinds[on] = seen
+    finally:
+        ca.quant.STORE8 = saved
+        ca.quant.RangeBNFunction.forward = staticmethod(real)
+    assert res[False][0] == res[True][0], (res[False][0], res[True][0])
+    for k, v in res[False][1].items():
+        assert torch.equal(v, res[True][1][k]), k
+    assert torch.uint8 in kinds[True] and torch.uint8 not in kinds[False], kinds
