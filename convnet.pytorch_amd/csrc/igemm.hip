@@ -954,6 +954,9 @@ struct IgLazyZ {   // XF mode 3 operands (see IgemmParams::xf2)
   unsigned char* mask;
 };
 
+int cn_dense_smallm(const void* A, const void* B, void* C, const float* bias, int M, int N, int Kd, int dtype, int out_f32,
+                    int relu, hipStream_t stream);
+
 static int ig_conv_fwd(const void* x, const void* w_krsc, void* y, const float* bias, float* stats, int N, int H,
                        int W, int C, int K, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w,
                        int dtype, int out_f32, int relu, void* stream, const float* xf = nullptr, int xf_relu = 0,
@@ -961,6 +964,13 @@ static int ig_conv_fwd(const void* x, const void* w_krsc, void* y, const float* 
   const int P = (H + 2 * pad_h - R) / stride_h + 1;
   const int Q = (W + 2 * pad_w - S) / stride_w + 1;
   if (P <= 0 || Q <= 0 || N <= 0) { cn_set_error("conv2d_fwd: empty output"); return CN_ESHAPE; }
+  // a dense layer on a batch (1 x 1 image, 1 x 1 filter: the classifier): 32 x 32 output tiles with a four-way split of the
+  // reduction (dense.hip) instead of 16 workgroups of the 128 x 128 tile
+  if (H == 1 && W == 1 && R == 1 && S == 1 && pad_h == 0 && pad_w == 0 && stats == nullptr && xf == nullptr && lz == nullptr &&
+      x != nullptr && w_krsc != nullptr && y != nullptr) {
+    const int rc = cn_dense_smallm(x, w_krsc, y, bias, N, K, C, dtype, out_f32, relu, (hipStream_t)stream);
+    if (rc != 1) return rc;
+  }
   IgemmParams p;
   memset(&p, 0, sizeof(p));
   p.x = (const char*)x; p.w = (const char*)w_krsc; p.y = (char*)y; p.bias = bias; p.stats = stats;
@@ -1069,6 +1079,12 @@ static int ig_conv_dgrad(const void* dy, const void* w_crsk, void* dx, const voi
   const int P = (H + 2 * pad_h - R) / stride_h + 1;
   const int Q = (W + 2 * pad_w - S) / stride_w + 1;
   if (P <= 0 || Q <= 0 || N <= 0) { cn_set_error("conv2d_dgrad: empty output"); return CN_ESHAPE; }
+  // the classifier's data gradient: dx[B][C] = dy[B][K] * w_crsk[C][K]^T (dense.hip)
+  if (H == 1 && W == 1 && R == 1 && S == 1 && pad_h == 0 && pad_w == 0 && stride_h == 1 && stride_w == 1 && addend == nullptr &&
+      bn == nullptr && lazy_y == nullptr && !out_f32 && dy != nullptr && w_crsk != nullptr && dx != nullptr) {
+    const int rc = cn_dense_smallm(dy, w_crsk, dx, nullptr, N, C, K, dtype, 0, 0, (hipStream_t)stream);
+    if (rc != 1) return rc;
+  }
   // One launch per output-parity class (ph, pw): dX[n, hg*st+ph, wg*st+pw, :] receives exactly the
   // taps r with (ph + pad - r) % st == 0, reading dY at row hg + (ph + pad - r)/st.
   for (int ph = 0; ph < stride_h; ++ph)

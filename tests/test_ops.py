@@ -595,6 +595,43 @@ def test_linear_with_bias_fp32_logits(mode, dtype):
     assert rel_l2(y.cpu().view(B, K), y_ref) < (1e-5 if dtype == torch.float32 else 2e-3)
 
 
+@pytest.mark.parametrize('mode', MODES)
+def test_classifier_runs_on_the_small_batch_dense_kernel(mode):
+    """Round 6 (csrc/dense.hip): nn.Linear on a batch - forward and data gradient - runs as 32 x 32 output tiles with a
+    four-way split of the reduction instead of 16 workgroups of the 128 x 128 tile; ragged batch (rows beyond M), ragged
+    width (1000 = 31 tiles + 8 columns) and a reduction length that is not a multiple of 16 (the data gradient reduces over
+    the 1000 outputs) are all in this one shape."""
+    dev = _dev(mode)
+    import convnet_amd as ca
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(2)
+    B, C, K = (37, 96, 1000) if mode == 'emul' else (256, 2048, 1000)
+    x = _q(torch.randn(B, C, generator=g), dtype)
+    w = _q(torch.randn(K, C, generator=g) * 0.05, dtype)
+    b = torch.randn(K, generator=g)
+    dy = _q(torch.randn(B, K, generator=g), dtype)
+    L = ca._lib.load()
+    y = ca.ops.conv2d_fwd(x.view(B, 1, 1, C).to(dtype).to(dev), w.to(dtype).to(dev), b.to(dev), K, 1, 1, (1, 1), (0, 0),
+                          out_f32=True)
+    assert 'dense_smallm_kernel' in L.cn_last_kernel_name().decode()
+    assert rel_l2(y.cpu().view(B, K), F.linear(x, w, b)) < 2e-3
+    w_crsk = w.t().contiguous()          # [C][K]: the copy the data gradient reads
+    dx = ca.ops.conv2d_dgrad(dy.view(B, 1, 1, K).to(dtype).to(dev), w_crsk.to(dtype).to(dev), (B, 1, 1, C), K, 1, 1,
+                             (1, 1), (0, 0))
+    assert 'dense_smallm_kernel' in L.cn_last_kernel_name().decode()
+    assert dx.dtype == dtype
+    assert rel_l2(dx.float().cpu().view(B, C), dy @ w) < 5e-3
+    # the tiled kernel (option dense_smallm = 0) gives the same numbers up to the summation order
+    L.cn_set_option(b'dense_smallm', 0)
+    try:
+        y0 = ca.ops.conv2d_fwd(x.view(B, 1, 1, C).to(dtype).to(dev), w.to(dtype).to(dev), b.to(dev), K, 1, 1, (1, 1),
+                               (0, 0), out_f32=True)
+        assert 'igemm' in L.cn_last_kernel_name().decode()
+    finally:
+        L.cn_set_option(b'dense_smallm', 1)
+    assert rel_l2(y.cpu(), y0.cpu()) < 1e-5
+
+
 def _bn_ref(y, gamma, beta, res, relu, eps=1e-5, momentum=0.1):
     y = y.clone().requires_grad_(True)
     gamma = gamma.clone().requires_grad_(True)
