@@ -110,6 +110,7 @@ _SIGNATURES = {
     'cn_avgpool_bwd': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     'cn_nchw_to_nhwc': (c_i, [c_p, c_p] + [c_i] * 6 + [c_p]),
     'cn_u8_nhwc_to_nchw_lut': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
+    'cn_resize_u8_crops': (c_i, [c_p] * 7 + [c_i] * 4 + [c_p]),
     'cn_nchw_to_pairs': (c_i, [c_p, c_p] + [c_i] * 6 + [c_p]),
     'cn_weight_prep_pairs': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     'cn_wgrad_unpack_pairs': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),

@@ -3,7 +3,7 @@
 # library used by the `-m "not gpu"` kernel-logic tests.
 set -e
 cd "$(dirname "$0")"
-SRCS="runtime.hip plan.hip igemm.hip dense.hip wgrad.hip junction.hip stem.hip conv3x3.hip bn.hip pool.hip loss.hip optim.hip probe.hip comm.hip quant.hip qconv_i8.hip"
+SRCS="runtime.hip plan.hip igemm.hip dense.hip wgrad.hip junction.hip stem.hip conv3x3.hip bn.hip pool.hip resize.hip loss.hip optim.hip probe.hip comm.hip quant.hip qconv_i8.hip"
 OUT=..
 if [ "$1" != "emul-only" ]; then
   # CN_EXTRA_FLAGS / CN_LIB_NAME: A/B builds (e.g. CN_EXTRA_FLAGS=-DCN_NT_STORES CN_LIB_NAME=libconvnet_hip_nt.so)

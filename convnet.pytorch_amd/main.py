@@ -58,6 +58,11 @@ def build_parser():
     p.add_argument('--host-normalize', action='store_true',
                    help='(not in the reference) keep ToTensor + Normalize in the loader workers; default: uint8 crops leave '
                         'the workers and the two transforms run on the device behind the copy - same batch, bit for bit')
+    p.add_argument('--device-resize', action='store_true',
+                   help='(not in the reference) also move the Resize step to the device: the uint8 crops leave the workers '
+                        'unresized and PIL\'s fixed-point BILINEAR resampler runs in csrc/resize.hip - same batch, bit for bit.  '
+                        'Opt-in: it pays where the host cores are slow (+15 %% per worker in the build container) and is a wash on '
+                        'the MI355X box (8.2k vs 8.7k img/s on its 16-core quota; profiles/r06_loader_gpu_box.txt)')
     p.add_argument('--epochs', default=90, type=int, metavar='N')
     p.add_argument('--start-epoch', default=-1, type=int, metavar='N')
     p.add_argument('-b', '--batch-size', default=256, type=int, metavar='N')
@@ -279,7 +284,8 @@ def main_worker(args):
                                         'augment': False, 'input_size': args.input_size,
                                         'batch_size': args.eval_batch_size, 'shuffle': False,
                                         'num_workers': args.workers, 'pin_memory': True, 'drop_last': False,
-                                        'device_normalize': not args.host_normalize})
+                                        'device_normalize': not args.host_normalize,
+                                        'device_resize': args.device_resize and not args.host_normalize})
         val_loader = val_data.get_loader
         if not args.evaluate:
             train_data = DataRegime(getattr(model, 'data_regime', None),
@@ -290,7 +296,8 @@ def main_worker(args):
                                               'distributed': args.distributed, 'duplicates': args.duplicates,
                                               'autoaugment': args.autoaugment,
                                               'cutout': {'holes': 1, 'length': 16} if args.cutout else None,
-                                              'device_normalize': not args.host_normalize})
+                                              'device_normalize': not args.host_normalize,
+                                        'device_resize': args.device_resize and not args.host_normalize})
             train_loader = train_data.get_loader
             logging.info('data regime: %s', train_data)
     if args.evaluate:

@@ -693,6 +693,21 @@ def normalize_lut(mean, std):
     return ((u - m) / s).contiguous()
 
 
+def resize_crops(batch):
+    """A device_resize loader's batch (data.collate_crops, already on the device) -> uint8 [B, S, S, C]: PIL's BILINEAR
+    resize of every crop, bit for bit (cn_resize_u8_crops), mirrored where the loader drew a horizontal flip."""
+    px, meta, tables = batch['crops'], batch['meta'], batch['tables']
+    row_owner, row_off = batch['row_owner'], batch['row_off']
+    S, C = (int(v) for v in batch['size'].tolist())
+    B, rows = meta.shape[0], row_owner.shape[0]
+    tmp = torch.empty(rows * S * C, dtype=torch.uint8, device=px.device)
+    out = torch.empty((B, S, S, C), dtype=torch.uint8, device=px.device)
+    PROFILER.run('resize_u8_crops', 2, 0.0, px.numel() + 2 * tmp.numel() + out.numel(),
+                 lambda: check(_L().cn_resize_u8_crops(ptr(px), ptr(meta), ptr(tables), ptr(row_owner), ptr(row_off), ptr(tmp),
+                                                       ptr(out), B, rows, S, C, stream_of(px)), 'cn_resize_u8_crops'), px.device)
+    return out
+
+
 def u8_nhwc_to_nchw(x_u8, lut):
     """uint8 [N, H, W, C] crops -> the normalised fp32 [N, C, H, W] batch (device-side ToTensor + Normalize)."""
     if x_u8.dtype != torch.uint8 or x_u8.dim() != 4:

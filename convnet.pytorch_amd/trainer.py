@@ -46,6 +46,8 @@ class DevicePrefetcher(object):
         self._lut = ops.normalize_lut(norm['mean'], norm['std']).to(device) if norm else None
 
     def _finish(self, inputs):
+        if isinstance(inputs, dict):      # device_resize loader: uint8 crops of any size + PIL's resampling tables
+            inputs = ops.resize_crops(inputs)
         if inputs.dtype == torch.uint8:
             if self._lut is None:
                 raise ValueError('uint8 batches need a loader built with device_normalize (mean / std travel with it)')
@@ -57,6 +59,17 @@ class DevicePrefetcher(object):
 
     def _stage(self, batch):
         inputs, target = batch
+        if isinstance(inputs, dict):
+            if self.stream is None:
+                return self._finish(inputs), target, None
+            with torch.cuda.stream(self.stream):
+                dev_in = {k: (v if k == 'size' else (v if v.is_pinned() else v.pin_memory()).to(self.device, non_blocking=True))
+                          for k, v in inputs.items()}
+                x = self._finish(dev_in)
+                t = target.to(self.device, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self.stream)
+            return x, t, ev
         if self.stream is None or (inputs.is_cuda and target.is_cuda):
             return self._finish(inputs), target, None
         with torch.cuda.stream(self.stream):

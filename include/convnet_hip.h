@@ -351,6 +351,14 @@ int cn_nchw_to_nhwc(const float* x_nchw, void* y_nhwc, int N, int C, int H, int 
  * operations, so the batch is bit-identical to the host pipeline's.  1 <= C <= 4. */
 int cn_u8_nhwc_to_nchw_lut(const unsigned char* x_nhwc, float* y_nchw, int N, int H, int W, int C, const float* lut,
                            void* stream);
+/* the Resize step of the input pipeline (preprocess.py:21-41,71-77: PIL's fixed-point two-pass BILINEAR resampler) on the
+ * device, bit for bit: B uint8 HWC crops of any size -> out[B][S][S][C].  pixels = the crops back to back; meta[B][8] = {byte
+ * offset, h, w, flip, horizontal table offset (int32 units), its taps, vertical table offset, its taps}; a table = S entries
+ * {first input index, count, coefficients round(k * 2^22)} computed on the host by PIL's recipe (data.resample_table);
+ * row_owner[total_rows] / row_off[B] index the crops' rows in tmp (total_rows * S * C bytes). */
+int cn_resize_u8_crops(const unsigned char* pixels, const long long* meta, const int* tables, const int* row_owner,
+                       const int* row_off, unsigned char* tmp, unsigned char* out, int B, int total_rows, int S, int C,
+                       void* stream);
 /* Stride-2 stem (models/resnet.py:226, 7x7/2 pad 3 on 3 channels) in "pixel pair" form: the fp32 NCHW batch
  * becomes a zero-padded bf16 image [N][H+2*pad_h][(W+2*pad_w)/2][8] whose 16-byte chunks hold two adjacent
  * pixels x 4 channels; with the filter packed the same way (cn_weight_prep_pairs: [K][R][ceil(S/2)][8]) the

@@ -257,3 +257,87 @@ def test_device_side_totensor_normalize_is_bit_identical(tmp_path):
     # uint8 batches without the loader's mean / std are refused, not guessed
     with pytest.raises(ValueError):
         list(ca.trainer.DevicePrefetcher([(torch.zeros(1, 4, 4, 3, dtype=torch.uint8), torch.zeros(1, dtype=torch.long))], dev))
+
+
+def _device_for_data():
+    import convnet_amd as ca
+    if torch.cuda.is_available() and not ca._lib.is_emulated():
+        return torch.device('cuda', 0)
+    return torch.device('cpu')
+
+
+def test_device_resize_matches_pil_bit_for_bit():
+    """Round 6 (csrc/resize.hip + data.resample_table): PIL's 8-bit BILINEAR resize is fixed-point arithmetic on coefficients
+    computed in double; the tables are computed by PIL's recipe on the host, the two integer passes run on the device.
+    Every byte equals Image.resize's, for down-scaling with antialiasing support, up-scaling, identity and degenerate
+    sizes, with and without the horizontal flip that follows the resize in the training transform."""
+    import convnet_amd as ca
+    from convnet_amd import data as D
+    dev = _device_for_data()
+    rng = np.random.RandomState(3)
+    S = 64
+    sizes = [(70, 90), (64, 64), (20, 33), (200, 64), (64, 150), (3, 5), (131, 257), (500, 375)]
+    batch, ref = [], []
+    for i, (h, w) in enumerate(sizes):
+        a = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        c = D.CropForDevice(a, D.resample_table(w, S), D.resample_table(h, S), S)
+        c.flip = bool(i % 2)
+        batch.append((c, i))
+        r = Image.fromarray(a).resize((S, S), Image.BILINEAR)
+        if c.flip:
+            r = r.transpose(Image.FLIP_LEFT_RIGHT)
+        ref.append(np.array(r))
+    inputs, target = D.collate_crops(batch)
+    assert target.tolist() == list(range(len(sizes)))
+    out = ca.ops.resize_crops({k: (v if k == 'size' else v.to(dev)) for k, v in inputs.items()}).cpu().numpy()
+    for i, r in enumerate(ref):
+        assert np.array_equal(out[i], r), (sizes[i], int(np.abs(out[i].astype(int) - r.astype(int)).max()))
+
+
+@pytest.mark.gpu
+def test_device_resize_matches_pil_bit_for_bit_gpu():
+    test_device_resize_matches_pil_bit_for_bit()
+
+
+def test_device_resize_loader_batches_are_the_host_pipelines(tmp_path):
+    """`device_resize` (DataRegime setting; main.py --device-resize): the workers
+    stop at the uint8 CROP of RandomResizedCrop (train) / the source window of Resize + CenterCrop (eval); trainer.
+    DevicePrefetcher resizes, flips and normalises behind the copy.  The fp32 NCHW batches the step receives are the host
+    pipeline's bit for bit - same crops and flips under the same seed - for both transforms."""
+    from convnet_amd import data as D
+    import convnet_amd as ca
+    root = tmp_path / 'ds'
+    rng = np.random.RandomState(2)
+    for split in ('train', 'val'):
+        for c in range(3):
+            d = root / 'imagenet' / split / ('c%d' % c)
+            d.mkdir(parents=True)
+            for i in range(4):
+                a = (rng.rand(60 + 17 * i, 90 - 11 * c, 3) * 255).astype(np.uint8)
+                Image.fromarray(a).save(str(d / ('%d.png' % i)))
+    dev = _device_for_data()
+    for split, augment in (('train', True), ('val', False)):
+        got = {}
+        for dr_on in (False, True):
+            torch.manual_seed(9)
+            reg = D.DataRegime([{'epoch': 0}], defaults={'datasets_path': str(root), 'name': 'imagenet', 'split': split,
+                                                          'augment': augment, 'input_size': 32, 'batch_size': 4,
+                                                          'shuffle': False, 'num_workers': 0, 'drop_last': False,
+                                                          'device_normalize': True, 'device_resize': dr_on})
+            loader = reg.get_loader()
+            first = next(iter(loader))[0]
+            assert isinstance(first, dict) == dr_on
+            torch.manual_seed(9)
+            got[dr_on] = [(x.cpu().clone(), t.cpu().clone()) for x, t in ca.trainer.DevicePrefetcher(loader, dev)]
+        assert len(got[False]) == len(got[True]) == 3
+        for (x0, t0), (x1, t1) in zip(got[False], got[True]):
+            assert x1.dtype == torch.float32 and tuple(x1.shape[1:]) == (3, 32, 32)
+            assert torch.equal(x0, x1) and torch.equal(t0, t1)
+    with pytest.raises(ValueError):
+        D.get_transform('imagenet', input_size=32, device_resize=True, device_normalize=False)
+
+
+@pytest.mark.gpu
+def test_device_resize_loader_on_the_gpu(tmp_path):
+    """The same through two worker processes and pinned buffers onto the MI355X."""
+    test_device_resize_loader_batches_are_the_host_pipelines(tmp_path)

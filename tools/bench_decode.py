@@ -20,6 +20,7 @@ def main():
     ap.add_argument('--workers', default='1,4,8')
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--device-normalize', action='store_true', help='workers stop at the uint8 crop (ToTensor + Normalize on the device)')
+    ap.add_argument('--device-resize', action='store_true', help='... and at the unresized crop (PIL resize on the device too)')
     args = ap.parse_args()
     from PIL import Image
     import torch
@@ -35,15 +36,16 @@ def main():
         dr = D.DataRegime([{'epoch': 0}], defaults={'datasets_path': root, 'name': 'imagenet', 'split': 'train',
                                                      'augment': True, 'input_size': 224, 'batch_size': args.batch,
                                                      'shuffle': True, 'num_workers': nw, 'drop_last': True,
-                                                     'device_normalize': args.device_normalize})
+                                                     'device_normalize': args.device_normalize or args.device_resize,
+                                                     'device_resize': args.device_resize})
         loader = dr.get_loader()
         n = 0
         for x, t in loader:     # warm-up epoch (worker start-up, page cache)
-            n += x.shape[0]
+            n += t.shape[0]
         t0 = time.time()
         n = 0
         for x, t in loader:
-            n += x.shape[0]
+            n += t.shape[0]
         dt = time.time() - t0
         print('workers %2d: %7.1f img/s (%d images, %.2f s; %.1f img/s per worker)' % (nw, n / dt, n, dt, n / dt / max(nw, 1)))
         del loader, dr
