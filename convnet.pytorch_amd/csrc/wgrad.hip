@@ -736,6 +736,8 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(Wg3Params p) {
   constexpr int NSLOT = WG3_XBYTES / 16 / 256;   // 16-byte x slots per thread and band (5)
   constexpr bool KSPLIT = (BI == 64);
   constexpr int NW = BI / 32;              // co blocks
+  // (round 6: padding the allocation so that only ONE workgroup of this kernel fits a CU - half the side stream's footprint, twice
+  // its duration - measured 15030 vs 15109 img/s over four interleaved rounds: not kept, profiles/r06_ab_whole_step.txt)
   __shared__ __attribute__((aligned(1024))) char lds[2 * DYSZ + WG3_XBYTES + NPX * 4];
   char* xb = lds + 2 * DYSZ;
   int* s_pos = (int*)(lds + 2 * DYSZ + WG3_XBYTES);
