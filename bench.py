@@ -170,6 +170,12 @@ def main():
         raise SystemExit('bench.py: rank %d has no device (%d visible)' % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
+    rccl_log = None
+    if distributed and 'NCCL_DEBUG' not in os.environ and os.environ.get('BENCH_DIST_BACKEND', 'nccl') == 'nccl':
+        # what RCCL builds for this job (channels, rings / trees, transports) goes into the line: INFO-level INIT / GRAPH
+        # messages into a per-process file (never stdout), read back after the communicators are up
+        rccl_log = '/tmp/cn_bench_rccl_%d.log' % os.getpid()
+        os.environ.update(NCCL_DEBUG='INFO', NCCL_DEBUG_SUBSYS='INIT,GRAPH', NCCL_DEBUG_FILE=rccl_log)
     if distributed:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29517')
@@ -431,7 +437,8 @@ def main():
                        'global_batch': B * world, 'final_loss': round(float(res['loss']), 4),
                        'parallelism': 'dp%d' % world, 'rank_devices': rank_devices, 'params_in_sync_across_ranks': params_in_sync,
                        'transport': (tr.reducer.describe() if tr.reducer is not None else None) if comm_note is None
-                       else '%s [%s]' % (tr.reducer.describe() if tr.reducer is not None else None, comm_note)},
+                       else '%s [%s]' % (tr.reducer.describe() if tr.reducer is not None else None, comm_note),
+                       'rccl': ca.comm.topology_summary(rccl_log) if rccl_log else None},
             'mfma_frac_whole_step': round(step_tflops / (elapsed / args.steps) / PEAK_TFLOPS[args.dtype], 4)
             if step_tflops else None,
             'hbm_frac_whole_step': round(MODEL_MB_PER_IMG[(args.depth, args.dtype)] * 1e6 * B / (elapsed / args.steps)

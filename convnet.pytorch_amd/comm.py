@@ -115,6 +115,37 @@ class RcclCommunicator(object):
         return 'direct RCCL %d (cn_comm_*), %d rank%s' % (self.rccl_version, self.world, '' if self.world == 1 else 's')
 
 
+def topology_summary(log_path):
+    """What RCCL said about the communicators of this process (NCCL_DEBUG=INFO lines in `log_path`, written because the
+    caller set NCCL_DEBUG / NCCL_DEBUG_SUBSYS=INIT,GRAPH / NCCL_DEBUG_FILE before the first RCCL call - bench.py does for
+    N > 1): channel count, whether rings / trees were built, and the transports the peers are reached over (P2P/IPC over
+    xGMI, SHM, NET).  Best effort: an unreadable or empty log gives {}."""
+    import re
+    try:
+        with open(log_path, errors='replace') as f:
+            text = f.read()
+    except OSError:
+        return {}
+    out = {}
+    m = re.findall(r'Channel (\d+)/(\d+)\s*:', text)
+    if m:
+        out['channels'] = max(int(b) for _, b in m)
+    m = re.search(r'(\d+) coll channels', text)
+    if m:
+        out['coll_channels'] = int(m.group(1))
+    if re.search(r'\bRing \d+\s*:', text) or 'Connected all rings' in text:
+        out['rings'] = True
+    if re.search(r'\bTrees? \[', text) or 'Connected all trees' in text:
+        out['trees'] = True
+    via = sorted(set(re.findall(r'via ([A-Za-z0-9/]+)', text)))
+    if via:
+        out['via'] = via[:6]
+    m = re.search(r'RCCL version\s*:?\s*([0-9][^\s]*)', text) or re.search(r'NCCL version ([0-9][^\s]*)', text)
+    if m:
+        out['version_line'] = m.group(1)
+    return out
+
+
 def wanted(device, process_group=None):
     """Direct RCCL is the transport whenever the ranks own HIP devices and the process group was brought up
     for RCCL (backend 'nccl'); CONVNET_AMD_COMM=torch forces the torch.distributed collectives (A/B)."""

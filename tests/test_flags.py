@@ -100,3 +100,21 @@ def test_graph_flag_spellings(monkeypatch):
     with pytest.raises(ValueError):
         ca.flags.graph_mode()
 
+
+
+def test_rccl_topology_summary_parses_info_lines(tmp_path):
+    """comm.topology_summary: what bench.py prints about the RCCL communicators of an N > 1 run (channels, rings / trees,
+    transports) is read back from RCCL's own INFO log; unreadable or empty logs give {} (never an exception)."""
+    import convnet_amd as ca
+    log = tmp_path / 'rccl.log'
+    log.write_text('h:1:1 [0] NCCL INFO Channel 00/08 :    0   1   2   3\n'
+                   'h:1:1 [0] NCCL INFO Channel 07/08 :    0   1\n'
+                   'h:1:1 [0] NCCL INFO Trees [0] 1/-1/-1->0->-1\n'
+                   'h:1:1 [0] NCCL INFO Channel 00 : 0[0] -> 1[1] via P2P/IPC\n'
+                   'h:1:1 [0] NCCL INFO Connected all rings\n'
+                   'h:1:1 [0] NCCL INFO 8 coll channels, 8 nvls channels, 8 p2p channels\n')
+    t = ca.comm.topology_summary(str(log))
+    assert t['channels'] == 8 and t['coll_channels'] == 8 and t['rings'] and t['trees'] and t['via'] == ['P2P/IPC']
+    assert ca.comm.topology_summary(str(tmp_path / 'missing.log')) == {}
+    (tmp_path / 'empty.log').write_text('')
+    assert ca.comm.topology_summary(str(tmp_path / 'empty.log')) == {}

@@ -15,6 +15,8 @@ cp $S/kernel_stats.csv $P/${R}_rocprofv3_kernel_stats_resnet50_bf16_b256.csv
 cp $S/kernel_trace_by_grid.txt $P/${R}_kernel_trace_by_grid.txt
 cp $S/layers.txt $P/${R}_conv_layers_b256_bf16.txt
 cp $S/pmc_traffic.json $P/${R}_pmc_traffic.json
+for f in plan_probe_b256.json plan_probe_b8.json; do [ -f $S/$f ] && cp $S/$f $P/${R}_$f; done
+[ -f $S/c5_kernel_stats.csv ] && cp $S/c5_kernel_stats.csv $P/${R}_rocprofv3_kernel_stats_config5_quantize_bf16.csv
 if [ -f $S/mfma_step.txt ]; then cp $S/mfma_step.txt $P/${R}_pmc_mfma_utilisation_per_kernel.txt; fi
 { cat $S/pytest_gpu.txt; echo; echo "== smoke"; cat $S/smoke.txt; } > $P/${R}_pytest_gpu_tail.txt
 ls -la $P | grep ${R}_ | wc -l

@@ -18,11 +18,14 @@ echo "== R18 fp32"; timeout 600 python bench.py --depth 18 --dtype f32 --steps 6
 echo "== R101 bf16"; timeout 600 python bench.py --depth 101 --steps 20 --warmup 10 --no-cpu-baseline --no-kernel-profile 2>/dev/null | grep '"metric"' | tee $OUT/bench_r101.json | cut -c1-250
 echo "== config 5"; timeout 600 python bench.py --quantize --steps 6 --warmup 3 --no-cpu-baseline 2>/dev/null | grep '"metric"' | tee $OUT/bench_config5.json | cut -c1-250
 echo "== rocprof"
-CONVNET_AMD_FLAGS=graph=0 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o r50 -- python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-kernel-profile > $OUT/rocprof.log 2>&1
+# (default flags: after four eager warm-up steps the traced steps are launch-plan replays - the shipped step)
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o r50 -- python bench.py --steps 6 --warmup 5 --no-cpu-baseline --no-kernel-profile > $OUT/rocprof.log 2>&1
 STATS=$(find $OUT/prof -name "*kernel_stats.csv" | head -1)
 [ -n "$STATS" ] && cp "$STATS" $OUT/kernel_stats.csv && head -30 $OUT/kernel_stats.csv | cut -c1-170
 python tools/trace_by_grid.py $(find $OUT/prof -name "*kernel_trace.csv" | head -1) > $OUT/kernel_trace_by_grid.txt 2>&1
 find $OUT/prof -name "*kernel_trace.csv" -size +20M -delete
 echo "== MFMA utilisation from SQ counters"; timeout 900 python tools/pmc_mfma_step.py $OUT 2>&1 | tail -32
 rm -rf $OUT/sqstep
+echo "== launch plan vs eager vs HIP graph"; timeout 600 python tools/plan_probe.py --out $OUT/plan_probe_b256.json 2>&1 | grep -E "step|plan\[" ; timeout 300 python tools/plan_probe.py --batch 8 --steps 100 --out $OUT/plan_probe_b8.json 2>&1 | grep step
+echo "== config 5 kernel stats"; tools/gpu_c5_stats.sh $(basename $OUT) "" "" | tail -30
 echo "== done"; date
