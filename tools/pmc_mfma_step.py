@@ -51,7 +51,7 @@ def main():
             a[cn] += v
     # the number of profiled steps is read off the trace (a kernel that runs exactly once per training step), the step time
     # the whole-step figure is priced on comes from the caller (argv[2], ms: the untraced bench line of the same tree)
-    once = [a['n'] for k, a in agg.items() if k.startswith('softmax_ce_kernel')]
+    once = [a['n'] for k, a in agg.items() if k.startswith('nchw_to_pairs_kernel') or k.startswith('nchw_to_nhwc_kernel')]
     steps = float(once[0]) if once and once[0] > 0 else 3.0
     step_ms = float(sys.argv[2]) if len(sys.argv) > 2 else 17.25
     CLOCK_GHZ = 2.4       # the guide's peak clock; under dense MFMA the part sustains ~1.9 GHz (NOTES.md), so 'of the dense peak'
