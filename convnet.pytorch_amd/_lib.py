@@ -138,7 +138,7 @@ _SIGNATURES = {
     'cn_rangebn_fwd_q8': (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_i,
                                 c_p, c_p, c_sz, c_p]),
     'cn_rangebn_bwd_q8': (c_i, [c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_i, c_i, c_p, c_p,
-                                c_sz, c_p]),
+                                c_p, c_sz, c_p]),
     'cn_quantize_rows': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
     'cn_quantize_rows_multi': (c_i, [c_p, c_p, c_p, c_i, c_p]),
     'cn_rangebn_workspace': (c_sz, [c_i, c_i, c_i]),
@@ -147,6 +147,7 @@ _SIGNATURES = {
     'cn_rangebn_bwd_mm': (c_i, [c_p] * 8 + [c_i, c_i, c_i, c_f, c_i, c_i, c_p, c_p, c_sz, c_p]),
     'cn_eltwise_mm_workspace': (c_sz, [c_ll, c_i, c_i]),
     'cn_eltwise_mm': (c_i, [c_i, c_p, c_p, c_p, c_ll, c_i, c_i, c_p, c_p, c_sz, c_p]),
+    'cn_eltwise_mm_qp': (c_i, [c_i, c_p, c_p, c_p, c_ll, c_i, c_i, c_p, c_p, c_p, c_sz, c_p]),
     'cn_rangebn_bwd': (c_i, [c_p] * 8 + [c_i, c_i, c_i, c_f, c_i, c_p, c_sz, c_p]),
     'cn_i8_prepare_activation': (c_i, [c_p] * 5 + [c_i] * 11 + [c_p, c_p, c_p, c_p, c_i, c_p]),
     'cn_i8_prepare_weight': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),

@@ -79,16 +79,31 @@ __global__ __launch_bounds__(Q_NT) void minmax_partial_kernel(const T* x, long l
   }
 }
 
-__global__ __launch_bounds__(Q_NT) void minmax_final_kernel(const float* partial, int rows, int splits, float* minmax) {
+// qp_extreme (optional, single-block launches only: rows <= Q_NT): additionally [zero_point, range] of the 'extreme' reduction
+// over the rows - cn_qparams(minmax, rows, mode 1)'s output, same values - for a consumer that is known to be a gradient
+// quantiser (round 6: 105 qparams launches per config-5 step less).
+__global__ __launch_bounds__(Q_NT) void minmax_final_kernel(const float* partial, int rows, int splits, float* minmax,
+                                                           float* qp_extreme) {
+  __shared__ float red[8];
   const int r = blockIdx.x * Q_NT + threadIdx.x;
-  if (r >= rows) return;
   float mn = INFINITY, mx = -INFINITY;
-  for (int s = 0; s < splits; ++s) {
-    mn = fminf(mn, partial[((size_t)r * splits + s) * 2]);
-    mx = fmaxf(mx, partial[((size_t)r * splits + s) * 2 + 1]);
+  if (r < rows) {
+    for (int s = 0; s < splits; ++s) {
+      mn = fminf(mn, partial[((size_t)r * splits + s) * 2]);
+      mx = fmaxf(mx, partial[((size_t)r * splits + s) * 2 + 1]);
+    }
+    minmax[2 * r] = mn;
+    minmax[2 * r + 1] = mx;
   }
-  minmax[2 * r] = mn;
-  minmax[2 * r + 1] = mx;
+  if (qp_extreme != nullptr) {      // (uniform: every thread of the one block takes part)
+    q_block_minmax(mn, mx, red);
+    if (threadIdx.x == 0) {
+      float range = mx - mn;
+      if (range == 0.f) range = 1.f;
+      qp_extreme[0] = mn;
+      qp_extreme[1] = range;
+    }
+  }
 }
 
 static int q_splits(int rows, long long row_len) {
@@ -122,7 +137,7 @@ extern "C" int cn_minmax_rows(const void* x, int rows, long long row_len, int dt
     CN_LAUNCH(minmax_partial_kernel<float>, grid, dim3(Q_NT), stream, (const float*)x, row_len, splits, vec, ws);
   } else { cn_set_error("minmax_rows: bad dtype %d", dtype); return CN_EINVAL; }
   CN_LAUNCH(minmax_final_kernel, dim3((unsigned)((rows + Q_NT - 1) / Q_NT)), dim3(Q_NT), stream, (const float*)ws, rows,
-            splits, minmax);
+            splits, minmax, (float*)nullptr);
   return cn_check_launch("minmax_rows");
 }
 
@@ -812,7 +827,7 @@ static int rangebn_fwd_impl(const void* x, const void* residual, void* z, const 
   else { if (qx8_out != nullptr) RAK(float, true); else RAK(float, false); }
 #undef RAK
   if (z_minmax != nullptr)
-    CN_LAUNCH(minmax_final_kernel, dim3((unsigned)((rows + Q_NT - 1) / Q_NT)), dim3(Q_NT), stream, (const float*)mmp, rows, (int)bpr, z_minmax);
+    CN_LAUNCH(minmax_final_kernel, dim3((unsigned)((rows + Q_NT - 1) / Q_NT)), dim3(Q_NT), stream, (const float*)mmp, rows, (int)bpr, z_minmax, (float*)nullptr);
   return cn_check_launch("rangebn_fwd");
 }
 
@@ -1074,7 +1089,8 @@ __global__ __launch_bounds__(Q_NT) void rangebn_bwd_route_kernel(T* dx, const fl
 static int rangebn_bwd_impl(const void* g, const void* x, const float* weight, const float* stats, const int* arg,
                               void* dx, float* dweight, float* dbias, int M, int C, int chunks, float scale_fix,
                               int dtype, float* ws, size_t ws_bytes, void* stream_, int mm_rows, float* dx_minmax,
-                              const float* g8qp = nullptr, int g_bits = 8, const float* x8qp = nullptr, int x_bits = 8) {
+                              const float* g8qp = nullptr, int g_bits = 8, const float* x8qp = nullptr, int x_bits = 8,
+                              float* dx_qp = nullptr) {
   // g8qp / x8qp: that operand holds 8-bit LEVELS of the grid (zero point, range) = g8qp[0..1] / x8qp[0..1] (cn_quantize_levels,
   // cn_rangebn_fwd_q8) instead of values
   if ((g8qp != nullptr && (g_bits < 1 || g_bits > 8)) || (x8qp != nullptr && (x_bits < 1 || x_bits > 8))) { cn_set_error("rangebn_bwd: level operands have <= 8 bits"); return CN_EINVAL; }
@@ -1122,7 +1138,7 @@ static int rangebn_bwd_impl(const void* g, const void* x, const float* weight, c
   }
 #undef RBW
   if (fused)
-    CN_LAUNCH(minmax_final_kernel, dim3((unsigned)((arows + Q_NT - 1) / Q_NT)), dim3(Q_NT), stream, (const float*)mmp, arows, (int)bpr, dx_minmax);
+    CN_LAUNCH(minmax_final_kernel, dim3((unsigned)((arows + Q_NT - 1) / Q_NT)), dim3(Q_NT), stream, (const float*)mmp, arows, (int)bpr, dx_minmax, arows <= Q_NT ? dx_qp : (float*)nullptr);
   return cn_check_launch("rangebn_bwd");
 }
 
@@ -1145,13 +1161,16 @@ extern "C" int cn_rangebn_bwd_mm(const void* g, const void* x, const float* weig
 // cn_rangebn_bwd_mm on operands stored as 8-bit LEVELS: g (the quantised output gradient: cn_quantize_levels with
 // g_qparams, g_bits) and / or x (the snapped input: cn_rangebn_fwd_q8 with x_qparams, x_bits); a null qparams pointer
 // means that operand holds values as before.  Same dx, dweight, dbias, dx_minmax bits as on the stored values.
+// dx_qp_extreme (optional, mm_rows <= 256): [zero_point, range] = cn_qparams(dx_minmax, mm_rows, 1), for the gradient quantiser
+// of the convolution in front.
 extern "C" int cn_rangebn_bwd_q8(const void* g, const float* g_qparams, int g_bits, const void* x, const float* x_qparams,
                                  int x_bits, const float* weight, const float* stats, const int* arg, void* dx,
                                  float* dweight, float* dbias, int M, int C, int chunks, float scale_fix, int dtype,
-                                 int mm_rows, float* dx_minmax, float* ws, size_t ws_bytes, void* stream_) {
+                                 int mm_rows, float* dx_minmax, float* dx_qp_extreme, float* ws, size_t ws_bytes, void* stream_) {
   if (dx_minmax == nullptr) { cn_set_error("rangebn_bwd_q8: needs dx_minmax"); return CN_EINVAL; }
+  if (dx_qp_extreme != nullptr && mm_rows > Q_NT) { cn_set_error("rangebn_bwd_q8: dx_qp_extreme needs mm_rows <= %d", Q_NT); return CN_ESHAPE; }
   return rangebn_bwd_impl(g, x, weight, stats, arg, dx, dweight, dbias, M, C, chunks, scale_fix, dtype, ws, ws_bytes, stream_,
-                          mm_rows, dx_minmax, g_qparams, g_bits, x_qparams, x_bits);
+                          mm_rows, dx_minmax, g_qparams, g_bits, x_qparams, x_bits, dx_qp_extreme);
 }
 
 // ------------------------------------------------------------------------------------------------ elementwise + min / max
@@ -1199,8 +1218,20 @@ extern "C" size_t cn_eltwise_mm_workspace(long long n, int rows, int dtype) {
   if (n <= 0 || rows < 1) return 0;
   return (size_t)rows * q_grid_rows(n / CH, rows, 1) * 2 * sizeof(float);
 }
+static int eltwise_mm_impl(int op, void* a, const void* b, const void* c, long long n, int dtype, int rows, float* minmax,
+                           float* qp_extreme, float* ws, size_t ws_bytes, void* stream_);
 extern "C" int cn_eltwise_mm(int op, void* a, const void* b, const void* c, long long n, int dtype, int rows, float* minmax,
                              float* ws, size_t ws_bytes, void* stream_) {
+  return eltwise_mm_impl(op, a, b, c, n, dtype, rows, minmax, nullptr, ws, ws_bytes, stream_);
+}
+// ... additionally qp_extreme[2] = cn_qparams(minmax, rows, 1) (rows <= 256): the consumer is a gradient quantiser
+extern "C" int cn_eltwise_mm_qp(int op, void* a, const void* b, const void* c, long long n, int dtype, int rows, float* minmax,
+                                float* qp_extreme, float* ws, size_t ws_bytes, void* stream_) {
+  if (qp_extreme == nullptr || rows > Q_NT) { cn_set_error("eltwise_mm_qp: needs qp_extreme and rows <= %d", Q_NT); return CN_EINVAL; }
+  return eltwise_mm_impl(op, a, b, c, n, dtype, rows, minmax, qp_extreme, ws, ws_bytes, stream_);
+}
+static int eltwise_mm_impl(int op, void* a, const void* b, const void* c, long long n, int dtype, int rows, float* minmax,
+                           float* qp_extreme, float* ws, size_t ws_bytes, void* stream_) {
   if (dtype != CN_BF16 && dtype != CN_F32) { cn_set_error("eltwise_mm: bad dtype"); return CN_EINVAL; }
   if (op != 2 && op != 4) { cn_set_error("eltwise_mm: op %d (2 or 4)", op); return CN_EINVAL; }
   const int CH = dtype == CN_F32 ? 4 : 8;
@@ -1215,6 +1246,6 @@ extern "C" int cn_eltwise_mm(int op, void* a, const void* b, const void* c, long
   if (dtype == CN_BF16) { if (op == 2) ELTMM(bf16_t, 2); else ELTMM(bf16_t, 4); }
   else { if (op == 2) ELTMM(float, 2); else ELTMM(float, 4); }
 #undef ELTMM
-  CN_LAUNCH(minmax_final_kernel, dim3((unsigned)((rows + Q_NT - 1) / Q_NT)), dim3(Q_NT), stream, (const float*)ws, rows, (int)bpr, minmax);
+  CN_LAUNCH(minmax_final_kernel, dim3((unsigned)((rows + Q_NT - 1) / Q_NT)), dim3(Q_NT), stream, (const float*)ws, rows, (int)bpr, minmax, rows <= Q_NT ? qp_extreme : (float*)nullptr);
   return cn_check_launch("eltwise_mm");
 }

@@ -52,6 +52,7 @@ _DEFAULTS = {
     # ---- config 5
     'quant_int8': 0,           # QConv2d forward on the int8 MFMA kernel
     'quant_fuse': 1,           # producer-side fusions of the quantised chain (quant.py: FUSE_QUANT)
+    'quant_qp_from_producer': 1,   # gradient producers also emit the gradient quantiser's [zero_point, range]
     'quant_store8': 1,         # RangeBN's snapped input and its quantised output gradient kept as 8-bit levels (bit-identical)
     'quant_wgrad_side': 1,     # QConv2d weight gradients on the weight-gradient side stream
     'quant_junction_add': 1,   # block-input gradient sum in the later data gradient's epilogue (fp32 identical; 16-bit: one rounding)

@@ -50,23 +50,33 @@ WGRAD_SIDE = flags.on('quant_wgrad_side')
 # backward kernels read are kept as one byte per element and de-quantised on load - bit-identical to storing the snapped
 # values, 6 of the 16 bytes per element RangeBN's passes move.  0: values in the compute dtype, as through round 5.
 STORE8 = flags.on('quant_store8')
+# the producers of a gradient (ReLU-mask pass, RangeBN's backward apply) also reduce its per-sample extremes to the gradient
+# quantiser's [zero_point, range]: ~105 cn_qparams launches per ResNet-50 step less (same values)
+QP_FROM_PRODUCER = flags.on('quant_qp_from_producer')
 
 # produced tensor -> its per-sample min / max ([rows][2] floats), keyed by storage address; the entry holds the tensor, so
 # the address cannot be recycled while it lives; `uses` consumers may take it, tick() (next forward) drops the rest
 _MM_STASH = {}
 
 
-def _stash_minmax(t, rows, mm, uses=1):
-    _MM_STASH[t.data_ptr()] = [t, rows, mm, uses]
+def _stash_minmax(t, rows, mm, uses=1, qp_extreme=None):
+    """qp_extreme: [zero_point, range] of the 'extreme' reduction of mm (what a GRADIENT quantiser derives from it), when the
+    producer's final kernel emitted it too."""
+    _MM_STASH[t.data_ptr()] = [t, rows, mm, uses, qp_extreme]
+
+
+_LAST_QP_EXTREME = [None]
 
 
 def _take_minmax(x, rows):
     e = _MM_STASH.get(x.data_ptr())
+    _LAST_QP_EXTREME[0] = None
     if e is None or e[1] != rows or e[0].shape != x.shape or e[0].dtype != x.dtype:
         return None
     e[3] -= 1
     if e[3] <= 0:
         del _MM_STASH[x.data_ptr()]
+    _LAST_QP_EXTREME[0] = e[4]
     return e[2]
 _NOISE_SOURCE = None
 _SEED = [0x5EED5EED]
@@ -148,17 +158,24 @@ def quantize(x, zp, rng, num_bits=8, noise=None, stochastic=False):
     return y
 
 
-def eltwise_mm(op, b, c, rows):
-    """a = b * (c > 0) (op 2) or relu(b + c) (op 4) and [rows][2] per-row min / max of a (cn_eltwise_mm)."""
+def eltwise_mm(op, b, c, rows, want_qp=False):
+    """a = b * (c > 0) (op 2) or relu(b + c) (op 4) and [rows][2] per-row min / max of a (cn_eltwise_mm).
+    want_qp: returns (a, mm, qp) with qp = the gradient quantiser's [zero_point, range] of a (None beyond 256 rows)."""
     L = _L()
     a = torch.empty_like(b)
     mm = torch.empty(rows * 2, dtype=torch.float32, device=b.device)
     code = dtype_code(b.dtype)
     ws = ops.workspace(L.cn_eltwise_mm_workspace(b.numel(), rows, code), b.device, 'quant')
+    if want_qp and rows <= 256 and QP_FROM_PRODUCER:
+        qp = torch.empty(2, dtype=torch.float32, device=b.device)
+        ops.PROFILER.run('quant: eltwise+minmax', 2, 0.0, 3 * b.numel() * b.element_size(),
+                         lambda: check(L.cn_eltwise_mm_qp(op, ptr(a), ptr(b), ptr(c), b.numel(), code, rows, ptr(mm), ptr(qp),
+                                                          ptr(ws), ws.numel() * 4, stream_of(b)), 'cn_eltwise_mm_qp'), b.device)
+        return a, mm, qp
     ops.PROFILER.run('quant: eltwise+minmax', 2, 0.0, 3 * b.numel() * b.element_size(),
                      lambda: check(L.cn_eltwise_mm(op, ptr(a), ptr(b), ptr(c), b.numel(), code, rows, ptr(mm), ptr(ws),
                                                    ws.numel() * 4, stream_of(b)), 'cn_eltwise_mm'), b.device)
-    return a, mm
+    return (a, mm, None) if want_qp else (a, mm)
 
 
 def _mm_ok(t):
@@ -184,7 +201,11 @@ def quantize_grad(g, num_bits=8, levels=False):
     backward kernels - de-quantises on load; one byte per element written and read instead of two)."""
     g = g.contiguous()
     rows = g.shape[0]
-    qp = qparams(minmax_rows(g, rows), rows, 1)
+    mm = minmax_rows(g, rows)
+    qp = _LAST_QP_EXTREME[0]          # the producer of g measured it AND reduced it (cn_eltwise_mm_qp / cn_rangebn_bwd_q8) ...
+    _LAST_QP_EXTREME[0] = None
+    if qp is None:
+        qp = qparams(mm, rows, 1)     # ... else one more tiny launch
     if not levels:
         return quantize(g, qp[0:1], qp[1:2], num_bits, noise=_noise_like(g), stochastic=True)
     noise = _noise_like(g)
@@ -586,8 +607,8 @@ class RangeBNFunction(Function):
         fuse = _mm_ok(dz)
         if ctx.relu:     # the ReLU that follows the output-gradient quantiser in the reference
             if fuse:     # ... masked and measured in one pass
-                g0, mm = eltwise_mm(2, dz, saved[4], N)
-                _stash_minmax(g0, N, mm)
+                g0, mm, gqp = eltwise_mm(2, dz, saved[4], N, want_qp=True)
+                _stash_minmax(g0, N, mm, qp_extreme=gqp)
             else:
                 g0 = torch.empty_like(dz)
                 check(L.cn_eltwise(2, ptr(g0), ptr(dz), ptr(saved[4]), dz.numel(), dtype_code(dz.dtype), stream_of(dz)),
@@ -607,6 +628,7 @@ class RangeBNFunction(Function):
             raise _lib.ConvNetHipError('RangeBN: the 8-bit level storage of the forward pass needs the fused backward pass')
         if fuse and (g8 or x_qp is not None):
             dxmm = torch.empty(N * 2, dtype=torch.float32, device=qy.device)
+            dxqp = torch.empty(2, dtype=torch.float32, device=qy.device) if (N <= 256 and QP_FROM_PRODUCER) else None
             esz = dx.element_size()
             ops.PROFILER.run('quant: rangebn_bwd reduce+finalize+apply(route, minmax) on 8-bit levels', 4, 0.0,
                              qy.numel() * (esz + (2 if g8 else 2 * esz) + (1 if x_qp is not None else esz)),
@@ -614,9 +636,10 @@ class RangeBNFunction(Function):
                                                                mod.quantize_input.num_bits, ptr(weight), ptr(stats), ptr(arg),
                                                                ptr(dx), ptr(mod.grad_view('weight')), ptr(mod.grad_view('bias')),
                                                                M, C, mod.num_chunks, ctx.fix, dtype_code(cdt), N, ptr(dxmm),
-                                                               ptr(ws), ws.numel() * 4, stream_of(qy)), 'cn_rangebn_bwd_q8'),
+                                                               ptr(dxqp), ptr(ws), ws.numel() * 4, stream_of(qy)),
+                                           'cn_rangebn_bwd_q8'),
                              qy.device)
-            _stash_minmax(dx, N, dxmm)     # for the gradient quantiser of the convolution in front (QConv2d.backward)
+            _stash_minmax(dx, N, dxmm, qp_extreme=dxqp)     # for the gradient quantiser of the convolution in front
         elif fuse:
             dxmm = torch.empty(N * 2, dtype=torch.float32, device=qy.device)
             ops.PROFILER.run('quant: rangebn_bwd reduce+finalize+apply(route, minmax)', 4, 0.0, 4 * qy.numel() * qy.element_size(),
@@ -712,8 +735,8 @@ class AddReLUFunction(Function):
         dz = dz.contiguous()
         if _mm_ok(dz):
             # g reaches the gradient quantiser of bn3 (and of the projection's RangeBN when the block has one)
-            g, mm = eltwise_mm(2, dz, z, dz.shape[0])
-            _stash_minmax(g, dz.shape[0], mm, uses=2)
+            g, mm, gqp = eltwise_mm(2, dz, z, dz.shape[0], want_qp=True)
+            _stash_minmax(g, dz.shape[0], mm, uses=2, qp_extreme=gqp)
         else:
             g = torch.empty_like(dz)
             check(_L().cn_eltwise(2, ptr(g), ptr(dz), ptr(z), dz.numel(), dtype_code(dz.dtype), stream_of(dz)), 'cn_eltwise')

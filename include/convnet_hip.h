@@ -493,11 +493,15 @@ int cn_rangebn_fwd_q8(const void* x, const float* x_qparams, int x_bits, unsigne
                       float* z_minmax, float* ws, size_t ws_bytes, void* stream);
 int cn_rangebn_bwd_q8(const void* g, const float* g_qparams, int g_bits, const void* x, const float* x_qparams, int x_bits,
                       const float* weight, const float* stats, const int* arg, void* dx, float* dweight, float* dbias,
-                      int M, int C, int chunks, float scale_fix, int dtype, int mm_rows, float* dx_minmax, float* ws,
+                      int M, int C, int chunks, float scale_fix, int dtype, int mm_rows, float* dx_minmax,
+                      float* dx_qp_extreme /* optional, mm_rows <= 256: cn_qparams(dx_minmax, mm_rows, 1) */, float* ws,
                       size_t ws_bytes, void* stream);
 size_t cn_eltwise_mm_workspace(long long n, int rows, int dtype);
 int cn_eltwise_mm(int op, void* a, const void* b, const void* c, long long n, int dtype, int rows, float* minmax, float* ws,
                   size_t ws_bytes, void* stream);
+/* ... additionally qp_extreme[2] = cn_qparams(minmax, rows, 1) when the consumer of `a` is a gradient quantiser (rows <= 256) */
+int cn_eltwise_mm_qp(int op, void* a, const void* b, const void* c, long long n, int dtype, int rows, float* minmax,
+                     float* qp_extreme, float* ws, size_t ws_bytes, void* stream);
 
 /* ---- true int8 MFMA forward product of QConv2d (v_mfma_i32_32x32x32_i8; csrc/qconv_i8.hip).  Both operands of
  * the reference's simulated convolution (quantize.py:195-219) live on integer grids, so
