@@ -490,10 +490,17 @@ class Trainer(object):
                 # A capture needs its own pool for the step's tensors, next to the blocks the eager steps keep cached.  When
                 # the capture was the WATCH's idea (a verdict withdrawn after many eager steps) and it does not fit, the
                 # configuration simply stays eager; a capture the configuration started with fails as it always did.
-                if not seen.get('withdrawn'):
+                # The same holds for a launch-plan recording in graph = auto: the plan is an optimisation of a step that already
+                # ran eagerly twice - whatever made its capture fail (memory, a runtime that refuses the capture with the
+                # communicators of a multi-rank job alive, ...) must not take the job down.  graph = 1 asked for a capture
+                # and still gets the error.
+                if not (seen.get('withdrawn') or (seen.get('plan') and self._graph_mode == 'auto')):
                     raise
-                logging.warning('HIP-graph capture of a running configuration failed (%s): staying with eager launches',
+                logging.warning('capture of the training step failed (%s): staying with eager launches',
                                 str(e).split('\n')[0][:200])
+                seen['plan'] = False
+                if 'eager_ms' in seen and not seen.get('withdrawn'):
+                    self._watch[eager_key] = EagerWatch(seen['eager_ms'])
                 gs['graph'] = None
                 seen['use'] = False
                 self._graph_eager_for.add(eager_key)
@@ -595,6 +602,22 @@ class Trainer(object):
         except BaseException:
             if rec is not None:
                 rec.destroy()
+            # an aborted step body leaves per-step mailboxes half filled: empty them, the next (eager) step starts clean
+            for m in self._model.modules():
+                h = getattr(m, '_holder', None)
+                if h is not None:
+                    h.dres, h.fused, h.sub = None, False, 1
+                m.__dict__.pop('_lazy_z', None)
+                m.__dict__.pop('_lazy_a', None)
+                if hasattr(m, '_lazy_dy'):
+                    m._lazy_dy = None
+            ops.SIDE._held.clear()
+            ops.SIDE._held_bytes, ops.SIDE.used, ops.SIDE._mark = 0, False, None
+            try:
+                from . import quant as _q
+                _q._MM_STASH.clear()
+            except Exception:
+                pass
             raise
         finally:
             ops.SIDE.capturing = False

@@ -36,17 +36,19 @@ def _find(table, *needles):
 def test_bn_streaming_passes_really_use_nontemporal_accesses(table):
     # NT = true instantiations: the activation loads are `nt`, the plain ones left are coefficient loads
     # (the reduction pass exists with cached loads only since round 4: non-temporal loads there measured slower)
-    assert not _find_any(table, 'bn_bwd_reduce_kernel<', ', true>')
-    for kern, sites in (('bn_apply_kernel', 'nt_load16'), ('bn_bwd_apply_kernel', 'nt_load16'),
-                        ('bn_bwd_apply_kernel', 'nt_store16')):
+    # (leading space: the BatchNorm kernels proper, not config 5's rangebn_* kernels, whose trailing template booleans
+    # since round 6 say "operand stored as 8-bit levels")
+    assert not _find_any(table, ' bn_bwd_reduce_kernel<', ', true>')
+    for kern, sites in ((' bn_apply_kernel', 'nt_load16'), (' bn_bwd_apply_kernel', 'nt_load16'),
+                        (' bn_bwd_apply_kernel', 'nt_store16')):
         # (bn_apply_kernel<T, NT, DUAL>: the cache policy is its second parameter; the others end with it)
-        on, off = ((', true, ', ', false, ') if kern == 'bn_apply_kernel' else (', true>', ', false>'))
+        on, off = ((', true, ', ', false, ') if kern == ' bn_apply_kernel' else (', true>', ', false>'))
         for name, c in _find(table, kern + '<', on):
             assert c[sites] > 0, (name, c)
         for name, c in _find(table, kern + '<', off):
             assert c['nt_load16'] == 0 and c['nt_store16'] == 0, (name, c)
     # z is stored with the default policy in both instantiations (its consumer follows at once)
-    for name, c in _find(table, 'bn_apply_kernel'):
+    for name, c in _find(table, ' bn_apply_kernel'):
         assert c['nt_store16'] == 0 and c['plain_store16'] > 0, (name, c)
 
 

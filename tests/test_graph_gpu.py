@@ -219,3 +219,52 @@ def test_step_periods_are_attributed_to_the_configuration_they_belong_to(tmp_pat
     env = dict(os.environ, CONVNET_AMD_EMULATE='0')
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and 'TWO_KEYS_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+FALLBACK_WORKER = r'''
+import sys, torch
+sys.path.insert(0, %(root)r)
+import convnet_amd as ca
+torch.cuda.set_device(0)
+kw = dict(depth=50, width=(16, 32, 64, 128), inplanes=16, num_classes=32)
+g = torch.Generator().manual_seed(9)
+data = [(torch.randn(16, 3, 64, 64, generator=g).cuda(), torch.randint(0, 32, (16,), generator=g).cuda()) for _ in range(8)]
+
+def run(break_capture):
+    torch.manual_seed(123)
+    model = ca.models.resnet(**kw)
+    tr = ca.Trainer(model, ca.CrossEntropyLoss(), ca.OptimRegime(model, model.regime), device='cuda:0',
+                    dtype=torch.bfloat16, print_freq=10**9)
+    assert tr._graph_mode == 'auto' and tr._plan
+    if break_capture:
+        real = ca.trainer.LaunchPlan.end
+        def boom(self):
+            real(self)
+            raise RuntimeError('injected: the recording cannot be finished')
+        ca.trainer.LaunchPlan.end = boom
+    try:
+        recs = [tr.train([b])['loss'] for b in data]
+    finally:
+        if break_capture:
+            ca.trainer.LaunchPlan.end = real
+    torch.cuda.synchronize()
+    return recs, tr
+
+ok, tr_ok = run(False)
+assert any(g['graph'] is not None and g['graph'].get('plan') is not None for g in tr_ok._gstates.values())
+bad, tr_bad = run(True)
+assert all(g['graph'] is None for g in tr_bad._gstates.values()) and len(tr_bad._graph_eager_for) == 1
+assert ok == bad, (ok, bad)          # the job went on with eager launches: the same numbers
+print('FALLBACK_OK')
+'''
+
+
+def test_a_failed_plan_capture_leaves_the_job_on_eager_launches(tmp_path):
+    """graph = auto (the default): the launch plan is an optimisation of a step that already ran eagerly - if its recording
+    fails for whatever reason the configuration stays on eager launches (with a warning and the watch armed) and trains to
+    the same numbers; nothing is left in the per-step mailboxes of the aborted capture."""
+    script = tmp_path / 'fallback_worker.py'
+    script.write_text(FALLBACK_WORKER % {'root': ROOT})
+    env = dict(os.environ, CONVNET_AMD_EMULATE='0')
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and 'FALLBACK_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -485,8 +485,8 @@ def test_block_input_gradient_sum_in_the_dgrad_epilogue_changes_no_bit_in_fp32(m
     gradient's epilogue of whichever branch arrives second (identity shortcut: conv1's; projection: conv1's or the
     projection's) instead of a separate add pass.  fp32: the same numbers bit for bit, and no separate add is launched."""
     dev = _dev(mode)
-    if mode == 'emul' and depth != 18:
-        pytest.skip('emulated suite: ResNet-18 only')
+    if mode == 'emul':
+        pytest.skip('GPU suite (two trajectories: 100 s on the emulator; test_quantised_block_switches_change_no_bit covers the emulator)')
     import convnet_amd as ca
     meta = json.load(open(os.path.join(GOLDEN, 'traj_r%ds_quant.json' % depth)))
     res, adds = {}, {}
@@ -520,8 +520,8 @@ def test_8bit_level_storage_changes_no_bit_of_a_trajectory(mode, dtype, referenc
     cn_rangebn_bwd_q8).  Same trajectory and same final state bit for bit as with the snapped values stored in the compute
     dtype, fp32 and bf16; and the level tensors really are what is saved (uint8)."""
     dev = _dev(mode)
-    if mode == 'emul' and dtype != torch.float32:
-        pytest.skip('emulated suite: fp32 only (the GPU run does both)')
+    if mode == 'emul':
+        pytest.skip('GPU suite (two trajectories: 100 s on the emulator; test_quantised_block_switches_change_no_bit covers the emulator)')
     import convnet_amd as ca
     meta = json.load(open(os.path.join(GOLDEN, 'traj_r18s_quant.json')))
     res, kinds = {}, {}
@@ -547,3 +547,51 @@ def test_8bit_level_storage_changes_no_bit_of_a_trajectory(mode, dtype, referenc
     for k, v in res[False][1].items():
         assert torch.equal(v, res[True][1][k]), k
     assert torch.uint8 in kinds[True] and torch.uint8 not in kinds[False], kinds
+
+
+@pytest.mark.parametrize('mode', MODES)
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_quantised_block_switches_change_no_bit(mode, dtype, reference_noise):
+    """One quantised bottleneck block (identity shortcut) + one with a projection, forward and backward, with each round-6
+    switch of quant.py off and on: STORE8 (8-bit level storage of RangeBN's saved input and its output gradient),
+    QP_FROM_PRODUCER (gradient producers emit the gradient quantiser's parameters) - the same output, input gradient and
+    parameter gradients bit for bit in fp32 and bf16; JUNCTION_ADD (block-input gradient sum in the later data gradient's
+    epilogue) - bit for bit in fp32, one rounding apart in bf16.  The fast, emulator-sized form of the trajectory tests above."""
+    dev = _dev(mode)
+    import convnet_amd as ca
+    from convnet_amd.models import resnet as R
+    torch.manual_seed(4)
+    model = ca.models.resnet(dataset='imagenet', quantize=True, depth=50, num_classes=8, inplanes=8, width=[8, 16, 16, 16])
+    ca.engine.prepare(model, dev, dtype)
+    model.train()
+    blocks = [model.layer1[0], model.layer1[1]]      # projection shortcut, identity shortcut
+    g = torch.Generator().manual_seed(6)
+    x0 = torch.randn(4, 8, 8, 8, generator=g).to(dev).to(dtype)      # NHWC, 8 channels = layer1's input
+    gy = None
+
+    def run():
+        nonlocal gy
+        model._cn_arena.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        torch.manual_seed(11)
+        y = blocks[1](blocks[0](x))
+        if gy is None:
+            gy = torch.randn(y.shape, generator=g).to(dev).to(dtype)
+        y.backward(gy)
+        return (y.detach().float().cpu().clone(), x.grad.float().cpu().clone(), model._cn_arena.grads.detach().cpu().clone())
+
+    Q = ca.quant
+    for name, exact_bf16 in (('STORE8', True), ('QP_FROM_PRODUCER', True), ('JUNCTION_ADD', False)):
+        saved = getattr(Q, name)
+        try:
+            setattr(Q, name, False)
+            a = run()
+            setattr(Q, name, True)
+            b = run()
+        finally:
+            setattr(Q, name, saved)
+        for u, v in zip(a, b):
+            if dtype == torch.float32 or exact_bf16:
+                assert torch.equal(u, v), name
+            else:
+                assert rel_l2(u, v) < 1e-2, name
