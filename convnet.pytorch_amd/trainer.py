@@ -571,7 +571,16 @@ class Trainer(object):
             if st.get('x_sites', 0) > 0:
                 check(_lib.load().cn_plan_set_input(st['plan'].handle, 0, ctypes.c_void_p(st['x'].data_ptr())), 'cn_plan_set_input')
             st['x'].copy_(inputs, non_blocking=True)
-        st['t'].copy_(target, non_blocking=True)
+        # the targets likewise (slot 1).  The copy they replace is 2 KB, but a device-to-device memcpy between the optimizer
+        # kernel of one step and the first kernel of the next left the queue idle for 155 + 20 us per step in the traced plan
+        # (profiles/r06_trace_gaps_plan.txt): 1 % of a ResNet-50 step
+        if st.get('t_sites', 0) > 0 and target.is_contiguous() and target.dtype == st['t'].dtype:
+            check(_lib.load().cn_plan_set_input(st['plan'].handle, 1, ctypes.c_void_p(target.data_ptr())), 'cn_plan_set_input')
+            st['t_live'] = target
+        else:
+            if st.get('t_sites', 0) > 0:
+                check(_lib.load().cn_plan_set_input(st['plan'].handle, 1, ctypes.c_void_p(st['t'].data_ptr())), 'cn_plan_set_input')
+            st['t'].copy_(target, non_blocking=True)
 
     def _replay(self, st):
         if st.get('plan') is not None:
@@ -638,8 +647,9 @@ class Trainer(object):
             sites = L.cn_plan_bind_input(rec.handle, 0, ctypes.c_void_p(x.data_ptr()), x.numel() * x.element_size())
             if sites > 0:
                 x.fill_(float('nan'))
+            t_sites = L.cn_plan_bind_input(rec.handle, 1, ctypes.c_void_p(t.data_ptr()), t.numel() * t.element_size())
             return {'key': key, 'graph': g, 'plan': rec, 'stream': cur.cuda_stream, 'x': x, 't': t, 'out': out,
-                    'loss': loss, 'grad': grad, 'x_sites': max(sites, 0)}
+                    'loss': loss, 'grad': grad, 'x_sites': max(sites, 0), 't_sites': max(t_sites, 0)}
         logging.debug('captured the training step as one HIP graph (%s)', (key[0],))
         return {'key': key, 'graph': g, 'x': x, 't': t, 'out': out, 'loss': loss, 'grad': grad}
 

@@ -88,6 +88,15 @@ def main():
             tr._replay = replay
         tr.train([pool[i % 2] for i in range(6)])      # warm-up + capture + first replays
         torch.cuda.synchronize()
+        if mode == 'plan':       # host time INSIDE every replay call in the steady state (a blocked host shows up here)
+            inner = tr._replay
+            tr._replay_times = []
+
+            def timed(st):
+                t0 = time.perf_counter()
+                inner(st)
+                tr._replay_times.append((time.perf_counter() - t0) * 1e3)
+            tr._replay = timed
         return tr
 
     modes = args.modes.split(',')
@@ -135,6 +144,12 @@ def main():
             t1 = time.perf_counter()
         torch.cuda.synchronize()
         res[m]['issue_ms'] = (t1 - t0) * 1e3 / 5
+    for m in modes:
+        ts = getattr(trainers[m], '_replay_times', None)
+        if ts:
+            srt = sorted(ts)
+            print('%s: host time inside cn_plan_replay over %d steady-state calls: median %.2f ms, p90 %.2f, max %.2f' %
+                  (m, len(ts), srt[len(srt) // 2], srt[int(len(srt) * 0.9)], srt[-1]))
     stop.value = 1
     out = {'batch': args.batch, 'burners': args.burners, 'cores_allowed': len(allowed),
            'cores_used': len(os.sched_getaffinity(0))}
