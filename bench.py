@@ -95,7 +95,7 @@ def run_pmc_passes(args):
     tmp = tempfile.mkdtemp(prefix='bench_pmc_', dir='/tmp')
     env = dict(os.environ, TMPDIR='/tmp', CONVNET_AMD_FLAGS=','.join(filter(None, [os.environ.get('CONVNET_AMD_FLAGS', ''), 'graph=0'])))
     cmd = [sys.executable, os.path.abspath(__file__), '--steps', '2', '--warmup', '1', '--no-cpu-baseline',
-           '--no-kernel-profile', '--batch', str(args.batch), '--depth', str(args.depth), '--dtype', args.dtype] + \
+           '--no-kernel-profile', '--no-issue-probe', '--batch', str(args.batch), '--depth', str(args.depth), '--dtype', args.dtype] + \
         (['--quantize'] if args.quantize else [])
     for name, ctr in (('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE')):
         r = subprocess.run(['rocprofv3', '--pmc', ctr, '--kernel-trace', '--output-format', 'csv', '-d',
@@ -130,6 +130,8 @@ def main():
                          "configuration, not the contract workload)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
+    ap.add_argument('--no-issue-probe', action='store_true',
+                    help='skip the three extra steps that time the host side of a step (the PMC sub-runs count steps)')
     ap.add_argument('--pmc', action='store_true',
                     help='also measure roofline.traffic LIVE: two extra rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; '
                          'kernel trace only) of a 3-step run of this same workload, ~2-4 min (N=1 only)')
@@ -245,14 +247,14 @@ def main():
         tr.model.train()
         xb, tb = (t.to(device) for t in pool[0])
         host_ms = None
-        for _ in range(3):          # ONE step issued into drained queues, three times (a deep backlog would make the host wait
+        for _ in range(0 if args.no_issue_probe else 3):          # ONE step issued into drained queues, three times (a deep backlog would make the host wait
             fence()                 # for queue space - that is device time, not issue time), the fastest counts
             th0 = time.perf_counter()
             tr._step(xb, tb, training=True)
             dt_ms = (time.perf_counter() - th0) * 1e3
             host_ms = dt_ms if host_ms is None else min(host_ms, dt_ms)
     fence()
-    step_issue = {'mode': modes[0] if modes else 'eager', 'host_ms_per_step': round(host_ms, 2)}
+    step_issue = {'mode': modes[0] if modes else 'eager', 'host_ms_per_step': round(host_ms, 2) if host_ms is not None else None}
     rank_devices, params_in_sync = [local_rank], None
     if distributed:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)

@@ -231,6 +231,36 @@ __host__ __device__ __forceinline__ float q_snap(float x, float zp, float scale,
   return q_dequant(q_level(x, zp, scale, qmax, noise), zp, scale);
 }
 
+// q_level for a whole chunk with ONE division-free pass where that is provably exact (round 6).  The level is
+// rint(clamp(fl(fl(d / scale) + noise))); with ta = fl(d * fl(1 / scale)) in place of the quotient the sum moves by at most
+// 5u|Q| + u (u = 2^-24: one rounding each in the reciprocal, the product and the two sums), i.e. < 4e-7 |ta| + 1e-7 - so
+// wherever fl(ta + noise) lies further than that from a half-integer, both forms round to the same integer (and clamp alike:
+// the bounds are integers).  A chunk holding ANY element inside that band (probability ~1e-4 per element), a NaN or an
+// overflowing product is redone with the division: the result is q_level's bit for bit, at ~5 fewer VALU issue slots per element
+// (the division is 10-11 of the 17 a deterministic quantiser spends per element, of ~32 with the noise hash).
+template <int CH>
+__host__ __device__ __forceinline__ void q_levels_chunk(const float* f, const float* nz, float zp, float scale, float inv,
+                                                        float qmax, float* lv) {
+#ifdef CN_EXACT_DIV          // (A/B build: csrc/build.sh with CN_EXTRA_FLAGS=-DCN_EXACT_DIV)
+  bool unsure = true;
+#else
+  bool unsure = false;
+#endif
+#pragma unroll
+  for (int e = 0; e < CH; ++e) {
+    const float ta = (f[e] + (-zp)) * inv;
+    const float sa = ta + nz[e];
+    const float r = rintf(sa);
+    const float tol = fmaf(fabsf(ta), 4e-7f, 1e-7f);
+    unsure = unsure || !(0.5f - fabsf(sa - r) > tol);      // (also true for NaN / Inf: every comparison with them is false)
+    lv[e] = fminf(fmaxf(r, 0.f), qmax);
+  }
+  if (unsure) {
+#pragma unroll
+    for (int e = 0; e < CH; ++e) lv[e] = q_level(f[e], zp, scale, qmax, nz[e]);
+  }
+}
+
 // ---- 8-bit level storage (round 6).  A tensor snapped to a <= 256-level grid is kept as one byte per element (CH bytes per
 // chunk of CH elements, same chunk order) and de-quantised on load: value = T-rounded q_dequant(level) - exactly what the
 // kernels that store snapped values write.  `raw` carries either the 16 bytes of a value chunk or the CH level bytes.
@@ -290,18 +320,23 @@ __global__ __launch_bounds__(Q_NT) void quantize_kernel(const T* x, T* y, long l
   const unsigned int key = q_noise_key(seed);
   const float zp = zero_point[0];
   const float scale = (range[0] == 0.f ? 1.f : range[0]) / qmax;
+  const float inv = 1.0f / scale;
   const long long nch = n / CH;
   auto snap_chunk = [&](const u32x4& v, long long c) {
-    float f[CH];
+    float f[CH], nz[CH], lv[CH];
     Chunk<T>::unpack(v, f);
 #pragma unroll
     for (int e = 0; e < CH; ++e) {
       const long long i = c * CH + e;
-      const float nz = noise != nullptr ? noise[i] : (stochastic ? q_hash_noise(key, (unsigned long long)i) : 0.f);
-      f[e] = Y8 ? q_level(f[e], zp, scale, qmax, nz) : q_snap(f[e], zp, scale, qmax, nz);
+      nz[e] = noise != nullptr ? noise[i] : (stochastic ? q_hash_noise(key, (unsigned long long)i) : 0.f);
     }
-    if (Y8) q_st_levels<T>(y8, c, f);      // (8-bit LEVELS: the consumer de-quantises on load, q_unpack_raw)
-    else cn_st16((char*)y + c * 16, Chunk<T>::pack(f));
+    q_levels_chunk<CH>(f, nz, zp, scale, inv, qmax, lv);      // = q_level per element, division-free where provably exact
+    if (Y8) q_st_levels<T>(y8, c, lv);      // (8-bit LEVELS: the consumer de-quantises on load, q_unpack_raw)
+    else {
+#pragma unroll
+      for (int e = 0; e < CH; ++e) f[e] = q_dequant(lv[e], zp, scale);
+      cn_st16((char*)y + c * 16, Chunk<T>::pack(f));
+    }
   };
   const long long stride = (long long)gridDim.x * Q_NT;
   long long c = (long long)blockIdx.x * Q_NT + threadIdx.x;
@@ -438,7 +473,7 @@ extern "C" int cn_quantize_rows_multi(const float* x, float* y, const long long*
 // never stored: the division three times per element made them VALU-bound and the step slower.)  xqp == nullptr: x is
 // already quantised.
 struct RbnSnap {
-  float zp, scale, qmax;
+  float zp, scale, qmax, inv;
   int on;
 };
 __device__ __forceinline__ RbnSnap rbn_snap_make(const float* xqp, float qmax) {
@@ -447,6 +482,7 @@ __device__ __forceinline__ RbnSnap rbn_snap_make(const float* xqp, float qmax) {
   q.zp = q.on ? xqp[0] : 0.f;
   const float range = q.on ? xqp[1] : 1.f;
   q.scale = (range == 0.f ? 1.f : range) / qmax;
+  q.inv = 1.0f / q.scale;
   q.qmax = qmax;
   return q;
 }
@@ -454,8 +490,12 @@ template <typename T>
 __device__ __forceinline__ void rbn_snap_chunk(const RbnSnap& q, float* f) {
   constexpr int CH = ElemTraits<T>::kChunk;
   if (!q.on) return;
+  float nz[CH], lv[CH];
 #pragma unroll
-  for (int e = 0; e < CH; ++e) f[e] = q_snap(f[e], q.zp, q.scale, q.qmax, 0.f);
+  for (int e = 0; e < CH; ++e) nz[e] = 0.f;
+  q_levels_chunk<CH>(f, nz, q.zp, q.scale, q.inv, q.qmax, lv);
+#pragma unroll
+  for (int e = 0; e < CH; ++e) f[e] = q_dequant(lv[e], q.zp, q.scale);
   Chunk<T>::unpack(Chunk<T>::pack(f), f);   // as stored in T
 }
 
@@ -498,12 +538,12 @@ __global__ __launch_bounds__(Q_NT) void rangebn_stats_kernel(const T* x, int M, 
       float f[CH];
       Chunk<T>::unpack(v, f);
       if (Q8OUT) {        // the snapped input kept as 8-bit levels; the statistics see the values a load gives back
-        float lv[CH];
+        float lv[CH], nz[CH];
 #pragma unroll
-        for (int e = 0; e < CH; ++e) {
-          lv[e] = q_level(f[e], snap.zp, snap.scale, snap.qmax, 0.f);
-          f[e] = q_round_to<T>(q_dequant(lv[e], snap.zp, snap.scale));
-        }
+        for (int e = 0; e < CH; ++e) nz[e] = 0.f;
+        q_levels_chunk<CH>(f, nz, snap.zp, snap.scale, snap.inv, snap.qmax, lv);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) f[e] = q_round_to<T>(q_dequant(lv[e], snap.zp, snap.scale));
         q_st_levels<T>(q8_out, (long long)p * CC + cc, lv);
       } else {
         rbn_snap_chunk<T>(snap, f);

@@ -595,3 +595,44 @@ def test_quantised_block_switches_change_no_bit(mode, dtype, reference_noise):
                 assert torch.equal(u, v), name
             else:
                 assert rel_l2(u, v) < 1e-2, name
+
+
+@pytest.mark.parametrize('mode', MODES)
+def test_division_free_quantiser_levels_are_exact_at_the_rounding_boundaries(mode):
+    """Round 6 (q_levels_chunk): the quantisers multiply by 1/scale where that provably gives the level of the reference's
+    division and redo a chunk with the division otherwise.  Brute force against IEEE fp32 arithmetic on the CPU
+    (rint(clamp((x + (-zp)) / scale + noise))): every level identical - random inputs, inputs packed within 1e-7 ... 1e-3
+    (relative) of every half-integer boundary on both sides, values far outside the range, with and without rounding noise."""
+    dev = _dev(mode)
+    import convnet_amd as ca
+    L = ca._lib.load()
+    g = torch.Generator().manual_seed(17)
+    zp, rng = -1.7320508, 5.4365637
+    scale = torch.tensor(rng, dtype=torch.float32) / 255.0
+    ks = torch.arange(0, 256, dtype=torch.float32)
+    eps = torch.tensor([0.0, 1e-7, 3e-7, 1e-6, 1e-5, 1e-4, 1e-3], dtype=torch.float32)
+    eps = torch.cat([eps, -eps])
+    near = (ks.view(-1, 1) + 0.5) * (1.0 + eps.view(1, -1))                        # targets for (x - zp) / scale
+    xs = [torch.tensor(zp, dtype=torch.float32) + near.flatten() * scale,
+          torch.tensor(zp, dtype=torch.float32) + (torch.rand(1 << 16, generator=g) * 300.0 - 20.0) * scale,
+          torch.tensor([1e9, -1e9, 1e30, 0.0, zp, zp + rng], dtype=torch.float32)]
+    x = torch.cat(xs)
+    x = torch.cat([x, torch.zeros((-x.numel()) % 4)])                              # whole fp32 chunks
+    n = x.numel()
+    for with_noise in (False, True):
+        noise = (torch.rand(n, generator=g) - 0.5) if with_noise else None
+        t = (x + (-torch.tensor(zp, dtype=torch.float32))) / scale
+        if noise is not None:
+            t = t + noise
+        want = torch.round(t.clamp(0.0, 255.0)).to(torch.uint8)                   # torch.round: half to even, like rintf
+        xd = x.to(dev)
+        y8 = torch.empty(n, dtype=torch.uint8, device=dev)
+        zpt = torch.tensor([zp], dtype=torch.float32, device=dev)
+        rgt = torch.tensor([rng], dtype=torch.float32, device=dev)
+        nd = noise.to(dev) if noise is not None else None
+        ca._lib.check(L.cn_quantize_levels(xd.data_ptr(), y8.data_ptr(), n, 0, zpt.data_ptr(), rgt.data_ptr(), 8,
+                                           nd.data_ptr() if nd is not None else None, int(with_noise), 0, None,
+                                           ca._lib.stream_of(xd)), 'cn_quantize_levels')
+        got = y8.cpu()
+        bad = (got != want).nonzero().flatten()
+        assert bad.numel() == 0, (with_noise, bad[:8].tolist(), x[bad[:8]].tolist(), got[bad[:8]].tolist(), want[bad[:8]].tolist())

@@ -13,7 +13,7 @@ run() { # name counters... -- cmd
 }
 run sq1 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA" python tools/bench_layers.py --iters 2 --variants 0 --only $LAYERS
 run sq2 "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_INSTS_VMEM SQ_INSTS_SALU" python tools/bench_layers.py --iters 2 --variants 0 --only $LAYERS
-run fetch "FETCH_SIZE" python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile
-run write "WRITE_SIZE" python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile
+run fetch "FETCH_SIZE" python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile --no-issue-probe
+run write "WRITE_SIZE" python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile --no-issue-probe
 python tools/pmc_summary.py $OUT > $OUT/summary.txt; python tools/pmc_traffic.py $OUT $OUT/pmc_traffic.json | tee $OUT/traffic.txt
 find $OUT -name "*.csv" -size +8M -delete
