@@ -100,7 +100,13 @@ def main():
         return tr
 
     modes = args.modes.split(',')
-    trainers = {m: make(m) for m in modes}
+    trainers = {}
+    for m in modes:        # device memory each mode's trainer holds after its warm-up (arenas + activation pools)
+        torch.cuda.synchronize()
+        r0 = torch.cuda.memory_reserved(dev)
+        trainers[m] = make(m)
+        print('%s: +%.1f GB reserved (allocated now %.1f GB)' % (m, (torch.cuda.memory_reserved(dev) - r0) / 2 ** 30,
+                                                                 torch.cuda.memory_allocated(dev) / 2 ** 30))
     for m, tr in trainers.items():
         for gs in tr._gstates.values():
             st = gs.get('graph')
