@@ -401,7 +401,10 @@ class ImageFolder(Dataset):
     def __getitem__(self, i):
         path, target = self.samples[i]
         with open(path, 'rb') as f:
-            img = _pil().open(f).convert('RGB')
+            img = _pil().open(f)
+            img.load()                      # (decode while the file is open)
+            if img.mode != 'RGB':           # the reference's pil_loader converts unconditionally; for an RGB image that is a
+                img = img.convert('RGB')    # plain copy of the decoded pixels (0.1 ms of the 2 ms per image) - skipped
         if self.transform is not None:
             img = self.transform(img)
         if self.target_transform is not None:
