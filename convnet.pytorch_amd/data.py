@@ -107,11 +107,13 @@ class RandomResizedCrop(object):
     def __init__(self, size, scale=(0.08, 1.0), ratio=(3.0 / 4.0, 4.0 / 3.0), device_resize=False):
         self.size, self.scale, self.ratio = int(size), scale, ratio
         self.device_resize = device_resize      # True: stop at the crop; the resize runs on the device (CropForDevice)
+        lr = torch.log(torch.tensor(self.ratio))
+        self._log_ratio = (lr[0].item(), lr[1].item())
 
     def get_params(self, w, h):
         """torchvision.transforms.RandomResizedCrop.get_params, draw for draw (returns left, top, cw, ch)."""
         area = h * w
-        log_ratio = torch.log(torch.tensor(self.ratio))
+        log_ratio = self._log_ratio      # torch.log(torch.tensor(self.ratio)): the same fp32 values, computed once
         for _ in range(10):
             target_area = area * torch.empty(1).uniform_(self.scale[0], self.scale[1]).item()
             aspect = torch.exp(torch.empty(1).uniform_(log_ratio[0], log_ratio[1])).item()
